@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py — the headline metric of BASELINE.json: fp64 CSR SpMV GEdges/s (+ achieved HBM GB/s against the roofline).
+
+A step = one pass of the hot path over the whole matrix: y = A·x on BASELINE configs[1], the 10M×10M R-MAT power-law
+matrix with ≈1e8 nonzeros (synthetic, generated in HBM by the kernels of g4s_amd/csrc/synth.hip). With N>1 ranks the rows
+are split by equal work (the rule of mm/inc/BIN.h:101-122), every rank owns its slab of x and y, and a step is
+{exchange x over RCCL/xGMI, local SpMV} — total work is fixed, so scaling is "strong". Inputs are resident in HBM before
+the timed region. Prints ONE JSON line (rank 0).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload rmat|banded|lap5|lap7] [--exchange allgatherv|needed]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (≈6.3 TB/s achievable on a float4 copy)
+
+WORKLOADS = {
+    # name: (description, builder kwargs)
+    "rmat": "fp64 CSR SpMV, 10M x 10M R-MAT (0.57,0.19,0.19,0.05) power-law, 1e8 edge draws deduplicated (BASELINE configs[1])",
+    "banded": "fp64 CSR SpMV, 10M x 10M banded, half-bandwidth 5 (north_star: 'power-law and banded')",
+    "lap5": "fp64 CSR SpMV, 1M x 1M 5-point Laplacian (BASELINE configs[0])",
+    "lap7": "fp64 CSR SpMV, 7-point 3-D Laplacian 431^3 = 80M rows (BASELINE configs[3])",
+}
+
+
+def build_matrix(name, host, small):
+    if name == "rmat":
+        n, scale, edges = (10_000_000, 24, 100_000_000) if not small else (200_000, 18, 2_000_000)
+        return host.rmat_csr(n, scale, edges, 20240521)
+    if name == "banded":
+        return host.banded_csr(10_000_000 if not small else 200_000, 5, 20240521)
+    if name == "lap5":
+        s = 1000 if not small else 300
+        return host.laplacian_csr(5, s, s)
+    if name == "lap7":
+        s = 431 if not small else 60
+        return host.laplacian_csr(7, s, s, s)
+    raise SystemExit(f"unknown workload {name}")
+
+
+def cpu_baseline(A, x, budget_s=12.0):
+    """The oracle's SpMV (oracle/g4s_oracle.c, 'port') timed on this box's host cores on the same matrix. Reported, not a target."""
+    import numpy as np
+    from tests import oracle_lib
+    o = oracle_lib.load()
+    rp, ci, va = A.to_host()
+    xh = x.cpu().numpy()
+    y = np.zeros(A.rows)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    out = {}
+    for threads in (1, cores):
+        o.spmv_mt(rp, ci, va, xh, y, threads)          # warm-up pass (page-in)
+        t0, passes = time.perf_counter(), 0
+        while True:
+            o.spmv_mt(rp, ci, va, xh, y, threads)
+            passes += 1
+            el = time.perf_counter() - t0
+            if el > budget_s / 2 or passes >= 20:
+                break
+        out[threads] = (A.nnz * passes / el / 1e9, passes, el)
+    v, passes, el = out[cores]
+    return {"value": round(v, 4), "unit": "GEdges/s", "cores": cores, "kind": "port",
+            "sample": f"whole matrix (nnz={A.nnz}), {passes} passes in {el:.1f}s, OpenMP rows split by equal nnz; "
+                      f"single thread: {out[1][0]:.4f} GEdges/s ({out[1][1]} passes)",
+            "single_thread_value": round(out[1][0], 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="rmat", choices=sorted(WORKLOADS))
+    ap.add_argument("--exchange", default="allgatherv", choices=["allgatherv", "needed"])
+    ap.add_argument("--small", action="store_true", help="reduced sizes for plumbing checks (not a valid benchmark)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-nt", action="store_true", help="plain loads for the matrix stream (A/B against nontemporal)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from g4s_amd import capi, host
+    from g4s_amd import dist as gdist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- inputs, resident in HBM
+    A_full = build_matrix(args.workload, host, args.small)
+    n_rows, n_cols, nnz_total = A_full.rows, A_full.cols, A_full.nnz
+    offs = gdist.row_partition(A_full.rowptr, world)
+    r0, r1 = offs[rank], offs[rank + 1]
+    flags = capi.SPMV_NO_NT if args.no_nt else 0
+    if world > 1:
+        rp, ci, va = gdist.slice_rows(A_full.rowptr, A_full.colids, A_full.values, r0, r1)
+        A = host.CSR(rp, ci, va, r1 - r0, n_cols, spmv_flags=flags)
+        del A_full
+        torch.cuda.empty_cache()
+    else:
+        A = host.CSR(A_full.rowptr, A_full.colids, A_full.values, n_rows, n_cols, spmv_flags=flags)
+    x_local = host.synth_vector(7, r1 - r0, i0=r0)
+    x_full = torch.zeros(n_cols, dtype=torch.float64, device="cuda")
+    y_local = torch.empty(r1 - r0, dtype=torch.float64, device="cuda")
+    exchange = gdist.VectorExchange(offs, rank, world, colids=A.colids, mode=args.exchange)
+    exchange(x_local, x_full)
+    info = A.info()
+
+    def step():
+        if world > 1:
+            exchange(x_local, x_full)
+        A.spmv(x_full, y_local)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel (spmv_csr_adaptive_kernel): HIP events on the launch stream around back-to-back launches.
+    # At N=1 the timed region above IS that (a step is one launch of it, plus the few-µs long-row fixup); at N>1 it is re-measured
+    # without the exchange, outside the timed region.
+    if world == 1:
+        kernel_ms = ev0.elapsed_time(ev1) / args.steps
+    else:
+        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k0.record()
+        for _ in range(args.steps):
+            A.spmv(x_full, y_local)
+        k1.record()
+        torch.cuda.synchronize()
+        kernel_ms = k0.elapsed_time(k1) / args.steps
+    achieved = info["algorithmic_bytes"] / (kernel_ms * 1e-3) / 1e9
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("workload") == args.workload and tj.get("n_gpus") == world and not args.small:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "fp64 SpMV GEdges/s",
+        "value": round(nnz_total * args.steps / elapsed / 1e9, 4),
+        "unit": "GEdges/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": WORKLOADS[args.workload] + (" [--small: NOT the benchmark size]" if args.small else ""),
+                   "rows": n_rows, "cols": n_cols, "nnz": nnz_total, "index": "int32",
+                   "partition": f"1-D rows by equal nnz+rows over {world} rank(s)",
+                   "exchange": ("none (single GPU)" if world == 1 else f"{args.exchange} over RCCL, {exchange.recv_bytes} B received per rank 0 step"),
+                   "matrix_loads": "plain" if args.no_nt else "nontemporal"},
+        "hbm_gbs_algorithmic_whole_job": round((12 * nnz_total + 4 * (n_rows + 1) + 8 * n_rows + 8 * n_cols) * args.steps / elapsed / 1e9, 2),
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "kernel": "spmv_csr_adaptive_kernel", "kernel_ms": round(kernel_ms, 5),
+                     "algorithmic_bytes_per_launch": info["algorithmic_bytes"],
+                     "launch_rows": info["rows"], "launch_nnz": info["nnz"]},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(A, x_full)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,121 @@
+"""ctypes binding of libg4s_hip.so (the C-ABI declared in include/g4s.h and include/g4s_synth.h).
+
+The library is the product; this module only loads it and declares argument types. It fails loudly when the
+shared object is missing — there is no CPU fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libg4s_hip.so")
+
+OK, ERR_INVALID, ERR_NOMEM, ERR_HIP, ERR_OVERFLOW, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+HOST_POINTERS, DEVICE_POINTERS, SORT_OUTPUT, SPMV_NO_NT = 0, 1, 2, 4
+PATTERN_ELEMENT_BLOCK_MATVEC, PATTERN_DENSE_ROW_TIMES_MATRIX, PATTERN_SYM_QUADRATIC_FORM = 1, 2, 3
+
+i32p = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
+f64p = C.POINTER(C.c_double)
+vp = C.c_void_p
+
+FUN_GATHER = C.CFUNCTYPE(None, C.c_int, C.c_int, C.POINTER(f64p), f64p, f64p)   # citcoms/lib/global_defs.h:48
+FUN_APPLY = C.CFUNCTYPE(None, C.c_int, C.POINTER(f64p), f64p, f64p)             # citcoms/lib/global_defs.h:49
+
+
+class CsrInfo(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("nnz", C.c_int64),
+                ("stream_blocks", C.c_int32), ("long_rows", C.c_int32), ("long_chunks", C.c_int32),
+                ("tile_nnz", C.c_int32), ("tile_rows", C.c_int32), ("long_chunk_nnz", C.c_int32),
+                ("algorithmic_bytes", C.c_int64), ("plan_bytes", C.c_int64)]
+
+
+class Timings(C.Structure):
+    """mm/inc/Timings.h:4-23 — seven stage times in milliseconds."""
+    _fields_ = [(n, C.c_double) for n in ("create", "spmm", "convert", "order", "export_csr", "destroy", "total")]
+
+
+class PatternDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("nodes_per_elem", C.c_int32), ("dof", C.c_int32),
+                ("ien", vp), ("id", vp), ("nno", C.c_int32), ("neq", C.c_int32), ("edge_weight_base", C.c_int32),
+                ("inner", C.c_int32), ("numbers", C.c_int32)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/*.h appears here (tests check the export list).
+SIGNATURES = {
+    "g4s_version": (C.c_char_p, []),
+    "g4s_last_error": (C.c_char_p, []),
+    "g4s_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "g4s_set_device": (C.c_int, [C.c_int]),
+    "g4s_device_synchronize": (C.c_int, []),
+    "g4s_shutdown": (C.c_int, []),
+    "g4s_malloc": (vp, [C.c_size_t]),
+    "g4s_free": (None, [vp]),
+    "g4s_dev_alloc": (C.c_int, [C.POINTER(vp), C.c_size_t]),
+    "g4s_dev_free": (C.c_int, [vp]),
+    "g4s_memcpy_h2d": (C.c_int, [vp, vp, C.c_size_t]),
+    "g4s_memcpy_d2h": (C.c_int, [vp, vp, C.c_size_t]),
+    "g4s_csr_create": (C.c_int, [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int64, vp, vp, vp, C.c_uint]),
+    "g4s_csr_destroy": (C.c_int, [vp]),
+    "g4s_csr_get_info": (C.c_int, [vp, C.POINTER(CsrInfo)]),
+    "g4s_csr_device_arrays": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+    "g4s_spmv": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, vp]),
+    "g4s_spmv_csr_i32_f64": (C.c_int, [C.c_int32, C.c_int32, vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_uint]),
+    "g4s_spgemm_flop": (C.c_int, [C.c_int32, vp, vp, vp, i64p, vp, C.c_uint]),
+    "g4s_spgemm_csr_i32_f64": (C.c_int, [vp, vp, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                          C.c_int32, C.c_int32, C.c_int32, i64p, C.POINTER(Timings), C.c_uint]),
+    "g4s_spgemm_symbolic": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, i64p, vp]),
+    "g4s_spgemm_numeric": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint, vp]),
+    "g4s_register_pattern": (C.c_int, [FUN_GATHER, FUN_APPLY, C.POINTER(PatternDesc)]),
+    "g4s_unregister_pattern": (C.c_int, [FUN_GATHER, FUN_APPLY]),
+    "spmm_dense": (None, [C.c_uint32, C.c_uint32, vp, vp, vp, vp, FUN_GATHER, FUN_APPLY, f64p, C.c_int]),
+    "g4s_spmm_dense": (C.c_int, [C.c_uint32, C.c_uint32, vp, vp, vp, vp, FUN_GATHER, FUN_APPLY, f64p, C.c_int]),
+    "g4s_elem_op_create": (C.c_int, [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp]),
+    "g4s_elem_op_destroy": (C.c_int, [vp]),
+    "g4s_elem_op_apply": (C.c_int, [vp, vp, vp, vp]),
+    "g4s_dense_rows_times_matrix": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]),
+    "g4s_sym_quadratic_form": (C.c_int, [C.c_int32, C.c_int32, vp, vp, vp, vp]),
+    # include/g4s_synth.h
+    "g4s_synth_rmat_keys": (C.c_int, [C.c_uint64, C.c_int32, C.c_int64, C.c_int64, C.c_int64, vp, vp]),
+    "g4s_synth_csr_from_keys": (C.c_int, [C.c_uint64, C.c_int64, C.c_int32, vp, C.c_int64, vp, vp, vp, vp]),
+    "g4s_synth_vector": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, vp, vp]),
+    "g4s_synth_laplacian_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, vp, vp, vp, vp,
+                                           C.c_int32, vp]),
+    "g4s_synth_banded": (C.c_int, [C.c_int32, C.c_int32, C.c_uint64, vp, vp, vp, vp]),
+}
+
+
+class G4SError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"g4s status {status}: {message}")
+        self.status = status
+
+
+_lib = None
+
+
+def load():
+    """Load libg4s_hip.so once. torch is imported first so that the HIP runtime both sides use is the one
+    already mapped (same SONAME, libamdhip64.so.7); two runtimes in one process would not share device pointers."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          f"or `make -C g4s_amd/csrc`. g4s_amd has no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (maps torch's libamdhip64.so.7 before ours resolves its NEEDED entry)
+    except Exception:  # pragma: no cover - torch is plumbing; a plain C++ host does not need it
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here == a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != OK:
+        raise G4SError(status, load().g4s_last_error().decode())
+    return status

@@ -1,0 +1,418 @@
+// spmv.hip — fp64 CSR SpMV for gfx950 (B2 of include/g4s.h):  y = alpha·A·x + beta·y.
+//
+// The reference has no CSR mat-vec (mv/mv.c:6-27 times dense BLAS-2 on a dense copy of the graph matrix); the
+// operation is defined in DESIGN.md §SpMV and restated on the CPU in oracle/g4s_oracle.c:oracle_spmv_csr.
+//
+// Execution plan (built once per matrix in g4s_csr_create, the role BIN plays for SpGEMM in mm/inc/BIN.h:
+// classify rows by work, then give each worker an equal share):
+//   * stream blocks — consecutive rows whose nonzeros fit one LDS tile (<= TILE_NNZ products, <= TILE_ROWS rows).
+//     A 256-thread workgroup streams colids/values with fully coalesced loads, gathers x, writes the products to
+//     LDS, then reduces each row out of LDS. With >128 rows in the block one lane sums one row left to right —
+//     the oracle's order, so those rows are bit-identical to it; with fewer rows 2..64 lanes share a row and
+//     finish with a wavefront shuffle reduction (segmented by row).
+//   * long rows (> TILE_NNZ nonzeros; the hubs of a power-law graph) — split into LONG_CHUNK pieces, one workgroup
+//     each, partial sums to a workspace; a second tiny kernel adds a row's partials in chunk order. No atomics, so
+//     results are reproducible run to run.
+// Stream blocks are dealt to the 8 XCDs in contiguous runs (blockIdx%8 selects the run) so that neighbouring row
+// blocks, which touch neighbouring parts of x on banded/stencil matrices, share one L2.
+#include "common.hpp"
+#include <vector>
+
+namespace {
+
+constexpr int WG = 256;
+constexpr int TILE_NNZ = 2048;            // fp64 products staged in LDS per workgroup (16 KiB)
+constexpr int TILE_ROWS = 1024;           // row cap per stream block (4 KiB of staged row pointers)
+constexpr int LONG_CHUNK = 8192;          // nonzeros per long-row chunk
+constexpr int UNROLL = TILE_NNZ / WG;     // independent loads in flight per lane
+
+struct LongChunk { int32_t row, k0, k1, slot; };
+struct LongRow { int32_t row, slot0, nslots, pad; };
+
+template <bool NT, typename T>
+__device__ __forceinline__ T stream_load(const T *p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ void store_y(double *y, int r, double s, double alpha, double beta)
+{
+    if (beta == 0.0) y[r] = alpha * s;
+    else y[r] = alpha * s + beta * y[r];
+}
+
+template <bool NT>
+__global__ __launch_bounds__(WG) void spmv_csr_adaptive_kernel(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colids, const double *__restrict__ values,
+    const double *__restrict__ x, double *__restrict__ y,
+    const int4 *__restrict__ blocks, int n_stream, int stream_per_xcd,
+    const LongChunk *__restrict__ chunks, int n_chunks, int chunks_pad, double *__restrict__ partials,
+    double alpha, double beta)
+{
+    __shared__ double prod[TILE_NNZ];
+    __shared__ int32_t rp[TILE_ROWS + 1];
+    const int tid = threadIdx.x;
+
+    if ((int)blockIdx.x < chunks_pad) {
+        // ---- long-row chunk: strided private sums, then workgroup reduction
+        if ((int)blockIdx.x >= n_chunks) return;
+        const LongChunk c = chunks[blockIdx.x];
+        double acc = 0.0;
+        int k = c.k0 + tid;
+        for (; k + 3 * WG < c.k1; k += 4 * WG) {
+            const int c0 = stream_load<NT>(colids + k), c1 = stream_load<NT>(colids + k + WG);
+            const int c2 = stream_load<NT>(colids + k + 2 * WG), c3 = stream_load<NT>(colids + k + 3 * WG);
+            const double v0 = stream_load<NT>(values + k), v1 = stream_load<NT>(values + k + WG);
+            const double v2 = stream_load<NT>(values + k + 2 * WG), v3 = stream_load<NT>(values + k + 3 * WG);
+            const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+            acc += v0 * x0; acc += v1 * x1; acc += v2 * x2; acc += v3 * x3;
+        }
+        for (; k < c.k1; k += WG) acc += stream_load<NT>(values + k) * x[stream_load<NT>(colids + k)];
+        acc = wave_sum(acc);
+        if ((tid & 63) == 0) prod[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) partials[c.slot] = (prod[0] + prod[1]) + (prod[2] + prod[3]);
+        return;
+    }
+
+    // ---- stream block (XCD-contiguous remap of the block index)
+    const int bid = (int)blockIdx.x - chunks_pad;
+    const int lb = (bid % g4s::kXcds) * stream_per_xcd + bid / g4s::kXcds;
+    if (lb >= n_stream) return;
+    const int4 blk = blocks[lb];
+    const int r0 = blk.x, nrows = blk.y, k0 = blk.z, nnzb = blk.w;
+
+    for (int r = tid; r <= nrows; r += WG) rp[r] = rowptr[r0 + r];
+
+    int cidx[UNROLL];
+    double val[UNROLL];
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) {
+        const int j = i * WG + tid;
+        cidx[i] = 0;
+        val[i] = 0.0;
+        if (j < nnzb) {
+            cidx[i] = stream_load<NT>(colids + k0 + j);
+            val[i] = stream_load<NT>(values + k0 + j);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) {
+        const int j = i * WG + tid;
+        if (j < nnzb) val[i] = val[i] * x[cidx[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) {
+        const int j = i * WG + tid;
+        if (j < nnzb) prod[j] = val[i];
+    }
+    __syncthreads();
+
+    if (nrows * 2 > WG) {
+        // one lane per row, left-to-right (the oracle's summation order)
+        for (int r = tid; r < nrows; r += WG) {
+            const int a = rp[r] - k0, b = rp[r + 1] - k0;
+            double s = 0.0;
+            for (int j = a; j < b; ++j) s += prod[j];
+            store_y(y, r0 + r, s, alpha, beta);
+        }
+    } else {
+        // tpr lanes per row (power of two, <= 64, tpr·nrows <= WG), strided partials + shuffle reduction
+        int tpr = 64;
+        while (tpr * nrows > WG) tpr >>= 1;
+        const int g = tid / tpr, sub = tid & (tpr - 1);
+        double s = 0.0;
+        if (g < nrows) {
+            const int a = rp[g] - k0, b = rp[g + 1] - k0;
+            for (int j = a + sub; j < b; j += tpr) s += prod[j];
+        }
+        for (int off = tpr >> 1; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (g < nrows && sub == 0) store_y(y, r0 + g, s, alpha, beta);
+    }
+}
+
+__global__ void spmv_long_fixup_kernel(const LongRow *__restrict__ lrows, int n_long,
+                                       const double *__restrict__ partials, double *__restrict__ y,
+                                       double alpha, double beta)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_long) return;
+    const LongRow lr = lrows[i];
+    double s = 0.0;
+    for (int j = 0; j < lr.nslots; ++j) s += partials[lr.slot0 + j];
+    store_y(y, lr.row, s, alpha, beta);
+}
+
+// flag |= 1 if any column index is outside [0, cols): an out-of-range gather would fault the GPU.
+__global__ void check_colids_kernel(const int32_t *__restrict__ colids, int64_t nnz, int32_t cols, int *flag)
+{
+    int bad = 0;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t c = colids[k];
+        bad |= (c < 0) | (c >= cols);
+    }
+    if (bad) atomicOr(flag, 1);
+}
+
+} // namespace
+
+struct g4s_csr_s {
+    int32_t rows = 0, cols = 0;
+    int64_t nnz = 0;
+    const int32_t *d_rowptr = nullptr;
+    const int32_t *d_colids = nullptr;
+    const double *d_values = nullptr;
+    bool owns = false;
+    bool use_nt = true;
+    int4 *d_blocks = nullptr;
+    int n_stream = 0, stream_per_xcd = 0;
+    LongChunk *d_chunks = nullptr;
+    int n_chunks = 0, chunks_pad = 0;
+    LongRow *d_long_rows = nullptr;
+    int n_long = 0;
+    double *d_partials = nullptr;
+    int64_t plan_bytes = 0;
+};
+
+namespace {
+
+// Row classification + equal-share blocking on the host (one pass over rowptr).
+int build_plan(g4s_csr_s *A, const int32_t *rowptr)
+{
+    const int32_t rows = A->rows;
+    if (rows > 0) {
+        if (rowptr[0] != 0) return g4s::set_error(G4S_ERR_INVALID, "g4s_csr_create: rowptr[0] != 0 (zero-based CSR expected)");
+        if ((int64_t)rowptr[rows] != A->nnz) return g4s::set_error(G4S_ERR_INVALID, "g4s_csr_create: rowptr[rows] != nnz");
+    }
+    std::vector<int4> blocks;
+    std::vector<LongChunk> chunks;
+    std::vector<LongRow> lrows;
+    blocks.reserve((size_t)(A->nnz / TILE_NNZ + rows / TILE_ROWS + 16));
+    int32_t r = 0;
+    while (r < rows) {
+        int64_t len = (int64_t)rowptr[r + 1] - rowptr[r];
+        if (len < 0) return g4s::set_error(G4S_ERR_INVALID, "g4s_csr_create: rowptr decreases at row %d", r);
+        if (len > TILE_NNZ) {
+            LongRow lr{r, (int32_t)chunks.size(), 0, 0};
+            for (int64_t k = rowptr[r]; k < rowptr[r + 1]; k += LONG_CHUNK) {
+                int64_t ke = k + LONG_CHUNK < rowptr[r + 1] ? k + LONG_CHUNK : rowptr[r + 1];
+                chunks.push_back(LongChunk{r, (int32_t)k, (int32_t)ke, (int32_t)chunks.size()});
+                lr.nslots++;
+            }
+            lrows.push_back(lr);
+            ++r;
+            continue;
+        }
+        const int32_t rb = r;
+        int64_t nz = 0;
+        while (r < rows && r - rb < TILE_ROWS) {
+            len = (int64_t)rowptr[r + 1] - rowptr[r];
+            if (len < 0) return g4s::set_error(G4S_ERR_INVALID, "g4s_csr_create: rowptr decreases at row %d", r);
+            if (len > TILE_NNZ || nz + len > TILE_NNZ) break;
+            nz += len;
+            ++r;
+        }
+        blocks.push_back(make_int4(rb, r - rb, rowptr[rb], (int)nz));
+    }
+    A->n_stream = (int)blocks.size();
+    A->stream_per_xcd = (A->n_stream + g4s::kXcds - 1) / g4s::kXcds;
+    A->n_chunks = (int)chunks.size();
+    A->chunks_pad = (A->n_chunks + g4s::kXcds - 1) / g4s::kXcds * g4s::kXcds;
+    A->n_long = (int)lrows.size();
+    if (A->n_stream) {
+        G4S_HIP_TRY(hipMalloc((void **)&A->d_blocks, sizeof(int4) * blocks.size()));
+        G4S_HIP_TRY(hipMemcpy(A->d_blocks, blocks.data(), sizeof(int4) * blocks.size(), hipMemcpyHostToDevice));
+    }
+    if (A->n_chunks) {
+        G4S_HIP_TRY(hipMalloc((void **)&A->d_chunks, sizeof(LongChunk) * chunks.size()));
+        G4S_HIP_TRY(hipMemcpy(A->d_chunks, chunks.data(), sizeof(LongChunk) * chunks.size(), hipMemcpyHostToDevice));
+        G4S_HIP_TRY(hipMalloc((void **)&A->d_long_rows, sizeof(LongRow) * lrows.size()));
+        G4S_HIP_TRY(hipMemcpy(A->d_long_rows, lrows.data(), sizeof(LongRow) * lrows.size(), hipMemcpyHostToDevice));
+        G4S_HIP_TRY(hipMalloc((void **)&A->d_partials, sizeof(double) * chunks.size()));
+    }
+    A->plan_bytes = (int64_t)(sizeof(int4) * blocks.size() + sizeof(LongChunk) * chunks.size() +
+                              sizeof(LongRow) * lrows.size() + sizeof(double) * chunks.size());
+    return G4S_OK;
+}
+
+void release(g4s_csr_s *A)
+{
+    if (!A) return;
+    if (A->owns) {
+        (void)hipFree((void *)A->d_rowptr);
+        (void)hipFree((void *)A->d_colids);
+        (void)hipFree((void *)A->d_values);
+    }
+    (void)hipFree(A->d_blocks);
+    (void)hipFree(A->d_chunks);
+    (void)hipFree(A->d_long_rows);
+    (void)hipFree(A->d_partials);
+    delete A;
+}
+
+} // namespace
+
+G4S_API g4s_status g4s_csr_create(g4s_csr_t *out, int32_t rows, int32_t cols, int64_t nnz,
+                                  const int32_t *rowptr, const int32_t *colids, const double *values, unsigned flags)
+{
+    G4S_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    G4S_REQUIRE(rows >= 0 && cols >= 0 && nnz >= 0, "negative dimension");
+    G4S_REQUIRE(nnz <= INT32_MAX, "nnz exceeds the int32 index type of the reference (mm/inc/define.h:14)");
+    G4S_REQUIRE(rowptr, "rowptr is NULL");
+    G4S_REQUIRE(nnz == 0 || (colids && values), "colids/values NULL with nnz > 0");
+    int ndev = 0;
+    G4S_HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return g4s::set_error(G4S_ERR_HIP, "no HIP device");
+
+    g4s_csr_s *A = new (std::nothrow) g4s_csr_s();
+    if (!A) return g4s::set_error(G4S_ERR_NOMEM, "host allocation failed");
+    A->rows = rows; A->cols = cols; A->nnz = nnz;
+    A->use_nt = !(flags & G4S_SPMV_NO_NT);
+
+    std::vector<int32_t> h_rowptr_copy;
+    const int32_t *h_rowptr = nullptr;
+    int st = G4S_OK;
+    auto fail = [&](int code) { release(A); return code; };
+
+    if (flags & G4S_DEVICE_POINTERS) {
+        A->d_rowptr = rowptr; A->d_colids = colids; A->d_values = values; A->owns = false;
+        h_rowptr_copy.resize((size_t)rows + 1);
+        if (hipMemcpy(h_rowptr_copy.data(), rowptr, sizeof(int32_t) * ((size_t)rows + 1), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(g4s::set_error(G4S_ERR_HIP, "g4s_csr_create: D2H copy of rowptr failed"));
+        h_rowptr = h_rowptr_copy.data();
+    } else {
+        A->owns = true;
+        void *p = nullptr;
+        if (hipMalloc(&p, sizeof(int32_t) * ((size_t)rows + 1)) != hipSuccess) return fail(g4s::set_error(G4S_ERR_NOMEM, "hipMalloc rowptr"));
+        A->d_rowptr = (const int32_t *)p;
+        if (hipMalloc(&p, sizeof(int32_t) * (size_t)(nnz ? nnz : 1)) != hipSuccess) return fail(g4s::set_error(G4S_ERR_NOMEM, "hipMalloc colids"));
+        A->d_colids = (const int32_t *)p;
+        if (hipMalloc(&p, sizeof(double) * (size_t)(nnz ? nnz : 1)) != hipSuccess) return fail(g4s::set_error(G4S_ERR_NOMEM, "hipMalloc values"));
+        A->d_values = (const double *)p;
+        if (hipMemcpy((void *)A->d_rowptr, rowptr, sizeof(int32_t) * ((size_t)rows + 1), hipMemcpyHostToDevice) != hipSuccess ||
+            (nnz && hipMemcpy((void *)A->d_colids, colids, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice) != hipSuccess) ||
+            (nnz && hipMemcpy((void *)A->d_values, values, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice) != hipSuccess))
+            return fail(g4s::set_error(G4S_ERR_HIP, "g4s_csr_create: H2D upload failed"));
+        h_rowptr = rowptr;
+    }
+
+    st = build_plan(A, h_rowptr);
+    if (st != G4S_OK) return fail(st);
+
+    // Column range check on the device copy (an out-of-range gather is a GPU fault, not an error code).
+    if (nnz > 0) {
+        int *d_flag = nullptr, h_flag = 0;
+        if (hipMalloc((void **)&d_flag, sizeof(int)) != hipSuccess) return fail(g4s::set_error(G4S_ERR_NOMEM, "hipMalloc flag"));
+        (void)hipMemset(d_flag, 0, sizeof(int));
+        int grid = (int)((nnz + 255) / 256 < 4096 ? (nnz + 255) / 256 : 4096);
+        hipLaunchKernelGGL(check_colids_kernel, dim3(grid), dim3(256), 0, 0, A->d_colids, nnz, cols, d_flag);
+        hipError_t e = hipMemcpy(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost);
+        (void)hipFree(d_flag);
+        if (e != hipSuccess) return fail(g4s::set_error(G4S_ERR_HIP, "g4s_csr_create: column check failed: %s", hipGetErrorString(e)));
+        if (h_flag) return fail(g4s::set_error(G4S_ERR_INVALID, "g4s_csr_create: a column index is outside [0, cols)"));
+    }
+    *out = A;
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_csr_destroy(g4s_csr_t A)
+{
+    release(A);
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_csr_get_info(g4s_csr_t A, g4s_csr_info *info)
+{
+    G4S_REQUIRE(A && info, "NULL argument");
+    info->rows = A->rows; info->cols = A->cols; info->nnz = A->nnz;
+    info->stream_blocks = A->n_stream; info->long_rows = A->n_long; info->long_chunks = A->n_chunks;
+    info->tile_nnz = TILE_NNZ; info->tile_rows = TILE_ROWS; info->long_chunk_nnz = LONG_CHUNK;
+    info->algorithmic_bytes = 12 * A->nnz + 4 * ((int64_t)A->rows + 1) + 8 * (int64_t)A->rows + 8 * (int64_t)A->cols;
+    info->plan_bytes = A->plan_bytes;
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_csr_device_arrays(g4s_csr_t A, const int32_t **rowptr, const int32_t **colids, const double **values)
+{
+    G4S_REQUIRE(A, "NULL handle");
+    if (rowptr) *rowptr = A->d_rowptr;
+    if (colids) *colids = A->d_colids;
+    if (values) *values = A->d_values;
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_spmv(g4s_csr_t A, const double *x_dev, double *y_dev, double alpha, double beta, void *stream)
+{
+    G4S_REQUIRE(A, "NULL handle");
+    if (A->rows == 0) return G4S_OK;
+    G4S_REQUIRE(y_dev, "y is NULL");
+    G4S_REQUIRE(x_dev || A->nnz == 0, "x is NULL");
+    G4S_REQUIRE((const void *)x_dev != (const void *)y_dev, "x and y must not alias");
+    hipStream_t s = g4s::as_stream(stream);
+    const int grid = A->chunks_pad + A->stream_per_xcd * g4s::kXcds;
+    if (grid > 0) {
+        if (A->use_nt)
+            hipLaunchKernelGGL(spmv_csr_adaptive_kernel<true>, dim3(grid), dim3(WG), 0, s, A->d_rowptr, A->d_colids, A->d_values,
+                               x_dev, y_dev, A->d_blocks, A->n_stream, A->stream_per_xcd, A->d_chunks, A->n_chunks,
+                               A->chunks_pad, A->d_partials, alpha, beta);
+        else
+            hipLaunchKernelGGL(spmv_csr_adaptive_kernel<false>, dim3(grid), dim3(WG), 0, s, A->d_rowptr, A->d_colids, A->d_values,
+                               x_dev, y_dev, A->d_blocks, A->n_stream, A->stream_per_xcd, A->d_chunks, A->n_chunks,
+                               A->chunks_pad, A->d_partials, alpha, beta);
+        G4S_HIP_TRY(hipGetLastError());
+    }
+    if (A->n_long > 0) {
+        hipLaunchKernelGGL(spmv_long_fixup_kernel, dim3((A->n_long + 255) / 256), dim3(256), 0, s, A->d_long_rows, A->n_long,
+                           A->d_partials, y_dev, alpha, beta);
+        G4S_HIP_TRY(hipGetLastError());
+    }
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_spmv_csr_i32_f64(int32_t rows, int32_t cols, const int32_t *rowptr, const int32_t *colids,
+                                        const double *values, const double *x, double *y,
+                                        double alpha, double beta, unsigned flags)
+{
+    G4S_REQUIRE(rows >= 0 && cols >= 0, "negative dimension");
+    G4S_REQUIRE(rowptr, "rowptr is NULL");
+    if (rows == 0) return G4S_OK;
+    G4S_REQUIRE(y, "y is NULL");
+    const bool dev = (flags & G4S_DEVICE_POINTERS) != 0;
+    int32_t nnz32 = 0;
+    if (dev) G4S_HIP_TRY(hipMemcpy(&nnz32, rowptr + rows, sizeof(int32_t), hipMemcpyDeviceToHost));
+    else nnz32 = rowptr[rows];
+    G4S_REQUIRE(nnz32 >= 0, "rowptr[rows] is negative");
+    g4s_csr_t A = nullptr;
+    G4S_TRY(g4s_csr_create(&A, rows, cols, nnz32, rowptr, colids, values, flags));
+    int st = G4S_OK;
+    if (dev) {
+        st = g4s_spmv(A, x, y, alpha, beta, nullptr);
+        if (st == G4S_OK && hipStreamSynchronize(nullptr) != hipSuccess) st = g4s::set_error(G4S_ERR_HIP, "synchronize failed");
+    } else {
+        double *dx = nullptr, *dy = nullptr;
+        if (hipMalloc((void **)&dx, sizeof(double) * (size_t)(cols ? cols : 1)) != hipSuccess ||
+            hipMalloc((void **)&dy, sizeof(double) * (size_t)rows) != hipSuccess) {
+            st = g4s::set_error(G4S_ERR_NOMEM, "hipMalloc of x/y failed");
+        } else if ((cols && hipMemcpy(dx, x, sizeof(double) * (size_t)cols, hipMemcpyHostToDevice) != hipSuccess) ||
+                   (beta != 0.0 && hipMemcpy(dy, y, sizeof(double) * (size_t)rows, hipMemcpyHostToDevice) != hipSuccess)) {
+            st = g4s::set_error(G4S_ERR_HIP, "H2D copy of x/y failed");
+        } else {
+            st = g4s_spmv(A, dx, dy, alpha, beta, nullptr);
+            if (st == G4S_OK && hipMemcpy(y, dy, sizeof(double) * (size_t)rows, hipMemcpyDeviceToHost) != hipSuccess)
+                st = g4s::set_error(G4S_ERR_HIP, "D2H copy of y failed");
+        }
+        (void)hipFree(dx);
+        (void)hipFree(dy);
+    }
+    g4s_csr_destroy(A);
+    return st;
+}

@@ -1,0 +1,99 @@
+"""1-D row partition of a CSR matrix over ranks and the per-SpMV vector exchange (one process per GPU, torch.distributed).
+
+The reference has no multi-device code on this path; its shared-memory analogue is the equal-work contiguous row split of
+BIN::set_rows_offset (mm/inc/BIN.h:101-122: prefix-sum the per-row work, boundary t = lower_bound(prefix, ceil(total/parts)·t)),
+and its distributed analogue is CitcomS's per-matvec neighbour exchange (citcoms/lib/Regional_parallel_related.c:744-789).
+Here the same split rule assigns rows to GPUs; each rank owns rows [r0,r1) of A, of y and of x, and before each SpMV receives
+the x entries it references from their owners:
+  * "allgatherv": every slab to every rank (grouped send/recv — exact slab sizes, each peer's slab over its own xGMI link);
+  * "needed": only the column ranges a rank's rows actually reference (computed once at setup; for stencil/banded matrices
+    this is the halo, a few planes, instead of the whole vector — SURVEY.md §8e).
+This module is device-agnostic torch code (the tests drive it with gloo on CPU tensors); the SpMV itself is g4s_amd.host.CSR.
+"""
+import torch
+import torch.distributed as dist
+
+
+def row_partition(rowptr, parts):
+    """Row offsets [parts+1] giving each part an equal share of work = nnz + rows (BIN.h:101-122 rule)."""
+    rows = rowptr.numel() - 1
+    rp = rowptr.to(torch.int64)
+    prefix = rp + torch.arange(rows + 1, device=rowptr.device, dtype=torch.int64)   # work prefix: nnz before row + rows before row
+    total = int(prefix[-1].item())
+    avg = (total + parts - 1) // parts
+    targets = torch.arange(1, parts + 1, device=rowptr.device, dtype=torch.int64) * avg
+    cut = torch.searchsorted(prefix, targets, right=False)                            # std::lower_bound
+    offs = [0] + [min(int(c), rows) for c in cut.tolist()]
+    offs[parts] = rows                                                                # BIN.h:120
+    for i in range(1, parts + 1):
+        offs[i] = max(offs[i], offs[i - 1])
+    return offs
+
+
+def slice_rows(rowptr, colids, values, r0, r1):
+    """Rows [r0,r1) as a local CSR with global column ids."""
+    k0, k1 = int(rowptr[r0].item()), int(rowptr[r1].item())
+    rp = (rowptr[r0:r1 + 1] - rowptr[r0]).to(torch.int32).contiguous()
+    return rp, colids[k0:k1].contiguous(), values[k0:k1].contiguous()
+
+
+class VectorExchange:
+    """Brings the x entries this rank's rows reference into a full-length local buffer.
+
+    offsets: the row partition (rank k owns x[offsets[k]:offsets[k+1]]).
+    mode "allgatherv": receive every peer's whole slab. mode "needed": receive, from each peer, only the contiguous
+    range [lo,hi) of its slab that local columns touch (empty ranges are skipped)."""
+
+    def __init__(self, offsets, rank, world, colids=None, mode="allgatherv", group=None):
+        self.offsets, self.rank, self.world, self.group = list(offsets), rank, world, group
+        self.mode = mode
+        # want[k] = (lo,hi) global range this rank needs from rank k
+        self.want = [(self.offsets[k], self.offsets[k + 1]) for k in range(world)]
+        if mode == "needed":
+            assert colids is not None
+            self.want = []
+            for k in range(world):
+                lo, hi = self.offsets[k], self.offsets[k + 1]
+                if k == rank or hi <= lo or colids.numel() == 0:
+                    self.want.append((lo, lo))
+                    continue
+                m = (colids >= lo) & (colids < hi)
+                if bool(m.any()):
+                    c = colids[m]
+                    self.want.append((int(c.min().item()), int(c.max().item()) + 1))
+                else:
+                    self.want.append((lo, lo))
+        # give[k] = (lo,hi) global range rank k needs from this rank: exchange the wish lists once
+        self.give = [(0, 0)] * world
+        if world > 1:
+            mine = torch.tensor([list(w) for w in self.want], dtype=torch.int64)
+            allw = [torch.zeros_like(mine) for _ in range(world)]
+            dev = None
+            if dist.get_backend(group) == "nccl":
+                dev = torch.device("cuda", torch.cuda.current_device())
+                mine = mine.to(dev)
+                allw = [a.to(dev) for a in allw]
+            dist.all_gather(allw, mine, group=group)
+            self.give = [tuple(int(v) for v in allw[k][rank].tolist()) for k in range(world)]
+        self.recv_bytes = sum(8 * (hi - lo) for k, (lo, hi) in enumerate(self.want) if k != rank)
+
+    def __call__(self, x_local, x_full):
+        """x_full[own slab] = x_local, and the wanted ranges of the peers' slabs arrive by grouped send/recv."""
+        r0, r1 = self.offsets[self.rank], self.offsets[self.rank + 1]
+        x_full[r0:r1].copy_(x_local)
+        if self.world == 1:
+            return x_full
+        ops = []
+        for k in range(self.world):
+            if k == self.rank:
+                continue
+            lo, hi = self.give[k]
+            if hi > lo:
+                ops.append(dist.P2POp(dist.isend, x_local[lo - r0:hi - r0], k, group=self.group))
+            lo, hi = self.want[k]
+            if hi > lo:
+                ops.append(dist.P2POp(dist.irecv, x_full[lo:hi], k, group=self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return x_full

@@ -1,0 +1,202 @@
+/*
+ * g4s.h — C-ABI of libg4s_hip.so: the MI355X (gfx950) drop-in for G4S's graph-as-sparse-matrix hot path.
+ *
+ * Plain C types only, no exceptions cross this boundary, every entry point returns a g4s_status
+ * (0 = success, negative = error; g4s_last_error() gives the message of the calling thread's last failure).
+ *
+ * Each entry point names the reference interface (file:line under the G4S tree) it replaces:
+ *
+ *   B1  raw-pointer CSR SpGEMM     mm/inc/mkl_mult.h:40-43      void mkl(arpt,acol,aval, brpt,bcol,bval, &crpt,&ccol,&cval, M,K,N,&cnnz, Timings&)
+ *                                   mm/inc/hash_mult.h:1028-1057 HashSpGEMM<vectorProbing,sortOutput>(a,b,c,multop,addop)
+ *   B2  CSR SpMV                   mv/mv.c:6-27                 void matrix_multiply_*(double*A,double*B,double*C,int dim)  (y = A·x; the
+ *                                                                reference ships only dense BLAS-2 forms, the CSR form is defined in DESIGN.md)
+ *   B3  graph gather/apply         citcoms/lib/global_defs.h:48-49,854-857  spmm_dense(numNodes,degree,edgeWeight,vertexStates,temp,result,gather,apply,time,threadNum)
+ *                                   deepmd/source/op/graph.h:5-32            struct Graph, GraphProcess(graph,result,gather,apply)
+ *                                   cantera/src/thermo/RedlichKwongMFTP.cpp:917-983  GraphProcess1/2
+ *
+ * Index type is int32 and value type fp64, as in the reference (mm/inc/define.h:14-15).
+ * The library fails loudly (G4S_ERR_HIP) when no HIP device is usable; there is no CPU fallback in it.
+ */
+#ifndef G4S_H
+#define G4S_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status codes */
+typedef int g4s_status;
+#define G4S_OK               0
+#define G4S_ERR_INVALID     -1 /* bad argument (null pointer, negative size, unsorted rowptr …)           */
+#define G4S_ERR_NOMEM       -2 /* host or device allocation failed                                        */
+#define G4S_ERR_HIP         -3 /* a HIP runtime call failed / no device                                   */
+#define G4S_ERR_OVERFLOW    -4 /* a result does not fit the reference's int32 index type (define.h:14)    */
+#define G4S_ERR_UNSUPPORTED -5 /* e.g. an unregistered gather/apply pair handed to the device dispatcher  */
+
+/* ------------------------------------------------------------------ flags */
+#define G4S_HOST_POINTERS    0u /* array arguments are host memory (default; H2D/D2H happen inside)       */
+#define G4S_DEVICE_POINTERS  1u /* array arguments are device memory, borrowed for the handle's lifetime  */
+#define G4S_SORT_OUTPUT      2u /* SpGEMM: rows of C sorted by column (HashSpGEMM sortOutput, hash_mult.h:526-553) */
+#define G4S_SPMV_NO_NT       4u /* SpMV: plain (cache-allocating) loads for the matrix stream instead of nontemporal */
+
+/* ------------------------------------------------------------------ runtime */
+const char *g4s_version(void);
+const char *g4s_last_error(void);                 /* thread-local, never NULL                              */
+g4s_status  g4s_device_count(int *count);
+g4s_status  g4s_set_device(int device);           /* also honours HIP_VISIBLE_DEVICES                      */
+g4s_status  g4s_device_synchronize(void);
+g4s_status  g4s_shutdown(void);                   /* releases cached workspaces                            */
+
+/* Allocator that matches every callee-allocated output of this library (the reference pairs
+ * my_malloc/my_free, mm/inc/utility.h:126-153; CSR::make_empty frees what mkl()/HashSpGEMM allocated,
+ * mm/inc/CSR.h:50-62). */
+void       *g4s_malloc(size_t bytes);
+void        g4s_free(void *p);
+
+/* Device buffers for callers without their own HIP code (the bench and the tests use torch tensors instead). */
+g4s_status  g4s_dev_alloc(void **dptr, size_t bytes);
+g4s_status  g4s_dev_free(void *dptr);
+g4s_status  g4s_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+g4s_status  g4s_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+
+/* ------------------------------------------------------------------ B2: CSR SpMV  y = alpha·A·x + beta·y */
+
+/* Opaque device-resident CSR matrix + its SpMV execution plan (row blocks, long-row chunks). */
+typedef struct g4s_csr_s *g4s_csr_t;
+
+typedef struct g4s_csr_info {
+    int32_t rows, cols;
+    int64_t nnz;
+    int32_t stream_blocks;    /* row-aligned blocks of <= tile_nnz nonzeros handled by the LDS-staged path */
+    int32_t long_rows;        /* rows longer than tile_nnz, split into chunks                             */
+    int32_t long_chunks;
+    int32_t tile_nnz, tile_rows, long_chunk_nnz;
+    int64_t algorithmic_bytes;/* 12·nnz + 4·(rows+1) + 8·rows + 8·cols                      */
+    int64_t plan_bytes;       /* extra device bytes the plan itself occupies                               */
+} g4s_csr_info;
+
+/* Create a handle. rowptr has rows+1 entries, zero-based, non-decreasing, rowptr[rows] == nnz; colids in [0,cols).
+ * With G4S_HOST_POINTERS the three arrays are copied to the device (the handle owns the copies);
+ * with G4S_DEVICE_POINTERS they are borrowed and must outlive the handle. Replaces the container role of
+ * CSR<int,double> (mm/inc/CSR.h:22-113) for device residency. */
+g4s_status g4s_csr_create(g4s_csr_t *out, int32_t rows, int32_t cols, int64_t nnz,
+                          const int32_t *rowptr, const int32_t *colids, const double *values, unsigned flags);
+g4s_status g4s_csr_destroy(g4s_csr_t A);
+g4s_status g4s_csr_get_info(g4s_csr_t A, g4s_csr_info *info);
+/* Device pointers of the handle's arrays (borrowed). */
+g4s_status g4s_csr_device_arrays(g4s_csr_t A, const int32_t **rowptr, const int32_t **colids, const double **values);
+
+/* Asynchronous SpMV on `stream` (a hipStream_t; NULL = the default stream). x_dev (cols doubles) and
+ * y_dev (rows doubles) are device pointers and must not alias. beta == 0 never reads y (BLAS convention). */
+g4s_status g4s_spmv(g4s_csr_t A, const double *x_dev, double *y_dev, double alpha, double beta, void *stream);
+
+/* One-shot form with the call shape of mv/mv.c:6-27 (caller-owned in/out arrays, synchronous).
+ * flags: G4S_HOST_POINTERS or G4S_DEVICE_POINTERS applies to all five arrays. */
+g4s_status g4s_spmv_csr_i32_f64(int32_t rows, int32_t cols, const int32_t *rowptr, const int32_t *colids,
+                                const double *values, const double *x, double *y,
+                                double alpha, double beta, unsigned flags);
+
+/* ------------------------------------------------------------------ B1: CSR SpGEMM  C = A·B */
+
+/* Stage timer with the reference's seven fields, milliseconds (mm/inc/Timings.h:4-23). */
+typedef struct g4s_timings {
+    double create, spmm, convert, order, export_csr, destroy, total;
+} g4s_timings;
+
+/* flop = Σ_i Σ_{j∈A(i,:)} nnz(B(acol_j,:))  (mm/inc/mkl_mult.h:8-38, hash_mult.h:46-62); device pointers
+ * when flags has G4S_DEVICE_POINTERS. row_flop (may be NULL) receives the per-row count as int64. */
+g4s_status g4s_spgemm_flop(int32_t M, const int32_t *arpt, const int32_t *acol, const int32_t *brpt,
+                           int64_t *flop, int64_t *row_flop, unsigned flags);
+
+/* Raw-pointer SpGEMM with the call shape of mkl(...) (mm/inc/mkl_mult.h:40-43): inputs borrowed,
+ * outputs allocated by the callee — with g4s_malloc for host pointers (free with g4s_free), with
+ * g4s_dev_alloc for G4S_DEVICE_POINTERS (free with g4s_dev_free). A is M×K, B is K×N, C is M×N.
+ * cnnz is int64; G4S_ERR_OVERFLOW is returned (and nothing allocated) if it exceeds INT32_MAX,
+ * because crpt keeps the reference's int32 type. timings may be NULL. */
+g4s_status g4s_spgemm_csr_i32_f64(const int32_t *arpt, const int32_t *acol, const double *aval,
+                                  const int32_t *brpt, const int32_t *bcol, const double *bval,
+                                  int32_t **crpt, int32_t **ccol, double **cval,
+                                  int32_t M, int32_t K, int32_t N, int64_t *cnnz,
+                                  g4s_timings *timings, unsigned flags);
+
+/* Two-phase form (hash_symbolic / hash_numeric, mm/inc/hash_mult.h:496-508,559-608) on device pointers:
+ * symbolic writes crpt_dev[M+1] (int32) and *cnnz; numeric fills ccol_dev/cval_dev (cnnz entries each). */
+g4s_status g4s_spgemm_symbolic(int32_t M, int32_t K, int32_t N,
+                               const int32_t *arpt_dev, const int32_t *acol_dev,
+                               const int32_t *brpt_dev, const int32_t *bcol_dev,
+                               int32_t *crpt_dev, int64_t *cnnz, void *stream);
+g4s_status g4s_spgemm_numeric(int32_t M, int32_t K, int32_t N,
+                              const int32_t *arpt_dev, const int32_t *acol_dev, const double *aval_dev,
+                              const int32_t *brpt_dev, const int32_t *bcol_dev, const double *bval_dev,
+                              const int32_t *crpt_dev, int32_t *ccol_dev, double *cval_dev,
+                              unsigned flags, void *stream);
+
+/* ------------------------------------------------------------------ B3: graph gather/apply */
+
+typedef void (*fun_gather)(int, int, const double **, const double *, double *); /* citcoms/lib/global_defs.h:48 */
+typedef void (*fun_apply)(int, const double **, const double *, double *);       /* citcoms/lib/global_defs.h:49 */
+
+/* Known gather/apply patterns the device can execute (host callbacks cannot run on the GPU).            */
+#define G4S_PATTERN_ELEMENT_BLOCK_MATVEC   1 /* CitcomS e_assemble_del2_u gather, Element_calculations.c:453-471 */
+#define G4S_PATTERN_DENSE_ROW_TIMES_MATRIX 2 /* DeePMD OptMatmul gather, opt_matmul.cc:52-58                     */
+#define G4S_PATTERN_SYM_QUADRATIC_FORM     3 /* Cantera gather1/apply1, gather2/apply2, RedlichKwongMFTP.cpp:927-970 */
+
+typedef struct g4s_pattern_desc {
+    int32_t kind;
+    /* ELEMENT_BLOCK_MATVEC: result[eq(e,a,i)] += Σ_b Σ_d K_e[(dof·a+i)·(npe·dof) + dof·b+d] · u[eq(e,b,d)],
+     * eq(e,a,i) = id[ ien[e·npe + a]·dof + i ]   (0-based restatement of IEN/ID, Element_calculations.c:460-468). */
+    int32_t nodes_per_elem;   /* 8  (enodes[3])                                                          */
+    int32_t dof;              /* 3  (mesh.nsd)                                                           */
+    const int32_t *ien;       /* [numNodes · nodes_per_elem] element → node, 0-based, host memory         */
+    const int32_t *id;        /* [nno · dof] node,dof → equation, 0-based, host memory                    */
+    int32_t nno;              /* number of nodes                                                         */
+    int32_t neq;              /* number of equations (length of vertexStates / result)                   */
+    int32_t edge_weight_base; /* 1 if edgeWeight[0] is unused and element e lives at edgeWeight[e+1] (CitcomS, Drive_solvers.c:52-55), else 0 */
+    /* DENSE_ROW_TIMES_MATRIX: result[e·degree + a] = Σ_k edgeWeight[e][k] · states[k·degree + a]        */
+    int32_t inner;            /* N (opt_matmul.cc:33, global Nsize)                                      */
+    /* SYM_QUADRATIC_FORM: see RedlichKwongMFTP.cpp:927-970                                              */
+    int32_t numbers;          /* coefficient stride (1 = gather1/apply1 form, >1 = gather2/apply2 form)   */
+} g4s_pattern_desc;
+
+/* Register a (gather, apply) pair as an instance of a known pattern; later spmm_dense calls with that
+ * pair run on the device. desc (and the ien/id arrays) are copied. */
+g4s_status g4s_register_pattern(fun_gather gather, fun_apply apply, const g4s_pattern_desc *desc);
+g4s_status g4s_unregister_pattern(fun_gather gather, fun_apply apply);
+
+/* The reference symbol, exactly (citcoms/lib/global_defs.h:854-857; bound at citcoms/bin/Citcom.c:93).
+ * Registered pairs run as HIP kernels; unregistered pairs abort with a message on stderr (callbacks are
+ * host code the device cannot execute — see g4s_spmm_dense for the status-returning form). */
+void spmm_dense(uint32_t numNodes, uint32_t degree, const double **edgeWeight, const double *vertexStates,
+                double *temp, double *result, fun_gather gather, fun_apply apply, double *time, int threadNum);
+g4s_status g4s_spmm_dense(uint32_t numNodes, uint32_t degree, const double **edgeWeight, const double *vertexStates,
+                          double *temp, double *result, fun_gather gather, fun_apply apply, double *time, int threadNum);
+
+/* Device-resident forms of the three patterns (what spmm_dense dispatches to; solvers call these directly
+ * to keep vectors on the device between iterations). */
+typedef struct g4s_elem_op_s *g4s_elem_op_t;
+/* elt_k_dev: numElems × (npe·dof)² doubles, contiguous, device memory (borrowed). ien/id host arrays as in the descriptor. */
+g4s_status g4s_elem_op_create(g4s_elem_op_t *out, int32_t numElems, int32_t nodes_per_elem, int32_t dof,
+                              const int32_t *ien_host, const int32_t *id_host, int32_t nno, int32_t neq,
+                              const double *elt_k_dev);
+g4s_status g4s_elem_op_destroy(g4s_elem_op_t op);
+/* Au_dev[0..neq) = Σ_e scatter(K_e · gather(u_dev))  — overwrites Au (the caller's zeroing at
+ * Element_calculations.c:495-496 is folded in). Deterministic (no atomics). */
+g4s_status g4s_elem_op_apply(g4s_elem_op_t op, const double *u_dev, double *Au_dev, void *stream);
+
+/* result[M×K] = xx[M×N] · w[N×K], row-major fp64, device pointers (opt_matmul.cc:24-62). */
+g4s_status g4s_dense_rows_times_matrix(int32_t M, int32_t N, int32_t K, const double *xx_dev, const double *w_dev,
+                                       double *result_dev, void *stream);
+
+/* result[0] += Σ_i Σ_{j<i} x_i x_j (a[num·(i+m·j)] + a[num·(j+m·i)]) + Σ_i x_i² a[num·(i+m·i)];
+ * numbers == 1: result[1] += Σ_i x_i·b_i (apply1); numbers > 1: result[1] likewise on a[…+1] (gather2/apply2).
+ * Host pointers (the operands are ~100×100); result is a host double[2] that is accumulated into. */
+g4s_status g4s_sym_quadratic_form(int32_t m, int32_t numbers, const double *a, const double *x, const double *b,
+                                  double *result);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+#endif /* G4S_H */

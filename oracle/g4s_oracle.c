@@ -1,0 +1,532 @@
+/*
+ * g4s_oracle.c — CPU restatement of the reference's algorithms for the G4S sparse hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it, and only as the checker / reported CPU baseline. The product (libg4s_hip.so, g4s_amd/) never
+ * links, imports or calls anything in this directory.
+ *
+ * Pinning status:
+ *   - graph gather/apply driver (oracle_graph_process): PINNED against the reference's own GraphProcess,
+ *     compiled in place from /root/reference/deepmd/source/op/graph.h into oracle/_ref/ (oracle/Makefile).
+ *   - SpGEMM / SpMV / MatrixMarket reader: PARITY UNPINNED. The reference holds no test, golden vector or
+ *     fixture for mm/ or mv/ (SURVEY.md §4), its shipped binaries need Intel MKL, and its header library
+ *     mm/inc cannot be compiled here without a stand-in for TBB's <scalable_allocator.h>
+ *     (mm/inc/utility.h:11), which the rules of this build forbid. These functions restate the published
+ *     source line by line (citations below) and are cross-checked against scipy.sparse in tests/.
+ *
+ * Every function names the reference file:line it follows. Build: oracle/Makefile (gcc -O2 -ffp-contract=off).
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ctype.h>
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------------
+ * SpMV  y = alpha·A·x + beta·y.
+ * The reference has no CSR mat-vec (mv/mv.c:6-27 only times dense BLAS-2 on a dense copy). Definition used
+ * here: per row, products accumulated left to right in stored order, multiply then add
+ * (the multiply-add of hash_numeric, mm/inc/hash_mult.h:583-593, with B an n×1 matrix), no FMA contraction.
+ * beta == 0 does not read y (BLAS-2 convention of the cblas_dgemv call at mv/mv.c:9). */
+ORACLE_API void oracle_spmv_csr(int32_t rows, const int32_t *rowptr, const int32_t *colids, const double *values,
+                                const double *x, double *y, double alpha, double beta)
+{
+    for (int32_t i = 0; i < rows; ++i) {
+        double s = 0.0;
+        for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+            double p = values[k] * x[colids[k]];
+            s = s + p;
+        }
+        if (beta == 0.0) y[i] = alpha * s;
+        else {
+            double t = alpha * s;
+            double u = beta * y[i];
+            y[i] = t + u;
+        }
+    }
+}
+
+/* Same sum in long double with the absolute-value sum beside it, to bound the condition-dependent error
+ * of any summation order:  |y_any_order − y_exact| ≤ rows_nnz · eps · abs_sum  (tests use it as the tolerance scale). */
+ORACLE_API void oracle_spmv_csr_ld(int32_t rows, const int32_t *rowptr, const int32_t *colids, const double *values,
+                                   const double *x, double *y_ld, double *abs_sum)
+{
+    for (int32_t i = 0; i < rows; ++i) {
+        long double s = 0.0L, a = 0.0L;
+        for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+            long double p = (long double)values[k] * (long double)x[colids[k]];
+            s += p;
+            a += p < 0 ? -p : p;
+        }
+        y_ld[i] = (double)s;
+        abs_sum[i] = (double)a;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Exclusive prefix sum with the reference's calling convention: N outputs from N-1 inputs,
+ * out[0] = 0, out[i+1] = out[i] + in[i]   (seq_scan, mm/inc/utility.h:156-163; callers pass rows+1). */
+static void oracle_scan_i32(const int32_t *in, int32_t *out, int32_t N)
+{
+    out[0] = 0;
+    for (int32_t i = 0; i < N - 1; ++i) out[i + 1] = out[i] + in[i];
+}
+
+/* flop = Σ_i Σ_{j∈A(i,:)} nnz(B(acol_j,:))  — compute_flop, mm/inc/mkl_mult.h:8-38; get_flop, hash_mult.h:46-62;
+ * per-row counts as in BIN::set_intprod_num, BIN.h:78-95 (there an int; int64 here so that hubs cannot wrap). */
+ORACLE_API int64_t oracle_spgemm_flop(int32_t M, const int32_t *arpt, const int32_t *acol, const int32_t *brpt,
+                                      int64_t *row_flop /* may be NULL */)
+{
+    int64_t total = 0;
+    for (int32_t i = 0; i < M; ++i) {
+        int64_t f = 0;
+        for (int32_t j = arpt[i]; j < arpt[i + 1]; ++j) f += brpt[acol[j] + 1] - brpt[acol[j]];
+        if (row_flop) row_flop[i] = f;
+        total += f;
+    }
+    return total;
+}
+
+/* bin_id[i]: 0 for an empty row, else 1 + min{ j : min(row_flop, cols) <= 8<<j } — BIN::set_bin_id, BIN.h:158-177
+ * (min_ht_size = 8, hash_mult.h MIN_HT_S/MIN_HT_N). Table entries for bin b>0: 8 << (b-1). */
+ORACLE_API void oracle_bin_id(int32_t rows, int32_t cols, const int64_t *row_flop, int8_t *bin_id)
+{
+    for (int32_t i = 0; i < rows; ++i) {
+        int64_t nz = row_flop[i];
+        if (nz > cols) nz = cols;
+        if (nz == 0) { bin_id[i] = 0; continue; }
+        int j = 0;
+        while (nz > ((int64_t)8 << j)) j++;
+        bin_id[i] = (int8_t)(j + 1);
+    }
+}
+
+/* Equal-work contiguous partition: prefix-sum the per-row work, target = ceil(total/parts), boundary p is
+ * lower_bound(prefix, target·p) — BIN::set_rows_offset, BIN.h:101-122. Used by the reference to split rows
+ * over threads; the build uses the same rule to split rows over GPUs. offsets has parts+1 entries. */
+ORACLE_API void oracle_rows_offset(int32_t rows, const int64_t *row_work, int32_t parts, int32_t *offsets)
+{
+    int64_t *ps = (int64_t *)malloc(sizeof(int64_t) * ((size_t)rows + 1));
+    ps[0] = 0;
+    for (int32_t i = 0; i < rows; ++i) ps[i + 1] = ps[i] + row_work[i];
+    int64_t total = ps[rows];
+    int64_t avg = (total + parts - 1) / parts;
+    offsets[0] = 0;
+    for (int32_t t = 0; t < parts; ++t) {
+        int64_t target = avg * (t + 1);
+        /* std::lower_bound over ps[0..rows] */
+        int64_t lo = 0, hi = (int64_t)rows + 1;
+        while (lo < hi) {
+            int64_t mid = lo + (hi - lo) / 2;
+            if (ps[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        offsets[t + 1] = (int32_t)lo;
+    }
+    offsets[parts] = rows; /* BIN.h:120 */
+    free(ps);
+}
+
+/* Symbolic phase: per output row, insert every B column reached into an open-addressing table
+ * (hash = (key·107) & (size−1), linear probing, empty = −1) and count distinct keys; then the exclusive scan gives
+ * crpt — hash_symbolic_kernel, mm/inc/hash_mult.h:65-109; hash_symbolic, :496-508; HASH_SCAL, define.h:12.
+ * Returns nnz(C) as int64, or −1 if it does not fit the reference's int32 crpt. crpt has M+1 entries. */
+ORACLE_API int64_t oracle_spgemm_symbolic(int32_t M, int32_t N, const int32_t *arpt, const int32_t *acol,
+                                          const int32_t *brpt, const int32_t *bcol, int32_t *crpt)
+{
+    int64_t *row_flop = (int64_t *)malloc(sizeof(int64_t) * (size_t)(M > 0 ? M : 1));
+    int8_t *bin = (int8_t *)malloc((size_t)(M > 0 ? M : 1));
+    int32_t *row_nz = (int32_t *)malloc(sizeof(int32_t) * ((size_t)M + 1));
+    oracle_spgemm_flop(M, arpt, acol, brpt, row_flop);
+    oracle_bin_id(M, N, row_flop, bin);
+    int64_t max_ht = 8;
+    for (int32_t i = 0; i < M; ++i)
+        if (bin[i] > 0 && ((int64_t)8 << (bin[i] - 1)) > max_ht) max_ht = (int64_t)8 << (bin[i] - 1);
+    int32_t *check = (int32_t *)malloc(sizeof(int32_t) * (size_t)max_ht);
+    int64_t total = 0;
+    for (int32_t i = 0; i < M; ++i) {
+        int32_t nz = 0;
+        int bid = bin[i];
+        if (bid > 0) {
+            int64_t ht = (int64_t)8 << (bid - 1);
+            for (int64_t j = 0; j < ht; ++j) check[j] = -1;
+            for (int32_t j = arpt[i]; j < arpt[i + 1]; ++j) {
+                int32_t t = acol[j];
+                for (int32_t k = brpt[t]; k < brpt[t + 1]; ++k) {
+                    int32_t key = bcol[k];
+                    int64_t h = ((int64_t)(int32_t)((uint32_t)key * 107u)) & (ht - 1); /* IT arithmetic wraps as int32 */
+                    for (;;) {
+                        if (check[h] == key) break;
+                        if (check[h] == -1) { check[h] = key; nz++; break; }
+                        h = (h + 1) & (ht - 1);
+                    }
+                }
+            }
+        }
+        row_nz[i] = nz;
+        total += nz;
+    }
+    row_nz[M] = 0;
+    if (total <= INT32_MAX) oracle_scan_i32(row_nz, crpt, M + 1);
+    free(check); free(row_nz); free(bin); free(row_flop);
+    return total <= INT32_MAX ? total : -1;
+}
+
+static int cmp_pair_col(const void *a, const void *b)
+{
+    int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+    return (x > y) - (x < y);
+}
+
+/* Numeric phase: same traversal, t = a·b, hit → value = t + value, miss → insert; then compact the table and,
+ * when sort_output, sort the row by column — hash_numeric, mm/inc/hash_mult.h:559-608;
+ * sort_and_store_table2mat, :526-553. Accumulation order per C(i,c) is (j outer, k inner), multiply then add. */
+ORACLE_API void oracle_spgemm_numeric(int32_t M, int32_t N, const int32_t *arpt, const int32_t *acol, const double *aval,
+                                      const int32_t *brpt, const int32_t *bcol, const double *bval,
+                                      const int32_t *crpt, int32_t *ccol, double *cval, int sort_output)
+{
+    int64_t *row_flop = (int64_t *)malloc(sizeof(int64_t) * (size_t)(M > 0 ? M : 1));
+    int8_t *bin = (int8_t *)malloc((size_t)(M > 0 ? M : 1));
+    oracle_spgemm_flop(M, arpt, acol, brpt, row_flop);
+    oracle_bin_id(M, N, row_flop, bin);
+    int64_t max_ht = 8;
+    for (int32_t i = 0; i < M; ++i)
+        if (bin[i] > 0 && ((int64_t)8 << (bin[i] - 1)) > max_ht) max_ht = (int64_t)8 << (bin[i] - 1);
+    int32_t *check = (int32_t *)malloc(sizeof(int32_t) * (size_t)max_ht);
+    double *value = (double *)malloc(sizeof(double) * (size_t)max_ht);
+    struct pr { int32_t c; int32_t pad; double v; } *pv = (struct pr *)malloc(sizeof(struct pr) * (size_t)max_ht);
+    for (int32_t i = 0; i < M; ++i) {
+        int bid = bin[i];
+        if (bid <= 0) continue;
+        int64_t ht = (int64_t)8 << (bid - 1);
+        int32_t off = crpt[i];
+        for (int64_t j = 0; j < ht; ++j) check[j] = -1;
+        for (int32_t j = arpt[i]; j < arpt[i + 1]; ++j) {
+            int32_t t = acol[j];
+            double av = aval[j];
+            for (int32_t k = brpt[t]; k < brpt[t + 1]; ++k) {
+                double tv = av * bval[k];
+                int32_t key = bcol[k];
+                int64_t h = ((int64_t)(int32_t)((uint32_t)key * 107u)) & (ht - 1);
+                for (;;) {
+                    if (check[h] == key) { value[h] = tv + value[h]; break; }
+                    if (check[h] == -1) { check[h] = key; value[h] = tv; break; }
+                    h = (h + 1) & (ht - 1);
+                }
+            }
+        }
+        int32_t idx = 0;
+        for (int64_t j = 0; j < ht; ++j)
+            if (check[j] != -1) { pv[idx].c = check[j]; pv[idx].pad = 0; pv[idx].v = value[j]; idx++; }
+        if (sort_output) qsort(pv, (size_t)idx, sizeof(struct pr), cmp_pair_col); /* keys are distinct: any sort gives one order */
+        for (int32_t j = 0; j < idx; ++j) { ccol[off + j] = pv[j].c; cval[off + j] = pv[j].v; }
+    }
+    free(pv); free(value); free(check); free(bin); free(row_flop);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * MatrixMarket coordinate reader with the semantics of CSR<IT,NT>::construct, mm/inc/CSR.h:485-669
+ * (banner rules :441-478): matrix/coordinate only; real|integer|pattern|complex (real part kept :544-554,
+ * pattern → 1.0 :532); 1-based → 0-based :565-568; symmetric / skew-symmetric mirror of off-diagonals
+ * :571-623 (hermitian rejected :477); sort by the fused key cols·I+J :640-651; counting row pointer :654-661.
+ * Duplicates are kept (not merged). Two-call protocol: pass NULL arrays to get sizes, then call again.
+ * Returns 0 or a negative error. */
+static int next_line(FILE *f, char *buf, size_t n) { return fgets(buf, (int)n, f) != NULL; }
+
+struct coo { int64_t key; double v; int64_t seq; };
+static int cmp_coo(const void *a, const void *b)
+{
+    const struct coo *x = (const struct coo *)a, *y = (const struct coo *)b;
+    if (x->key != y->key) return (x->key > y->key) - (x->key < y->key);
+    return (x->seq > y->seq) - (x->seq < y->seq); /* stable among duplicates (std::sort leaves it unspecified) */
+}
+
+ORACLE_API int oracle_mtx_read(const char *path, int32_t *rows_out, int32_t *cols_out, int64_t *nnz_out,
+                               int32_t *rowptr, int32_t *colids, double *values)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    char line[4096];
+    if (!next_line(f, line, sizeof line)) { fclose(f); return -2; }
+    char t0[64], t1[64], t2[64], t3[64], t4[64], t5[64];
+    int nt = sscanf(line, "%63s %63s %63s %63s %63s %63s", t0, t1, t2, t3, t4, t5);
+    if (nt != 5 || strcmp(t0, "%%MatrixMarket") != 0 || strcmp(t1, "matrix") != 0) { fclose(f); return -3; }
+    if (strcmp(t2, "coordinate") != 0) { fclose(f); return -4; }
+    int is_pattern = !strcmp(t3, "pattern"), is_complex = !strcmp(t3, "complex");
+    if (!is_pattern && !is_complex && strcmp(t3, "real") && strcmp(t3, "integer")) { fclose(f); return -5; }
+    int sym = 0;
+    if (!strcmp(t4, "general")) sym = 0;
+    else if (!strcmp(t4, "symmetric")) sym = 1;
+    else if (!strcmp(t4, "skew-symmetric")) sym = 2;
+    else { fclose(f); return -6; } /* hermitian: not implemented in the reference either */
+    do { if (!next_line(f, line, sizeof line)) { fclose(f); return -7; } } while (line[0] == '%');
+    long long r, c, n;
+    if (sscanf(line, "%lld %lld %lld", &r, &c, &n) != 3) { fclose(f); return -8; }
+    struct coo *e = (struct coo *)malloc(sizeof(struct coo) * (size_t)(2 * n + 1));
+    int64_t cnt = 0;
+    for (long long k = 0; k < n; ++k) {
+        long long i, j; double v = 1.0, im;
+        if (fscanf(f, "%lld %lld", &i, &j) != 2) { free(e); fclose(f); return -9; }
+        if (is_complex) { if (fscanf(f, "%lf %lf", &v, &im) != 2) { free(e); fclose(f); return -9; } }
+        else if (!is_pattern) { if (fscanf(f, "%lf", &v) != 1) { free(e); fclose(f); return -9; } }
+        i -= 1; j -= 1;
+        e[cnt].key = (int64_t)c * i + j; e[cnt].v = v; e[cnt].seq = cnt; cnt++;
+        if (sym && i != j) { e[cnt].key = (int64_t)c * j + i; e[cnt].v = (sym == 2) ? -v : v; e[cnt].seq = cnt; cnt++; }
+    }
+    fclose(f);
+    *rows_out = (int32_t)r; *cols_out = (int32_t)c; *nnz_out = cnt;
+    if (rowptr && colids && values) {
+        qsort(e, (size_t)cnt, sizeof(struct coo), cmp_coo);
+        memset(rowptr, 0, sizeof(int32_t) * ((size_t)r + 1));
+        for (int64_t k = 0; k < cnt; ++k) {
+            int64_t I = e[k].key / c, J = e[k].key % c;
+            rowptr[I + 1]++;
+            colids[k] = (int32_t)J; values[k] = e[k].v;
+        }
+        for (long long i = 1; i <= r; ++i) rowptr[i] += rowptr[i - 1];
+    }
+    free(e);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Graph gather/apply driver: for vi in [0,numNodes): for nb in [0,degree): gather(vi,nb,…); apply(vi,…)
+ * — GraphProcess, deepmd/source/op/graph.h:21-32, and the contract of spmm_dense inferred from its call
+ * site citcoms/lib/Element_calculations.c:500 (the symbol itself is defined nowhere in the reference).
+ * Sequential vertex order (the reference's threadNum=1 case; CitcomS's gather is only race-free there). */
+typedef void (*fun_gather)(int, int, const double **, const double *, double *); /* global_defs.h:48 */
+typedef void (*fun_apply)(int, const double **, const double *, double *);       /* global_defs.h:49 */
+
+ORACLE_API void oracle_spmm_dense(uint32_t numNodes, uint32_t degree, const double **edgeWeight,
+                                  const double *vertexStates, double *temp, double *result,
+                                  fun_gather gather, fun_apply apply, double *time, int threadNum)
+{
+    (void)temp; (void)threadNum;
+    for (uint32_t vi = 0; vi < numNodes; ++vi) {
+        for (uint32_t nb = 0; nb < degree; ++nb) gather((int)vi, (int)nb, edgeWeight, vertexStates, result);
+        apply((int)vi, edgeWeight, vertexStates, result);
+    }
+    if (time) *time = 0.0;
+}
+
+/* CitcomS element-by-element stiffness mat-vec, the arithmetic of gather(), Element_calculations.c:453-471, with the
+ * process globals (tempE->IEN, ->ID) made explicit and 0-based: for element e, local node a, dof i:
+ *   Au[id[ien[e][a]][i]] += Σ_b ( K_e[ii]·u[id[nb][0]] + K_e[ii+1]·u[id[nb][1]] + K_e[ii+2]·u[id[nb][2]] ),
+ *   ii = (dof·a + i)·n + dof·b, n = npe·dof  (index algebra of :463).
+ * The three products of one b are summed first, then added to Au, exactly as the source expression does.
+ * elt_k[e] is a row pointer (edgeWeight), base = 1 reproduces CitcomS's unused slot 0 (Drive_solvers.c:52-55). */
+ORACLE_API void oracle_element_matvec(int32_t nel, int32_t npe, int32_t dof, const int32_t *ien, const int32_t *id,
+                                      const double **elt_k, int32_t base, const double *u, double *Au, int32_t neq)
+{
+    const int32_t n = npe * dof;
+    for (int32_t i = 0; i < neq; ++i) Au[i] = 0.0; /* Element_calculations.c:495-496 */
+    for (int32_t e = 0; e < nel; ++e) {
+        const double *K = elt_k[e + base];
+        for (int32_t a = 0; a < npe; ++a) {
+            int32_t node = ien[e * npe + a];
+            for (int32_t i = 0; i < dof; ++i) {
+                int32_t aa = id[node * dof + i];
+                for (int32_t b = 0; b < npe; ++b) {
+                    int32_t ii = (dof * a + i) * n + dof * b;
+                    int32_t nb = ien[e * npe + b];
+                    double t = 0.0;
+                    /* source: K[ii]*u0 + K[ii+1]*u1 + K[ii+2]*u2 evaluated left to right */
+                    for (int32_t d = 0; d < dof; ++d) {
+                        double p = K[ii + d] * u[id[nb * dof + d]];
+                        t = (d == 0) ? p : t + p;
+                    }
+                    Au[aa] = Au[aa] + t;
+                }
+            }
+        }
+    }
+}
+
+/* DeePMD OptMatmul gather: result[e·K + a] = Σ_k xx[e][k]·w[k·K + a], accumulated from 0 in k order
+ * — the lambda at deepmd/source/op/opt_matmul.cc:52-58 (apply is empty :59-61). xx rows via row pointers. */
+ORACLE_API void oracle_dense_rows_times_matrix(int32_t M, int32_t N, int32_t K, const double **xx_rows, const double *w,
+                                               double *result)
+{
+    for (int32_t e = 0; e < M; ++e)
+        for (int32_t a = 0; a < K; ++a) {
+            double s = 0.0;
+            for (int32_t k = 0; k < N; ++k) { double p = xx_rows[e][k] * w[k * K + a]; s = s + p; }
+            result[e * K + a] = s;
+        }
+}
+
+/* Cantera mixing rule: strictly-lower-triangle gather plus diagonal apply
+ * — gather1/apply1/GraphProcess1 and gather2/apply2/GraphProcess2, cantera/src/thermo/RedlichKwongMFTP.cpp:927-983,
+ * single rank (myid=0, numprocs=1), sequential. numbers==1 → form 1 (result[1] += x_i·b_i), else form 2. */
+ORACLE_API void oracle_sym_quadratic_form(int32_t m, int32_t numbers, const double *a, const double *x, const double *b,
+                                          double *result)
+{
+    for (int32_t i = 0; i < m; ++i) {
+        for (int32_t j = 0; j < i; ++j) {
+            size_t c1 = (size_t)i + (size_t)m * j, c2 = (size_t)j + (size_t)m * i;
+            double tmp = x[i] * x[j];
+            if (numbers == 1) {
+                result[0] += tmp * (a[c1] + a[c2]);
+            } else {
+                result[0] += tmp * (a[numbers * c1] + a[numbers * c2]);
+                result[1] += tmp * (a[numbers * c1 + 1] + a[numbers * c2 + 1]);
+            }
+        }
+        size_t c = (size_t)i + (size_t)m * i;
+        double tmp = x[i] * x[i];
+        if (numbers == 1) {
+            result[0] += tmp * a[c];
+            result[1] += x[i] * b[i];
+        } else {
+            result[0] += tmp * a[numbers * c];
+            result[1] += tmp * a[numbers * c + 1];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Synthetic inputs (the build's own definitions; no reference counterpart — the reference reads
+ * .mtx files that are not shipped). Counter-based so that the device generator reproduces them bit for bit.
+ *
+ * mix64 = SplitMix64 finaliser. R-MAT edge e of stream `seed`: for attempt t = 0,1,…: draw `scale` quadrant
+ * choices from successive mix64 words (16 bits each, 4 per word) with (a,b,c,d) = (0.57,0.19,0.19,0.05); accept the
+ * first attempt with row < n and col < n. Value of entry (i,j) depends only on (seed, i, j): U(−1,1). */
+static inline uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+ORACLE_API uint64_t oracle_mix64(uint64_t z) { return mix64(z); }
+
+ORACLE_API double oracle_entry_value(uint64_t seed, int64_t i, int64_t j, int64_t n)
+{
+    uint64_t h = mix64(seed ^ mix64((uint64_t)(i * n + j) + 0x5851F42D4C957F2Dull));
+    return (double)(h >> 11) * (2.0 / 9007199254740992.0) - 1.0; /* 53 bits → [−1,1) */
+}
+
+ORACLE_API double oracle_vector_value(uint64_t seed, int64_t i)
+{
+    uint64_t h = mix64(seed + 0xD1B54A32D192ED03ull * (uint64_t)(i + 1));
+    return (double)(h >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+}
+
+/* keys[e] = row·n + col for e in [e0, e0+count) */
+ORACLE_API void oracle_rmat_edges(uint64_t seed, int32_t scale, int64_t n, int64_t e0, int64_t count, int64_t *keys)
+{
+    /* thresholds on a 16-bit draw: a=0.57, a+b=0.76, a+b+c=0.95 */
+    const uint32_t TA = 37356u, TB = 49807u, TC = 62259u;
+    for (int64_t q = 0; q < count; ++q) {
+        uint64_t e = (uint64_t)(e0 + q);
+        for (uint64_t attempt = 0;; ++attempt) {
+            uint64_t base = mix64(seed ^ (e * 0x9E3779B97F4A7C15ull)) + attempt * 0xC2B2AE3D27D4EB4Full;
+            int64_t row = 0, col = 0;
+            uint64_t w = 0;
+            for (int32_t lvl = 0; lvl < scale; ++lvl) {
+                if ((lvl & 3) == 0) w = mix64(base + (uint64_t)(lvl >> 2));
+                uint32_t r16 = (uint32_t)(w & 0xFFFFu);
+                w >>= 16;
+                int rb, cb;
+                if (r16 < TA) { rb = 0; cb = 0; }
+                else if (r16 < TB) { rb = 0; cb = 1; }
+                else if (r16 < TC) { rb = 1; cb = 0; }
+                else { rb = 1; cb = 1; }
+                row = (row << 1) | rb;
+                col = (col << 1) | cb;
+            }
+            if (row < n && col < n) { keys[q] = row * n + col; break; }
+        }
+    }
+}
+
+/* 5-point Laplacian on an nx×ny grid, natural row-major order, diag 4, off −1, Dirichlet;
+ * columns ascending within a row. Returns nnz; arrays may be NULL to query. */
+ORACLE_API int64_t oracle_laplacian5(int32_t nx, int32_t ny, int32_t *rowptr, int32_t *colids, double *values)
+{
+    int64_t k = 0;
+    for (int32_t j = 0; j < ny; ++j)
+        for (int32_t i = 0; i < nx; ++i) {
+            int64_t r = (int64_t)j * nx + i;
+            if (rowptr) rowptr[r] = (int32_t)k;
+#define EMIT(cc, vv) do { if (colids) { colids[k] = (int32_t)(cc); values[k] = (vv); } k++; } while (0)
+            if (j > 0) EMIT(r - nx, -1.0);
+            if (i > 0) EMIT(r - 1, -1.0);
+            EMIT(r, 4.0);
+            if (i < nx - 1) EMIT(r + 1, -1.0);
+            if (j < ny - 1) EMIT(r + nx, -1.0);
+        }
+    if (rowptr) rowptr[(int64_t)nx * ny] = (int32_t)k;
+    return k;
+}
+
+/* 7-point Laplacian on nx×ny×nz, diag 6, off −1, rows [r0, r1) only (slab), global columns. */
+ORACLE_API int64_t oracle_laplacian7_rows(int32_t nx, int32_t ny, int32_t nz, int64_t r0, int64_t r1,
+                                          int32_t *rowptr, int32_t *colids, double *values)
+{
+    int64_t k = 0;
+    const int64_t pl = (int64_t)nx * ny;
+    for (int64_t r = r0; r < r1; ++r) {
+        int32_t z = (int32_t)(r / pl), y = (int32_t)((r % pl) / nx), x = (int32_t)(r % nx);
+        if (rowptr) rowptr[r - r0] = (int32_t)k;
+        if (z > 0) EMIT(r - pl, -1.0);
+        if (y > 0) EMIT(r - nx, -1.0);
+        if (x > 0) EMIT(r - 1, -1.0);
+        EMIT(r, 6.0);
+        if (x < nx - 1) EMIT(r + 1, -1.0);
+        if (y < ny - 1) EMIT(r + nx, -1.0);
+        if (z < nz - 1) EMIT(r + pl, -1.0);
+    }
+#undef EMIT
+    if (rowptr) rowptr[r1 - r0] = (int32_t)k;
+    (void)nz;
+    return k;
+}
+
+/* Banded matrix: row i holds columns max(0,i−hb) … min(n−1,i+hb), values from oracle_entry_value. */
+ORACLE_API int64_t oracle_banded(int32_t n, int32_t hb, uint64_t seed, int32_t *rowptr, int32_t *colids, double *values)
+{
+    int64_t k = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        if (rowptr) rowptr[i] = (int32_t)k;
+        int32_t lo = i - hb < 0 ? 0 : i - hb, hi = i + hb > n - 1 ? n - 1 : i + hb;
+        for (int32_t c = lo; c <= hi; ++c) {
+            if (colids) { colids[k] = c; values[k] = oracle_entry_value(seed, i, c, n); }
+            k++;
+        }
+    }
+    if (rowptr) rowptr[n] = (int32_t)k;
+    return k;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-threaded SpMV used ONLY as bench.py's reported cpu_baseline ("port"): rows split by equal nnz with the
+ * rule of BIN::set_rows_offset (BIN.h:101-122), one OpenMP thread per range, same per-row arithmetic as oracle_spmv_csr. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+ORACLE_API int oracle_spmv_csr_mt(int32_t rows, const int32_t *rowptr, const int32_t *colids, const double *values,
+                                  const double *x, double *y, double alpha, double beta, int threads)
+{
+#ifdef _OPENMP
+    if (threads < 1) threads = 1;
+    int64_t *work = (int64_t *)malloc(sizeof(int64_t) * (size_t)(rows > 0 ? rows : 1));
+    int32_t *off = (int32_t *)malloc(sizeof(int32_t) * ((size_t)threads + 1));
+    for (int32_t i = 0; i < rows; ++i) work[i] = rowptr[i + 1] - rowptr[i] + 1;
+    oracle_rows_offset(rows, work, threads, off);
+#pragma omp parallel num_threads(threads)
+    {
+        int t = omp_get_thread_num();
+        int32_t r0 = off[t], r1 = off[t + 1];
+        oracle_spmv_csr(r1 - r0, rowptr + r0, colids, values, x, y + r0, alpha, beta);
+    }
+    free(off); free(work);
+    return threads;
+#else
+    oracle_spmv_csr(rows, rowptr, colids, values, x, y, alpha, beta);
+    (void)threads;
+    return 1;
+#endif
+}

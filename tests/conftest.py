@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from tests import oracle_lib
+    return oracle_lib.load()
+
+
+@pytest.fixture(scope="session")
+def g4s():
+    """The product library through ctypes. GPU tests fail loudly if it is missing (no fallback)."""
+    from g4s_amd import capi
+    return capi.load()

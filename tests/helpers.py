@@ -1,0 +1,58 @@
+"""Shared input builders for the tests (numpy/scipy only)."""
+import numpy as np
+import scipy.sparse as sp
+
+
+def random_csr(rows, cols, density, seed, empty_rows=(), dense_rows=()):
+    rng = np.random.default_rng(seed)
+    m = sp.random(rows, cols, density=density, format="lil", random_state=rng, data_rvs=lambda k: rng.uniform(-1, 1, k))
+    for r in empty_rows:
+        m.rows[r] = []
+        m.data[r] = []
+    for r in dense_rows:
+        m[r, :] = rng.uniform(-1, 1, cols)
+    m = m.tocsr()
+    m.sort_indices()
+    return m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.astype(np.float64)
+
+
+def to_scipy(rowptr, colids, values, rows, cols):
+    return sp.csr_matrix((values, colids, rowptr), shape=(rows, cols))
+
+
+def power_law_csr(rows, cols, seed, max_len):
+    """Row lengths ~ Zipf, clipped: mixes empty rows, short rows and a few hubs."""
+    rng = np.random.default_rng(seed)
+    lens = np.minimum(rng.zipf(1.6, rows) - 1, max_len).astype(np.int64)
+    lens = np.minimum(lens, cols)
+    rowptr = np.zeros(rows + 1, np.int64)
+    rowptr[1:] = np.cumsum(lens)
+    colids = np.empty(rowptr[-1], np.int32)
+    for r in range(rows):
+        colids[rowptr[r]:rowptr[r + 1]] = np.sort(rng.choice(cols, lens[r], replace=False))
+    values = rng.uniform(-1, 1, rowptr[-1])
+    return rowptr.astype(np.int32), colids, values
+
+
+def hex_mesh(ex, ey, ez):
+    """Structured hexahedral mesh: returns (ien[nel,8], id[nno,3], nno, neq) with CitcomS's numbering rule
+    eqn = 3·node + d (citcoms/lib/Construct_arrays.c), 0-based."""
+    nx, ny, nz = ex + 1, ey + 1, ez + 1
+    nno = nx * ny * nz
+    node = lambda i, j, k: (k * ny + j) * nx + i
+    ien = []
+    for k in range(ez):
+        for j in range(ey):
+            for i in range(ex):
+                ien.append([node(i, j, k), node(i + 1, j, k), node(i + 1, j + 1, k), node(i, j + 1, k),
+                            node(i, j, k + 1), node(i + 1, j, k + 1), node(i + 1, j + 1, k + 1), node(i, j + 1, k + 1)])
+    ien = np.array(ien, np.int32)
+    idmap = (3 * np.arange(nno)[:, None] + np.arange(3)[None, :]).astype(np.int32)
+    return ien, idmap, nno, 3 * nno
+
+
+def spd_blocks(nel, n, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.uniform(-1, 1, (nel, n, n))
+    k = a @ a.transpose(0, 2, 1) + n * np.eye(n)[None]
+    return np.ascontiguousarray(k.reshape(nel, n * n))

@@ -1,0 +1,159 @@
+"""GPU parity: the HIP SpMV (through the C-ABI) against the oracle on the same inputs.
+
+Tolerance (fp64): |y_gpu − y_oracle|_i ≤ 1e-10 · Σ_k |a_ik x_k|  (north_star: 1e-10 relative). Rows reduced by one lane
+(blocks with > 128 rows) are summed in the oracle's order and must be BIT-identical.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import power_law_csr, random_csr
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _check(oracle, A, rp, ci, va, x, alpha=1.0, beta=0.0, y0=None, exact=False):
+    xd = torch.from_numpy(x).cuda()
+    yd = None if y0 is None else torch.from_numpy(y0.copy()).cuda()
+    y = A.spmv(xd, yd, alpha, beta).cpu().numpy()
+    want = oracle.spmv(rp, ci, va, x, y0, alpha, beta)
+    _, asum = oracle.spmv_ld(rp, ci, va, x)
+    scale = abs(alpha) * asum + (abs(beta) * np.abs(y0) if y0 is not None else 0.0)
+    err = np.abs(y - want)
+    assert np.all(err <= TOL * scale + 1e-300), f"max rel err {np.max(err / (scale + 1e-300))}"
+    if exact:
+        assert np.array_equal(y, want)
+    return y
+
+
+@pytest.mark.parametrize("rows,cols,density,seed", [(1, 1, 1.0, 0), (5, 7, 0.5, 1), (300, 300, 0.05, 2), (5000, 4000, 0.004, 3),
+                                                    (20000, 20000, 0.0005, 4)])
+def test_spmv_random(oracle, rows, cols, density, seed):
+    from g4s_amd import host
+    rp, ci, va = random_csr(rows, cols, density, seed, empty_rows=[0, rows // 2] if rows > 4 else [])
+    A = host.CSR.from_host(rp, ci, va, rows, cols)
+    x = np.random.default_rng(seed).uniform(-1, 1, cols)
+    _check(oracle, A, rp, ci, va, x)
+    _check(oracle, A, rp, ci, va, x, alpha=-2.5, beta=0.75, y0=np.random.default_rng(9).uniform(-1, 1, rows))
+
+
+def test_spmv_short_rows_bit_exact(oracle):
+    # ≥ 129 rows per block → one lane per row, oracle's left-to-right order → bit-identical
+    from g4s_amd import host
+    rp, ci, va = oracle.laplacian5(200, 150)
+    A = host.CSR.from_host(rp, ci, va, 30000, 30000)
+    x = np.random.default_rng(0).uniform(-1, 1, 30000)
+    _check(oracle, A, rp, ci, va, x, exact=True)
+    inf = A.info()
+    assert inf["long_rows"] == 0 and inf["stream_blocks"] >= 30000 * 5 // 2048
+
+
+def test_spmv_power_law_with_hubs(oracle):
+    # empty rows, short rows, medium rows (shuffle path) and hubs > TILE_NNZ / > LONG_CHUNK (chunked path)
+    from g4s_amd import host
+    rows = cols = 30000
+    rp, ci, va = power_law_csr(rows, cols, 17, 25000)
+    lens = np.diff(rp)
+    assert lens.max() > 8192 and (lens == 0).sum() > 100 and ((lens > 2048) & (lens <= 8192)).sum() >= 0
+    A = host.CSR.from_host(rp, ci, va, rows, cols)
+    inf = A.info()
+    assert inf["long_rows"] == int((lens > inf["tile_nnz"]).sum()) and inf["long_chunks"] >= inf["long_rows"]
+    x = np.random.default_rng(1).uniform(-1, 1, cols)
+    _check(oracle, A, rp, ci, va, x)
+    _check(oracle, A, rp, ci, va, x, alpha=0.5, beta=-1.0, y0=np.ones(rows))
+    # NT and plain-load variants agree bit for bit (same arithmetic, different cache policy)
+    B = host.CSR.from_host(rp, ci, va, rows, cols, spmv_flags=4)
+    xd = torch.from_numpy(x).cuda()
+    assert torch.equal(A.spmv(xd), B.spmv(xd))
+    # reproducible run to run (no atomics)
+    assert torch.equal(A.spmv(xd), A.spmv(xd))
+
+
+def test_spmv_edge_shapes(oracle):
+    from g4s_amd import host
+    # all rows empty
+    rp = np.zeros(11, np.int32)
+    A = host.CSR.from_host(rp, np.zeros(0, np.int32), np.zeros(0), 10, 10)
+    y0 = np.arange(10, dtype=np.float64)
+    y = A.spmv(torch.ones(10, dtype=torch.float64, device="cuda"), torch.from_numpy(y0.copy()).cuda(), 1.0, 2.0).cpu().numpy()
+    assert np.array_equal(y, 2.0 * y0)
+    yn = A.spmv(torch.ones(10, dtype=torch.float64, device="cuda"), torch.full((10,), float("nan"), dtype=torch.float64, device="cuda"))
+    assert torch.all(yn == 0)                                   # beta == 0 never reads y
+    # one fully dense row among empties; a single row exactly TILE_NNZ and TILE_NNZ+1 long
+    for n in (2048, 2049, 8192, 8193):
+        rp = np.array([0, 0, n, n], np.int32)
+        ci = np.arange(n, dtype=np.int32)
+        va = np.random.default_rng(n).uniform(-1, 1, n)
+        A = host.CSR.from_host(rp, ci, va, 3, n)
+        _check(oracle, A, rp, ci, va, np.random.default_rng(1).uniform(-1, 1, n))
+    # exactly TILE_ROWS+1 single-entry rows (row cap boundary)
+    n = 1025
+    rp = np.arange(n + 1, dtype=np.int32)
+    A = host.CSR.from_host(rp, np.arange(n, dtype=np.int32)[::-1].copy(), np.ones(n), n, n)
+    x = np.arange(n, dtype=np.float64)
+    _check(oracle, A, rp, np.arange(n, dtype=np.int32)[::-1].copy(), np.ones(n), x, exact=True)
+
+
+def test_spmv_rejects_bad_input(g4s):
+    from g4s_amd import capi
+    h = C.c_void_p()
+    rp = np.array([0, 2, 1], np.int32)           # decreasing
+    ci = np.array([0, 1], np.int32)
+    va = np.ones(2)
+    st = g4s.g4s_csr_create(C.byref(h), 2, 2, 1, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, 0)
+    assert st == capi.ERR_INVALID
+    rp = np.array([0, 1, 2], np.int32)
+    ci = np.array([0, 5], np.int32)              # column out of range: must be refused, not gathered
+    st = g4s.g4s_csr_create(C.byref(h), 2, 2, 2, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, 0)
+    assert st == capi.ERR_INVALID and b"column" in g4s.g4s_last_error()
+
+
+def test_spmv_one_shot_host_pointers(oracle, g4s):
+    # the mv.c-shaped call: caller-owned host arrays in and out, synchronous
+    from g4s_amd import capi
+    rp, ci, va = random_csr(400, 300, 0.03, 12)
+    x = np.random.default_rng(2).uniform(-1, 1, 300)
+    y = np.zeros(400)
+    capi.check(g4s.g4s_spmv_csr_i32_f64(400, 300, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, x.ctypes.data, y.ctypes.data, 1.0, 0.0, 0))
+    want = oracle.spmv(rp, ci, va, x)
+    _, asum = oracle.spmv_ld(rp, ci, va, x)
+    assert np.all(np.abs(y - want) <= TOL * asum + 1e-300)
+
+
+def test_spmv_golden_fixture():
+    import os
+    from g4s_amd import host
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "spgemm_rmat8.npz"))
+    n = int(g["n"])
+    A = host.CSR.from_host(g["arpt"], g["acol"], g["aval"], n, n)
+    y = A.spmv(torch.from_numpy(g["x"]).cuda()).cpu().numpy()
+    assert np.allclose(y, g["y"], rtol=0, atol=1e-10 * np.abs(g["y"]).max())
+
+
+def test_spmv_full_size_properties():
+    """BASELINE config 2 scale (10M×10M R-MAT, ≈1e8 nnz): size-independent properties instead of the oracle —
+    linearity A(ax+bz) = aAx + bAz, row-sum identity A·1 = Σ_k values (segment sums), reproducibility."""
+    from g4s_amd import host
+    n = 10_000_000
+    A = host.rmat_csr(n, 24, 100_000_000, 20240521)
+    assert 0.9e8 < A.nnz <= 1.0e8
+    x = host.synth_vector(7, n)
+    z = host.synth_vector(8, n)
+    yx, yz = A.spmv(x), A.spmv(z)
+    ycomb = A.spmv(2.0 * x - 0.5 * z)
+    # scale for the tolerance: |A|·(|2x| + |0.5z|)
+    Aabs = host.CSR(A.rowptr, A.colids, A.values.abs(), n, n)
+    scale = Aabs.spmv(2.0 * x.abs() + 0.5 * z.abs())
+    assert torch.all((ycomb - (2.0 * yx - 0.5 * yz)).abs() <= 1e-10 * scale + 1e-300)
+    ones = torch.ones(n, dtype=torch.float64, device="cuda")
+    rowsum = torch.zeros(n, dtype=torch.float64, device="cuda")
+    rows = torch.repeat_interleave(torch.arange(n, device="cuda"), (A.rowptr[1:] - A.rowptr[:-1]).long())
+    rowsum.index_add_(0, rows, A.values)
+    abs_rowsum = Aabs.spmv(ones)
+    assert torch.all((A.spmv(ones) - rowsum).abs() <= 1e-10 * abs_rowsum + 1e-300)
+    assert torch.equal(A.spmv(x), yx)
+    inf = A.info()
+    assert inf["algorithmic_bytes"] == 12 * A.nnz + 4 * (n + 1) + 16 * n
