@@ -46,6 +46,19 @@ def build_matrix(name, host, small):
     raise SystemExit(f"unknown workload {name}")
 
 
+def host_threads():
+    """Threads for the CPU baseline: the affinity mask, clipped by the cgroup CPU quota and by the GPU box's CPU share
+    (16 cores per GPU slot; oversubscribing the 256 visible cores measured SLOWER than 16 threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("G4S_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(A, x, budget_s=12.0):
     """The oracle's SpMV (oracle/g4s_oracle.c, 'port') timed on this box's host cores on the same matrix. Reported, not a target."""
     import numpy as np
@@ -54,7 +67,7 @@ def cpu_baseline(A, x, budget_s=12.0):
     rp, ci, va = A.to_host()
     xh = x.cpu().numpy()
     y = np.zeros(A.rows)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_threads()
     out = {}
     for threads in (1, cores):
         o.spmv_mt(rp, ci, va, xh, y, threads)          # warm-up pass (page-in)

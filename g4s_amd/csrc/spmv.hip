@@ -92,27 +92,22 @@ __global__ __launch_bounds__(WG) void spmv_csr_adaptive_kernel(
 
     for (int r = tid; r <= nrows; r += WG) rp[r] = rowptr[r0 + r];
 
-    int cidx[UNROLL];
-    double val[UNROLL];
+    if (nnzb > 0) {
+        // Branch-free: lanes past the block's last nonzero re-read it (a broadcast, never used) so that all UNROLL
+        // index/value loads, then all UNROLL gathers, are in flight together instead of one wait per predicated load.
+        const int last = nnzb - 1;
+        int cidx[UNROLL];
+        double val[UNROLL];
 #pragma unroll
-    for (int i = 0; i < UNROLL; ++i) {
-        const int j = i * WG + tid;
-        cidx[i] = 0;
-        val[i] = 0.0;
-        if (j < nnzb) {
+        for (int i = 0; i < UNROLL; ++i) {
+            const int j = min(i * WG + tid, last);
             cidx[i] = stream_load<NT>(colids + k0 + j);
             val[i] = stream_load<NT>(values + k0 + j);
         }
-    }
 #pragma unroll
-    for (int i = 0; i < UNROLL; ++i) {
-        const int j = i * WG + tid;
-        if (j < nnzb) val[i] = val[i] * x[cidx[i]];
-    }
+        for (int i = 0; i < UNROLL; ++i) val[i] = val[i] * x[cidx[i]];
 #pragma unroll
-    for (int i = 0; i < UNROLL; ++i) {
-        const int j = i * WG + tid;
-        if (j < nnzb) prod[j] = val[i];
+        for (int i = 0; i < UNROLL; ++i) prod[i * WG + tid] = val[i];   // slots >= nnzb are written but never read
     }
     __syncthreads();
 
