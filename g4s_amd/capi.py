@@ -35,9 +35,9 @@ class Timings(C.Structure):
 
 
 class PatternDesc(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("nodes_per_elem", C.c_int32), ("dof", C.c_int32),
+    _fields_ = [("kind", C.c_int32), ("num_elems", C.c_int32), ("nodes_per_elem", C.c_int32), ("dof", C.c_int32),
                 ("ien", vp), ("id", vp), ("nno", C.c_int32), ("neq", C.c_int32), ("edge_weight_base", C.c_int32),
-                ("inner", C.c_int32), ("numbers", C.c_int32)]
+                ("static_weights", C.c_int32), ("inner", C.c_int32), ("numbers", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/*.h appears here (tests check the export list).

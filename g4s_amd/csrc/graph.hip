@@ -1,0 +1,459 @@
+// graph.hip — the vertex-centric gather/apply graph interface (B3 of include/g4s.h) on gfx950.
+//
+// Reference contract (deepmd/source/op/graph.h:21-32; citcoms/lib/global_defs.h:48-49,854-857):
+//     for vi in [0,numNodes): for nb in [0,degree): gather(vi, nb, …);  apply(vi, …)
+// with host callbacks. Host code cannot run on the GPU, so the three gather/apply pairs that exist in the reference are
+// recognised as PATTERNS (registered with g4s_register_pattern) and executed by hand-written kernels:
+//   ELEMENT_BLOCK_MATVEC    CitcomS gather(), citcoms/lib/Element_calculations.c:453-471 — element-by-element K·u with
+//                           scatter-add into shared equations. Done here node-centrically: each node owns the (element, local
+//                           node) terms that scatter into it (the transpose map the reference's stale CUDA built on the host,
+//                           citcoms/lib/cgrad_kernel.cu:89-180), so there are no atomics and the sum order is fixed.
+//                           HBM-bound (every 24×24 block is read exactly once): not an MFMA shape (one right-hand side).
+//   DENSE_ROW_TIMES_MATRIX  DeePMD OptMatmul lambda, deepmd/source/op/opt_matmul.cc:52-58 — a dense fp64 GEMM
+//                           result[M×K] = xx[M×N]·w[N×K]: the dense-tile case, on v_mfma_f64_16x16x4_f64.
+//   SYM_QUADRATIC_FORM      Cantera gather1/apply1, gather2/apply2, cantera/src/thermo/RedlichKwongMFTP.cpp:927-970.
+// An unregistered callback pair is refused (G4S_ERR_UNSUPPORTED): there is no host fallback in this library.
+#include "common.hpp"
+#include <map>
+#include <memory>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n)
+    {
+        if (p && n <= bytes) return G4S_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        hipError_t e = hipMalloc(&p, n ? n : 1);
+        if (e != hipSuccess) return g4s::set_error(e == hipErrorOutOfMemory ? G4S_ERR_NOMEM : G4S_ERR_HIP, "hipMalloc(%zu): %s", n, hipGetErrorString(e));
+        bytes = n;
+        return G4S_OK;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// ------------------------------------------------------------------------------------------------ element-block mat-vec
+// One wavefront per node. The node's terms (element e, local node a) — at most 8 on a hexahedral mesh — are taken 8 at a time,
+// 8 lanes per term: lane q of a term handles columns q, q+8, q+16, … of the element's n = npe·dof unknowns for the `dof` rows
+// (dof·a + i) of K_e. Partial sums are combined by shuffles inside the 8 lanes, then across terms in term order (fixed ⇒ the
+// result is reproducible). Rows of K_e for one node are contiguous (dof·n doubles), and consecutive nodes are handled by
+// consecutive waves.
+constexpr int kMaxDof = 4;
+
+__global__ __launch_bounds__(256) void elem_matvec_kernel(int nno, int npe, int dof, const int *__restrict__ node_ptr,
+                                                           const int *__restrict__ node_terms, const int *__restrict__ elem_eq,
+                                                           const int *__restrict__ node_eq, const double *__restrict__ elt_k,
+                                                           const double *__restrict__ u, double *__restrict__ Au, double beta)
+{
+    const int lane = threadIdx.x & 63;
+    const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (node >= nno) return;
+    const int n = npe * dof;
+    const int t0 = node_ptr[node], t1 = node_ptr[node + 1];
+    const int g = lane >> 3, q = lane & 7;
+    double tot[kMaxDof] = {0.0, 0.0, 0.0, 0.0};
+    for (int tb = t0; tb < t1; tb += 8) {
+        double acc[kMaxDof] = {0.0, 0.0, 0.0, 0.0};
+        const int t = tb + g;
+        if (t < t1) {
+            const int term = node_terms[t];          // e·npe + a
+            const int e = term / npe, a = term - e * npe;
+            const double *K = elt_k + (size_t)e * n * n + (size_t)(dof * a) * n;
+            const int *eq = elem_eq + (size_t)e * n;
+            for (int c = q; c < n; c += 8) {
+                const double uc = u[eq[c]];
+                for (int i = 0; i < dof; ++i) acc[i] += K[i * n + c] * uc;
+            }
+        }
+        for (int i = 0; i < dof; ++i) {
+            double v = acc[i];
+            v += __shfl_down(v, 4, 8);
+            v += __shfl_down(v, 2, 8);
+            v += __shfl_down(v, 1, 8);
+            // term sums now sit in lanes 0, 8, …, 56: add them in term order
+            for (int gg = 0; gg < 8; ++gg) tot[i] += __shfl(v, gg * 8, 64);
+        }
+    }
+    if (lane < dof) {
+        const int eqn = node_eq[node * dof + lane];
+        double r = tot[0];
+        if (lane == 1) r = tot[1];
+        if (lane == 2) r = tot[2];
+        if (lane == 3) r = tot[3];
+        Au[eqn] = beta == 0.0 ? r : r + beta * Au[eqn];
+    }
+}
+
+} // namespace
+
+struct g4s_elem_op_s {
+    int nel = 0, npe = 0, dof = 0, nno = 0, neq = 0;
+    DevBuf node_ptr, node_terms, elem_eq, node_eq;
+    const double *elt_k = nullptr;  // borrowed device pointer
+};
+
+G4S_API g4s_status g4s_elem_op_create(g4s_elem_op_t *out, int32_t numElems, int32_t npe, int32_t dof,
+                                      const int32_t *ien, const int32_t *id, int32_t nno, int32_t neq, const double *elt_k_dev)
+{
+    G4S_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    G4S_REQUIRE(numElems >= 0 && npe > 0 && dof > 0 && dof <= kMaxDof && nno >= 0 && neq >= 0, "bad sizes (dof <= 4)");
+    G4S_REQUIRE(ien && id, "ien/id is NULL");
+    G4S_REQUIRE((int64_t)numElems * npe * dof * npe * dof < ((int64_t)1 << 40), "element matrix array too large");
+    const int n = npe * dof;
+    // validate the index maps on the host: an out-of-range id would be a GPU fault, a duplicated equation a race
+    std::vector<char> seen((size_t)neq, 0);
+    for (int64_t k = 0; k < (int64_t)nno * dof; ++k) {
+        const int eqn = id[k];
+        if (eqn < 0 || eqn >= neq) return g4s::set_error(G4S_ERR_INVALID, "g4s_elem_op_create: id[%lld] = %d outside [0,%d)", (long long)k, eqn, neq);
+        if (seen[eqn]) return g4s::set_error(G4S_ERR_INVALID, "g4s_elem_op_create: equation %d is owned by two (node,dof) pairs", eqn);
+        seen[eqn] = 1;
+    }
+    std::vector<int> cnt((size_t)nno + 1, 0);
+    for (int64_t k = 0; k < (int64_t)numElems * npe; ++k) {
+        if (ien[k] < 0 || ien[k] >= nno) return g4s::set_error(G4S_ERR_INVALID, "g4s_elem_op_create: ien[%lld] = %d outside [0,%d)", (long long)k, ien[k], nno);
+        cnt[ien[k] + 1]++;
+    }
+    for (int i = 0; i < nno; ++i) cnt[i + 1] += cnt[i];
+    std::vector<int> terms((size_t)numElems * npe), cur(cnt.begin(), cnt.end() - 1), eeq((size_t)numElems * n);
+    for (int e = 0; e < numElems; ++e)
+        for (int a = 0; a < npe; ++a) {
+            const int node = ien[e * npe + a];
+            terms[cur[node]++] = e * npe + a;           // ascending e within a node: the order the reference visits elements in
+            for (int d = 0; d < dof; ++d) eeq[(size_t)e * n + a * dof + d] = id[node * dof + d];
+        }
+    auto op = std::make_unique<g4s_elem_op_s>();
+    op->nel = numElems; op->npe = npe; op->dof = dof; op->nno = nno; op->neq = neq; op->elt_k = elt_k_dev;
+    G4S_TRY(op->node_ptr.alloc(sizeof(int) * cnt.size()));
+    G4S_TRY(op->node_terms.alloc(sizeof(int) * terms.size()));
+    G4S_TRY(op->elem_eq.alloc(sizeof(int) * eeq.size()));
+    G4S_TRY(op->node_eq.alloc(sizeof(int) * (size_t)nno * dof));
+    G4S_HIP_TRY(hipMemcpy(op->node_ptr.p, cnt.data(), sizeof(int) * cnt.size(), hipMemcpyHostToDevice));
+    if (!terms.empty()) G4S_HIP_TRY(hipMemcpy(op->node_terms.p, terms.data(), sizeof(int) * terms.size(), hipMemcpyHostToDevice));
+    if (!eeq.empty()) G4S_HIP_TRY(hipMemcpy(op->elem_eq.p, eeq.data(), sizeof(int) * eeq.size(), hipMemcpyHostToDevice));
+    if (nno) G4S_HIP_TRY(hipMemcpy(op->node_eq.p, id, sizeof(int) * (size_t)nno * dof, hipMemcpyHostToDevice));
+    *out = op.release();
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_elem_op_destroy(g4s_elem_op_t op)
+{
+    delete op;
+    return G4S_OK;
+}
+
+static int elem_op_launch(g4s_elem_op_t op, const double *elt_k, const double *u, double *Au, double beta, hipStream_t s)
+{
+    // equations no node owns receive nothing: with beta == 0 they must read 0 (Element_calculations.c:495-496 zeroes Au first)
+    if (beta == 0.0 && op->neq) G4S_HIP_TRY(hipMemsetAsync(Au, 0, sizeof(double) * (size_t)op->neq, s));
+    if (op->nno) {
+        hipLaunchKernelGGL(elem_matvec_kernel, dim3((op->nno + 3) / 4), dim3(256), 0, s, op->nno, op->npe, op->dof, op->node_ptr.as<int>(),
+                           op->node_terms.as<int>(), op->elem_eq.as<int>(), op->node_eq.as<int>(), elt_k, u, Au, beta);
+        G4S_HIP_TRY(hipGetLastError());
+    }
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_elem_op_apply(g4s_elem_op_t op, const double *u_dev, double *Au_dev, void *stream)
+{
+    G4S_REQUIRE(op && u_dev && Au_dev, "NULL argument");
+    G4S_REQUIRE(op->elt_k || op->nel == 0, "no element matrices bound");
+    return elem_op_launch(op, op->elt_k, u_dev, Au_dev, 0.0, g4s::as_stream(stream));
+}
+
+// ------------------------------------------------------------------------------------------------ dense rows × matrix (fp64 MFMA)
+namespace {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+constexpr int kGemmKC = 64;    // rows of w staged per step
+constexpr int kGemmNC = 128;   // columns of w / result per workgroup pass (8 MFMA column tiles)
+
+// result[M×K] = xx[M×N]·w[N×K]. Workgroup = 4 waves = 64 rows of xx; wave = 16 rows × up to 128 columns (8 accumulator tiles
+// of v_mfma_f64_16x16x4_f64: A lane map row = lane&15, k = lane>>4; B k = lane>>4, col = lane&15; D col = lane&15,
+// row = (lane>>4) + 4·reg — cdna_hip_programming.md §3). w is staged through LDS in 64×128 panels (64 KiB); xx fragments are
+// read straight from global (each 16×N strip is private to one wave and stays in L1 across the k loop).
+__global__ __launch_bounds__(256) void dense_rows_times_matrix_kernel(int M, int N, int K, const double *__restrict__ xx,
+                                                                       const double *__restrict__ w, double *__restrict__ result)
+{
+    __shared__ double ws[kGemmKC * kGemmNC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.x * 64 + wave * 16;
+    const int arow = row0 + (lane & 15), kk = lane >> 4;
+    const bool arow_ok = arow < M;
+    for (int c0 = 0; c0 < K; c0 += kGemmNC) {
+        double4_t acc[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < N; k0 += kGemmKC) {
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < kGemmKC * kGemmNC; idx += 256) {
+                const int r = idx / kGemmNC, c = idx - r * kGemmNC;
+                ws[idx] = (k0 + r < N && c0 + c < K) ? w[(size_t)(k0 + r) * K + c0 + c] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int ks = 0; ks < kGemmKC; ks += 4) {
+                const int k = k0 + ks + kk;
+                const double a = (arow_ok && k < N) ? xx[(size_t)arow * N + k] : 0.0;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const double b = ws[(ks + kk) * kGemmNC + t * 16 + (lane & 15)];
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int col = c0 + t * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + (lane >> 4) + 4 * r;
+                if (row < M && col < K) result[(size_t)row * K + col] = acc[t][r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ symmetric quadratic form
+// result[0] += Σ_i Σ_{j<i} x_i x_j (a[num·(i+m·j)] + a[num·(j+m·i)]) + Σ_i x_i² a[num·(i+m·i)];  result[1]: see g4s.h.
+// One workgroup; thread t owns rows t, t+256, …; workgroup tree reduction in a fixed shape.
+__global__ __launch_bounds__(256) void sym_quadratic_form_kernel(int m, int numbers, const double *__restrict__ a, const double *__restrict__ x,
+                                                                  const double *__restrict__ b, double *__restrict__ out2)
+{
+    __shared__ double s0[256], s1[256];
+    double r0 = 0.0, r1 = 0.0;
+    for (int i = threadIdx.x; i < m; i += 256) {
+        for (int j = 0; j < i; ++j) {
+            const size_t c1 = (size_t)i + (size_t)m * j, c2 = (size_t)j + (size_t)m * i;
+            const double tmp = x[i] * x[j];
+            r0 += tmp * (a[numbers * c1] + a[numbers * c2]);
+            if (numbers > 1) r1 += tmp * (a[numbers * c1 + 1] + a[numbers * c2 + 1]);
+        }
+        const size_t c = (size_t)i + (size_t)m * i;
+        const double tmp = x[i] * x[i];
+        r0 += tmp * a[numbers * c];
+        if (numbers > 1) r1 += tmp * a[numbers * c + 1];
+        else if (b) r1 += x[i] * b[i];
+    }
+    s0[threadIdx.x] = r0; s1[threadIdx.x] = r1;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { s0[threadIdx.x] += s0[threadIdx.x + off]; s1[threadIdx.x] += s1[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out2[0] = s0[0]; out2[1] = s1[0]; }
+}
+
+} // namespace
+
+G4S_API g4s_status g4s_dense_rows_times_matrix(int32_t M, int32_t N, int32_t K, const double *xx_dev, const double *w_dev,
+                                               double *result_dev, void *stream)
+{
+    G4S_REQUIRE(M >= 0 && N >= 0 && K >= 0, "negative dimension");
+    if (M == 0 || K == 0) return G4S_OK;
+    G4S_REQUIRE(result_dev && (N == 0 || (xx_dev && w_dev)), "NULL argument");
+    hipLaunchKernelGGL(dense_rows_times_matrix_kernel, dim3((M + 63) / 64), dim3(256), 0, g4s::as_stream(stream), M, N, K, xx_dev, w_dev, result_dev);
+    G4S_HIP_TRY(hipGetLastError());
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_sym_quadratic_form(int32_t m, int32_t numbers, const double *a, const double *x, const double *b, double *result)
+{
+    G4S_REQUIRE(m >= 0 && numbers >= 1 && result, "bad argument");
+    if (m == 0) return G4S_OK;
+    G4S_REQUIRE(a && x, "NULL argument");
+    DevBuf da, dx, db, dout;
+    const size_t na = (size_t)m * m * numbers;
+    G4S_TRY(da.alloc(sizeof(double) * na));
+    G4S_TRY(dx.alloc(sizeof(double) * (size_t)m));
+    G4S_TRY(dout.alloc(sizeof(double) * 2));
+    G4S_HIP_TRY(hipMemcpy(da.p, a, sizeof(double) * na, hipMemcpyHostToDevice));
+    G4S_HIP_TRY(hipMemcpy(dx.p, x, sizeof(double) * (size_t)m, hipMemcpyHostToDevice));
+    if (b && numbers == 1) {
+        G4S_TRY(db.alloc(sizeof(double) * (size_t)m));
+        G4S_HIP_TRY(hipMemcpy(db.p, b, sizeof(double) * (size_t)m, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(sym_quadratic_form_kernel, dim3(1), dim3(256), 0, nullptr, m, numbers, da.as<double>(), dx.as<double>(),
+                       (b && numbers == 1) ? db.as<double>() : nullptr, dout.as<double>());
+    G4S_HIP_TRY(hipGetLastError());
+    double h[2] = {0.0, 0.0};
+    G4S_HIP_TRY(hipMemcpy(h, dout.p, sizeof(h), hipMemcpyDeviceToHost));
+    result[0] += h[0];      // the callbacks accumulate into result (RedlichKwongMFTP.cpp:930-931, 962-963)
+    result[1] += h[1];
+    return G4S_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ pattern registry + spmm_dense
+namespace {
+
+struct Pattern {
+    g4s_pattern_desc desc{};
+    std::vector<int32_t> ien, id;
+    // device-side state reused across calls
+    g4s_elem_op_t op = nullptr;
+    DevBuf elt_k, u, Au, xx, w, res;
+    double *stage = nullptr;                   // pinned host staging buffer for the row-pointer → contiguous pack
+    size_t stage_bytes = 0;
+    const double **cached_weights = nullptr;   // edgeWeight pointer whose contents elt_k currently holds (static_weights)
+    ~Pattern() { delete op; if (stage) (void)hipHostFree(stage); }
+    int stage_alloc(size_t bytes)
+    {
+        if (stage && bytes <= stage_bytes) return G4S_OK;
+        if (stage) { (void)hipHostFree(stage); stage = nullptr; stage_bytes = 0; }
+        if (hipHostMalloc((void **)&stage, bytes ? bytes : 1) != hipSuccess) return g4s::set_error(G4S_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
+        stage_bytes = bytes;
+        return G4S_OK;
+    }
+};
+
+std::mutex g_mu;
+std::map<std::pair<void *, void *>, std::unique_ptr<Pattern>> g_patterns;
+
+std::pair<void *, void *> key_of(fun_gather g, fun_apply a) { return {reinterpret_cast<void *>(g), reinterpret_cast<void *>(a)}; }
+
+} // namespace
+
+G4S_API g4s_status g4s_register_pattern(fun_gather gather, fun_apply apply, const g4s_pattern_desc *desc)
+{
+    G4S_REQUIRE(gather && desc, "NULL argument");
+    auto p = std::make_unique<Pattern>();
+    p->desc = *desc;
+    switch (desc->kind) {
+    case G4S_PATTERN_ELEMENT_BLOCK_MATVEC:
+        G4S_REQUIRE(desc->ien && desc->id && desc->num_elems >= 0 && desc->nodes_per_elem > 0 && desc->dof > 0 && desc->nno >= 0 && desc->neq >= 0,
+                    "incomplete ELEMENT_BLOCK_MATVEC descriptor");
+        G4S_REQUIRE(desc->edge_weight_base == 0 || desc->edge_weight_base == 1, "edge_weight_base must be 0 or 1");
+        p->id.assign(desc->id, desc->id + (size_t)desc->nno * desc->dof);
+        p->ien.assign(desc->ien, desc->ien + (size_t)desc->num_elems * desc->nodes_per_elem);
+        p->desc.id = nullptr;    // the copies above are what later calls use
+        p->desc.ien = nullptr;
+        break;
+    case G4S_PATTERN_DENSE_ROW_TIMES_MATRIX:
+        G4S_REQUIRE(desc->inner >= 0, "inner (N) must be >= 0");
+        break;
+    case G4S_PATTERN_SYM_QUADRATIC_FORM:
+        G4S_REQUIRE(desc->numbers >= 1, "numbers must be >= 1");
+        break;
+    default:
+        return g4s::set_error(G4S_ERR_INVALID, "g4s_register_pattern: unknown pattern kind %d", desc->kind);
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_patterns[key_of(gather, apply)] = std::move(p);
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_unregister_pattern(fun_gather gather, fun_apply apply)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_patterns.erase(key_of(gather, apply));
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_spmm_dense(uint32_t numNodes, uint32_t degree, const double **edgeWeight, const double *vertexStates,
+                                  double *temp, double *result, fun_gather gather, fun_apply apply, double *time, int threadNum)
+{
+    (void)threadNum; // CPU thread count of the reference; the device needs none
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_patterns.find(key_of(gather, apply));
+    if (it == g_patterns.end())
+        return g4s::set_error(G4S_ERR_UNSUPPORTED, "spmm_dense: this (gather, apply) pair is not registered with g4s_register_pattern; "
+                                                   "host callbacks cannot run on the GPU and this library has no CPU fallback");
+    Pattern &P = *it->second;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    G4S_HIP_TRY(hipEventCreate(&e0));
+    G4S_HIP_TRY(hipEventCreate(&e1));
+    int st = G4S_OK;
+    auto finish = [&](int code) {
+        if (code == G4S_OK && time) {
+            float ms = 0.f;
+            if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) *time = ms * 1e-3;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        return code;
+    };
+    switch (P.desc.kind) {
+    case G4S_PATTERN_ELEMENT_BLOCK_MATVEC: {
+        const int npe = P.desc.nodes_per_elem, dof = P.desc.dof, n = npe * dof, base = P.desc.edge_weight_base;
+        if (degree != (uint32_t)npe) return finish(g4s::set_error(G4S_ERR_INVALID, "spmm_dense: degree %u != nodes_per_elem %d", degree, npe));
+        if (numNodes != (uint32_t)P.desc.num_elems) return finish(g4s::set_error(G4S_ERR_INVALID, "spmm_dense: numNodes %u != registered num_elems %d", numNodes, P.desc.num_elems));
+        if (!edgeWeight || !vertexStates || !result) return finish(g4s::set_error(G4S_ERR_INVALID, "spmm_dense: NULL argument"));
+        const size_t kbytes = sizeof(double) * (size_t)numNodes * n * n;
+        if (!P.op || P.op->nel != (int)numNodes) {
+            delete P.op; P.op = nullptr; P.cached_weights = nullptr;
+            st = g4s_elem_op_create(&P.op, (int)numNodes, npe, dof, P.ien.data(), P.id.data(), P.desc.nno, P.desc.neq, nullptr);
+            if (st != G4S_OK) return finish(st);
+        }
+        if ((st = P.elt_k.alloc(kbytes)) != G4S_OK || (st = P.u.alloc(sizeof(double) * (size_t)P.desc.neq)) != G4S_OK ||
+            (st = P.Au.alloc(sizeof(double) * (size_t)P.desc.neq)) != G4S_OK)
+            return finish(st);
+        // element matrices arrive as an array of row pointers (Drive_solvers.c:52-55): pack them into pinned memory, one H2D copy
+        if (!(P.desc.static_weights && P.cached_weights == edgeWeight)) {
+            if ((st = P.stage_alloc(kbytes)) != G4S_OK) return finish(st);
+            for (uint32_t e = 0; e < numNodes; ++e) memcpy(P.stage + (size_t)e * n * n, edgeWeight[e + base], sizeof(double) * n * n);
+            if (kbytes && hipMemcpyAsync(P.elt_k.p, P.stage, kbytes, hipMemcpyHostToDevice, nullptr) != hipSuccess)
+                return finish(g4s::set_error(G4S_ERR_HIP, "spmm_dense: H2D copy of the element matrices failed"));
+            P.cached_weights = edgeWeight;
+        }
+        if (hipMemcpyAsync(P.u.p, vertexStates, sizeof(double) * (size_t)P.desc.neq, hipMemcpyHostToDevice, nullptr) != hipSuccess ||
+            hipMemcpyAsync(P.Au.p, result, sizeof(double) * (size_t)P.desc.neq, hipMemcpyHostToDevice, nullptr) != hipSuccess)
+            return finish(g4s::set_error(G4S_ERR_HIP, "spmm_dense: H2D copy of u/Au failed"));
+        (void)hipEventRecord(e0, nullptr);
+        st = elem_op_launch(P.op, P.elt_k.as<double>(), P.u.as<double>(), P.Au.as<double>(), 1.0, nullptr); // gather does Au[aa] += …
+        (void)hipEventRecord(e1, nullptr);
+        if (st != G4S_OK) return finish(st);
+        if (hipMemcpy(result, P.Au.p, sizeof(double) * (size_t)P.desc.neq, hipMemcpyDeviceToHost) != hipSuccess)
+            return finish(g4s::set_error(G4S_ERR_HIP, "spmm_dense: D2H copy of Au failed"));
+        (void)temp;
+        return finish(G4S_OK);
+    }
+    case G4S_PATTERN_DENSE_ROW_TIMES_MATRIX: {
+        const int M = (int)numNodes, K = (int)degree, N = P.desc.inner;
+        if (!edgeWeight || !vertexStates || !result) return finish(g4s::set_error(G4S_ERR_INVALID, "spmm_dense: NULL argument"));
+        if ((st = P.xx.alloc(sizeof(double) * (size_t)M * N)) != G4S_OK || (st = P.w.alloc(sizeof(double) * (size_t)N * K)) != G4S_OK ||
+            (st = P.res.alloc(sizeof(double) * (size_t)M * K)) != G4S_OK)
+            return finish(st);
+        // rows of xx arrive as row pointers (opt_matmul.cc:46-50); contiguous runs are merged into one copy
+        for (int e = 0; e < M;) {
+            int run = 1;
+            while (e + run < M && edgeWeight[e + run] == edgeWeight[e] + (size_t)run * N) ++run;
+            if (N && hipMemcpyAsync(P.xx.as<double>() + (size_t)e * N, edgeWeight[e], sizeof(double) * (size_t)run * N, hipMemcpyHostToDevice, nullptr) != hipSuccess)
+                return finish(g4s::set_error(G4S_ERR_HIP, "spmm_dense: H2D copy of xx failed"));
+            e += run;
+        }
+        if (N && K && hipMemcpyAsync(P.w.p, vertexStates, sizeof(double) * (size_t)N * K, hipMemcpyHostToDevice, nullptr) != hipSuccess)
+            return finish(g4s::set_error(G4S_ERR_HIP, "spmm_dense: H2D copy of w failed"));
+        (void)hipEventRecord(e0, nullptr);
+        st = g4s_dense_rows_times_matrix(M, N, K, P.xx.as<double>(), P.w.as<double>(), P.res.as<double>(), nullptr);
+        (void)hipEventRecord(e1, nullptr);
+        if (st != G4S_OK) return finish(st);
+        if (M && K && hipMemcpy(result, P.res.p, sizeof(double) * (size_t)M * K, hipMemcpyDeviceToHost) != hipSuccess)
+            return finish(g4s::set_error(G4S_ERR_HIP, "spmm_dense: D2H copy of the result failed"));
+        return finish(G4S_OK);
+    }
+    case G4S_PATTERN_SYM_QUADRATIC_FORM: {
+        if (!edgeWeight || !edgeWeight[0] || !vertexStates || !result) return finish(g4s::set_error(G4S_ERR_INVALID, "spmm_dense: NULL argument"));
+        (void)hipEventRecord(e0, nullptr);
+        st = g4s_sym_quadratic_form((int)numNodes, P.desc.numbers, edgeWeight[0], vertexStates, temp, result);
+        (void)hipEventRecord(e1, nullptr);
+        return finish(st);
+    }
+    }
+    return finish(g4s::set_error(G4S_ERR_INVALID, "spmm_dense: corrupt pattern"));
+}
+
+G4S_API void spmm_dense(uint32_t numNodes, uint32_t degree, const double **edgeWeight, const double *vertexStates,
+                        double *temp, double *result, fun_gather gather, fun_apply apply, double *time, int threadNum)
+{
+    // The reference symbol returns void (citcoms/lib/global_defs.h:854-857): failures cannot be reported, so they are fatal.
+    if (g4s_spmm_dense(numNodes, degree, edgeWeight, vertexStates, temp, result, gather, apply, time, threadNum) != G4S_OK) {
+        fprintf(stderr, "g4s: spmm_dense failed: %s\n", g4s_last_error());
+        abort();
+    }
+}

@@ -1,0 +1,803 @@
+// spgemm.hip — fp64 CSR SpGEMM C = A·B for gfx950 (B1 of include/g4s.h).
+//
+// Follows the reference's two-phase row-wise Gustavson algorithm with a per-row open-addressing hash accumulator
+// (HashSpGEMM, mm/inc/hash_mult.h:1028-1057): symbolic counts the distinct columns of every output row and an exclusive
+// scan gives crpt (hash_symbolic, :496-508, kernel :65-109); numeric re-inserts with multiply/add, then compacts and sorts
+// each row by column (hash_numeric, :559-608; sort_and_store_table2mat, :526-553). Hash = (key·107) & (size−1), linear
+// probing, empty = −1 (hash_mult.h:89,100; define.h:12). Rows are classified by the same flop upper bound the reference
+// bins by (BIN::set_intprod_num / set_bin_id, BIN.h:78-95,158-177: min(Σ_j nnz(B(acol_j,:)), cols)).
+//
+// MI355X mapping (one table per ROW in LDS instead of one table per THREAD in cache):
+//   * tiny rows  (bound ≤ 32)     one wavefront per row, 64-slot table, 8 lanes per A-entry
+//   * small rows (bound ≤ 512)    one 256-thread workgroup per row, 1024-slot table
+//   * medium rows                 one workgroup per row, 16K-slot (symbolic, keys only) / 8K-slot (numeric, keys+fp64) table
+//   * large rows                  symbolic: optimistic 32K-slot key table (128 KiB LDS) that aborts when it fills up;
+//   * hub rows (table > LDS)      bitmap-rank path in HBM: mark columns in a per-row bitmap, popcount-prefix it; a column's
+//                                 rank is its position in the sorted output row, so products are atomically added straight
+//                                 into C (no table, no sort).
+// Numeric classes use the EXACT row sizes known from symbolic, so the tables are at most half full.
+// Integer results (crpt, ccol) are exact; fp64 sums are accumulated with LDS/HBM atomics, i.e. in a different order than
+// the reference's (j outer, k inner): equal within the 1e-10 relative tolerance of the north star, not bit for bit.
+#include "common.hpp"
+#include <algorithm>
+#include <chrono>
+#include <vector>
+
+namespace {
+
+constexpr int kHashScal = 107; // HASH_SCAL, mm/inc/define.h:12
+constexpr int kEmpty = -1;
+
+// ------------------------------------------------------------------------------------------------ small utilities
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes)
+    {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+        if (e != hipSuccess) return g4s::set_error(e == hipErrorOutOfMemory ? G4S_ERR_NOMEM : G4S_ERR_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        return G4S_OK;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; } }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+__device__ __forceinline__ int lds_peek(const int *p) { return *reinterpret_cast<const volatile int *>(p); }
+
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_ll(long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------ flop per row (a4)
+// One wavefront per row: lanes stride the row's A-entries. BIN::set_intprod_num (BIN.h:78-95) / compute_flop (mkl_mult.h:8-38).
+__global__ __launch_bounds__(256) void row_flop_kernel(int M, const int *__restrict__ arpt, const int *__restrict__ acol,
+                                                        const int *__restrict__ brpt, long long *__restrict__ row_flop,
+                                                        unsigned long long *__restrict__ total)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    long long f = 0;
+    for (int j = arpt[row] + lane; j < arpt[row + 1]; j += 64) {
+        const int c = acol[j];
+        f += brpt[c + 1] - brpt[c];
+    }
+    f = wave_sum_ll(f);
+    if (lane == 0) {
+        row_flop[row] = f;
+        if (f) atomicAdd(total, (unsigned long long)f);
+    }
+}
+
+// Range check of A's column ids against B's row count (an out-of-range id would fault in brpt[c]).
+__global__ void check_range_kernel(const int *__restrict__ ids, long long n, int bound, int *flag)
+{
+    int bad = 0;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
+        const int c = ids[k];
+        bad |= (c < 0) | (c >= bound);
+    }
+    if (bad) atomicOr(flag, 1);
+}
+
+// ------------------------------------------------------------------------------------------------ row classes
+enum { CLS_EMPTY = 0, CLS_TINY, CLS_SMALL, CLS_MEDIUM, CLS_LARGE, CLS_HUB, CLS_COUNT };
+
+struct ClassLimits { long long tiny, small_, medium, large; };
+// symbolic: by the flop upper bound u = min(flop, cols); tables are keys only
+constexpr ClassLimits kSymLimits{32, 512, 8192, 393216};   // large = optimistic 32K-slot table unless flop is hopeless (16 × 24576)
+// numeric: by the exact nz of the output row; tables hold keys + fp64
+constexpr ClassLimits kNumLimits{32, 512, 4096, 4096};     // > 4096 → hub (bitmap-rank)
+
+__global__ void classify_kernel(int M, const long long *__restrict__ size, ClassLimits lim, int cols_clip,
+                                int *__restrict__ cls, int *__restrict__ hist)
+{
+    __shared__ int s_hist[CLS_COUNT];
+    if (threadIdx.x < CLS_COUNT) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) {
+        const long long u = size[i];
+        int c;
+        if (u == 0) c = CLS_EMPTY;
+        else {
+            const long long uc = (cols_clip > 0 && u > cols_clip) ? cols_clip : u; // BIN.h:164 clips the bound at cols
+            if (uc <= lim.tiny) c = CLS_TINY;
+            else if (uc <= lim.small_) c = CLS_SMALL;
+            else if (uc <= lim.medium) c = CLS_MEDIUM;
+            else if (u <= lim.large) c = CLS_LARGE;
+            else c = CLS_HUB;
+        }
+        cls[i] = c;
+        atomicAdd(&s_hist[c], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < CLS_COUNT && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_hist[threadIdx.x]);
+}
+
+__global__ void scatter_rows_kernel(int M, const int *__restrict__ cls, int *__restrict__ cursor, int *__restrict__ lists)
+{
+    __shared__ int s_cnt[CLS_COUNT], s_base[CLS_COUNT];
+    if (threadIdx.x < CLS_COUNT) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int c = 0, local = 0;
+    if (i < M) { c = cls[i]; local = atomicAdd(&s_cnt[c], 1); }
+    __syncthreads();
+    if (threadIdx.x < CLS_COUNT && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], s_cnt[threadIdx.x]); // cursor[c] starts at the class offset
+    __syncthreads();
+    if (i < M) lists[s_base[c] + local] = i;
+}
+
+__global__ void gather_ranges_kernel(const int *__restrict__ rows, int n, const int *__restrict__ arpt, int *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { out[2 * i] = arpt[rows[i]]; out[2 * i + 1] = arpt[rows[i] + 1]; }
+}
+
+__global__ void nz_to_ll_kernel(int M, const int *__restrict__ crpt, long long *__restrict__ nz)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) nz[i] = (long long)crpt[i + 1] - crpt[i];
+}
+
+// ------------------------------------------------------------------------------------------------ LDS hash kernels
+// THREADS threads cooperate on one row; WG = 256 (or 1024) threads host WG/THREADS rows. GROUP lanes share one A-entry and
+// stride the matching B row (coalesced bcol/bval reads).
+template <int TABLE>
+__device__ __forceinline__ int hash_of(int key) { return (key * kHashScal) & (TABLE - 1); }
+
+template <int WGSIZE, int THREADS, int TABLE, int GROUP, bool OPTIMISTIC>
+__global__ __launch_bounds__(WGSIZE) void spgemm_symbolic_lds_kernel(
+    const int *__restrict__ rows, int nrows, const int *__restrict__ arpt, const int *__restrict__ acol,
+    const int *__restrict__ brpt, const int *__restrict__ bcol, int *__restrict__ row_nz,
+    int *__restrict__ overflow_rows, int *__restrict__ overflow_count)
+{
+    extern __shared__ int lds_i[];
+    constexpr int RPB = WGSIZE / THREADS;           // rows per workgroup
+    constexpr int LIMIT = TABLE / 4 * 3;            // optimistic tables give up at 75 % fill
+    __shared__ int s_cnt[RPB];
+    const int sub = threadIdx.x / THREADS, t = threadIdx.x % THREADS;
+    const int ridx = blockIdx.x * RPB + sub;
+    const int row = ridx < nrows ? rows[ridx] : -1;
+    int *T = lds_i + sub * TABLE;
+    for (int s = t; s < TABLE; s += THREADS) T[s] = kEmpty;
+    if (t == 0) s_cnt[sub] = 0;
+    __syncthreads();
+    if (row >= 0) {
+        const int a0 = arpt[row], a1 = arpt[row + 1];
+        int cnt = 0;
+        for (int j = a0 + t / GROUP; j < a1; j += THREADS / GROUP) {
+            if (OPTIMISTIC && lds_peek(&s_cnt[sub]) > LIMIT) break;
+            const int c = acol[j];
+            for (int k = brpt[c] + t % GROUP; k < brpt[c + 1]; k += GROUP) {
+                const int key = bcol[k];
+                int h = hash_of<TABLE>(key);
+                for (int probes = 0;; ++probes) {
+                    const int old = atomicCAS(&T[h], kEmpty, key);
+                    if (old == kEmpty) {
+                        if (OPTIMISTIC) atomicAdd(&s_cnt[sub], 1); else cnt++;
+                        break;
+                    }
+                    if (old == key) break;
+                    h = (h + 1) & (TABLE - 1);
+                    if (probes >= TABLE) break;                                        // cannot happen for a correctly sized table; never spin
+                    if (OPTIMISTIC && (probes & 63) == 63 && lds_peek(&s_cnt[sub]) > LIMIT) break;
+                }
+                if (OPTIMISTIC && lds_peek(&s_cnt[sub]) > LIMIT) break;
+            }
+        }
+        if (!OPTIMISTIC) atomicAdd(&s_cnt[sub], cnt);
+    }
+    __syncthreads();
+    if (row >= 0 && t == 0) {
+        const int total = s_cnt[sub];
+        if (OPTIMISTIC && total > LIMIT) overflow_rows[atomicAdd(overflow_count, 1)] = row;
+        else row_nz[row] = total;
+    }
+}
+
+template <int WGSIZE, int THREADS, int TABLE, int GROUP>
+__global__ __launch_bounds__(WGSIZE) void spgemm_numeric_lds_kernel(
+    const int *__restrict__ rows, int nrows, const int *__restrict__ arpt, const int *__restrict__ acol, const double *__restrict__ aval,
+    const int *__restrict__ brpt, const int *__restrict__ bcol, const double *__restrict__ bval,
+    const int *__restrict__ crpt, int *__restrict__ ccol, double *__restrict__ cval)
+{
+    extern __shared__ int lds_i[];
+    constexpr int RPB = WGSIZE / THREADS;
+    const int sub = threadIdx.x / THREADS, t = threadIdx.x % THREADS;
+    const int ridx = blockIdx.x * RPB + sub;
+    const int row = ridx < nrows ? rows[ridx] : -1;
+    // layout: all fp64 value tables first (8-byte aligned), then the key tables
+    double *V = reinterpret_cast<double *>(lds_i) + sub * TABLE;
+    int *K = lds_i + RPB * TABLE * 2 + sub * TABLE;
+    for (int s = t; s < TABLE; s += THREADS) { K[s] = kEmpty; V[s] = 0.0; }
+    __syncthreads();
+    if (row >= 0) {
+        const int a0 = arpt[row], a1 = arpt[row + 1];
+        for (int j = a0 + t / GROUP; j < a1; j += THREADS / GROUP) {
+            const int c = acol[j];
+            const double av = aval[j];
+            for (int k = brpt[c] + t % GROUP; k < brpt[c + 1]; k += GROUP) {
+                const int key = bcol[k];
+                const double tv = av * bval[k];                 // multop, hash_mult.h:583
+                int h = hash_of<TABLE>(key);
+                for (int probes = 0; probes < TABLE; ++probes) {   // bounded: a wrong crpt from the caller must not hang the GPU
+                    const int old = atomicCAS(&K[h], kEmpty, key);
+                    if (old == kEmpty || old == key) { atomicAdd(&V[h], tv); break; }   // addop, hash_mult.h:588-593
+                    h = (h + 1) & (TABLE - 1);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // sort_and_store_table2mat (hash_mult.h:526-553): empties to the end, ascending keys, then store the first nz slots
+    for (int s = t; s < TABLE; s += THREADS) if (K[s] == kEmpty) K[s] = INT_MAX;
+    __syncthreads();
+    for (int k = 2; k <= TABLE; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < TABLE; i += THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const int ki = K[i], kj = K[ixj];
+                    const bool asc = (i & k) == 0;
+                    if ((ki > kj) == asc) {
+                        K[i] = kj; K[ixj] = ki;
+                        const double vi = V[i]; V[i] = V[ixj]; V[ixj] = vi;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (row >= 0) {
+        const int off = crpt[row], nz = crpt[row + 1] - off;
+        for (int s = t; s < nz; s += THREADS) { ccol[off + s] = K[s]; cval[off + s] = V[s]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ bitmap-rank path (hub rows)
+struct HubItem { int slot, row, j0, j1; };   // a workgroup's share of one hub row: A-entries [j0, j1)
+constexpr int kHubJChunk = 32;
+
+__global__ __launch_bounds__(256) void hub_mark_kernel(const HubItem *__restrict__ items, int W,
+                                                        const int *__restrict__ acol, const int *__restrict__ brpt,
+                                                        const int *__restrict__ bcol, unsigned *__restrict__ bitmap)
+{
+    const HubItem it = items[blockIdx.x];
+    unsigned *bm = bitmap + (size_t)it.slot * W;
+    const int t = threadIdx.x;
+    for (int j = it.j0 + (t >> 5); j < it.j1; j += 8) {
+        const int c = acol[j];
+        for (int k = brpt[c] + (t & 31); k < brpt[c + 1]; k += 32) {
+            const int col = bcol[k];
+            atomicOr(&bm[col >> 5], 1u << (col & 31));
+        }
+    }
+}
+
+// One workgroup per hub row: exclusive popcount prefix over the row's bitmap words; total = nz of the row.
+__global__ __launch_bounds__(256) void hub_prefix_kernel(const int *__restrict__ slot_rows, int W, const unsigned *__restrict__ bitmap,
+                                                          int *__restrict__ prefix, int *__restrict__ row_nz)
+{
+    __shared__ int s_part[256];
+    __shared__ int s_carry;
+    const int slot = blockIdx.x, t = threadIdx.x;
+    const unsigned *bm = bitmap + (size_t)slot * W;
+    int *pf = prefix + (size_t)slot * W;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < W; base += 256 * 8) {
+        int loc[8], sum = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int w = base + t * 8 + u;
+            loc[u] = w < W ? __popc(bm[w]) : 0;
+            sum += loc[u];
+        }
+        s_part[t] = sum;
+        __syncthreads();
+        // exclusive scan of s_part by Hillis–Steele (256 entries)
+        for (int off = 1; off < 256; off <<= 1) {
+            const int v = t >= off ? s_part[t - off] : 0;
+            __syncthreads();
+            s_part[t] += v;
+            __syncthreads();
+        }
+        int run = s_carry + s_part[t] - sum;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int w = base + t * 8 + u;
+            if (w < W) pf[w] = run;
+            run += loc[u];
+        }
+        __syncthreads();
+        if (t == 255) s_carry += s_part[255];
+        __syncthreads();
+    }
+    if (t == 0 && row_nz) row_nz[slot_rows[slot]] = s_carry;
+}
+
+// Column ids of a hub row in ascending order, values zeroed (products are accumulated afterwards).
+__global__ __launch_bounds__(256) void hub_emit_kernel(const int *__restrict__ slot_rows, int W, const unsigned *__restrict__ bitmap,
+                                                        const int *__restrict__ prefix, const int *__restrict__ crpt,
+                                                        int *__restrict__ ccol, double *__restrict__ cval)
+{
+    const int slot = blockIdx.y;
+    const int off = crpt[slot_rows[slot]];
+    const unsigned *bm = bitmap + (size_t)slot * W;
+    const int *pf = prefix + (size_t)slot * W;
+    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < W; w += gridDim.x * blockDim.x) {
+        unsigned bits = bm[w];
+        int pos = off + pf[w];
+        while (bits) {
+            const int b = __ffs(bits) - 1;
+            bits &= bits - 1;
+            ccol[pos] = (w << 5) + b;
+            cval[pos] = 0.0;
+            ++pos;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void hub_accumulate_kernel(const HubItem *__restrict__ items, int W,
+                                                              const int *__restrict__ acol, const double *__restrict__ aval,
+                                                              const int *__restrict__ brpt, const int *__restrict__ bcol,
+                                                              const double *__restrict__ bval, const unsigned *__restrict__ bitmap,
+                                                              const int *__restrict__ prefix, const int *__restrict__ crpt,
+                                                              double *__restrict__ cval)
+{
+    const HubItem it = items[blockIdx.x];
+    const unsigned *bm = bitmap + (size_t)it.slot * W;
+    const int *pf = prefix + (size_t)it.slot * W;
+    double *out = cval + crpt[it.row];
+    const int t = threadIdx.x;
+    for (int j = it.j0 + (t >> 5); j < it.j1; j += 8) {
+        const int c = acol[j];
+        const double av = aval[j];
+        for (int k = brpt[c] + (t & 31); k < brpt[c + 1]; k += 32) {
+            const int col = bcol[k];
+            const int w = col >> 5;
+            const int pos = pf[w] + __popc(bm[w] & ((1u << (col & 31)) - 1u));
+            atomicAdd(&out[pos], av * bval[k]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ exclusive scan → crpt
+constexpr int kScanChunk = 2048; // elements per workgroup
+
+__global__ __launch_bounds__(256) void scan_block_sums_kernel(int M, const int *__restrict__ row_nz, long long *__restrict__ block_sums)
+{
+    __shared__ long long s[4];
+    long long v = 0;
+    const int base = blockIdx.x * kScanChunk;
+    for (int i = threadIdx.x; i < kScanChunk; i += 256) {
+        const int r = base + i;
+        if (r < M) v += row_nz[r];
+    }
+    v = wave_sum_ll(v);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ void scan_block_offsets_kernel(int nblocks, long long *__restrict__ block_sums, long long *__restrict__ total)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {   // a few thousand entries: serial is fine
+        long long run = 0;
+        for (int b = 0; b < nblocks; ++b) { const long long v = block_sums[b]; block_sums[b] = run; run += v; }
+        *total = run;
+    }
+}
+
+__global__ __launch_bounds__(256) void scan_write_kernel(int M, const int *__restrict__ row_nz, const long long *__restrict__ block_offs,
+                                                          int *__restrict__ crpt)
+{
+    // out[0] = 0, out[i+1] = out[i] + in[i]  (seq_scan, mm/inc/utility.h:156-163)
+    __shared__ long long s_scan[256];
+    const int base = blockIdx.x * kScanChunk;
+    constexpr int PER = kScanChunk / 256;
+    int loc[PER];
+    long long sum = 0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int r = base + threadIdx.x * PER + u;
+        loc[u] = r < M ? row_nz[r] : 0;
+        sum += loc[u];
+    }
+    s_scan[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const long long v = threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0;
+        __syncthreads();
+        s_scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    long long run = block_offs[blockIdx.x] + s_scan[threadIdx.x] - sum;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int r = base + threadIdx.x * PER + u;
+        if (r < M) crpt[r] = (int)run;
+        run += loc[u];
+        if (r == M - 1) crpt[M] = (int)run;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host orchestration
+struct RowClasses {
+    DevBuf cls, lists, hist;
+    int count[CLS_COUNT] = {0};
+    int offset[CLS_COUNT + 1] = {0};
+    const int *list(int c) const { return lists.as<int>() + offset[c]; }
+};
+
+int classify_rows(int M, const long long *d_size, const ClassLimits &lim, int cols_clip, RowClasses &rc, hipStream_t s)
+{
+    G4S_TRY(rc.cls.alloc(sizeof(int) * (size_t)M));
+    G4S_TRY(rc.lists.alloc(sizeof(int) * (size_t)M));
+    G4S_TRY(rc.hist.alloc(sizeof(int) * 2 * CLS_COUNT));
+    G4S_HIP_TRY(hipMemsetAsync(rc.hist.p, 0, sizeof(int) * 2 * CLS_COUNT, s));
+    const int grid = (M + 255) / 256;
+    hipLaunchKernelGGL(classify_kernel, dim3(grid), dim3(256), 0, s, M, d_size, lim, cols_clip, rc.cls.as<int>(), rc.hist.as<int>());
+    G4S_HIP_TRY(hipMemcpyAsync(rc.count, rc.hist.p, sizeof(int) * CLS_COUNT, hipMemcpyDeviceToHost, s));
+    G4S_HIP_TRY(hipStreamSynchronize(s));
+    rc.offset[0] = 0;
+    for (int c = 0; c < CLS_COUNT; ++c) rc.offset[c + 1] = rc.offset[c] + rc.count[c];
+    int *cursor = rc.hist.as<int>() + CLS_COUNT;
+    G4S_HIP_TRY(hipMemcpyAsync(cursor, rc.offset, sizeof(int) * CLS_COUNT, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid), dim3(256), 0, s, M, rc.cls.as<int>(), cursor, rc.lists.as<int>());
+    G4S_HIP_TRY(hipGetLastError());
+    return G4S_OK;
+}
+
+template <typename Kernel>
+int allow_lds(Kernel k, size_t bytes)
+{
+    if (bytes > 64 * 1024) G4S_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return G4S_OK;
+}
+
+// Hub rows: mark → prefix (→ counts) [→ emit → accumulate], in batches bounded by the bitmap workspace.
+int run_hub_rows(bool numeric, const std::vector<int> &hub_rows, const std::vector<int> &h_arpt_of_rows /*2 per row*/, int N,
+                 const int *arpt, const int *acol, const double *aval, const int *brpt, const int *bcol, const double *bval,
+                 int *row_nz, const int *crpt, int *ccol, double *cval, hipStream_t s)
+{
+    (void)arpt;
+    if (hub_rows.empty()) return G4S_OK;
+    const int W = (N + 31) / 32;
+    const size_t per_row = (size_t)W * 8; // bitmap + prefix words
+    const size_t budget = (size_t)1 << 30;
+    const int max_slots = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(hub_rows.size(), 32768), budget / per_row));
+    DevBuf bitmap, prefix, slot_rows, items;
+    G4S_TRY(bitmap.alloc((size_t)max_slots * W * 4));
+    G4S_TRY(prefix.alloc((size_t)max_slots * W * 4));
+    G4S_TRY(slot_rows.alloc(sizeof(int) * (size_t)max_slots));
+    for (size_t b0 = 0; b0 < hub_rows.size(); b0 += max_slots) {
+        const int nslots = (int)std::min<size_t>(max_slots, hub_rows.size() - b0);
+        std::vector<HubItem> h_items;
+        for (int sidx = 0; sidx < nslots; ++sidx) {
+            const int a0 = h_arpt_of_rows[2 * (b0 + sidx)], a1 = h_arpt_of_rows[2 * (b0 + sidx) + 1];
+            for (int j = a0; j < a1; j += kHubJChunk) h_items.push_back(HubItem{sidx, hub_rows[b0 + sidx], j, std::min(a1, j + kHubJChunk)});
+        }
+        G4S_TRY(items.alloc(sizeof(HubItem) * h_items.size()));
+        G4S_HIP_TRY(hipMemcpyAsync(items.p, h_items.data(), sizeof(HubItem) * h_items.size(), hipMemcpyHostToDevice, s));
+        G4S_HIP_TRY(hipMemcpyAsync(slot_rows.p, hub_rows.data() + b0, sizeof(int) * nslots, hipMemcpyHostToDevice, s));
+        G4S_HIP_TRY(hipMemsetAsync(bitmap.p, 0, (size_t)nslots * W * 4, s));
+        if (!h_items.empty())
+            hipLaunchKernelGGL(hub_mark_kernel, dim3((unsigned)h_items.size()), dim3(256), 0, s, items.as<HubItem>(), W, acol, brpt, bcol, bitmap.as<unsigned>());
+        hipLaunchKernelGGL(hub_prefix_kernel, dim3(nslots), dim3(256), 0, s, slot_rows.as<int>(), W, bitmap.as<unsigned>(), prefix.as<int>(),
+                           numeric ? nullptr : row_nz);
+        if (numeric) {
+            const int gx = std::min(64, (W + 255) / 256);
+            hipLaunchKernelGGL(hub_emit_kernel, dim3(gx, nslots), dim3(256), 0, s, slot_rows.as<int>(), W, bitmap.as<unsigned>(), prefix.as<int>(),
+                               crpt, ccol, cval);
+            if (!h_items.empty())
+                hipLaunchKernelGGL(hub_accumulate_kernel, dim3((unsigned)h_items.size()), dim3(256), 0, s, items.as<HubItem>(), W, acol, aval, brpt,
+                                   bcol, bval, bitmap.as<unsigned>(), prefix.as<int>(), crpt, cval);
+        }
+        G4S_HIP_TRY(hipGetLastError());
+        G4S_HIP_TRY(hipStreamSynchronize(s)); // h_items is reused; workspace is reused by the next batch
+    }
+    return G4S_OK;
+}
+
+int fetch_rows_and_ranges(const int *d_list, int n, const int *d_arpt, std::vector<int> &rows, std::vector<int> &ranges, hipStream_t s)
+{
+    rows.resize(n);
+    ranges.resize(2 * (size_t)n);
+    if (!n) return G4S_OK;
+    G4S_HIP_TRY(hipMemcpyAsync(rows.data(), d_list, sizeof(int) * n, hipMemcpyDeviceToHost, s));
+    G4S_HIP_TRY(hipStreamSynchronize(s));
+    std::sort(rows.begin(), rows.end());
+    DevBuf d_rows, d_rng;
+    G4S_TRY(d_rows.alloc(sizeof(int) * (size_t)n));
+    G4S_TRY(d_rng.alloc(sizeof(int) * 2 * (size_t)n));
+    G4S_HIP_TRY(hipMemcpyAsync(d_rows.p, rows.data(), sizeof(int) * n, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(gather_ranges_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_rows.as<int>(), n, d_arpt, d_rng.as<int>());
+    G4S_HIP_TRY(hipMemcpyAsync(ranges.data(), d_rng.p, sizeof(int) * 2 * (size_t)n, hipMemcpyDeviceToHost, s));
+    G4S_HIP_TRY(hipStreamSynchronize(s));
+    return G4S_OK;
+}
+
+int compute_row_flop(int M, const int *arpt, const int *acol, const int *brpt, long long *d_row_flop, int64_t *total, hipStream_t s)
+{
+    DevBuf tot;
+    G4S_TRY(tot.alloc(sizeof(unsigned long long)));
+    G4S_HIP_TRY(hipMemsetAsync(tot.p, 0, sizeof(unsigned long long), s));
+    if (M > 0) hipLaunchKernelGGL(row_flop_kernel, dim3((M + 3) / 4), dim3(256), 0, s, M, arpt, acol, brpt, d_row_flop, tot.as<unsigned long long>());
+    G4S_HIP_TRY(hipGetLastError());
+    unsigned long long h = 0;
+    G4S_HIP_TRY(hipMemcpyAsync(&h, tot.p, sizeof(h), hipMemcpyDeviceToHost, s));
+    G4S_HIP_TRY(hipStreamSynchronize(s));
+    if (total) *total = (int64_t)h;
+    return G4S_OK;
+}
+
+int check_ids(const int *ids, long long n, int bound, const char *what, hipStream_t s)
+{
+    if (n <= 0) return G4S_OK;
+    DevBuf flag;
+    G4S_TRY(flag.alloc(sizeof(int)));
+    G4S_HIP_TRY(hipMemsetAsync(flag.p, 0, sizeof(int), s));
+    const int grid = (int)std::min<long long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(check_range_kernel, dim3(grid), dim3(256), 0, s, ids, n, bound, flag.as<int>());
+    int h = 0;
+    G4S_HIP_TRY(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    G4S_HIP_TRY(hipStreamSynchronize(s));
+    if (h) return g4s::set_error(G4S_ERR_INVALID, "SpGEMM: %s outside its valid range [0,%d)", what, bound);
+    return G4S_OK;
+}
+
+int read_last(const int *d_rpt, int n, int *out, hipStream_t s)
+{
+    G4S_HIP_TRY(hipMemcpyAsync(out, d_rpt + n, sizeof(int), hipMemcpyDeviceToHost, s));
+    G4S_HIP_TRY(hipStreamSynchronize(s));
+    return G4S_OK;
+}
+
+} // namespace
+
+// ================================================================================================ C-ABI
+G4S_API g4s_status g4s_spgemm_symbolic(int32_t M, int32_t K, int32_t N,
+                                       const int32_t *arpt, const int32_t *acol, const int32_t *brpt, const int32_t *bcol,
+                                       int32_t *crpt, int64_t *cnnz, void *stream)
+{
+    G4S_REQUIRE(M >= 0 && K >= 0 && N >= 0, "negative dimension");
+    G4S_REQUIRE(arpt && brpt && crpt && cnnz, "NULL argument");
+    hipStream_t s = g4s::as_stream(stream);
+    *cnnz = 0;
+    if (M == 0) { G4S_HIP_TRY(hipMemsetAsync(crpt, 0, sizeof(int), s)); return G4S_OK; }
+    int annz = 0, bnnz = 0;
+    G4S_TRY(read_last(arpt, M, &annz, s));
+    G4S_TRY(read_last(brpt, K, &bnnz, s));
+    G4S_TRY(check_ids(acol, annz, K, "a column id of A", s));
+    G4S_TRY(check_ids(bcol, bnnz, N, "a column id of B", s));
+
+    DevBuf row_flop, row_nz, ovf_rows, ovf_count;
+    G4S_TRY(row_flop.alloc(sizeof(long long) * (size_t)M));
+    G4S_TRY(row_nz.alloc(sizeof(int) * ((size_t)M + 1)));
+    G4S_HIP_TRY(hipMemsetAsync(row_nz.p, 0, sizeof(int) * ((size_t)M + 1), s));
+    int64_t flop = 0;
+    G4S_TRY(compute_row_flop(M, arpt, acol, brpt, row_flop.as<long long>(), &flop, s));
+
+    RowClasses rc;
+    G4S_TRY(classify_rows(M, row_flop.as<long long>(), kSymLimits, N, rc, s));
+    G4S_TRY(ovf_rows.alloc(sizeof(int) * (size_t)std::max(1, rc.count[CLS_LARGE])));
+    G4S_TRY(ovf_count.alloc(sizeof(int)));
+    G4S_HIP_TRY(hipMemsetAsync(ovf_count.p, 0, sizeof(int), s));
+    int *nz = row_nz.as<int>();
+
+    if (int n = rc.count[CLS_TINY]) {
+        auto k = spgemm_symbolic_lds_kernel<256, 64, 64, 8, false>;
+        hipLaunchKernelGGL(k, dim3((n + 3) / 4), dim3(256), 4 * 64 * sizeof(int), s, rc.list(CLS_TINY), n, arpt, acol, brpt, bcol, nz, nullptr, nullptr);
+    }
+    if (int n = rc.count[CLS_SMALL]) {
+        auto k = spgemm_symbolic_lds_kernel<256, 256, 1024, 16, false>;
+        hipLaunchKernelGGL(k, dim3(n), dim3(256), 1024 * sizeof(int), s, rc.list(CLS_SMALL), n, arpt, acol, brpt, bcol, nz, nullptr, nullptr);
+    }
+    if (int n = rc.count[CLS_MEDIUM]) {
+        auto k = spgemm_symbolic_lds_kernel<256, 256, 16384, 16, false>;
+        G4S_TRY(allow_lds(k, 16384 * sizeof(int)));
+        hipLaunchKernelGGL(k, dim3(n), dim3(256), 16384 * sizeof(int), s, rc.list(CLS_MEDIUM), n, arpt, acol, brpt, bcol, nz, nullptr, nullptr);
+    }
+    if (int n = rc.count[CLS_LARGE]) {
+        auto k = spgemm_symbolic_lds_kernel<1024, 1024, 32768, 32, true>;
+        G4S_TRY(allow_lds(k, 32768 * sizeof(int)));
+        hipLaunchKernelGGL(k, dim3(n), dim3(1024), 32768 * sizeof(int), s, rc.list(CLS_LARGE), n, arpt, acol, brpt, bcol, nz, ovf_rows.as<int>(),
+                           ovf_count.as<int>());
+    }
+    G4S_HIP_TRY(hipGetLastError());
+
+    // hub rows = class HUB + the rows whose optimistic table filled up
+    int n_ovf = 0;
+    G4S_HIP_TRY(hipMemcpyAsync(&n_ovf, ovf_count.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    G4S_HIP_TRY(hipStreamSynchronize(s));
+    std::vector<int> hub, hub2, ranges, ranges2;
+    G4S_TRY(fetch_rows_and_ranges(rc.list(CLS_HUB), rc.count[CLS_HUB], arpt, hub, ranges, s));
+    G4S_TRY(fetch_rows_and_ranges(ovf_rows.as<int>(), n_ovf, arpt, hub2, ranges2, s));
+    hub.insert(hub.end(), hub2.begin(), hub2.end());
+    ranges.insert(ranges.end(), ranges2.begin(), ranges2.end());
+    G4S_TRY(run_hub_rows(false, hub, ranges, N, arpt, acol, nullptr, brpt, bcol, nullptr, nz, nullptr, nullptr, nullptr, s));
+
+    // scan(bin.row_nz, crpt, nrow+1); *nnz = crpt[nrow]   (hash_mult.h:506-507)
+    const int nblocks = (M + kScanChunk - 1) / kScanChunk;
+    DevBuf block_sums, total;
+    G4S_TRY(block_sums.alloc(sizeof(long long) * (size_t)nblocks));
+    G4S_TRY(total.alloc(sizeof(long long)));
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nblocks), dim3(256), 0, s, M, nz, block_sums.as<long long>());
+    hipLaunchKernelGGL(scan_block_offsets_kernel, dim3(1), dim3(64), 0, s, nblocks, block_sums.as<long long>(), total.as<long long>());
+    long long h_total = 0;
+    G4S_HIP_TRY(hipMemcpyAsync(&h_total, total.p, sizeof(long long), hipMemcpyDeviceToHost, s));
+    G4S_HIP_TRY(hipStreamSynchronize(s));
+    *cnnz = h_total;
+    if (h_total > INT32_MAX)
+        return g4s::set_error(G4S_ERR_OVERFLOW, "nnz(C) = %lld exceeds the reference's int32 row pointer (mm/inc/define.h:14)", h_total);
+    hipLaunchKernelGGL(scan_write_kernel, dim3(nblocks), dim3(256), 0, s, M, nz, block_sums.as<long long>(), crpt);
+    G4S_HIP_TRY(hipGetLastError());
+    G4S_HIP_TRY(hipStreamSynchronize(s));
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_spgemm_numeric(int32_t M, int32_t K, int32_t N,
+                                      const int32_t *arpt, const int32_t *acol, const double *aval,
+                                      const int32_t *brpt, const int32_t *bcol, const double *bval,
+                                      const int32_t *crpt, int32_t *ccol, double *cval, unsigned flags, void *stream)
+{
+    (void)K; (void)flags; // rows always come out sorted by column: the sorted form is the only ordering contract (hash_mult.h:530-551)
+    G4S_REQUIRE(M >= 0 && N >= 0, "negative dimension");
+    G4S_REQUIRE(arpt && brpt && crpt, "NULL argument");
+    hipStream_t s = g4s::as_stream(stream);
+    if (M == 0) return G4S_OK;
+    DevBuf row_size;
+    G4S_TRY(row_size.alloc(sizeof(long long) * (size_t)M));
+    hipLaunchKernelGGL(nz_to_ll_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, crpt, row_size.as<long long>());
+    RowClasses rc;
+    G4S_TRY(classify_rows(M, row_size.as<long long>(), kNumLimits, 0, rc, s));
+
+    if (int n = rc.count[CLS_TINY]) {
+        auto k = spgemm_numeric_lds_kernel<256, 64, 64, 8>;
+        hipLaunchKernelGGL(k, dim3((n + 3) / 4), dim3(256), 4 * 64 * 12, s, rc.list(CLS_TINY), n, arpt, acol, aval, brpt, bcol, bval, crpt, ccol, cval);
+    }
+    if (int n = rc.count[CLS_SMALL]) {
+        auto k = spgemm_numeric_lds_kernel<256, 256, 1024, 16>;
+        hipLaunchKernelGGL(k, dim3(n), dim3(256), 1024 * 12, s, rc.list(CLS_SMALL), n, arpt, acol, aval, brpt, bcol, bval, crpt, ccol, cval);
+    }
+    if (int n = rc.count[CLS_MEDIUM]) {
+        auto k = spgemm_numeric_lds_kernel<1024, 1024, 8192, 32>;
+        G4S_TRY(allow_lds(k, 8192 * 12));
+        hipLaunchKernelGGL(k, dim3(n), dim3(1024), 8192 * 12, s, rc.list(CLS_MEDIUM), n, arpt, acol, aval, brpt, bcol, bval, crpt, ccol, cval);
+    }
+    G4S_HIP_TRY(hipGetLastError());
+    std::vector<int> hub, ranges, hub2, ranges2;
+    G4S_TRY(fetch_rows_and_ranges(rc.list(CLS_LARGE), rc.count[CLS_LARGE], arpt, hub, ranges, s));
+    G4S_TRY(fetch_rows_and_ranges(rc.list(CLS_HUB), rc.count[CLS_HUB], arpt, hub2, ranges2, s));
+    hub.insert(hub.end(), hub2.begin(), hub2.end());
+    ranges.insert(ranges.end(), ranges2.begin(), ranges2.end());
+    G4S_TRY(run_hub_rows(true, hub, ranges, N, arpt, acol, aval, brpt, bcol, bval, nullptr, crpt, ccol, cval, s));
+    G4S_HIP_TRY(hipStreamSynchronize(s));
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_spgemm_flop(int32_t M, const int32_t *arpt, const int32_t *acol, const int32_t *brpt,
+                                   int64_t *flop, int64_t *row_flop, unsigned flags)
+{
+    G4S_REQUIRE(M >= 0 && arpt && brpt && flop, "bad argument");
+    *flop = 0;
+    if (M == 0) return G4S_OK;
+    DevBuf rf;
+    if (flags & G4S_DEVICE_POINTERS) {
+        long long *d_rf = reinterpret_cast<long long *>(row_flop);
+        if (!d_rf) { G4S_TRY(rf.alloc(sizeof(long long) * (size_t)M)); d_rf = rf.as<long long>(); }
+        return compute_row_flop(M, arpt, acol, brpt, d_rf, flop, nullptr);
+    }
+    // host pointers: brpt's length is implied by the largest column id of A
+    const int annz = arpt[M];
+    G4S_REQUIRE(annz >= 0, "arpt[M] is negative");
+    int maxc = -1;
+    for (int k = 0; k < annz; ++k) { G4S_REQUIRE(acol[k] >= 0, "negative column id in A"); if (acol[k] > maxc) maxc = acol[k]; }
+    DevBuf d_arpt, d_acol, d_brpt;
+    G4S_TRY(d_arpt.alloc(sizeof(int) * ((size_t)M + 1)));
+    G4S_TRY(d_acol.alloc(sizeof(int) * (size_t)annz));
+    G4S_TRY(d_brpt.alloc(sizeof(int) * ((size_t)maxc + 2)));
+    G4S_TRY(rf.alloc(sizeof(long long) * (size_t)M));
+    G4S_HIP_TRY(hipMemcpy(d_arpt.p, arpt, sizeof(int) * ((size_t)M + 1), hipMemcpyHostToDevice));
+    if (annz) G4S_HIP_TRY(hipMemcpy(d_acol.p, acol, sizeof(int) * (size_t)annz, hipMemcpyHostToDevice));
+    G4S_HIP_TRY(hipMemcpy(d_brpt.p, brpt, sizeof(int) * ((size_t)maxc + 2), hipMemcpyHostToDevice));
+    G4S_TRY(compute_row_flop(M, d_arpt.as<int>(), d_acol.as<int>(), d_brpt.as<int>(), rf.as<long long>(), flop, nullptr));
+    if (row_flop) G4S_HIP_TRY(hipMemcpy(row_flop, rf.p, sizeof(long long) * (size_t)M, hipMemcpyDeviceToHost));
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_spgemm_csr_i32_f64(const int32_t *arpt, const int32_t *acol, const double *aval,
+                                          const int32_t *brpt, const int32_t *bcol, const double *bval,
+                                          int32_t **crpt_out, int32_t **ccol_out, double **cval_out,
+                                          int32_t M, int32_t K, int32_t N, int64_t *cnnz_out,
+                                          g4s_timings *timings, unsigned flags)
+{
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    G4S_REQUIRE(crpt_out && ccol_out && cval_out && cnnz_out, "NULL output argument");
+    G4S_REQUIRE(M >= 0 && K >= 0 && N >= 0 && arpt && brpt, "bad argument");
+    *crpt_out = nullptr; *ccol_out = nullptr; *cval_out = nullptr; *cnnz_out = 0;
+    g4s_timings t{};
+    const auto t_total = clk::now();
+    const bool dev = (flags & G4S_DEVICE_POINTERS) != 0;
+
+    // ---- create: inputs to the device (mkl_sparse_d_create_csr ×2 in the reference's timed path, mkl_mult.h:50-52)
+    auto t0 = clk::now();
+    DevBuf d_arpt, d_acol, d_aval, d_brpt, d_bcol, d_bval;
+    const int *p_arpt = arpt, *p_acol = acol, *p_brpt = brpt, *p_bcol = bcol;
+    const double *p_aval = aval, *p_bval = bval;
+    if (!dev) {
+        const int annz = M ? arpt[M] : 0, bnnz = K ? brpt[K] : 0;
+        G4S_REQUIRE(annz >= 0 && bnnz >= 0, "negative nnz");
+        auto up = [&](DevBuf &b, const void *src, size_t bytes) -> int {
+            G4S_TRY(b.alloc(bytes));
+            if (bytes) G4S_HIP_TRY(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+            return G4S_OK;
+        };
+        G4S_TRY(up(d_arpt, arpt, sizeof(int) * ((size_t)M + 1)));
+        G4S_TRY(up(d_acol, acol, sizeof(int) * (size_t)annz));
+        G4S_TRY(up(d_aval, aval, sizeof(double) * (size_t)annz));
+        G4S_TRY(up(d_brpt, brpt, sizeof(int) * ((size_t)K + 1)));
+        G4S_TRY(up(d_bcol, bcol, sizeof(int) * (size_t)bnnz));
+        G4S_TRY(up(d_bval, bval, sizeof(double) * (size_t)bnnz));
+        p_arpt = d_arpt.as<int>(); p_acol = d_acol.as<int>(); p_aval = d_aval.as<double>();
+        p_brpt = d_brpt.as<int>(); p_bcol = d_bcol.as<int>(); p_bval = d_bval.as<double>();
+    }
+    t.create = ms_since(t0);
+
+    // ---- spmm: symbolic + numeric (rows come out sorted: the reference's separate `order` stage is folded in)
+    t0 = clk::now();
+    DevBuf d_crpt;
+    G4S_TRY(d_crpt.alloc(sizeof(int) * ((size_t)M + 1)));
+    int64_t cnnz = 0;
+    G4S_TRY(g4s_spgemm_symbolic(M, K, N, p_arpt, p_acol, p_brpt, p_bcol, d_crpt.as<int>(), &cnnz, nullptr));
+    *cnnz_out = cnnz;
+    DevBuf d_ccol, d_cval;
+    G4S_TRY(d_ccol.alloc(sizeof(int) * (size_t)cnnz));
+    G4S_TRY(d_cval.alloc(sizeof(double) * (size_t)cnnz));
+    G4S_TRY(g4s_spgemm_numeric(M, K, N, p_arpt, p_acol, p_aval, p_brpt, p_bcol, p_bval, d_crpt.as<int>(), d_ccol.as<int>(), d_cval.as<double>(),
+                               flags, nullptr));
+    t.spmm = ms_since(t0);
+    t.convert = 0.0;
+    t.order = 0.0;
+
+    // ---- export_csr: hand the result to the caller (mkl_sparse_d_export_csr + memcpy, mkl_mult.h:79-99)
+    t0 = clk::now();
+    if (dev) {
+        *crpt_out = d_crpt.as<int>(); d_crpt.p = nullptr;
+        *ccol_out = d_ccol.as<int>(); d_ccol.p = nullptr;
+        *cval_out = d_cval.as<double>(); d_cval.p = nullptr;
+    } else {
+        int *h_rpt = (int *)g4s_malloc(sizeof(int) * ((size_t)M + 1));
+        int *h_col = (int *)g4s_malloc(sizeof(int) * (size_t)cnnz);
+        double *h_val = (double *)g4s_malloc(sizeof(double) * (size_t)cnnz);
+        if (!h_rpt || !h_col || !h_val) { g4s_free(h_rpt); g4s_free(h_col); g4s_free(h_val); return g4s::set_error(G4S_ERR_NOMEM, "host allocation of C failed"); }
+        hipError_t e1 = hipMemcpy(h_rpt, d_crpt.p, sizeof(int) * ((size_t)M + 1), hipMemcpyDeviceToHost);
+        hipError_t e2 = cnnz ? hipMemcpy(h_col, d_ccol.p, sizeof(int) * (size_t)cnnz, hipMemcpyDeviceToHost) : hipSuccess;
+        hipError_t e3 = cnnz ? hipMemcpy(h_val, d_cval.p, sizeof(double) * (size_t)cnnz, hipMemcpyDeviceToHost) : hipSuccess;
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { g4s_free(h_rpt); g4s_free(h_col); g4s_free(h_val); return g4s::set_error(G4S_ERR_HIP, "D2H copy of C failed"); }
+        *crpt_out = h_rpt; *ccol_out = h_col; *cval_out = h_val;
+    }
+    t.export_csr = ms_since(t0);
+
+    t0 = clk::now();
+    d_arpt.release(); d_acol.release(); d_aval.release(); d_brpt.release(); d_bcol.release(); d_bval.release();
+    d_crpt.release(); d_ccol.release(); d_cval.release();
+    t.destroy = ms_since(t0);
+    t.total = ms_since(t_total);
+    if (timings) *timings = t;
+    return G4S_OK;
+}

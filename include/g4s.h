@@ -148,6 +148,7 @@ typedef struct g4s_pattern_desc {
     int32_t kind;
     /* ELEMENT_BLOCK_MATVEC: result[eq(e,a,i)] += Σ_b Σ_d K_e[(dof·a+i)·(npe·dof) + dof·b+d] · u[eq(e,b,d)],
      * eq(e,a,i) = id[ ien[e·npe + a]·dof + i ]   (0-based restatement of IEN/ID, Element_calculations.c:460-468). */
+    int32_t num_elems;        /* nel: number of elements (= numNodes of the spmm_dense calls that follow)                */
     int32_t nodes_per_elem;   /* 8  (enodes[3])                                                          */
     int32_t dof;              /* 3  (mesh.nsd)                                                           */
     const int32_t *ien;       /* [numNodes · nodes_per_elem] element → node, 0-based, host memory         */
@@ -155,6 +156,8 @@ typedef struct g4s_pattern_desc {
     int32_t nno;              /* number of nodes                                                         */
     int32_t neq;              /* number of equations (length of vertexStates / result)                   */
     int32_t edge_weight_base; /* 1 if edgeWeight[0] is unused and element e lives at edgeWeight[e+1] (CitcomS, Drive_solvers.c:52-55), else 0 */
+    int32_t static_weights;   /* 1: the element matrices behind an edgeWeight pointer do not change between calls (true inside one
+                                 CitcomS CG solve); they are uploaded once per distinct edgeWeight pointer. Re-register to invalidate. */
     /* DENSE_ROW_TIMES_MATRIX: result[e·degree + a] = Σ_k edgeWeight[e][k] · states[k·degree + a]        */
     int32_t inner;            /* N (opt_matmul.cc:33, global Nsize)                                      */
     /* SYM_QUADRATIC_FORM: see RedlichKwongMFTP.cpp:927-970                                              */

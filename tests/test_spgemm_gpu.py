@@ -1,0 +1,173 @@
+"""GPU parity: HIP SpGEMM (through the C-ABI) against the oracle's restatement of HashSpGEMM (mm/inc/hash_mult.h).
+
+crpt and ccol must be bit-exact (integer work). cval: |c_gpu − c_oracle| ≤ 1e-10 · Σ|a_ij·b_jk| (fp64 atomics add the
+products in a different order than the reference's (j outer, k inner) loop)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import power_law_csr, random_csr, to_scipy
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _abs(A):
+    return (A[0], A[1], np.abs(A[2]))
+
+
+def _check(oracle, A, B, M, K, N):
+    from g4s_amd import host
+    a = host.CSR.from_host(*A, M, K)
+    b = host.CSR.from_host(*B, K, N)
+    c = host.HashSpGEMM(a, b)
+    crpt, ccol, cval = c.to_host()
+    orpt, ocol, oval = oracle.spgemm(A, B, N, sort_output=True)
+    assert np.array_equal(crpt, orpt), "row pointer differs"
+    assert np.array_equal(ccol, ocol), "column ids differ"
+    _, _, scale = oracle.spgemm(_abs(A), _abs(B), N, sort_output=True)
+    assert np.all(np.abs(cval - oval) <= TOL * scale + 1e-300), f"max err {np.max(np.abs(cval - oval) / (scale + 1e-300))}"
+    assert host.get_flop(a, b) == oracle.flop(A[0], A[1], B[0])
+    return c
+
+
+@pytest.mark.parametrize("M,K,N,da,db,seed", [(1, 1, 1, 1.0, 1.0, 0), (4, 4, 4, 0.6, 0.6, 1), (40, 30, 50, 0.15, 0.2, 2),
+                                              (300, 300, 300, 0.03, 0.03, 3), (64, 8, 64, 0.9, 0.9, 4), (2000, 1500, 1800, 0.01, 0.01, 5)])
+def test_spgemm_random(oracle, M, K, N, da, db, seed):
+    A = random_csr(M, K, da, seed, empty_rows=[1] if M > 2 else [])
+    B = random_csr(K, N, db, seed + 100, empty_rows=[0] if K > 2 else [])
+    _check(oracle, A, B, M, K, N)
+
+
+def test_spgemm_golden_fixture(oracle):
+    import os
+    from g4s_amd import host
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "spgemm_rmat8.npz"))
+    n = int(g["n"])
+    a = host.CSR.from_host(g["arpt"], g["acol"], g["aval"], n, n)
+    c = host.HashSpGEMM(a, a)
+    crpt, ccol, cval = c.to_host()
+    assert np.array_equal(crpt, g["crpt"]) and np.array_equal(ccol, g["ccol"])
+    assert np.allclose(cval, g["cval"], rtol=1e-12, atol=1e-12)
+
+
+def test_spgemm_all_row_classes(oracle):
+    """Rows that land in every class: empty, tiny, small, medium, large (optimistic table), overflow → hub, flop-hub."""
+    rng = np.random.default_rng(7)
+    K, N = 3000, 60000
+    # B: 3000 rows × 60000 cols, 100 entries per row (row 0 empty)
+    bl = np.full(K, 100)
+    bl[0] = 0
+    brp = np.concatenate([[0], np.cumsum(bl)]).astype(np.int32)
+    bci = np.concatenate([np.sort(rng.choice(N, l, replace=False)) for l in bl]).astype(np.int32)
+    bva = rng.uniform(-1, 1, brp[-1])
+    # A rows with 0, 1 (→ empty B row), 1, 4, 30, 120, 1000, 2900 entries → flop 0,0,100,400,3000,12000,1e5,2.9e5; plus a 3000-entry row (flop 3e5.. <393216) and duplicates
+    lens = [0, 1, 1, 4, 30, 120, 1000, 2900, 2999] + [2] * 50
+    rows = []
+    for i, l in enumerate(lens):
+        if i == 1:
+            rows.append(np.array([0]))
+        else:
+            rows.append(np.sort(rng.choice(np.arange(1, K), l, replace=False)))
+    arp = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    aci = np.concatenate(rows).astype(np.int32)
+    ava = rng.uniform(-1, 1, arp[-1])
+    M = len(lens)
+    c = _check(oracle, (arp, aci, ava), (brp, bci, bva), M, K, N)
+    nz = np.diff(c.to_host()[0])
+    assert nz[0] == 0 and nz[1] == 0 and nz[6] > 24576 and nz[5] > 4096      # exercised: overflow→hub (symbolic), hub (numeric)
+
+
+def test_spgemm_flop_hub_path(oracle):
+    # flop > 393216 for one row → straight to the bitmap-rank path in symbolic; small N so that distinct ≪ flop
+    rng = np.random.default_rng(11)
+    K, N = 2000, 9000
+    brp = (np.arange(K + 1) * 300).astype(np.int32)
+    bci = np.concatenate([np.sort(rng.choice(N, 300, replace=False)) for _ in range(K)]).astype(np.int32)
+    bva = rng.uniform(0, 1, brp[-1])
+    arp = np.array([0, 1500, 1503, 1503], np.int32)
+    aci = np.concatenate([np.sort(rng.choice(K, 1500, replace=False)), [3, 7, 9]]).astype(np.int32)
+    ava = rng.uniform(0, 1, arp[-1])
+    c = _check(oracle, (arp, aci, ava), (brp, bci, bva), 3, K, N)
+    assert np.diff(c.to_host()[0])[0] > 8000
+
+
+def test_spgemm_power_law_square(oracle):
+    rp, ci, va = power_law_csr(6000, 6000, 23, 1500)
+    _check(oracle, (rp, ci, va), (rp, ci, va), 6000, 6000, 6000)
+
+
+def test_spgemm_raw_pointer_host_call(oracle, g4s):
+    """The mkl(...)-shaped entry point (mm/inc/mkl_mult.h:40-43): host arrays in, callee-allocated host arrays out, 7 stage timings."""
+    from g4s_amd import capi
+    A = random_csr(500, 400, 0.02, 31)
+    B = random_csr(400, 450, 0.02, 32)
+    crpt, ccol, cval = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    cnnz = C.c_int64()
+    t = capi.Timings()
+    p = lambda a: a.ctypes.data
+    capi.check(g4s.g4s_spgemm_csr_i32_f64(p(A[0]), p(A[1]), p(A[2]), p(B[0]), p(B[1]), p(B[2]), C.byref(crpt), C.byref(ccol), C.byref(cval),
+                                          500, 400, 450, C.byref(cnnz), C.byref(t), capi.SORT_OUTPUT))
+    orpt, ocol, oval = oracle.spgemm(A, B, 450)
+    n = cnnz.value
+    assert n == orpt[-1]
+    got_rpt = np.ctypeslib.as_array(C.cast(crpt, C.POINTER(C.c_int32)), (501,)).copy()
+    got_col = np.ctypeslib.as_array(C.cast(ccol, C.POINTER(C.c_int32)), (n,)).copy()
+    got_val = np.ctypeslib.as_array(C.cast(cval, C.POINTER(C.c_double)), (n,)).copy()
+    for ptr in (crpt, ccol, cval):
+        g4s.g4s_free(ptr)                                   # allocator pairing (utility.h:126-153)
+    assert np.array_equal(got_rpt, orpt) and np.array_equal(got_col, ocol) and np.allclose(got_val, oval, rtol=1e-12, atol=1e-13)
+    assert t.total >= t.spmm > 0 and t.create > 0 and t.export_csr > 0
+    # flop, host-pointer form
+    flop = C.c_int64()
+    capi.check(g4s.g4s_spgemm_flop(500, p(A[0]), p(A[1]), p(B[0]), C.byref(flop), None, 0))
+    assert flop.value == oracle.flop(A[0], A[1], B[0])
+
+
+def test_spgemm_rejects_bad_ids(g4s):
+    from g4s_amd import capi, host
+    A = host.CSR.from_host(np.array([0, 1], np.int32), np.array([5], np.int32), np.ones(1), 1, 6)
+    B = host.CSR.from_host(np.array([0, 1, 1], np.int32), np.array([0], np.int32), np.ones(1), 2, 2)   # only 2 rows: A's column 5 is out of range
+    crpt = torch.empty(2, dtype=torch.int32, device="cuda")
+    cnnz = C.c_int64()
+    st = g4s.g4s_spgemm_symbolic(1, 2, 2, A.rowptr.data_ptr(), A.colids.data_ptr(), B.rowptr.data_ptr(), B.colids.data_ptr(), crpt.data_ptr(),
+                                 C.byref(cnnz), None)
+    assert st == capi.ERR_INVALID
+
+
+def test_spgemm_full_size_properties():
+    """BASELINE config 3: R-MAT scale 21 (n = 2 097 152), C = A·A. Edge factor 2 here (nnz(C) ≈ 0.96e9; EF 3 gives 1.94e9, the
+    largest that still fits the reference's int32 row pointer; EF 8 gives 9.56e9 and must be refused). Size-independent checks:
+    (A·A)·x == A·(A·x), rows strictly sorted, crpt consistent, integer part reproducible."""
+    import ctypes as C
+    from g4s_amd import capi, host
+    n = 1 << 21
+    A8 = host.rmat_csr(n, 21, 8 * n, 20240522)
+    crpt = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    cnnz = C.c_int64()
+    st = capi.load().g4s_spgemm_symbolic(n, n, n, A8.rowptr.data_ptr(), A8.colids.data_ptr(), A8.rowptr.data_ptr(), A8.colids.data_ptr(),
+                                         crpt.data_ptr(), C.byref(cnnz), None)
+    assert st == capi.ERR_OVERFLOW and cnnz.value > 2 ** 31      # int32 crpt of the reference (define.h:14) cannot hold it
+    del A8, crpt
+    A = host.rmat_csr(n, 21, 2 * n, 20240522)
+    A.values.abs_()                                            # values U(0,1): no cancellation in the check
+    Cm = host.HashSpGEMM(A, A)
+    assert Cm.rows == n and Cm.nnz == int(Cm.rowptr[-1].item()) and int(Cm.rowptr[0].item()) == 0
+    assert bool(torch.all(Cm.rowptr[1:] >= Cm.rowptr[:-1]))
+    # strictly ascending columns inside every row
+    d = Cm.colids[1:].long() - Cm.colids[:-1].long()
+    row_start = torch.zeros(Cm.nnz, dtype=torch.bool, device="cuda")
+    starts = Cm.rowptr[:-1][(Cm.rowptr[1:] > Cm.rowptr[:-1])].long()
+    row_start[starts] = True
+    assert bool(torch.all((d > 0) | row_start[1:]))
+    x = host.synth_vector(3, n).abs_()
+    lhs = Cm.spmv(x)
+    rhs = A.spmv(A.spmv(x))
+    assert bool(torch.all((lhs - rhs).abs() <= 1e-10 * rhs.abs() + 1e-300))
+    flop = host.get_flop(A, A)
+    assert flop >= Cm.nnz
+    C2 = host.HashSpGEMM(A, A)
+    assert torch.equal(C2.rowptr, Cm.rowptr) and torch.equal(C2.colids, Cm.colids)
+    print(f"RMAT-21 A·A: nnz(A)={A.nnz} flop={flop} nnz(C)={Cm.nnz} compression={flop / Cm.nnz:.2f}")
