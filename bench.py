@@ -59,7 +59,7 @@ def host_threads():
     return max(1, min(n, int(os.environ.get("G4S_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(A, x, budget_s=12.0):
+def cpu_baseline(A, x, budget_s=16.0):
     """The oracle's SpMV (oracle/g4s_oracle.c, 'port') timed on this box's host cores on the same matrix. Reported, not a target."""
     import numpy as np
     from tests import oracle_lib
@@ -76,7 +76,7 @@ def cpu_baseline(A, x, budget_s=12.0):
             o.spmv_mt(rp, ci, va, xh, y, threads)
             passes += 1
             el = time.perf_counter() - t0
-            if el > budget_s / 2 or passes >= 20:
+            if el > budget_s / 2 or passes >= 400:
                 break
         out[threads] = (A.nnz * passes / el / 1e9, passes, el)
     v, passes, el = out[cores]
@@ -96,6 +96,10 @@ def main():
     ap.add_argument("--small", action="store_true", help="reduced sizes for plumbing checks (not a valid benchmark)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nt", action="store_true", help="plain loads for the matrix stream (A/B against nontemporal)")
+    ap.add_argument("--path", default="auto", choices=["auto", "stream", "blocked"],
+                    help="SpMV path: auto = the library's locality probe picks (row-streaming CSR kernel, or the propagation-blocked path)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + G4S_BENCH_SAME_DEVICE=1 rehearses the N>1 path with all ranks on cuda:0 (plumbing check only)")
     args = ap.parse_args()
 
     import torch
@@ -110,16 +114,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
+    if os.environ.get("G4S_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     # ---- inputs, resident in HBM
     A_full = build_matrix(args.workload, host, args.small)
     n_rows, n_cols, nnz_total = A_full.rows, A_full.cols, A_full.nnz
     offs = gdist.row_partition(A_full.rowptr, world)
     r0, r1 = offs[rank], offs[rank + 1]
-    flags = capi.SPMV_NO_NT if args.no_nt else 0
+    flags = (capi.SPMV_NO_NT if args.no_nt else 0) | {"auto": 0, "stream": capi.SPMV_STREAM, "blocked": capi.SPMV_BLOCKED}[args.path]
     if world > 1:
         rp, ci, va = gdist.slice_rows(A_full.rowptr, A_full.colids, A_full.values, r0, r1)
         A = host.CSR(rp, ci, va, r1 - r0, n_cols, spmv_flags=flags)
@@ -161,9 +170,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    # ---- roofline of the dominant kernel (spmv_csr_adaptive_kernel): HIP events on the launch stream around back-to-back launches.
-    # At N=1 the timed region above IS that (a step is one launch of it, plus the few-µs long-row fixup); at N>1 it is re-measured
-    # without the exchange, outside the timed region.
+    # ---- roofline of the SpMV launch: HIP events on the launch stream around back-to-back launches. One launch of the hot path is
+    # spmv_csr_adaptive_kernel (+ the few-µs long-row fixup) on the streaming path, or pb_producer_kernel + pb_consumer_kernel on
+    # the blocked path (their durations add up to kernel_ms; profiles/ holds the rocprofv3 split). At N=1 the timed region above
+    # IS that; at N>1 it is re-measured without the exchange, outside the timed region.
     if world == 1:
         kernel_ms = ev0.elapsed_time(ev1) / args.steps
     else:
@@ -198,11 +208,14 @@ def main():
                    "rows": n_rows, "cols": n_cols, "nnz": nnz_total, "index": "int32",
                    "partition": f"1-D rows by equal nnz+rows over {world} rank(s)",
                    "exchange": ("none (single GPU)" if world == 1 else f"{args.exchange} over RCCL, {exchange.recv_bytes} B received per rank 0 step"),
-                   "matrix_loads": "plain" if args.no_nt else "nontemporal"},
+                   "matrix_loads": "plain" if args.no_nt else "nontemporal",
+                   "spmv_path": "blocked" if info["spmv_path"] == 1 else "stream",
+                   **({"backend": "gloo (rehearsal, not a valid multi-GPU number)"} if args.backend != "nccl" else {})},
         "hbm_gbs_algorithmic_whole_job": round((12 * nnz_total + 4 * (n_rows + 1) + 8 * n_rows + 8 * n_cols) * args.steps / elapsed / 1e9, 2),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "spmv_csr_adaptive_kernel", "kernel_ms": round(kernel_ms, 5),
+                     "kernel": ("pb_producer_kernel+pb_consumer_kernel (propagation-blocked SpMV)" if info["spmv_path"] == 1
+                                else "spmv_csr_adaptive_kernel"), "kernel_ms": round(kernel_ms, 5),
                      "algorithmic_bytes_per_launch": info["algorithmic_bytes"],
                      "launch_rows": info["rows"], "launch_nnz": info["nnz"]},
     }

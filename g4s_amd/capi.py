@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libg4s_hip.so")
 
 OK, ERR_INVALID, ERR_NOMEM, ERR_HIP, ERR_OVERFLOW, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
-HOST_POINTERS, DEVICE_POINTERS, SORT_OUTPUT, SPMV_NO_NT = 0, 1, 2, 4
+HOST_POINTERS, DEVICE_POINTERS, SORT_OUTPUT, SPMV_NO_NT, SPMV_BLOCKED, SPMV_STREAM = 0, 1, 2, 4, 8, 16
 PATTERN_ELEMENT_BLOCK_MATVEC, PATTERN_DENSE_ROW_TIMES_MATRIX, PATTERN_SYM_QUADRATIC_FORM = 1, 2, 3
 
 i32p = C.POINTER(C.c_int32)
@@ -26,7 +26,7 @@ class CsrInfo(C.Structure):
     _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("nnz", C.c_int64),
                 ("stream_blocks", C.c_int32), ("long_rows", C.c_int32), ("long_chunks", C.c_int32),
                 ("tile_nnz", C.c_int32), ("tile_rows", C.c_int32), ("long_chunk_nnz", C.c_int32),
-                ("algorithmic_bytes", C.c_int64), ("plan_bytes", C.c_int64)]
+                ("algorithmic_bytes", C.c_int64), ("plan_bytes", C.c_int64), ("spmv_path", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Timings(C.Structure):

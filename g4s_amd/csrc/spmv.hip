@@ -16,6 +16,7 @@
 // Stream blocks are dealt to the 8 XCDs in contiguous runs (blockIdx%8 selects the run) so that neighbouring row
 // blocks, which touch neighbouring parts of x on banded/stencil matrices, share one L2.
 #include "common.hpp"
+#include "spmv_pb.hpp"
 #include <vector>
 
 namespace {
@@ -175,6 +176,7 @@ struct g4s_csr_s {
     int n_long = 0;
     double *d_partials = nullptr;
     int64_t plan_bytes = 0;
+    g4s::PbPlan *pb = nullptr;      // propagation-blocked path (spmv_pb.hip) for matrices without gather locality
 };
 
 namespace {
@@ -250,6 +252,7 @@ void release(g4s_csr_s *A)
     (void)hipFree(A->d_chunks);
     (void)hipFree(A->d_long_rows);
     (void)hipFree(A->d_partials);
+    g4s::pb_destroy(A->pb);
     delete A;
 }
 
@@ -315,6 +318,13 @@ G4S_API g4s_status g4s_csr_create(g4s_csr_t *out, int32_t rows, int32_t cols, in
         if (e != hipSuccess) return fail(g4s::set_error(G4S_ERR_HIP, "g4s_csr_create: column check failed: %s", hipGetErrorString(e)));
         if (h_flag) return fail(g4s::set_error(G4S_ERR_INVALID, "g4s_csr_create: a column index is outside [0, cols)"));
     }
+    // Path choice: the row-streaming kernel unless the x gathers have no locality (or the caller forces one).
+    const bool want_pb = (flags & G4S_SPMV_BLOCKED) || (!(flags & G4S_SPMV_STREAM) && g4s::pb_should_use(rows, cols, nnz, A->d_colids));
+    if (want_pb && nnz > 0) {
+        st = g4s::pb_build(&A->pb, rows, cols, nnz, A->d_rowptr, A->d_colids, A->d_values);
+        if (st != G4S_OK && (flags & G4S_SPMV_BLOCKED)) return fail(st);   // auto mode falls back to the streaming path
+        A->plan_bytes += g4s::pb_bytes(A->pb);
+    }
     *out = A;
     return G4S_OK;
 }
@@ -333,6 +343,7 @@ G4S_API g4s_status g4s_csr_get_info(g4s_csr_t A, g4s_csr_info *info)
     info->tile_nnz = TILE_NNZ; info->tile_rows = TILE_ROWS; info->long_chunk_nnz = LONG_CHUNK;
     info->algorithmic_bytes = 12 * A->nnz + 4 * ((int64_t)A->rows + 1) + 8 * (int64_t)A->rows + 8 * (int64_t)A->cols;
     info->plan_bytes = A->plan_bytes;
+    info->spmv_path = A->pb ? 1 : 0;
     return G4S_OK;
 }
 
@@ -353,6 +364,7 @@ G4S_API g4s_status g4s_spmv(g4s_csr_t A, const double *x_dev, double *y_dev, dou
     G4S_REQUIRE(x_dev || A->nnz == 0, "x is NULL");
     G4S_REQUIRE((const void *)x_dev != (const void *)y_dev, "x and y must not alias");
     hipStream_t s = g4s::as_stream(stream);
+    if (A->pb) return g4s::pb_spmv(A->pb, x_dev, y_dev, alpha, beta, s);
     const int grid = A->chunks_pad + A->stream_per_xcd * g4s::kXcds;
     if (grid > 0) {
         if (A->use_nt)

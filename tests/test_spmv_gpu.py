@@ -154,6 +154,45 @@ def test_spmv_full_size_properties():
     rowsum.index_add_(0, rows, A.values)
     abs_rowsum = Aabs.spmv(ones)
     assert torch.all((A.spmv(ones) - rowsum).abs() <= 1e-10 * abs_rowsum + 1e-300)
-    assert torch.equal(A.spmv(x), yx)
+    assert torch.all((A.spmv(x) - yx).abs() <= 1e-10 * Aabs.spmv(x.abs()) + 1e-300)   # blocked path: LDS atomics, last bits may differ
     inf = A.info()
     assert inf["algorithmic_bytes"] == 12 * A.nnz + 4 * (n + 1) + 16 * n
+
+
+@pytest.mark.parametrize("kind", ["random", "powerlaw", "lap5", "tiny", "wide"])
+def test_spmv_blocked_path(oracle, kind):
+    """The propagation-blocked path (G4S_SPMV_BLOCKED): same parity bar as the streaming path. Matrices larger than one 16K band
+    in both directions, with empty rows, hubs, alpha/beta, and rows/cols that are not multiples of the band."""
+    from g4s_amd import capi, host
+    if kind == "random":
+        rows, cols = 40000, 50000
+        rp, ci, va = random_csr(rows, cols, 0.0004, 3, empty_rows=[0, 17000, 39999])
+    elif kind == "powerlaw":
+        rows = cols = 70000
+        rp, ci, va = power_law_csr(rows, cols, 29, 30000)
+    elif kind == "lap5":
+        rows = cols = 200 * 150
+        rp, ci, va = oracle.laplacian5(200, 150)
+    elif kind == "tiny":
+        rows, cols = 3, 5
+        rp, ci, va = random_csr(rows, cols, 0.8, 1)
+    else:
+        rows, cols = 100, 100000
+        rp, ci, va = random_csr(rows, cols, 0.01, 5)
+    A = host.CSR.from_host(rp, ci, va, rows, cols, spmv_flags=capi.SPMV_BLOCKED)
+    assert A.info()["spmv_path"] == 1
+    x = np.random.default_rng(2).uniform(-1, 1, cols)
+    _check(oracle, A, rp, ci, va, x)
+    _check(oracle, A, rp, ci, va, x, alpha=-1.5, beta=0.25, y0=np.random.default_rng(3).uniform(-1, 1, rows))
+    yn = A.spmv(torch.from_numpy(x).cuda(), torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda"))
+    assert not torch.isnan(yn).any()                                   # beta == 0 never reads y
+    S = host.CSR.from_host(rp, ci, va, rows, cols, spmv_flags=capi.SPMV_STREAM)
+    assert S.info()["spmv_path"] == 0
+
+
+def test_spmv_path_selection():
+    from g4s_amd import host
+    # banded 10M: gathers are local → streaming path; R-MAT 10M: no locality → blocked path
+    assert host.banded_csr(6_000_000, 5, 1).info()["spmv_path"] == 0
+    A = host.rmat_csr(6_000_000, 23, 30_000_000, 5)
+    assert A.info()["spmv_path"] == 1

@@ -13,7 +13,10 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
     with open(f) as fh:
         for row in csv.DictReader(fh):
             k = row["Kernel_Name"]
-            short = "spmv_csr_adaptive" if "spmv_csr_adaptive" in k else ("spmv_long_fixup" if "long_fixup" in k else None)
+            short = None
+            for key in ("spmv_csr_adaptive", "spmv_long_fixup", "pb_producer", "pb_consumer", "pb_scale_rows"):
+                if key in k:
+                    short = key
             if short is None:
                 for key in ("spgemm", "elem_", "dense_rows"):
                     if key in k:
