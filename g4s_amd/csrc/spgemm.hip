@@ -91,13 +91,16 @@ __global__ void check_range_kernel(const int *__restrict__ ids, long long n, int
 }
 
 // ------------------------------------------------------------------------------------------------ row classes
-enum { CLS_EMPTY = 0, CLS_TINY, CLS_SMALL, CLS_MEDIUM, CLS_LARGE, CLS_HUB, CLS_COUNT };
+enum { CLS_EMPTY = 0, CLS_TINY, CLS_SMALL, CLS_MEDIUM, CLS_LARGE, CLS_M2, CLS_M3, CLS_HUB, CLS_COUNT };
 
-struct ClassLimits { long long tiny, small_, medium, large; };
-// symbolic: by the flop upper bound u = min(flop, cols); tables are keys only
-constexpr ClassLimits kSymLimits{32, 512, 8192, 393216};   // large = optimistic 32K-slot table unless flop is hopeless (16 × 24576)
-// numeric: by the exact nz of the output row; tables hold keys + fp64
-constexpr ClassLimits kNumLimits{32, 512, 4096, 4096};     // > 4096 → hub (bitmap-rank)
+// Class i (1..6) takes a row whose size is <= lim[i-1]; sizes are the flop bound clipped at cols (BIN.h:164), except where
+// raw[i-1] is set (the unclipped bound decides). Beyond the last limit: hub.
+struct ClassLimits { long long lim[6]; int raw[6]; };
+// symbolic: tables are keys only. TINY 64 slots, SMALL 1 K, MEDIUM 16 K, LARGE = optimistic 32 K-slot table — a failed attempt costs
+// more than the bitmap path, so only rows whose raw bound is within 4/3 of the table's 24 K-entry limit try it.
+constexpr ClassLimits kSymLimits{{32, 512, 8192, 32768, -1, -1}, {0, 0, 0, 1, 0, 0}};
+// numeric: by the exact nz of the output row; tables hold keys + fp64 at <= 50 % fill: TINY 64, SMALL 1 K, MEDIUM 2 K, LARGE 4 K, M2 8 K slots.
+constexpr ClassLimits kNumLimits{{32, 512, 1024, 2048, 4096, -1}, {0, 0, 0, 0, 0, 0}};
 
 __global__ void classify_kernel(int M, const long long *__restrict__ size, ClassLimits lim, int cols_clip,
                                 int *__restrict__ cls, int *__restrict__ hist)
@@ -112,11 +115,10 @@ __global__ void classify_kernel(int M, const long long *__restrict__ size, Class
         if (u == 0) c = CLS_EMPTY;
         else {
             const long long uc = (cols_clip > 0 && u > cols_clip) ? cols_clip : u; // BIN.h:164 clips the bound at cols
-            if (uc <= lim.tiny) c = CLS_TINY;
-            else if (uc <= lim.small_) c = CLS_SMALL;
-            else if (uc <= lim.medium) c = CLS_MEDIUM;
-            else if (u <= lim.large) c = CLS_LARGE;
-            else c = CLS_HUB;
+            c = CLS_HUB;
+#pragma unroll
+            for (int i = 5; i >= 0; --i)
+                if ((lim.raw[i] ? u : uc) <= lim.lim[i]) c = CLS_TINY + i;
         }
         cls[i] = c;
         atomicAdd(&s_hist[c], 1);
@@ -157,60 +159,76 @@ __global__ void nz_to_ll_kernel(int M, const int *__restrict__ crpt, long long *
 template <int TABLE>
 __device__ __forceinline__ int hash_of(int key) { return (key * kHashScal) & (TABLE - 1); }
 
-template <int WGSIZE, int THREADS, int TABLE, int GROUP, bool OPTIMISTIC>
+// Lanes per A-entry: the smallest power of two >= the row's average B-row length (flop_i / nnz(A_i)), at most 64 and at most
+// the cooperating thread count. Short B rows (the common case in a power-law graph) then keep many A-entries — i.e. many
+// independent acol → brpt → bcol load chains — in flight; long B rows still get coalesced 64-lane reads.
+__device__ __forceinline__ int group_shift(long long flop, int nnz_a, int threads)
+{
+    if (nnz_a <= 0) return 0;
+    const long long avg = (flop + nnz_a - 1) / nnz_a;
+    int g = 0;
+    while ((1 << g) < avg && g < 6 && (2 << g) <= threads) ++g;
+    return g;
+}
+
+template <int WGSIZE, int THREADS, int TABLE, bool OPTIMISTIC>
 __global__ __launch_bounds__(WGSIZE) void spgemm_symbolic_lds_kernel(
     const int *__restrict__ rows, int nrows, const int *__restrict__ arpt, const int *__restrict__ acol,
-    const int *__restrict__ brpt, const int *__restrict__ bcol, int *__restrict__ row_nz,
+    const int *__restrict__ brpt, const int *__restrict__ bcol, const long long *__restrict__ row_flop, int *__restrict__ row_nz,
     int *__restrict__ overflow_rows, int *__restrict__ overflow_count)
 {
     extern __shared__ int lds_i[];
     constexpr int RPB = WGSIZE / THREADS;           // rows per workgroup
-    constexpr int LIMIT = TABLE / 4 * 3;            // optimistic tables give up at 75 % fill
-    __shared__ int s_cnt[RPB];
+    constexpr int LIMIT = TABLE / 4 * 3;            // optimistic tables give up beyond 75 % fill …
+    constexpr int MAX_PROBES = OPTIMISTIC ? 512 : TABLE;   // … which shows up as long probe sequences well before the table is full
+    __shared__ int s_cnt[RPB], s_ovf[RPB];
     const int sub = threadIdx.x / THREADS, t = threadIdx.x % THREADS;
     const int ridx = blockIdx.x * RPB + sub;
     const int row = ridx < nrows ? rows[ridx] : -1;
     int *T = lds_i + sub * TABLE;
     for (int s = t; s < TABLE; s += THREADS) T[s] = kEmpty;
-    if (t == 0) s_cnt[sub] = 0;
+    if (t == 0) { s_cnt[sub] = 0; s_ovf[sub] = 0; }
     __syncthreads();
     if (row >= 0) {
         const int a0 = arpt[row], a1 = arpt[row + 1];
+        const int gs = group_shift(row_flop[row], a1 - a0, THREADS), gmask = (1 << gs) - 1;
         int cnt = 0;
-        for (int j = a0 + t / GROUP; j < a1; j += THREADS / GROUP) {
-            if (OPTIMISTIC && lds_peek(&s_cnt[sub]) > LIMIT) break;
+        bool stop = false;
+        for (int j = a0 + (t >> gs); j < a1 && !stop; j += THREADS >> gs) {
             const int c = acol[j];
-            for (int k = brpt[c] + t % GROUP; k < brpt[c + 1]; k += GROUP) {
+            for (int k = brpt[c] + (t & gmask); k < brpt[c + 1]; k += gmask + 1) {
                 const int key = bcol[k];
                 int h = hash_of<TABLE>(key);
-                for (int probes = 0;; ++probes) {
+                int probes = 0;
+                for (;; ++probes) {
                     const int old = atomicCAS(&T[h], kEmpty, key);
                     if (old == kEmpty) {
-                        if (OPTIMISTIC) atomicAdd(&s_cnt[sub], 1); else cnt++;
+                        cnt++;
+                        if (OPTIMISTIC && (cnt & 3) == 0) atomicAdd(&s_cnt[sub], 4);   // shared fill level, 4 inserts at a time
                         break;
                     }
                     if (old == key) break;
                     h = (h + 1) & (TABLE - 1);
-                    if (probes >= TABLE) break;                                        // cannot happen for a correctly sized table; never spin
-                    if (OPTIMISTIC && (probes & 63) == 63 && lds_peek(&s_cnt[sub]) > LIMIT) break;
+                    if (probes >= MAX_PROBES) break;               // never spin: sized tables cannot fill, optimistic ones give up
                 }
-                if (OPTIMISTIC && lds_peek(&s_cnt[sub]) > LIMIT) break;
+                if (OPTIMISTIC && (probes >= MAX_PROBES || lds_peek(&s_cnt[sub]) > LIMIT)) { s_ovf[sub] = 1; stop = true; break; }
             }
+            if (OPTIMISTIC && lds_peek(&s_ovf[sub])) stop = true;
         }
-        if (!OPTIMISTIC) atomicAdd(&s_cnt[sub], cnt);
+        atomicAdd(&s_cnt[sub], OPTIMISTIC ? (cnt & 3) : cnt);
     }
     __syncthreads();
     if (row >= 0 && t == 0) {
         const int total = s_cnt[sub];
-        if (OPTIMISTIC && total > LIMIT) overflow_rows[atomicAdd(overflow_count, 1)] = row;
+        if (OPTIMISTIC && (s_ovf[sub] || total > LIMIT)) overflow_rows[atomicAdd(overflow_count, 1)] = row;
         else row_nz[row] = total;
     }
 }
 
-template <int WGSIZE, int THREADS, int TABLE, int GROUP>
+template <int WGSIZE, int THREADS, int TABLE>
 __global__ __launch_bounds__(WGSIZE) void spgemm_numeric_lds_kernel(
     const int *__restrict__ rows, int nrows, const int *__restrict__ arpt, const int *__restrict__ acol, const double *__restrict__ aval,
-    const int *__restrict__ brpt, const int *__restrict__ bcol, const double *__restrict__ bval,
+    const int *__restrict__ brpt, const int *__restrict__ bcol, const double *__restrict__ bval, const long long *__restrict__ row_flop,
     const int *__restrict__ crpt, int *__restrict__ ccol, double *__restrict__ cval)
 {
     extern __shared__ int lds_i[];
@@ -225,10 +243,11 @@ __global__ __launch_bounds__(WGSIZE) void spgemm_numeric_lds_kernel(
     __syncthreads();
     if (row >= 0) {
         const int a0 = arpt[row], a1 = arpt[row + 1];
-        for (int j = a0 + t / GROUP; j < a1; j += THREADS / GROUP) {
+        const int gs = group_shift(row_flop[row], a1 - a0, THREADS), gmask = (1 << gs) - 1;
+        for (int j = a0 + (t >> gs); j < a1; j += THREADS >> gs) {
             const int c = acol[j];
             const double av = aval[j];
-            for (int k = brpt[c] + t % GROUP; k < brpt[c + 1]; k += GROUP) {
+            for (int k = brpt[c] + (t & gmask); k < brpt[c + 1]; k += gmask + 1) {
                 const int key = bcol[k];
                 const double tv = av * bval[k];                 // multop, hash_mult.h:583
                 int h = hash_of<TABLE>(key);
@@ -593,28 +612,31 @@ G4S_API g4s_status g4s_spgemm_symbolic(int32_t M, int32_t K, int32_t N,
 
     RowClasses rc;
     G4S_TRY(classify_rows(M, row_flop.as<long long>(), kSymLimits, N, rc, s));
+    if (getenv("G4S_DEBUG"))
+        fprintf(stderr, "g4s symbolic classes: empty %d tiny %d small %d medium %d large %d hub %d (flop %lld)\n", rc.count[CLS_EMPTY], rc.count[CLS_TINY],
+                rc.count[CLS_SMALL], rc.count[CLS_MEDIUM], rc.count[CLS_LARGE], rc.count[CLS_HUB], (long long)flop);
     G4S_TRY(ovf_rows.alloc(sizeof(int) * (size_t)std::max(1, rc.count[CLS_LARGE])));
     G4S_TRY(ovf_count.alloc(sizeof(int)));
     G4S_HIP_TRY(hipMemsetAsync(ovf_count.p, 0, sizeof(int), s));
     int *nz = row_nz.as<int>();
 
     if (int n = rc.count[CLS_TINY]) {
-        auto k = spgemm_symbolic_lds_kernel<256, 64, 64, 8, false>;
-        hipLaunchKernelGGL(k, dim3((n + 3) / 4), dim3(256), 4 * 64 * sizeof(int), s, rc.list(CLS_TINY), n, arpt, acol, brpt, bcol, nz, nullptr, nullptr);
+        auto k = spgemm_symbolic_lds_kernel<256, 64, 64, false>;
+        hipLaunchKernelGGL(k, dim3((n + 3) / 4), dim3(256), 4 * 64 * sizeof(int), s, rc.list(CLS_TINY), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr);
     }
     if (int n = rc.count[CLS_SMALL]) {
-        auto k = spgemm_symbolic_lds_kernel<256, 256, 1024, 16, false>;
-        hipLaunchKernelGGL(k, dim3(n), dim3(256), 1024 * sizeof(int), s, rc.list(CLS_SMALL), n, arpt, acol, brpt, bcol, nz, nullptr, nullptr);
+        auto k = spgemm_symbolic_lds_kernel<256, 256, 1024, false>;
+        hipLaunchKernelGGL(k, dim3(n), dim3(256), 1024 * sizeof(int), s, rc.list(CLS_SMALL), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr);
     }
     if (int n = rc.count[CLS_MEDIUM]) {
-        auto k = spgemm_symbolic_lds_kernel<256, 256, 16384, 16, false>;
+        auto k = spgemm_symbolic_lds_kernel<256, 256, 16384, false>;
         G4S_TRY(allow_lds(k, 16384 * sizeof(int)));
-        hipLaunchKernelGGL(k, dim3(n), dim3(256), 16384 * sizeof(int), s, rc.list(CLS_MEDIUM), n, arpt, acol, brpt, bcol, nz, nullptr, nullptr);
+        hipLaunchKernelGGL(k, dim3(n), dim3(256), 16384 * sizeof(int), s, rc.list(CLS_MEDIUM), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr);
     }
     if (int n = rc.count[CLS_LARGE]) {
-        auto k = spgemm_symbolic_lds_kernel<1024, 1024, 32768, 32, true>;
+        auto k = spgemm_symbolic_lds_kernel<1024, 1024, 32768, true>;
         G4S_TRY(allow_lds(k, 32768 * sizeof(int)));
-        hipLaunchKernelGGL(k, dim3(n), dim3(1024), 32768 * sizeof(int), s, rc.list(CLS_LARGE), n, arpt, acol, brpt, bcol, nz, ovf_rows.as<int>(),
+        hipLaunchKernelGGL(k, dim3(n), dim3(1024), 32768 * sizeof(int), s, rc.list(CLS_LARGE), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, ovf_rows.as<int>(),
                            ovf_count.as<int>());
     }
     G4S_HIP_TRY(hipGetLastError());
@@ -623,6 +645,7 @@ G4S_API g4s_status g4s_spgemm_symbolic(int32_t M, int32_t K, int32_t N,
     int n_ovf = 0;
     G4S_HIP_TRY(hipMemcpyAsync(&n_ovf, ovf_count.p, sizeof(int), hipMemcpyDeviceToHost, s));
     G4S_HIP_TRY(hipStreamSynchronize(s));
+    if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s symbolic: %d optimistic tables overflowed\n", n_ovf);
     std::vector<int> hub, hub2, ranges, ranges2;
     G4S_TRY(fetch_rows_and_ranges(rc.list(CLS_HUB), rc.count[CLS_HUB], arpt, hub, ranges, s));
     G4S_TRY(fetch_rows_and_ranges(ovf_rows.as<int>(), n_ovf, arpt, hub2, ranges2, s));
@@ -659,31 +682,42 @@ G4S_API g4s_status g4s_spgemm_numeric(int32_t M, int32_t K, int32_t N,
     G4S_REQUIRE(arpt && brpt && crpt, "NULL argument");
     hipStream_t s = g4s::as_stream(stream);
     if (M == 0) return G4S_OK;
-    DevBuf row_size;
+    DevBuf row_size, row_flop;
     G4S_TRY(row_size.alloc(sizeof(long long) * (size_t)M));
+    G4S_TRY(row_flop.alloc(sizeof(long long) * (size_t)M));
+    G4S_TRY(compute_row_flop(M, arpt, acol, brpt, row_flop.as<long long>(), nullptr, s));
     hipLaunchKernelGGL(nz_to_ll_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, crpt, row_size.as<long long>());
     RowClasses rc;
     G4S_TRY(classify_rows(M, row_size.as<long long>(), kNumLimits, 0, rc, s));
+    if (getenv("G4S_DEBUG"))
+        fprintf(stderr, "g4s numeric classes: empty %d <=32 %d <=512 %d <=1024 %d <=2048 %d <=4096 %d hub %d\n", rc.count[CLS_EMPTY], rc.count[CLS_TINY],
+                rc.count[CLS_SMALL], rc.count[CLS_MEDIUM], rc.count[CLS_LARGE], rc.count[CLS_M2], rc.count[CLS_HUB]);
 
     if (int n = rc.count[CLS_TINY]) {
-        auto k = spgemm_numeric_lds_kernel<256, 64, 64, 8>;
-        hipLaunchKernelGGL(k, dim3((n + 3) / 4), dim3(256), 4 * 64 * 12, s, rc.list(CLS_TINY), n, arpt, acol, aval, brpt, bcol, bval, crpt, ccol, cval);
+        auto k = spgemm_numeric_lds_kernel<256, 64, 64>;
+        hipLaunchKernelGGL(k, dim3((n + 3) / 4), dim3(256), 4 * 64 * 12, s, rc.list(CLS_TINY), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
     if (int n = rc.count[CLS_SMALL]) {
-        auto k = spgemm_numeric_lds_kernel<256, 256, 1024, 16>;
-        hipLaunchKernelGGL(k, dim3(n), dim3(256), 1024 * 12, s, rc.list(CLS_SMALL), n, arpt, acol, aval, brpt, bcol, bval, crpt, ccol, cval);
+        auto k = spgemm_numeric_lds_kernel<256, 256, 1024>;
+        hipLaunchKernelGGL(k, dim3(n), dim3(256), 1024 * 12, s, rc.list(CLS_SMALL), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
     if (int n = rc.count[CLS_MEDIUM]) {
-        auto k = spgemm_numeric_lds_kernel<1024, 1024, 8192, 32>;
+        auto k = spgemm_numeric_lds_kernel<256, 256, 2048>;
+        hipLaunchKernelGGL(k, dim3(n), dim3(256), 2048 * 12, s, rc.list(CLS_MEDIUM), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
+    }
+    if (int n = rc.count[CLS_LARGE]) {
+        auto k = spgemm_numeric_lds_kernel<512, 512, 4096>;
+        hipLaunchKernelGGL(k, dim3(n), dim3(512), 4096 * 12, s, rc.list(CLS_LARGE), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
+    }
+    if (int n = rc.count[CLS_M2]) {
+        auto k = spgemm_numeric_lds_kernel<1024, 1024, 8192>;
         G4S_TRY(allow_lds(k, 8192 * 12));
-        hipLaunchKernelGGL(k, dim3(n), dim3(1024), 8192 * 12, s, rc.list(CLS_MEDIUM), n, arpt, acol, aval, brpt, bcol, bval, crpt, ccol, cval);
+        hipLaunchKernelGGL(k, dim3(n), dim3(1024), 8192 * 12, s, rc.list(CLS_M2), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
     G4S_HIP_TRY(hipGetLastError());
     std::vector<int> hub, ranges, hub2, ranges2;
-    G4S_TRY(fetch_rows_and_ranges(rc.list(CLS_LARGE), rc.count[CLS_LARGE], arpt, hub, ranges, s));
-    G4S_TRY(fetch_rows_and_ranges(rc.list(CLS_HUB), rc.count[CLS_HUB], arpt, hub2, ranges2, s));
-    hub.insert(hub.end(), hub2.begin(), hub2.end());
-    ranges.insert(ranges.end(), ranges2.begin(), ranges2.end());
+    G4S_TRY(fetch_rows_and_ranges(rc.list(CLS_HUB), rc.count[CLS_HUB], arpt, hub, ranges, s));
+    (void)hub2; (void)ranges2;
     G4S_TRY(run_hub_rows(true, hub, ranges, N, arpt, acol, aval, brpt, bcol, bval, nullptr, crpt, ccol, cval, s));
     G4S_HIP_TRY(hipStreamSynchronize(s));
     return G4S_OK;

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""SpGEMM benchmark in the reference's protocol (mm/src/mkl_spgemm.cpp:60-85): 1 warm-up + mean of N runs of C = A·A, GFLOPS = 2·flop/t.
+BASELINE configs[2]: R-MAT scale 21 (n = 2 097 152); edge factor 3 is the largest whose nnz(C) fits the reference's int32 crpt.
+usage: python tools/bench_spgemm.py [--ef 3] [--runs 3] [--scale 21]"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from g4s_amd import capi, host  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--ef", type=float, default=3.0)
+ap.add_argument("--scale", type=int, default=21)
+ap.add_argument("--runs", type=int, default=3)
+args = ap.parse_args()
+lib = capi.load()
+n = 1 << args.scale
+A = host.rmat_csr(n, args.scale, int(args.ef * n), 20240522)
+A.values.abs_()
+flop = host.get_flop(A, A)
+crpt = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+cnnz = C.c_int64()
+
+
+def run():
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    capi.check(lib.g4s_spgemm_symbolic(n, n, n, A.rowptr.data_ptr(), A.colids.data_ptr(), A.rowptr.data_ptr(), A.colids.data_ptr(), crpt.data_ptr(),
+                                       C.byref(cnnz), None))
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    ccol = torch.empty(cnnz.value, dtype=torch.int32, device="cuda")
+    cval = torch.empty(cnnz.value, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    capi.check(lib.g4s_spgemm_numeric(n, n, n, A.rowptr.data_ptr(), A.colids.data_ptr(), A.values.data_ptr(), A.rowptr.data_ptr(), A.colids.data_ptr(),
+                                      A.values.data_ptr(), crpt.data_ptr(), ccol.data_ptr(), cval.data_ptr(), capi.DEVICE_POINTERS | capi.SORT_OUTPUT, None))
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    del ccol, cval
+    return (t1 - t0) * 1e3, (t3 - t2) * 1e3
+
+
+run()
+sym, num = zip(*[run() for _ in range(args.runs)])
+s, m = sum(sym) / len(sym), sum(num) / len(num)
+print(json.dumps({"metric": "fp64 SpGEMM A*A GFLOPS (2*flop/t)", "value": round(2 * flop / ((s + m) * 1e-3) / 1e9, 3), "unit": "GFLOPS",
+                  "config": {"workload": f"R-MAT scale {args.scale}, edge factor {args.ef}, C = A*A", "rows": n, "nnz_A": A.nnz, "flop": flop, "nnz_C": cnnz.value,
+                             "compression": round(flop / max(cnnz.value, 1), 3)},
+                  "symbolic_ms": round(s, 2), "numeric_ms": round(m, 2), "runs": args.runs,
+                  "compulsory_bytes": 12 * (2 * A.nnz + cnnz.value), "compulsory_GBps": round(12 * (2 * A.nnz + cnnz.value) / ((s + m) * 1e-3) / 1e9, 1)}))
