@@ -72,6 +72,8 @@ SIGNATURES = {
     "g4s_elem_op_create": (C.c_int, [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp]),
     "g4s_elem_op_destroy": (C.c_int, [vp]),
     "g4s_elem_op_apply": (C.c_int, [vp, vp, vp, vp]),
+    "g4s_elem_op_inverse_diagonal": (C.c_int, [vp, vp, vp]),
+    "g4s_conj_grad": (C.c_int, [vp, vp, C.c_int32, vp, vp, C.c_int32, vp, vp, C.c_double, C.POINTER(C.c_int32), f64p, vp]),
     "g4s_dense_rows_times_matrix": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]),
     "g4s_sym_quadratic_form": (C.c_int, [C.c_int32, C.c_int32, vp, vp, vp, vp]),
     # include/g4s_synth.h

@@ -142,6 +142,36 @@ G4S_API g4s_status g4s_elem_op_create(g4s_elem_op_t *out, int32_t numElems, int3
     return G4S_OK;
 }
 
+namespace {
+// diag[eq(node,i)] = Σ over the node's terms of K_e[p·n + p], p = dof·a + i  (build_diagonal_of_K, Element_calculations.c:580-611)
+__global__ void elem_diagonal_kernel(int nno, int npe, int dof, const int *__restrict__ node_ptr, const int *__restrict__ node_terms,
+                                     const int *__restrict__ node_eq, const double *__restrict__ elt_k, double *__restrict__ diag)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nno * dof) return;
+    const int node = idx / dof, i = idx - node * dof, n = npe * dof;
+    double s = 0.0;
+    for (int t = node_ptr[node]; t < node_ptr[node + 1]; ++t) {
+        const int term = node_terms[t], e = term / npe, a = term - e * npe, p = dof * a + i;
+        s += elt_k[(size_t)e * n * n + (size_t)p * n + p];
+    }
+    diag[node_eq[idx]] = s;
+}
+} // namespace
+
+extern "C" g4s_status g4s_elem_op_diagonal_sum(g4s_elem_op_t op, double *diag_dev, void *stream)
+{
+    G4S_REQUIRE(op && diag_dev && (op->elt_k || op->nel == 0), "NULL argument / no element matrices bound");
+    hipStream_t s = g4s::as_stream(stream);
+    if (op->neq) G4S_HIP_TRY(hipMemsetAsync(diag_dev, 0, sizeof(double) * (size_t)op->neq, s));
+    const int total = op->nno * op->dof;
+    if (total) hipLaunchKernelGGL(elem_diagonal_kernel, dim3((total + 255) / 256), dim3(256), 0, s, op->nno, op->npe, op->dof, op->node_ptr.as<int>(),
+                                  op->node_terms.as<int>(), op->node_eq.as<int>(), op->elt_k, diag_dev);
+    G4S_HIP_TRY(hipGetLastError());
+    return G4S_OK;
+}
+int g4s_elem_op_neq(g4s_elem_op_t op) { return op ? op->neq : 0; }
+
 G4S_API g4s_status g4s_elem_op_destroy(g4s_elem_op_t op)
 {
     delete op;

@@ -193,6 +193,20 @@ g4s_status g4s_elem_op_destroy(g4s_elem_op_t op);
  * Element_calculations.c:495-496 is folded in). Deterministic (no atomics). */
 g4s_status g4s_elem_op_apply(g4s_elem_op_t op, const double *u_dev, double *Au_dev, void *stream);
 
+/* BI_dev[eq] = 1 / Σ_e K_e[p·n+p] over the (element, local dof p) pairs that map to eq — build_diagonal_of_K
+ * (citcoms/lib/Element_calculations.c:580-611) followed by the inversion at Construct_arrays.c:469. Equations with a zero
+ * diagonal get 0 (the reference asserts instead). */
+g4s_status g4s_elem_op_inverse_diagonal(g4s_elem_op_t op, double *BI_dev, void *stream);
+
+/* Device-resident Jacobi-preconditioned conjugate gradient with the update order of conj_grad
+ * (citcoms/lib/General_matrix_functions.c:307-424): d0 = 0, r = F; loop while (residual > acc && count < *cycles) || count == 0;
+ * the mat-vec is g4s_elem_op_apply followed by zeroing the boundary rows (assemble_del2_u(..., strip_bcs = 1), the list of
+ * citcoms/lib/BC_util.c:89-102). All vectors stay in HBM; one 8-byte D2H per iteration carries the residual to the host loop.
+ * *cycles: in = iteration cap (vlowstep), out = iterations done. zero_resid_dev may be NULL when n_zero == 0.
+ * Exactly one of op / A selects the operator (element-by-element or assembled CSR). */
+g4s_status g4s_conj_grad(g4s_elem_op_t op, g4s_csr_t A, int32_t neq, const double *BI_dev, const int32_t *zero_resid_dev, int32_t n_zero,
+                         const double *F_dev, double *d0_dev, double acc, int32_t *cycles, double *residual, void *stream);
+
 /* result[M×K] = xx[M×N] · w[N×K], row-major fp64, device pointers (opt_matmul.cc:24-62). */
 g4s_status g4s_dense_rows_times_matrix(int32_t M, int32_t N, int32_t K, const double *xx_dev, const double *w_dev,
                                        double *result_dev, void *stream);

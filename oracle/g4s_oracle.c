@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <ctype.h>
+#include <math.h>
 
 #define ORACLE_API __attribute__((visibility("default")))
 
@@ -529,4 +530,75 @@ ORACLE_API int oracle_spmv_csr_mt(int32_t rows, const int32_t *rowptr, const int
     (void)threads;
     return 1;
 #endif
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * CitcomS Jacobi-preconditioned conjugate gradient around the element mat-vec — conj_grad,
+ * citcoms/lib/General_matrix_functions.c:307-424, single process (global_vdot = plain dot product,
+ * Global_operations.c:534-562 with Skip_neq = 0 and one rank), with the update order of the source:
+ *   r1 = F, d0 = 0; residual = sqrt(r1·r1)
+ *   while ((residual > acc && count < steps) || count == 0):
+ *     z1 = BI∘r1; dotr1z1 = r1·z1; p2 = z1 (first) | z1 + (dotr1z1/dotr0z0)·p1; dotr0z0 = dotr1z1
+ *     Ap = K·p2 with boundary rows zeroed (assemble_del2_u(...,strip_bcs=1), Element_calculations.c:428-509; BC_util.c:89-102)
+ *     dotprod = p2·Ap; alpha = dotprod == 0 ? 1e-3 : dotr1z1/dotprod
+ *     d0 += alpha·p2; r2 = r1 − alpha·Ap; residual = sqrt(r2·r2); rotate (r,z,p); count++
+ *   strip_bcs_from_residual(d0)
+ * BI is the inverse diagonal (build_diagonal_of_K, Element_calculations.c:580-611, inverted at Construct_arrays.c:469).
+ * Returns the final residual; *cycles in: max steps, out: iterations done. res_hist (may be NULL) gets the residual per iteration. */
+ORACLE_API void oracle_element_inverse_diagonal(int32_t nel, int32_t npe, int32_t dof, const int32_t *ien, const int32_t *id,
+                                                const double *elt_k /* contiguous nel·n·n */, double *BI, int32_t neq)
+{
+    const int32_t n = npe * dof;
+    for (int32_t i = 0; i < neq; ++i) BI[i] = 0.0;
+    for (int32_t e = 0; e < nel; ++e)
+        for (int32_t a = 0; a < npe; ++a)
+            for (int32_t d = 0; d < dof; ++d) {
+                int32_t p = a * dof + d;
+                BI[id[ien[e * npe + a] * dof + d]] += elt_k[(size_t)e * n * n + (size_t)p * n + p];
+            }
+    for (int32_t i = 0; i < neq; ++i) BI[i] = 1.0 / BI[i];
+}
+
+ORACLE_API double oracle_conj_grad_elem(int32_t nel, int32_t npe, int32_t dof, const int32_t *ien, const int32_t *id,
+                                        const double *elt_k /* contiguous */, int32_t neq, const double *BI,
+                                        const int32_t *zero_resid, int32_t n_zero, const double *F, double *d0,
+                                        double acc, int32_t *cycles, double *res_hist)
+{
+    const int32_t n = npe * dof;
+    const double **rows = (const double **)malloc(sizeof(double *) * (size_t)(nel > 0 ? nel : 1));
+    for (int32_t e = 0; e < nel; ++e) rows[e] = elt_k + (size_t)e * n * n;
+    double *r1 = malloc(sizeof(double) * neq), *r2 = malloc(sizeof(double) * neq), *z1 = malloc(sizeof(double) * neq);
+    double *p1 = malloc(sizeof(double) * neq), *p2 = malloc(sizeof(double) * neq), *Ap = malloc(sizeof(double) * neq);
+    const int32_t steps = *cycles;
+    double dotr0z0 = 0.0, residual, t = 0.0;
+    for (int32_t i = 0; i < neq; ++i) { r1[i] = F[i]; d0[i] = 0.0; p1[i] = 0.0; }
+    for (int32_t i = 0; i < neq; ++i) t += r1[i] * r1[i];
+    residual = sqrt(t);
+    int32_t count = 0;
+    while ((residual > acc && count < steps) || count == 0) {
+        double dotr1z1 = 0.0, dotprod = 0.0, alpha;
+        for (int32_t i = 0; i < neq; ++i) z1[i] = BI[i] * r1[i];
+        for (int32_t i = 0; i < neq; ++i) dotr1z1 += r1[i] * z1[i];
+        if (count == 0) for (int32_t i = 0; i < neq; ++i) p2[i] = z1[i];
+        else {
+            const double beta = dotr1z1 / dotr0z0;
+            for (int32_t i = 0; i < neq; ++i) p2[i] = z1[i] + beta * p1[i];
+        }
+        dotr0z0 = dotr1z1;
+        oracle_element_matvec(nel, npe, dof, ien, id, rows, 0, p2, Ap, neq);
+        for (int32_t i = 0; i < n_zero; ++i) Ap[zero_resid[i]] = 0.0;
+        for (int32_t i = 0; i < neq; ++i) dotprod += p2[i] * Ap[i];
+        alpha = (dotprod == 0.0) ? 1.0e-3 : dotr1z1 / dotprod;
+        t = 0.0;
+        for (int32_t i = 0; i < neq; ++i) { d0[i] += alpha * p2[i]; r2[i] = r1[i] - alpha * Ap[i]; }
+        for (int32_t i = 0; i < neq; ++i) t += r2[i] * r2[i];
+        residual = sqrt(t);
+        if (res_hist) res_hist[count] = residual;
+        { double *s = r1; r1 = r2; r2 = s; s = p1; p1 = p2; p2 = s; }
+        count++;
+    }
+    *cycles = count;
+    for (int32_t i = 0; i < n_zero; ++i) d0[zero_resid[i]] = 0.0;
+    free(r1); free(r2); free(z1); free(p1); free(p2); free(Ap); free(rows);
+    return residual;
 }

@@ -43,6 +43,10 @@ class Oracle:
         L.oracle_element_matvec.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i32, _i32, vp, C.c_int32, _f64, _f64, C.c_int32]
         L.oracle_dense_rows_times_matrix.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, _f64, _f64]
         L.oracle_sym_quadratic_form.argtypes = [C.c_int32, C.c_int32, _f64, _f64, vp, _f64]
+        L.oracle_element_inverse_diagonal.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i32, _i32, _f64, _f64, C.c_int32]
+        L.oracle_conj_grad_elem.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i32, _i32, _f64, C.c_int32, _f64, vp, C.c_int32, _f64, _f64,
+                                            C.c_double, C.POINTER(C.c_int32), vp]
+        L.oracle_conj_grad_elem.restype = C.c_double
         L.oracle_mix64.argtypes = [C.c_uint64]
         L.oracle_mix64.restype = C.c_uint64
         L.oracle_entry_value.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int64]
@@ -129,6 +133,23 @@ class Oracle:
                                        np.ascontiguousarray(idmap, np.int32).ravel(), C.cast(rows, vp), base,
                                        np.ascontiguousarray(u, np.float64), Au, neq)
         return Au
+
+    def element_inverse_diagonal(self, ien, idmap, elt_k, neq, npe=8, dof=3):
+        BI = np.zeros(neq)
+        self.lib.oracle_element_inverse_diagonal(elt_k.shape[0], npe, dof, np.ascontiguousarray(ien, np.int32).ravel(),
+                                                 np.ascontiguousarray(idmap, np.int32).ravel(), np.ascontiguousarray(elt_k).ravel(), BI, neq)
+        return BI
+
+    def conj_grad_elem(self, ien, idmap, elt_k, neq, BI, zero_resid, F, acc, steps, npe=8, dof=3):
+        d0 = np.zeros(neq)
+        cyc = C.c_int32(steps)
+        hist = np.zeros(max(steps, 1))
+        zr = np.ascontiguousarray(zero_resid, np.int32)
+        res = self.lib.oracle_conj_grad_elem(elt_k.shape[0], npe, dof, np.ascontiguousarray(ien, np.int32).ravel(),
+                                             np.ascontiguousarray(idmap, np.int32).ravel(), np.ascontiguousarray(elt_k).ravel(), neq,
+                                             np.ascontiguousarray(BI), zr.ctypes.data if len(zr) else None, len(zr), np.ascontiguousarray(F), d0,
+                                             acc, C.byref(cyc), hist.ctypes.data)
+        return d0, cyc.value, res, hist[:cyc.value]
 
     def dense_rows_times_matrix(self, xx, w):
         M, N = xx.shape

@@ -266,3 +266,24 @@ def test_golden_fixtures(oracle):
     assert np.array_equal(oracle.dense_rows_times_matrix(d["xx"], d["w"]), d["result"])
     e = np.load(os.path.join(GOLD, "element_matvec.npz"))
     assert np.array_equal(oracle.element_matvec(e["ien"], e["id"], e["elt_k"], e["u"], int(e["neq"])), e["Au"])
+
+
+# ------------------------------------------------------------------ CG around the element mat-vec (conj_grad, General_matrix_functions.c:307-424)
+def test_conj_grad_solves_the_system(oracle):
+    ien, idmap, nno, neq = hex_mesh(4, 3, 3)
+    K = spd_blocks(len(ien), 24, 6)
+    BI = oracle.element_inverse_diagonal(ien, idmap, K, neq)
+    A = np.zeros((neq, neq))
+    for e in range(len(ien)):
+        eq = idmap[ien[e]].ravel()
+        A[np.ix_(eq, eq)] += K[e].reshape(24, 24)
+    assert np.allclose(BI, 1.0 / np.diag(A), rtol=1e-14)
+    bc = np.array(sorted(set(idmap[np.arange(0, nno, 7)].ravel().tolist())), np.int32)      # some boundary equations
+    F = np.random.default_rng(1).uniform(-1, 1, neq)
+    F[bc] = 0.0
+    d0, cycles, res, hist = oracle.conj_grad_elem(ien, idmap, K, neq, BI, bc, F, 1e-8 * np.linalg.norm(F), 250)
+    assert 1 <= cycles < 250 and res <= 1e-8 * np.linalg.norm(F) and np.all(d0[bc] == 0.0)
+    free = np.setdiff1d(np.arange(neq), bc)
+    sol = np.linalg.solve(A[np.ix_(free, free)], F[free])
+    assert np.allclose(d0[free], sol, rtol=1e-6, atol=1e-9)
+    assert np.all(np.diff(np.log(hist + 1e-300))[-3:] < 0)        # converging at the end
