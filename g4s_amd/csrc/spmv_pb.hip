@@ -3,17 +3,19 @@
 // Why: on R-MAT 10M/1e8 the row-streaming CSR kernel (spmv.hip) is bound by the x gather, not by the matrix stream — every
 // 8-byte gather that misses L2 moves a 128-byte line (PMC: 6.1 GB fetched for 1.4 GB of algorithmic bytes; the gathers alone
 // cost 0.89 ms, tools/gather_probe.hip). Blocking turns both random sides into streams:
-//   producer  — nonzeros regrouped by 16K-column band. A workgroup loads that band of x into LDS (128 KiB) and streams
-//               (local column u16, value f64) → product, which it writes to the slot the consumer will read it from.
-//   consumer  — products regrouped by 16K-row band. A workgroup keeps that band of y in LDS, streams (product, local row u16)
-//               and accumulates with LDS fp64 atomics, then writes the band of y once.
-// HBM traffic is ≈28 B per nonzero (10 read + 8 written by the producer, 10 read by the consumer), all of it sequential,
-// instead of ≈62 B per nonzero of 128-byte line fetches.
-// Both orders are stable regroupings of the CSR order, so the cell (column band c, row band r) holds the same entries in the
-// same order on both sides and one per-cell offset (delta[c][r]) maps a producer slot to its consumer slot.
-// The regrouping is built once per matrix (g4s_csr_create) with rocPRIM radix sorts; the values are stored a second time in
-// producer order. Sums are accumulated by LDS atomics: equal to the oracle within the fp64 tolerance, not bit for bit, and the
-// last bits may differ from run to run.
+//   producer  — nonzeros regrouped by 16K-column band. A workgroup loads that band of x into LDS (128 KiB); each thread takes a
+//               span of 8 consecutive entries (local column u16, value f64), multiplies, and sums the products of equal rows
+//               (a "micro-run": same row, same cell, same span) before writing them — on R-MAT only ≈0.55 products per nonzero
+//               leave the producer (tools/cell_hist.py: 0.51 distinct (row, column band) pairs per nonzero).
+//   consumer  — micro-run sums regrouped by 16K-row band. A workgroup keeps that band of y in LDS, streams (sum f64, local row
+//               u16), accumulates with LDS fp64 atomics, and writes the band of y once.
+// HBM traffic ≈ 10.6 B/nonzero read + 4.4 written by the producer and 5.5 read by the consumer, all sequential, instead of
+// ≈62 B/nonzero of 128-byte line fetches.
+// The cell (column band c, row band r) holds its entries in CSR order (a stable regrouping), so the micro-runs of a cell are
+// numbered consecutively on both sides and one per-cell offset maps a producer micro-run to its consumer slot.
+// The regrouping is built once per matrix (g4s_csr_create) with a rocPRIM radix sort and scan; the values are stored a second
+// time in producer order. Sums are accumulated by LDS atomics: equal to the oracle within the fp64 tolerance, not bit for bit,
+// and the last bits may differ from run to run.
 #include "common.hpp"
 #include "spmv_pb.hpp"
 #include <hipcub/hipcub.hpp>
@@ -25,14 +27,17 @@ namespace g4s {
 
 namespace {
 
-#ifndef G4S_PB_BAND_BITS
-#define G4S_PB_BAND_BITS 14
-#endif
-constexpr int kBandBits = G4S_PB_BAND_BITS;
+constexpr int kBandBits = 14;
 constexpr int kBand = 1 << kBandBits;        // 16384 columns / rows per band: 128 KiB of fp64 in LDS
 constexpr int kPbThreads = 1024;
-constexpr int kProducerChunk = 1 << 17;      // entries per producer workgroup (x band load amortised over ≥ 2.3 MiB of stream)
-constexpr int kConsumerChunk = 1 << 17;      // entries per consumer workgroup of a split (heavy) row band
+constexpr int kSpan = 8;                     // consecutive entries per producer thread; cells are padded to a multiple of it
+constexpr int kProducerChunk = 1 << 17;      // entries per producer workgroup (x band load amortised over ≥ 1.3 MiB of stream)
+constexpr int kConsumerChunk = 1 << 17;      // micro-runs per consumer workgroup of a split (heavy) row band
+constexpr unsigned kPadFlag = 0x8000u;       // local-column flag of a pad slot (its product is forced to 0)
+
+typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+typedef unsigned short ushort4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
 
 struct DevBuf {
     void *p = nullptr;
@@ -46,68 +51,36 @@ struct DevBuf {
         bytes = n;
         return G4S_OK;
     }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
-// ---- plan construction kernels
+inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 65536 ? 65536 : g)); }
+
+// ================================================================================================ plan construction kernels
+// key = (column band << bits) | row band; rowid[k] = row of CSR entry k; idx[k] = k
 __global__ void pb_keys_kernel(int rows, long long nnz, const int *__restrict__ rowptr, const int *__restrict__ colids, int band_key_bits,
-                               unsigned *__restrict__ keyP, unsigned *__restrict__ keyC, unsigned *__restrict__ idx)
+                               unsigned *__restrict__ key, int *__restrict__ rowid, unsigned *__restrict__ idx)
 {
     for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long long)gridDim.x * blockDim.x) {
-        // row of entry k: last r with rowptr[r] <= k
-        int lo = 0, hi = rows;
+        int lo = 0, hi = rows;                       // last r with rowptr[r] <= k
         while (hi - lo > 1) {
             const int mid = lo + ((hi - lo) >> 1);
             if (rowptr[mid] <= k) lo = mid; else hi = mid;
         }
-        const unsigned rb = (unsigned)lo >> kBandBits, cb = (unsigned)colids[k] >> kBandBits;
-        keyP[k] = (cb << band_key_bits) | rb;
-        keyC[k] = (rb << band_key_bits) | cb;
+        key[k] = (((unsigned)colids[k] >> kBandBits) << band_key_bits) | ((unsigned)lo >> kBandBits);
+        rowid[k] = lo;
         idx[k] = (unsigned)k;
     }
 }
 
-// Padded layout: every band segment starts at a multiple of 4 entries and every cell at a multiple of 2 (on BOTH sides), so an
-// aligned pair of entries never straddles a cell and its consumer slot is 16-byte aligned: the producer moves pairs with 16-byte
-// loads and stores, the consumer groups of 4. Entry i of the sorted order lives at i + shift[cell]. Pad slots: producer local
-// column 0xFFFF (flag → product forced to 0) and value 0; consumer local row 0 and product 0 — harmless to the sums.
-__global__ void pb_fill_producer_kernel(long long nnz, const int *__restrict__ colids, const double *__restrict__ values,
-                                        const unsigned *__restrict__ permP, const unsigned *__restrict__ keyP_sorted, int band_key_bits,
-                                        int nminor, const int *__restrict__ shiftP, unsigned short *__restrict__ p_lcol, double *__restrict__ p_val)
+// start[q] = first sorted position whose key >= key(q), q = c·RB + r; start[ncells] = nnz
+__global__ void pb_cell_starts_kernel(long long nnz, const unsigned *__restrict__ sorted_keys, int CB, int RB, int band_key_bits, int *__restrict__ start)
 {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (long long)gridDim.x * blockDim.x) {
-        const unsigned k = permP[i];
-        const unsigned key = keyP_sorted[i];
-        const long long pos = i + shiftP[(long long)(key >> band_key_bits) * nminor + (key & ((1u << band_key_bits) - 1u))];
-        p_lcol[pos] = (unsigned short)(colids[k] & (kBand - 1));
-        p_val[pos] = values[k];
-    }
-}
-
-__global__ void pb_fill_consumer_kernel(int rows, long long nnz, const int *__restrict__ rowptr, const unsigned *__restrict__ permC,
-                                        const unsigned *__restrict__ keyC_sorted, int band_key_bits, int nminor, const int *__restrict__ shiftC,
-                                        unsigned short *__restrict__ c_lrow)
-{
-    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < nnz; j += (long long)gridDim.x * blockDim.x) {
-        const long long k = permC[j];
-        int lo = 0, hi = rows;
-        while (hi - lo > 1) {
-            const int mid = lo + ((hi - lo) >> 1);
-            if (rowptr[mid] <= k) lo = mid; else hi = mid;
-        }
-        const unsigned key = keyC_sorted[j];
-        c_lrow[j + shiftC[(long long)(key >> band_key_bits) * nminor + (key & ((1u << band_key_bits) - 1u))]] = (unsigned short)(lo & (kBand - 1));
-    }
-}
-
-// start[q] = first position whose sorted key >= key(q), for every cell q = major·nminor + minor, plus start[ncells] = nnz
-__global__ void pb_cell_starts_kernel(long long nnz, const unsigned *__restrict__ sorted_keys, int nmajor, int nminor, int band_key_bits,
-                                      int *__restrict__ start)
-{
-    const long long ncells = (long long)nmajor * nminor;
+    const long long ncells = (long long)CB * RB;
     for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q <= ncells; q += (long long)gridDim.x * blockDim.x) {
         if (q == ncells) { start[q] = (int)nnz; continue; }
-        const unsigned key = ((unsigned)(q / nminor) << band_key_bits) | (unsigned)(q % nminor);
+        const unsigned key = ((unsigned)(q / RB) << band_key_bits) | (unsigned)(q % RB);
         long long lo = 0, hi = nnz;
         while (lo < hi) {
             const long long mid = lo + ((hi - lo) >> 1);
@@ -117,74 +90,146 @@ __global__ void pb_cell_starts_kernel(long long nnz, const unsigned *__restrict_
     }
 }
 
-// ---- SpMV kernels
-struct ProducerItem { int cband, k0, k1, pad; };
-struct ConsumerItem { int rband, k0, k1, split; };
+// Padded producer layout: sorted entry i of cell q lives at i + shift[q] (cells start at multiples of kSpan).
+__global__ void pb_fill_producer_kernel(long long nnz, const int *__restrict__ colids, const double *__restrict__ values, const int *__restrict__ rowid,
+                                        const unsigned *__restrict__ perm, const unsigned *__restrict__ sorted_keys, int band_key_bits, int RB,
+                                        const int *__restrict__ shift, unsigned short *__restrict__ p_lcol, double *__restrict__ p_val,
+                                        int *__restrict__ t_row, int *__restrict__ t_cell)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned k = perm[i], key = sorted_keys[i];
+        const int q = (int)((long long)(key >> band_key_bits) * RB + (key & ((1u << band_key_bits) - 1u)));
+        const long long pos = i + shift[q];
+        p_lcol[pos] = (unsigned short)(colids[k] & (kBand - 1));
+        p_val[pos] = values[k];
+        t_row[pos] = rowid[k];
+        t_cell[pos] = q;
+    }
+}
 
-constexpr int kPbUnroll = 2;          // consumer: groups of 4 consecutive entries per thread per iteration
-constexpr int kPbProducerUnroll = 4;  // producer: pairs of consecutive entries per thread per iteration
-constexpr unsigned kPadFlag = 0x8000u;
+// Micro-run heads of a span: a real entry whose row differs from the previous entry's (or that opens the span). t_row < 0 marks pads.
+__global__ void pb_span_heads_kernel(long long nspans, const int *__restrict__ t_row, unsigned char *__restrict__ masks, int *__restrict__ counts)
+{
+    for (long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x; s < nspans; s += (long long)gridDim.x * blockDim.x) {
+        unsigned m = 0;
+        int prev = -2;
+        for (int j = 0; j < kSpan; ++j) {
+            const int r = t_row[s * kSpan + j];
+            if (r >= 0 && r != prev) m |= 1u << j;
+            if (r >= 0) prev = r;
+        }
+        masks[s] = (unsigned char)m;
+        counts[s] = __popc(m);
+    }
+}
 
-typedef unsigned short ushort4_t __attribute__((ext_vector_type(4)));
-typedef double double2_t __attribute__((ext_vector_type(2)));
+__global__ void pb_gather_kernel(long long n, const int *__restrict__ index, const int *__restrict__ src, int *__restrict__ dst)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = src[index[i]];
+}
+
+// mbase[s] += delta[cell of span s]: from the span's first micro-run index to its consumer slot.
+__global__ void pb_span_slots_kernel(long long nspans, const int *__restrict__ t_cell, const int *__restrict__ delta, int *__restrict__ mbase)
+{
+    for (long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x; s < nspans; s += (long long)gridDim.x * blockDim.x)
+        mbase[s] += delta[t_cell[s * kSpan]];
+}
+
+// Local row of every micro-run, at its consumer slot.
+__global__ void pb_fill_consumer_kernel(long long nspans, const int *__restrict__ t_row, const int *__restrict__ t_cell,
+                                        const unsigned char *__restrict__ masks, const int *__restrict__ mbase,
+                                        unsigned short *__restrict__ c_lrow)
+{
+    for (long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x; s < nspans; s += (long long)gridDim.x * blockDim.x) {
+        const unsigned m = masks[s];
+        if (!m) continue;
+        int dst = mbase[s];   // already a consumer slot (pb_span_slots_kernel)
+        for (int j = 0; j < kSpan; ++j)
+            if ((m >> j) & 1u) c_lrow[dst++] = (unsigned short)(t_row[s * kSpan + j] & (kBand - 1));
+    }
+}
+
+// ================================================================================================ SpMV kernels
+struct ProducerItem { int cband, s0, s1, pad; };     // spans [s0, s1) of one column band
+struct ConsumerItem { int rband, k0, k1, split; };   // micro-run slots [k0, k1) of one row band (multiples of 4)
+
+// Producer: one lane per PAIR of consecutive entries (unit-stride 4-byte / 16-byte loads), four lanes per 8-entry span. The
+// products of a span are summed per micro-run with a backward segmented reduction across the span's four lanes (shuffles), and
+// each lane stores the sums of the micro-runs that START in its pair (0, 1 or 2 stores).
+constexpr int kPairUnroll = 4;
 
 __global__ __launch_bounds__(kPbThreads) void pb_producer_kernel(const ProducerItem *__restrict__ items, int cols, int RB,
-                                                                  const unsigned short *__restrict__ p_lcol, const int *__restrict__ stP,
-                                                                  const double *__restrict__ p_val, const int *__restrict__ delta,
+                                                                  const unsigned short *__restrict__ p_lcol, const double *__restrict__ p_val,
+                                                                  const unsigned char *__restrict__ masks, const int *__restrict__ mbase /* consumer slot of each span's first micro-run */,
                                                                   const double *__restrict__ x, double *__restrict__ prod)
 {
     extern __shared__ double pb_lds[];
     double *xs = pb_lds;                                           // kBand doubles
-    int *dl = reinterpret_cast<int *>(pb_lds + kBand);             // RB ints: this band's row of the delta table
-    int *st = dl + RB;                                             // RB+1 ints: this band's cell starts (padded producer coordinates)
-    const ProducerItem it = items[blockIdx.x];                     // [k0, k1): even bounds
+    (void)RB;
+    const ProducerItem it = items[blockIdx.x];
     const int c0 = it.cband << kBandBits;
-    const int last_pair = it.k1 - 2;
-    constexpr int STEP = 2 * kPbThreads * kPbProducerUnroll;
-    int base = it.k0 + 2 * (int)threadIdx.x;
-    unsigned lc[kPbProducerUnroll], lc_n[kPbProducerUnroll];
-    double2_t v[kPbProducerUnroll], v_n[kPbProducerUnroll];
+    const int p_end = it.s1 * 4, p_last = p_end - 1;               // pair indices: pair p = entries 2p, 2p+1; span = p >> 2
+    constexpr int STEP = kPbThreads * kPairUnroll;
+    int base = it.s0 * 4 + (int)threadIdx.x;
+    unsigned lc[kPairUnroll], lc_n[kPairUnroll], mk[kPairUnroll], mk_n[kPairUnroll];
+    int mb[kPairUnroll], mb_n[kPairUnroll];
+    double2_t v[kPairUnroll], v_n[kPairUnroll];
     // first tile's stream loads go out before the x band is staged: their latency hides under the staging
 #pragma unroll
-    for (int u = 0; u < kPbProducerUnroll; ++u) {
-        const int k = min(base + u * 2 * kPbThreads, last_pair);
-        lc[u] = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(p_lcol + k));
-        v[u] = __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(p_val + k));
+    for (int u = 0; u < kPairUnroll; ++u) {
+        const long long p = min(base + u * kPbThreads, p_last);
+        lc[u] = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(p_lcol) + p);
+        v[u] = __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(p_val) + p);
+        mk[u] = masks[p >> 2];
+        mb[u] = mbase[p >> 2];
     }
     for (int i = threadIdx.x; i < kBand; i += kPbThreads) xs[i] = (c0 + i < cols) ? x[c0 + i] : 0.0;
-    for (int r = threadIdx.x; r < RB; r += kPbThreads) dl[r] = delta[(long long)it.cband * RB + r];
-    for (int r = threadIdx.x; r <= RB; r += kPbThreads) st[r] = stP[(long long)it.cband * (RB + 1) + r];
     __syncthreads();
-    for (; base < it.k1; base += STEP) {
-        const bool more = base + STEP < it.k1;
+    const int q = threadIdx.x & 3;                                 // position of this lane's pair inside its span
+    for (; base - (int)threadIdx.x < p_end; base += STEP) {        // uniform trip count per workgroup: every lane takes part in the shuffles
+        const bool more = base - (int)threadIdx.x + STEP < p_end;
         if (more) {
 #pragma unroll
-            for (int u = 0; u < kPbProducerUnroll; ++u) {
-                const int k = min(base + STEP + u * 2 * kPbThreads, last_pair);
-                lc_n[u] = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(p_lcol + k));
-                v_n[u] = __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(p_val + k));
+            for (int u = 0; u < kPairUnroll; ++u) {
+                const long long p = min(base + STEP + u * kPbThreads, p_last);
+                lc_n[u] = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(p_lcol) + p);
+                v_n[u] = __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(p_val) + p);
+                mk_n[u] = masks[p >> 2];
+                mb_n[u] = mbase[p >> 2];
             }
         }
 #pragma unroll
-        for (int u = 0; u < kPbProducerUnroll; ++u) {
-            const int kk = base + u * 2 * kPbThreads;
-            if (kk < it.k1) {
-                int lo = 0, hi = RB;                               // last r with st[r] <= k (empty cells share a start: the last one wins)
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (st[mid] <= kk) lo = mid; else hi = mid;
+        for (int u = 0; u < kPairUnroll; ++u) {
+            const int p = base + u * kPbThreads;
+            const bool live = p < p_end;                           // whole spans are live or not (p_end is a multiple of 4)
+            const unsigned l0 = lc[u] & 0xFFFFu, l1 = lc[u] >> 16;
+            const double p0 = (!live || (l0 & kPadFlag)) ? 0.0 : v[u][0] * xs[l0 & (kBand - 1)];
+            const double p1 = (!live || (l1 & kPadFlag)) ? 0.0 : v[u][1] * xs[l1 & (kBand - 1)];
+            const unsigned m = live ? mk[u] : 0u;
+            const bool h0 = (m >> (2 * q)) & 1u, h1 = (m >> (2 * q + 1)) & 1u;
+            // open prefix: the part of this pair that continues a micro-run begun in an earlier lane of the span
+            const double op = h0 ? 0.0 : (h1 ? p0 : p0 + p1);
+            const bool closed = h0 | h1;
+            const double op1 = __shfl_down(op, 1, 4), op2 = __shfl_down(op, 2, 4), op3 = __shfl_down(op, 3, 4);
+            const int cl1 = __shfl_down((int)closed, 1, 4), cl2 = __shfl_down((int)closed, 2, 4);
+            // ext: what the following lanes of the span add to the micro-run that contains this pair's last entry
+            double ext = 0.0;
+            if (q < 3) {
+                ext = op1;
+                if (!cl1 && q < 2) {
+                    ext += op2;
+                    if (!cl2 && q < 1) ext += op3;
                 }
-                const int dst = kk + dl[lo];
-                const unsigned l0 = lc[u] & 0xFFFFu, l1 = lc[u] >> 16;
-                double2_t pr;
-                pr[0] = (l0 & kPadFlag) ? 0.0 : v[u][0] * xs[l0 & (kBand - 1)];
-                pr[1] = (l1 & kPadFlag) ? 0.0 : v[u][1] * xs[l1 & (kBand - 1)];
-                *reinterpret_cast<double2_t *>(prod + dst) = pr;
+            }
+            if (live && closed) {
+                const int d0 = mb[u];
+                if (h0) prod[d0 + __popc(m & ((1u << (2 * q)) - 1u))] = h1 ? p0 : p0 + p1 + ext;
+                if (h1) prod[d0 + __popc(m & ((1u << (2 * q + 1)) - 1u))] = p1 + ext;
             }
         }
         if (more) {
 #pragma unroll
-            for (int u = 0; u < kPbProducerUnroll; ++u) { lc[u] = lc_n[u]; v[u] = v_n[u]; }
+            for (int u = 0; u < kPairUnroll; ++u) { lc[u] = lc_n[u]; v[u] = v_n[u]; mk[u] = mk_n[u]; mb[u] = mb_n[u]; }
         }
     }
 }
@@ -196,13 +241,15 @@ __global__ void pb_scale_rows_kernel(const int *__restrict__ split_bands, int ro
     if (i < rows && i < r0 + kBand) y[i] = beta == 0.0 ? 0.0 : beta * y[i];
 }
 
+constexpr int kPbUnroll = 2;   // consumer: groups of 4 consecutive slots per thread per iteration
+
 __global__ __launch_bounds__(kPbThreads) void pb_consumer_kernel(const ConsumerItem *__restrict__ items, int rows,
                                                                   const unsigned short *__restrict__ c_lrow, const double *__restrict__ prod,
                                                                   double *__restrict__ y, double alpha, double beta)
 {
     extern __shared__ double pb_lds[];
     double *ys = pb_lds;
-    const ConsumerItem it = items[blockIdx.x];                     // [k0, k1): multiples of 4; pad slots carry product 0 for row 0
+    const ConsumerItem it = items[blockIdx.x];                     // [k0, k1): multiples of 4; pad slots carry 0 for local row 0
     const int last_group = it.k1 - 4;
     constexpr int STEP = 4 * kPbThreads * kPbUnroll;
     int base = it.k0 + 4 * (int)threadIdx.x;
@@ -256,14 +303,12 @@ __global__ __launch_bounds__(kPbThreads) void pb_consumer_kernel(const ConsumerI
     }
 }
 
-inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 65536 ? 65536 : g)); }
-
 } // namespace
 
 struct PbPlan {
     int rows = 0, cols = 0, CB = 0, RB = 0;
-    long long nnz = 0;
-    DevBuf p_lcol, p_val, c_lrow, prod, delta, stP, pitems, citems, split_bands;
+    long long nnz = 0, micro_runs = 0;
+    DevBuf p_lcol, p_val, masks, mbase, c_lrow, prod, delta, pitems, citems, split_bands;
     int n_pitems = 0, n_citems = 0, n_split = 0;
     size_t lds_producer = 0, lds_consumer = 0;
     long long bytes = 0;
@@ -277,114 +322,128 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     if (!P) return set_error(G4S_ERR_NOMEM, "host allocation failed");
     std::unique_ptr<PbPlan> guard(P);
     P->rows = rows; P->cols = cols; P->nnz = nnz;
-    P->CB = (cols + kBand - 1) >> kBandBits;
-    P->RB = (rows + kBand - 1) >> kBandBits;
+    const int CB = P->CB = (cols + kBand - 1) >> kBandBits;
+    const int RB = P->RB = (rows + kBand - 1) >> kBandBits;
     int bits = 1;
-    while ((1 << bits) < std::max(P->CB, P->RB)) ++bits;
+    while ((1 << bits) < std::max(CB, RB)) ++bits;
     if (2 * bits > 32) return set_error(G4S_ERR_UNSUPPORTED, "pb_build: too many bands");
-    P->lds_producer = sizeof(double) * kBand + sizeof(int) * (2 * (size_t)P->RB + 1);
+    P->lds_producer = sizeof(double) * kBand;
     P->lds_consumer = sizeof(double) * kBand;
-    if (P->lds_producer > 160 * 1024) return set_error(G4S_ERR_UNSUPPORTED, "pb_build: delta row does not fit LDS (rows > 134M)");
+    const long long ncells = (long long)CB * RB;
 
-    DevBuf keyP, keyC, idx, keyP_s, keyC_s, permP, permC, tmp, startC;
+    // 1. regroup: stable sort of the CSR entries by (column band, row band)
+    DevBuf key, key_s, idx, perm, rowid, tmp, startP;
     const size_t n4 = sizeof(unsigned) * (size_t)nnz;
-    G4S_TRY(keyP.alloc(n4)); G4S_TRY(keyC.alloc(n4)); G4S_TRY(idx.alloc(n4));
-    G4S_TRY(keyP_s.alloc(n4)); G4S_TRY(keyC_s.alloc(n4)); G4S_TRY(permP.alloc(n4)); G4S_TRY(permC.alloc(n4));
-    hipLaunchKernelGGL(pb_keys_kernel, dim3(grid_for(nnz)), dim3(256), 0, nullptr, rows, nnz, d_rowptr, d_colids, bits,
-                       keyP.as<unsigned>(), keyC.as<unsigned>(), idx.as<unsigned>());
+    G4S_TRY(key.alloc(n4)); G4S_TRY(key_s.alloc(n4)); G4S_TRY(idx.alloc(n4)); G4S_TRY(perm.alloc(n4)); G4S_TRY(rowid.alloc(n4));
+    hipLaunchKernelGGL(pb_keys_kernel, dim3(grid_for(nnz)), dim3(256), 0, nullptr, rows, nnz, d_rowptr, d_colids, bits, key.as<unsigned>(),
+                       rowid.as<int>(), idx.as<unsigned>());
     G4S_HIP_TRY(hipGetLastError());
     size_t tmp_bytes = 0;
-    G4S_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keyP.as<unsigned>(), keyP_s.as<unsigned>(), idx.as<unsigned>(),
-                                                   permP.as<unsigned>(), (int)nnz, 0, 2 * bits, nullptr));
+    G4S_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, key.as<unsigned>(), key_s.as<unsigned>(), idx.as<unsigned>(), perm.as<unsigned>(),
+                                                   (int)nnz, 0, 2 * bits, nullptr));
     G4S_TRY(tmp.alloc(tmp_bytes));
-    G4S_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keyP.as<unsigned>(), keyP_s.as<unsigned>(), idx.as<unsigned>(),
-                                                   permP.as<unsigned>(), (int)nnz, 0, 2 * bits, nullptr));
-    G4S_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keyC.as<unsigned>(), keyC_s.as<unsigned>(), idx.as<unsigned>(),
-                                                   permC.as<unsigned>(), (int)nnz, 0, 2 * bits, nullptr));
-    const long long ncells = (long long)P->CB * P->RB;
-    DevBuf startP;
+    G4S_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, key.as<unsigned>(), key_s.as<unsigned>(), idx.as<unsigned>(), perm.as<unsigned>(),
+                                                   (int)nnz, 0, 2 * bits, nullptr));
+    G4S_HIP_TRY(hipDeviceSynchronize());
+    key.release(); idx.release();
     G4S_TRY(startP.alloc(sizeof(int) * (size_t)(ncells + 1)));
-    G4S_TRY(startC.alloc(sizeof(int) * (size_t)(ncells + 1)));
-    hipLaunchKernelGGL(pb_cell_starts_kernel, dim3(grid_for(ncells + 1)), dim3(256), 0, nullptr, nnz, keyP_s.as<unsigned>(), P->CB, P->RB, bits, startP.as<int>());
-    hipLaunchKernelGGL(pb_cell_starts_kernel, dim3(grid_for(ncells + 1)), dim3(256), 0, nullptr, nnz, keyC_s.as<unsigned>(), P->RB, P->CB, bits, startC.as<int>());
+    hipLaunchKernelGGL(pb_cell_starts_kernel, dim3(grid_for(ncells + 1)), dim3(256), 0, nullptr, nnz, key_s.as<unsigned>(), CB, RB, bits, startP.as<int>());
     G4S_HIP_TRY(hipGetLastError());
 
-    // cell boundaries (host) → padded layout: band segments at multiples of 4, cells at multiples of 2, on both sides
-    std::vector<int> hP((size_t)ncells + 1), hC((size_t)ncells + 1);
+    // 2. padded producer layout (host): every cell starts at a multiple of kSpan
+    std::vector<int> hP((size_t)ncells + 1);
     G4S_HIP_TRY(hipMemcpy(hP.data(), startP.p, sizeof(int) * hP.size(), hipMemcpyDeviceToHost));
-    G4S_HIP_TRY(hipMemcpy(hC.data(), startC.p, sizeof(int) * hC.size(), hipMemcpyDeviceToHost));
-    const int CB = P->CB, RB = P->RB;
-    std::vector<int> padP((size_t)CB * (RB + 1)), padC((size_t)RB * (CB + 1)), shP((size_t)ncells), shC((size_t)ncells), h_delta((size_t)ncells);
-    long long totP = 0, totC = 0;
-    for (int c = 0; c < CB; ++c) {
-        totP = (totP + 3) & ~3ll;
-        for (int r = 0; r < RB; ++r) {
-            const size_t q = (size_t)c * RB + r;
-            padP[(size_t)c * (RB + 1) + r] = (int)totP;
-            shP[q] = (int)(totP - hP[q]);
-            totP += hP[q + 1] - hP[q];
-            totP = (totP + 1) & ~1ll;
-        }
-        padP[(size_t)c * (RB + 1) + RB] = (int)totP;               // end of the band's last cell (its pad included)
+    std::vector<int> padP((size_t)ncells + 1), shP((size_t)ncells);
+    long long totP = 0;
+    for (long long q = 0; q < ncells; ++q) {
+        padP[q] = (int)totP;
+        shP[q] = (int)(totP - hP[q]);
+        totP += hP[q + 1] - hP[q];
+        totP = (totP + kSpan - 1) & ~(long long)(kSpan - 1);
     }
+    padP[ncells] = (int)totP;
+    if (totP + 64 > INT32_MAX) return set_error(G4S_ERR_UNSUPPORTED, "pb_build: padded length exceeds int32");
+    const long long nspans = totP / kSpan;
+    DevBuf d_shP, t_row, t_cell, counts;
+    G4S_TRY(d_shP.alloc(sizeof(int) * shP.size()));
+    G4S_HIP_TRY(hipMemcpy(d_shP.p, shP.data(), sizeof(int) * shP.size(), hipMemcpyHostToDevice));
+    G4S_TRY(P->p_lcol.alloc(sizeof(unsigned short) * (size_t)(totP + 64)));
+    G4S_TRY(P->p_val.alloc(sizeof(double) * (size_t)(totP + 64)));
+    G4S_TRY(t_row.alloc(sizeof(int) * (size_t)(totP + 64)));
+    G4S_TRY(t_cell.alloc(sizeof(int) * (size_t)(totP + 64)));
+    G4S_HIP_TRY(hipMemset(P->p_lcol.p, 0xFF, P->p_lcol.bytes));   // pad flag everywhere; real entries overwrite it
+    G4S_HIP_TRY(hipMemset(P->p_val.p, 0, P->p_val.bytes));
+    G4S_HIP_TRY(hipMemset(t_row.p, 0xFF, t_row.bytes));           // −1 = pad
+    G4S_HIP_TRY(hipMemset(t_cell.p, 0, t_cell.bytes));
+    hipLaunchKernelGGL(pb_fill_producer_kernel, dim3(grid_for(nnz)), dim3(256), 0, nullptr, nnz, d_colids, d_values, rowid.as<int>(), perm.as<unsigned>(),
+                       key_s.as<unsigned>(), bits, RB, d_shP.as<int>(), P->p_lcol.as<unsigned short>(), P->p_val.as<double>(), t_row.as<int>(), t_cell.as<int>());
+    G4S_HIP_TRY(hipGetLastError());
+    G4S_HIP_TRY(hipDeviceSynchronize());
+    key_s.release(); perm.release(); rowid.release(); startP.release();
+
+    // 3. micro-runs: head mask per span, exclusive scan → index of each span's first micro-run
+    G4S_TRY(P->masks.alloc((size_t)nspans + 64));
+    G4S_TRY(counts.alloc(sizeof(int) * ((size_t)nspans + 1)));
+    G4S_TRY(P->mbase.alloc(sizeof(int) * ((size_t)nspans + 64)));
+    G4S_HIP_TRY(hipMemset(counts.p, 0, counts.bytes));
+    hipLaunchKernelGGL(pb_span_heads_kernel, dim3(grid_for(nspans)), dim3(256), 0, nullptr, nspans, t_row.as<int>(), P->masks.as<unsigned char>(), counts.as<int>());
+    G4S_HIP_TRY(hipGetLastError());
+    G4S_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, counts.as<int>(), P->mbase.as<int>(), (int)nspans + 1, nullptr));
+    G4S_TRY(tmp.alloc(tmp_bytes));
+    G4S_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, counts.as<int>(), P->mbase.as<int>(), (int)nspans + 1, nullptr));
+
+    // 4. micro-run index at every cell start → consumer layout (host): row band segments at multiples of 4
+    std::vector<int> span_of_cell((size_t)ncells + 1), mstart((size_t)ncells + 1);
+    for (long long q = 0; q <= ncells; ++q) span_of_cell[q] = padP[q] / kSpan;
+    DevBuf d_soc, d_mstart;
+    G4S_TRY(d_soc.alloc(sizeof(int) * span_of_cell.size())); G4S_TRY(d_mstart.alloc(sizeof(int) * mstart.size()));
+    G4S_HIP_TRY(hipMemcpy(d_soc.p, span_of_cell.data(), sizeof(int) * span_of_cell.size(), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(pb_gather_kernel, dim3(grid_for(ncells + 1)), dim3(256), 0, nullptr, ncells + 1, d_soc.as<int>(), P->mbase.as<int>(), d_mstart.as<int>());
+    G4S_HIP_TRY(hipMemcpy(mstart.data(), d_mstart.p, sizeof(int) * mstart.size(), hipMemcpyDeviceToHost));
+    P->micro_runs = mstart[ncells];
+    std::vector<int> h_delta((size_t)ncells), bandC((size_t)RB + 1);
+    long long totC = 0;
     for (int r = 0; r < RB; ++r) {
         totC = (totC + 3) & ~3ll;
+        bandC[r] = (int)totC;
         for (int c = 0; c < CB; ++c) {
-            const size_t q = (size_t)r * CB + c;
-            padC[(size_t)r * (CB + 1) + c] = (int)totC;
-            shC[q] = (int)(totC - hC[q]);
-            totC += hC[q + 1] - hC[q];
-            totC = (totC + 1) & ~1ll;
+            const size_t q = (size_t)c * RB + r;
+            h_delta[q] = (int)(totC - mstart[q]);
+            totC += mstart[q + 1] - mstart[q];
         }
-        padC[(size_t)r * (CB + 1) + CB] = (int)totC;
     }
-    for (int c = 0; c < CB; ++c)
-        for (int r = 0; r < RB; ++r) h_delta[(size_t)c * RB + r] = padC[(size_t)r * (CB + 1) + c] - padP[(size_t)c * (RB + 1) + r];
-    totP = (totP + 3) & ~3ll; totC = (totC + 3) & ~3ll;
-    if (totP + 8 > INT32_MAX || totC + 8 > INT32_MAX) return set_error(G4S_ERR_UNSUPPORTED, "pb_build: padded length exceeds int32");
-    DevBuf d_shP, d_shC;
-    G4S_TRY(d_shP.alloc(sizeof(int) * shP.size())); G4S_TRY(d_shC.alloc(sizeof(int) * shC.size()));
-    G4S_HIP_TRY(hipMemcpy(d_shP.p, shP.data(), sizeof(int) * shP.size(), hipMemcpyHostToDevice));
-    G4S_HIP_TRY(hipMemcpy(d_shC.p, shC.data(), sizeof(int) * shC.size(), hipMemcpyHostToDevice));
-
-    G4S_TRY(P->p_lcol.alloc(sizeof(unsigned short) * (size_t)(totP + 8)));
-    G4S_TRY(P->p_val.alloc(sizeof(double) * (size_t)(totP + 8)));
-    G4S_TRY(P->c_lrow.alloc(sizeof(unsigned short) * (size_t)(totC + 8)));
-    G4S_TRY(P->prod.alloc(sizeof(double) * (size_t)(totC + 8)));
-    G4S_HIP_TRY(hipMemset(P->p_lcol.p, 0xFF, P->p_lcol.bytes));   // pad flag (bit 15) everywhere; real entries overwrite it
-    G4S_HIP_TRY(hipMemset(P->p_val.p, 0, P->p_val.bytes));
-    G4S_HIP_TRY(hipMemset(P->c_lrow.p, 0, P->c_lrow.bytes));
-    G4S_HIP_TRY(hipMemset(P->prod.p, 0, P->prod.bytes));
-    hipLaunchKernelGGL(pb_fill_producer_kernel, dim3(grid_for(nnz)), dim3(256), 0, nullptr, nnz, d_colids, d_values, permP.as<unsigned>(),
-                       keyP_s.as<unsigned>(), bits, RB, d_shP.as<int>(), P->p_lcol.as<unsigned short>(), P->p_val.as<double>());
-    hipLaunchKernelGGL(pb_fill_consumer_kernel, dim3(grid_for(nnz)), dim3(256), 0, nullptr, rows, nnz, d_rowptr, permC.as<unsigned>(),
-                       keyC_s.as<unsigned>(), bits, CB, d_shC.as<int>(), P->c_lrow.as<unsigned short>());
-    G4S_HIP_TRY(hipGetLastError());
-    G4S_TRY(P->stP.alloc(sizeof(int) * padP.size()));
+    totC = (totC + 3) & ~3ll;
+    bandC[RB] = (int)totC;
     G4S_TRY(P->delta.alloc(sizeof(int) * h_delta.size()));
-    G4S_HIP_TRY(hipMemcpy(P->stP.p, padP.data(), sizeof(int) * padP.size(), hipMemcpyHostToDevice));
     G4S_HIP_TRY(hipMemcpy(P->delta.p, h_delta.data(), sizeof(int) * h_delta.size(), hipMemcpyHostToDevice));
-
-    const int kPC = (getenv("G4S_PB_PCHUNK") ? atoi(getenv("G4S_PB_PCHUNK")) : kProducerChunk) & ~3;   // tuning knobs (experiments)
-    const int kCC = (getenv("G4S_PB_CCHUNK") ? atoi(getenv("G4S_PB_CCHUNK")) : kConsumerChunk) & ~3;
+    G4S_TRY(P->c_lrow.alloc(sizeof(unsigned short) * (size_t)(totC + 64)));
+    G4S_TRY(P->prod.alloc(sizeof(double) * (size_t)(totC + 64)));
+    G4S_HIP_TRY(hipMemset(P->c_lrow.p, 0, P->c_lrow.bytes));
+    G4S_HIP_TRY(hipMemset(P->prod.p, 0, P->prod.bytes));          // pad slots stay 0 for ever: the producer never writes them
+    hipLaunchKernelGGL(pb_span_slots_kernel, dim3(grid_for(nspans)), dim3(256), 0, nullptr, nspans, t_cell.as<int>(), P->delta.as<int>(), P->mbase.as<int>());
+    hipLaunchKernelGGL(pb_fill_consumer_kernel, dim3(grid_for(nspans)), dim3(256), 0, nullptr, nspans, t_row.as<int>(), t_cell.as<int>(),
+                       P->masks.as<unsigned char>(), P->mbase.as<int>(), P->c_lrow.as<unsigned short>());
+    G4S_HIP_TRY(hipGetLastError());
+    // 5. work items, heaviest first (the tail of each launch is then made of light bands)
+    const int kPC = std::max(kSpan * kPbThreads, (getenv("G4S_PB_PCHUNK") ? atoi(getenv("G4S_PB_PCHUNK")) : kProducerChunk)) / kSpan;   // spans per item
+    const int kCC = std::max(4, (getenv("G4S_PB_CCHUNK") ? atoi(getenv("G4S_PB_CCHUNK")) : kConsumerChunk) & ~3);
     std::vector<ProducerItem> pit;
-    for (int c = 0; c < P->CB; ++c) {
-        const int b0 = padP[(size_t)c * (RB + 1)], b1 = padP[(size_t)c * (RB + 1) + RB];                 // b0 multiple of 4, b1 even
-        for (int k = b0; k < b1; k += kPC) pit.push_back(ProducerItem{c, k, std::min(b1, k + kPC), 0});
+    for (int c = 0; c < CB; ++c) {
+        const int s0 = padP[(size_t)c * RB] / kSpan, s1 = padP[(size_t)(c + 1) * RB] / kSpan;
+        for (int s = s0; s < s1; s += kPC) pit.push_back(ProducerItem{c, s, std::min(s1, s + kPC), 0});
     }
     std::vector<ConsumerItem> cit;
     std::vector<int> split;
-    for (int r = 0; r < P->RB; ++r) {
-        const int b0 = padC[(size_t)r * (CB + 1)], b1 = (padC[(size_t)r * (CB + 1) + CB] + 3) & ~3;      // pads included: harmless
+    for (int r = 0; r < RB; ++r) {
+        const int b0 = bandC[r], b1 = bandC[r + 1];   // both multiples of 4; slots past the band's true end are pads
         if (b1 - b0 <= kCC) cit.push_back(ConsumerItem{r, b0, b1, 0});   // also the empty bands: their rows must still be written
         else {
             split.push_back(r);
             for (int k = b0; k < b1; k += kCC) cit.push_back(ConsumerItem{r, k, std::min(b1, k + kCC), 1});
         }
     }
-    // heaviest items first: the tail of each launch is then made of light bands
     std::stable_sort(cit.begin(), cit.end(), [](const ConsumerItem &a, const ConsumerItem &b) { return (a.k1 - a.k0) > (b.k1 - b.k0); });
-    std::stable_sort(pit.begin(), pit.end(), [](const ProducerItem &a, const ProducerItem &b) { return (a.k1 - a.k0) > (b.k1 - b.k0); });
+    std::stable_sort(pit.begin(), pit.end(), [](const ProducerItem &a, const ProducerItem &b) { return (a.s1 - a.s0) > (b.s1 - b.s0); });
     P->n_pitems = (int)pit.size(); P->n_citems = (int)cit.size(); P->n_split = (int)split.size();
     G4S_TRY(P->pitems.alloc(sizeof(ProducerItem) * pit.size()));
     G4S_TRY(P->citems.alloc(sizeof(ConsumerItem) * cit.size()));
@@ -395,8 +454,11 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     G4S_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pb_producer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_producer));
     G4S_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pb_consumer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_consumer));
     G4S_HIP_TRY(hipDeviceSynchronize());
-    P->bytes = (long long)(P->p_lcol.bytes + P->stP.bytes + P->p_val.bytes + P->c_lrow.bytes + P->prod.bytes + P->delta.bytes +
+    P->bytes = (long long)(P->p_lcol.bytes + P->p_val.bytes + P->masks.bytes + P->mbase.bytes + P->c_lrow.bytes + P->prod.bytes + P->delta.bytes +
                            P->pitems.bytes + P->citems.bytes + P->split_bands.bytes);
+    if (getenv("G4S_DEBUG"))
+        fprintf(stderr, "g4s blocked SpMV plan: %d x %d bands, nnz %lld, padded %lld, micro-runs %lld (%.3f per nonzero), %d producer / %d consumer items, %d split bands, %.2f GB\n",
+                CB, RB, nnz, totP, P->micro_runs, (double)P->micro_runs / (double)nnz, P->n_pitems, P->n_citems, P->n_split, P->bytes / 1e9);
     *out = guard.release();
     return G4S_OK;
 }
@@ -411,7 +473,7 @@ int pb_spmv(PbPlan *P, const double *x, double *y, double alpha, double beta, hi
         hipLaunchKernelGGL(pb_scale_rows_kernel, dim3(kBand / 256, P->n_split), dim3(256), 0, s, P->split_bands.as<int>(), P->rows, y, beta);
     if (P->n_pitems)
         hipLaunchKernelGGL(pb_producer_kernel, dim3(P->n_pitems), dim3(kPbThreads), P->lds_producer, s, P->pitems.as<ProducerItem>(), P->cols, P->RB,
-                           P->p_lcol.as<unsigned short>(), P->stP.as<int>(), P->p_val.as<double>(), P->delta.as<int>(), x, P->prod.as<double>());
+                           P->p_lcol.as<unsigned short>(), P->p_val.as<double>(), P->masks.as<unsigned char>(), P->mbase.as<int>(), x, P->prod.as<double>());
     if (P->n_citems)
         hipLaunchKernelGGL(pb_consumer_kernel, dim3(P->n_citems), dim3(kPbThreads), P->lds_consumer, s, P->citems.as<ConsumerItem>(), P->rows,
                            P->c_lrow.as<unsigned short>(), P->prod.as<double>(), y, alpha, beta);
