@@ -80,7 +80,7 @@ def test_cpp_mkl_spgemm_cli(tmp_path, oracle):
         with open(tmp_path / name, "w") as f:
             f.write(f"%%MatrixMarket matrix coordinate real general\n{M.shape[0]} {M.shape[1]} {M.nnz}\n")
             for i, j, v in zip(M.row, M.col, M.data):
-                f.write(f"{i + 1} {j + 1} {v!r}\n")
+                f.write(f"{int(i) + 1} {int(j) + 1} {float(v)!r}\n")
     out = subprocess.run([exe, str(tmp_path / "a.mtx"), str(tmp_path / "b.mtx"), "2", "--dump"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "spmm" in out.stdout and "GFLOPS" in out.stdout
