@@ -100,7 +100,7 @@ struct ClassLimits { long long lim[6]; int raw[6]; };
 // more than the bitmap path, so only rows whose raw bound is within 4/3 of the table's 24 K-entry limit try it.
 constexpr ClassLimits kSymLimits{{32, 512, 8192, 32768, -1, -1}, {0, 0, 0, 1, 0, 0}};
 // numeric: by the exact nz of the output row; tables hold keys + fp64 at <= 50 % fill: TINY 64, SMALL 1 K, MEDIUM 2 K, LARGE 4 K, M2 8 K slots.
-constexpr ClassLimits kNumLimits{{32, 512, 1024, 2048, 4096, -1}, {0, 0, 0, 0, 0, 0}};
+constexpr ClassLimits kNumLimits{{32, 512, 1024, 2048, 4096, 32768}, {0, 0, 0, 0, 0, 0}};   // M3 (<= 32 K): the all-LDS big-row kernel
 
 __global__ void classify_kernel(int M, const long long *__restrict__ size, ClassLimits lim, int cols_clip,
                                 int *__restrict__ cls, int *__restrict__ hist)
@@ -159,15 +159,79 @@ __global__ void nz_to_ll_kernel(int M, const int *__restrict__ crpt, long long *
 template <int TABLE>
 __device__ __forceinline__ int hash_of(int key) { return (key * kHashScal) & (TABLE - 1); }
 
-// Lanes per A-entry: the smallest power of two >= the row's average B-row length (flop_i / nnz(A_i)), at most 64 and at most
-// the cooperating thread count. Short B rows (the common case in a power-law graph) then keep many A-entries — i.e. many
-// independent acol → brpt → bcol load chains — in flight; long B rows still get coalesced 64-lane reads.
+// Walk the A-entries first, first+stride, … of one row with a two-stage software pipeline: while the B row of entry j is
+// processed, the row-pointer pair of entry j+stride and the column id of entry j+2·stride are already in flight. Without it
+// every entry pays three dependent memory latencies (acol → brpt → bcol) back to back, and the one-workgroup-per-CU classes
+// (128 KiB tables) are bound by exactly that chain. body(b0, b1, av) returns false to stop early.
+template <bool WITH_VAL, typename Body>
+__device__ __forceinline__ void walk_a_entries(int a0, int a1, int first, int stride, const int *__restrict__ acol,
+                                               const double *__restrict__ aval, const int *__restrict__ brpt, Body body)
+{
+    int j = a0 + first;
+    int c1 = 0, b0 = 0, b1 = 0;
+    double av0 = 0.0, av1 = 0.0;
+    if (j < a1) {
+        const int c0 = acol[j];
+        if (WITH_VAL) av0 = aval[j];
+        b0 = brpt[c0];
+        b1 = brpt[c0 + 1];
+    }
+    if (j + stride < a1) {
+        c1 = acol[j + stride];
+        if (WITH_VAL) av1 = aval[j + stride];
+    }
+    while (j < a1) {
+        const int j1 = j + stride, j2 = j1 + stride;
+        int c2 = 0, nb0 = 0, nb1 = 0;
+        double av2 = 0.0;
+        if (j2 < a1) {
+            c2 = acol[j2];
+            if (WITH_VAL) av2 = aval[j2];
+        }
+        if (j1 < a1) {
+            nb0 = brpt[c1];
+            nb1 = brpt[c1 + 1];
+        }
+        if (!body(b0, b1, av0)) return;
+        b0 = nb0; b1 = nb1; av0 = av1; c1 = c2; av1 = av2; j = j1;
+    }
+}
+
+// Long B rows. A lane group of 2^gs lanes walking a B row of thousands of entries serialises thousands of load → insert rounds
+// while the rest of the workgroup idles (B-row lengths in a power-law graph are as skewed as A's). In the one-workgroup-per-row
+// kernels a B row longer than kLongB is therefore only RECORDED (b0, b1, a's value) in a small LDS list during the walk and is
+// processed afterwards by the whole workgroup, lanes striding it coalesced. A full list falls back to in-group processing.
+constexpr int kLongCap = 255;                        // entries; slot 0 of the int4 array holds the counter
+constexpr size_t kLongListBytes = sizeof(int4) * (kLongCap + 1);
+constexpr size_t sym_lds_bytes(int rpb, int table) { return sizeof(int) * ((size_t)rpb * table + 2 * rpb) + (rpb == 1 ? kLongListBytes : 0); }
+__device__ __forceinline__ int long_b_threshold(int threads) { return threads >= 256 ? threads / 4 : 1 << 30; }
+
+// Called by every lane of a group with the same (b0, b1). Returns true if the B row was deferred to the cooperative phase.
+__device__ __forceinline__ bool defer_long_b(int4 *list, int b0, int b1, double av, int lane_in_group, int gmask, int threshold)
+{
+    if (b1 - b0 <= threshold) return false;
+    int slot = kLongCap;
+    if (lane_in_group == 0) slot = atomicAdd(&list[0].x, 1);
+    slot = __shfl(slot, (int)(threadIdx.x & 63) & ~gmask, 64);      // the group leader's answer
+    if (slot >= kLongCap) return false;
+    if (lane_in_group == 0) {
+        const long long bits = __double_as_longlong(av);
+        list[1 + slot] = make_int4(b0, b1, (int)(bits & 0xFFFFFFFFll), (int)(bits >> 32));
+    }
+    return true;
+}
+__device__ __forceinline__ double long_b_value(const int4 &e) { return __longlong_as_double(((long long)e.w << 32) | (unsigned)e.z); }
+
+// Lanes per A-entry: a power of two near a quarter of the row's average B-row length (flop_i / nnz(A_i)), at most 64 and at most
+// the cooperating thread count. These kernels are bound by the number of sequential acol → brpt → bcol rounds, so the more
+// A-entries in flight the better; long B rows still get wide coalesced reads.
 __device__ __forceinline__ int group_shift(long long flop, int nnz_a, int threads)
 {
     if (nnz_a <= 0) return 0;
-    const long long avg = (flop + nnz_a - 1) / nnz_a;
+    // a lane takes ~4 entries of a B row (independent loads, all in flight at once): a quarter of the average B-row length
+    const long long avg = (flop + nnz_a - 1) / nnz_a, target = (avg + 3) / 4;
     int g = 0;
-    while ((1 << g) < avg && g < 6 && (2 << g) <= threads) ++g;
+    while ((1 << g) < target && g < 6 && (2 << g) <= threads) ++g;
     return g;
 }
 
@@ -179,48 +243,60 @@ __global__ __launch_bounds__(WGSIZE) void spgemm_symbolic_lds_kernel(
 {
     extern __shared__ int lds_i[];
     constexpr int RPB = WGSIZE / THREADS;           // rows per workgroup
-    constexpr int LIMIT = TABLE / 4 * 3;            // optimistic tables give up beyond 75 % fill …
-    constexpr int MAX_PROBES = OPTIMISTIC ? 512 : TABLE;   // … which shows up as long probe sequences well before the table is full
-    __shared__ int s_cnt[RPB], s_ovf[RPB];
+    constexpr int MAX_PROBES = OPTIMISTIC ? 512 : TABLE;   // optimistic tables give up when a probe sequence gets long, i.e. before they are full
+    // Dynamic LDS only (a static array in front would break the 16-byte alignment of the int4 list, Guideline 17):
+    // [tables: RPB·TABLE ints][long-B list: (kLongCap+1) int4, RPB == 1 only][s_cnt: RPB ints][s_ovf: RPB ints]
+    int *s_cnt = lds_i + RPB * TABLE + (RPB == 1 ? 4 * (kLongCap + 1) : 0);
+    int *s_ovf = s_cnt + RPB;
     const int sub = threadIdx.x / THREADS, t = threadIdx.x % THREADS;
     const int ridx = blockIdx.x * RPB + sub;
     const int row = ridx < nrows ? rows[ridx] : -1;
     int *T = lds_i + sub * TABLE;
+    int4 *longs = reinterpret_cast<int4 *>(lds_i + RPB * TABLE);   // RPB == 1 kernels only (TABLE·4 bytes is a multiple of 16)
+    const int long_thr = RPB == 1 ? long_b_threshold(THREADS) : (1 << 30);
     for (int s = t; s < TABLE; s += THREADS) T[s] = kEmpty;
-    if (t == 0) { s_cnt[sub] = 0; s_ovf[sub] = 0; }
+    if (t == 0) { s_cnt[sub] = 0; s_ovf[sub] = 0; if (RPB == 1) longs[0].x = 0; }
     __syncthreads();
     if (row >= 0) {
         const int a0 = arpt[row], a1 = arpt[row + 1];
         const int gs = group_shift(row_flop[row], a1 - a0, THREADS), gmask = (1 << gs) - 1;
         int cnt = 0;
         bool stop = false;
-        for (int j = a0 + (t >> gs); j < a1 && !stop; j += THREADS >> gs) {
-            const int c = acol[j];
-            for (int k = brpt[c] + (t & gmask); k < brpt[c + 1]; k += gmask + 1) {
-                const int key = bcol[k];
-                int h = hash_of<TABLE>(key);
-                int probes = 0;
-                for (;; ++probes) {
-                    const int old = atomicCAS(&T[h], kEmpty, key);
-                    if (old == kEmpty) {
-                        cnt++;
-                        if (OPTIMISTIC && (cnt & 3) == 0) atomicAdd(&s_cnt[sub], 4);   // shared fill level, 4 inserts at a time
-                        break;
-                    }
-                    if (old == key) break;
-                    h = (h + 1) & (TABLE - 1);
-                    if (probes >= MAX_PROBES) break;               // never spin: sized tables cannot fill, optimistic ones give up
-                }
-                if (OPTIMISTIC && (probes >= MAX_PROBES || lds_peek(&s_cnt[sub]) > LIMIT)) { s_ovf[sub] = 1; stop = true; break; }
+        auto insert = [&](int key) {
+            int h = hash_of<TABLE>(key);
+            int probes = 0;
+            for (;; ++probes) {
+                const int old = atomicCAS(&T[h], kEmpty, key);
+                if (old == kEmpty) { cnt++; break; }
+                if (old == key) break;
+                h = (h + 1) & (TABLE - 1);
+                if (probes >= MAX_PROBES) break;                   // never spin: sized tables cannot fill, optimistic ones give up
             }
-            if (OPTIMISTIC && lds_peek(&s_ovf[sub])) stop = true;
+            if (OPTIMISTIC && probes >= MAX_PROBES) { s_ovf[sub] = 1; stop = true; }   // the table is filling up: give the row to the bitmap path
+        };
+        walk_a_entries<false>(a0, a1, t >> gs, THREADS >> gs, acol, nullptr, brpt, [&](int b0, int b1, double) {
+            // the abort flag is read by all lanes of the wave in one instruction: the lanes of a group leave together, so the
+            // shuffle inside defer_long_b never reads a lane that has already left
+            if (OPTIMISTIC && lds_peek(&s_ovf[sub])) return false;
+            if (RPB == 1 && defer_long_b(longs, b0, b1, 0.0, t & gmask, gmask, long_thr)) return true;
+            for (int k = b0 + (t & gmask); k < b1 && !stop; k += gmask + 1) insert(bcol[k]);
+            return true;
+        });
+        if (RPB == 1) {
+            __syncthreads();                                        // RPB == 1: every thread of the workgroup has a row, so this is uniform
+            const int nl = min(longs[0].x, kLongCap);
+            for (int i = 0; i < nl && !stop; ++i) {
+                const int4 e = longs[1 + i];
+                for (int k = e.x + t; k < e.y && !stop; k += THREADS) insert(bcol[k]);
+                if (OPTIMISTIC && lds_peek(&s_ovf[sub])) stop = true;
+            }
         }
-        atomicAdd(&s_cnt[sub], OPTIMISTIC ? (cnt & 3) : cnt);
+        atomicAdd(&s_cnt[sub], cnt);
     }
     __syncthreads();
     if (row >= 0 && t == 0) {
         const int total = s_cnt[sub];
-        if (OPTIMISTIC && (s_ovf[sub] || total > LIMIT)) overflow_rows[atomicAdd(overflow_count, 1)] = row;
+        if (OPTIMISTIC && s_ovf[sub]) overflow_rows[atomicAdd(overflow_count, 1)] = row;   // no abort ⇒ every key was inserted ⇒ the count is exact
         else row_nz[row] = total;
     }
 }
@@ -239,23 +315,34 @@ __global__ __launch_bounds__(WGSIZE) void spgemm_numeric_lds_kernel(
     // layout: all fp64 value tables first (8-byte aligned), then the key tables
     double *V = reinterpret_cast<double *>(lds_i) + sub * TABLE;
     int *K = lds_i + RPB * TABLE * 2 + sub * TABLE;
+    int4 *longs = reinterpret_cast<int4 *>(lds_i + RPB * TABLE * 3);   // RPB == 1 kernels only (TABLE·12 bytes is a multiple of 16)
+    const int long_thr = RPB == 1 ? long_b_threshold(THREADS) : (1 << 30);
     for (int s = t; s < TABLE; s += THREADS) { K[s] = kEmpty; V[s] = 0.0; }
+    if (RPB == 1 && t == 0) longs[0].x = 0;
     __syncthreads();
     if (row >= 0) {
         const int a0 = arpt[row], a1 = arpt[row + 1];
         const int gs = group_shift(row_flop[row], a1 - a0, THREADS), gmask = (1 << gs) - 1;
-        for (int j = a0 + (t >> gs); j < a1; j += THREADS >> gs) {
-            const int c = acol[j];
-            const double av = aval[j];
-            for (int k = brpt[c] + (t & gmask); k < brpt[c + 1]; k += gmask + 1) {
-                const int key = bcol[k];
-                const double tv = av * bval[k];                 // multop, hash_mult.h:583
-                int h = hash_of<TABLE>(key);
-                for (int probes = 0; probes < TABLE; ++probes) {   // bounded: a wrong crpt from the caller must not hang the GPU
-                    const int old = atomicCAS(&K[h], kEmpty, key);
-                    if (old == kEmpty || old == key) { atomicAdd(&V[h], tv); break; }   // addop, hash_mult.h:588-593
-                    h = (h + 1) & (TABLE - 1);
-                }
+        auto insert = [&](int key, double tv) {
+            int h = hash_of<TABLE>(key);
+            for (int probes = 0; probes < TABLE; ++probes) {       // bounded: a wrong crpt from the caller must not hang the GPU
+                const int old = atomicCAS(&K[h], kEmpty, key);
+                if (old == kEmpty || old == key) { atomicAdd(&V[h], tv); break; }   // addop, hash_mult.h:588-593
+                h = (h + 1) & (TABLE - 1);
+            }
+        };
+        walk_a_entries<true>(a0, a1, t >> gs, THREADS >> gs, acol, aval, brpt, [&](int b0, int b1, double av) {
+            if (RPB == 1 && defer_long_b(longs, b0, b1, av, t & gmask, gmask, long_thr)) return true;
+            for (int k = b0 + (t & gmask); k < b1; k += gmask + 1) insert(bcol[k], av * bval[k]);   // multop, hash_mult.h:583
+            return true;
+        });
+        if (RPB == 1) {
+            __syncthreads();                                        // uniform: with RPB == 1 every thread of the workgroup has this row
+            const int nl = min(longs[0].x, kLongCap);
+            for (int i = 0; i < nl; ++i) {
+                const int4 e = longs[1 + i];
+                const double av = long_b_value(e);
+                for (int k = e.x + t; k < e.y; k += THREADS) insert(bcol[k], av * bval[k]);
             }
         }
     }
@@ -285,6 +372,128 @@ __global__ __launch_bounds__(WGSIZE) void spgemm_numeric_lds_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------ big rows, all in LDS
+// Rows with 4 K < nz <= 32 K do not fit a keys+fp64 table in LDS, and the HBM bitmap path pays a global atomic per product.
+// Instead, one 1024-thread workgroup per row:
+//   phase 1 — the row's distinct columns, SORTED, without a sort: per window of 2^20 columns, mark the window's columns in an LDS
+//             bitmap (128 KiB), popcount-prefix it and emit the set bits in order into ccol;
+//   phase 2 — per chunk of 8192 consecutive output entries: their (sorted) columns in LDS as keys, fp64 accumulators beside them,
+//             every product whose column falls in the chunk finds its slot by binary search and is added with ds_add_f64.
+// The products are traversed (#windows + #chunks) times; B rows come from L2. No global atomics, sorted output for free.
+constexpr int kBigThreads = 1024;
+constexpr int kBigWindowBits = 20;                    // columns per bitmap window
+constexpr int kBigWindowWords = 1 << (kBigWindowBits - 5);
+constexpr int kBigChunk = 8192;                       // output entries per value pass
+
+__global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
+    const int *__restrict__ rows, int nrows, int N, const int *__restrict__ arpt, const int *__restrict__ acol, const double *__restrict__ aval,
+    const int *__restrict__ brpt, const int *__restrict__ bcol, const double *__restrict__ bval, const long long *__restrict__ row_flop,
+    const int *__restrict__ crpt, int *__restrict__ ccol, double *__restrict__ cval)
+{
+    // No static __shared__ in this kernel: it would sit in front of the dynamic region and push the fp64 table of phase 2 off its
+    // 8-byte alignment (cdna_hip_programming.md Guideline 17). Everything is carved from the dynamic region instead.
+    extern __shared__ int lds_i[];
+    int *s_scan = lds_i + kBigWindowWords;                         // kBigThreads ints
+    int &s_base = s_scan[kBigThreads];
+    int4 *longs = reinterpret_cast<int4 *>(s_scan + kBigThreads + 4);   // 16-byte aligned: (32768 + 1024 + 4) ints
+    const int long_thr = long_b_threshold(kBigThreads);
+    const int t = threadIdx.x;
+    const int row = rows[blockIdx.x];
+    (void)nrows;
+    const int a0 = arpt[row], a1 = arpt[row + 1];
+    const int off = crpt[row], nz = crpt[row + 1] - off;
+    const int gs = group_shift(row_flop[row], a1 - a0, kBigThreads), gmask = (1 << gs) - 1;
+
+    // ---- phase 1: sorted distinct columns
+    unsigned *bm = reinterpret_cast<unsigned *>(lds_i);
+    if (t == 0) s_base = 0;
+    for (int w0 = 0; w0 < N; w0 += (1 << kBigWindowBits)) {
+        for (int i = t; i < kBigWindowWords; i += kBigThreads) bm[i] = 0u;
+        if (t == 0) longs[0].x = 0;
+        __syncthreads();
+        const int w1 = min(N, w0 + (1 << kBigWindowBits));
+        auto mark = [&](int col) { if (col >= w0 && col < w1) atomicOr(&bm[(col - w0) >> 5], 1u << ((col - w0) & 31)); };
+        walk_a_entries<false>(a0, a1, t >> gs, kBigThreads >> gs, acol, nullptr, brpt, [&](int b0, int b1, double) {
+            if (defer_long_b(longs, b0, b1, 0.0, t & gmask, gmask, long_thr)) return true;
+            for (int k = b0 + (t & gmask); k < b1; k += gmask + 1) mark(bcol[k]);
+            return true;
+        });
+        __syncthreads();
+        {
+            const int nl = min(longs[0].x, kLongCap);
+            for (int i = 0; i < nl; ++i) {
+                const int4 e = longs[1 + i];
+                for (int k = e.x + t; k < e.y; k += kBigThreads) mark(bcol[k]);
+            }
+        }
+        __syncthreads();
+        constexpr int WPT = kBigWindowWords / kBigThreads;   // 32 consecutive words per thread
+        int cnt = 0;
+#pragma unroll 8
+        for (int i = 0; i < WPT; ++i) cnt += __popc(bm[t * WPT + i]);
+        s_scan[t] = cnt;
+        __syncthreads();
+        for (int d = 1; d < kBigThreads; d <<= 1) {
+            const int v = t >= d ? s_scan[t - d] : 0;
+            __syncthreads();
+            s_scan[t] += v;
+            __syncthreads();
+        }
+        int pos = off + s_base + s_scan[t] - cnt;
+        for (int i = 0; i < WPT; ++i) {
+            unsigned bits = bm[t * WPT + i];
+            while (bits) {
+                const int b = __ffs(bits) - 1;
+                bits &= bits - 1;
+                ccol[pos++] = w0 + ((t * WPT + i) << 5) + b;
+            }
+        }
+        __syncthreads();
+        if (t == kBigThreads - 1) s_base += s_scan[t];
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- phase 2: values, one chunk of the sorted columns at a time
+    double *V = reinterpret_cast<double *>(lds_i);                 // kBigChunk doubles
+    int *K = lds_i + 2 * kBigChunk;                                // kBigChunk ints
+    for (int q0 = 0; q0 < nz; q0 += kBigChunk) {
+        const int qn = min(kBigChunk, nz - q0);
+        for (int i = t; i < qn; i += kBigThreads) { K[i] = ccol[off + q0 + i]; V[i] = 0.0; }
+        if (t == 0) longs[0].x = 0;
+        __syncthreads();
+        const int kfirst = K[0], klast = K[qn - 1];
+        auto add = [&](int k, double av) {
+            const int col = bcol[k];
+            if (col < kfirst || col > klast) return;
+            int lo = 0, hi = qn - 1;                               // col is present: find its slot
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (K[mid] < col) lo = mid + 1; else hi = mid;
+            }
+            atomicAdd(&V[lo], av * bval[k]);
+        };
+        walk_a_entries<true>(a0, a1, t >> gs, kBigThreads >> gs, acol, aval, brpt, [&](int b0, int b1, double av) {
+            if (defer_long_b(longs, b0, b1, av, t & gmask, gmask, long_thr)) return true;
+            for (int k = b0 + (t & gmask); k < b1; k += gmask + 1) add(k, av);
+            return true;
+        });
+        __syncthreads();
+        {
+            const int nl = min(longs[0].x, kLongCap);
+            for (int i = 0; i < nl; ++i) {
+                const int4 e = longs[1 + i];
+                const double av = long_b_value(e);
+                for (int k = e.x + t; k < e.y; k += kBigThreads) add(k, av);
+            }
+        }
+        __syncthreads();
+        for (int i = t; i < qn; i += kBigThreads) cval[off + q0 + i] = V[i];
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ bitmap-rank path (hub rows)
 struct HubItem { int slot, row, j0, j1; };   // a workgroup's share of one hub row: A-entries [j0, j1)
 constexpr int kHubJChunk = 32;
@@ -293,12 +502,26 @@ __global__ __launch_bounds__(256) void hub_mark_kernel(const HubItem *__restrict
                                                         const int *__restrict__ acol, const int *__restrict__ brpt,
                                                         const int *__restrict__ bcol, unsigned *__restrict__ bitmap)
 {
+    __shared__ int4 longs[kLongCap + 1];                          // the only shared array of this kernel: 16-byte aligned
     const HubItem it = items[blockIdx.x];
     unsigned *bm = bitmap + (size_t)it.slot * W;
     const int t = threadIdx.x;
-    for (int j = it.j0 + (t >> 5); j < it.j1; j += 8) {
+    if (t == 0) longs[0].x = 0;
+    __syncthreads();
+    for (int j = it.j0 + (t >> 5); j < it.j1; j += 8) {           // 32 lanes per A-entry; long B rows are deferred to the whole workgroup
         const int c = acol[j];
-        for (int k = brpt[c] + (t & 31); k < brpt[c + 1]; k += 32) {
+        const int b0 = brpt[c], b1 = brpt[c + 1];
+        if (defer_long_b(longs, b0, b1, 0.0, t & 31, 31, 256)) continue;
+        for (int k = b0 + (t & 31); k < b1; k += 32) {
+            const int col = bcol[k];
+            atomicOr(&bm[col >> 5], 1u << (col & 31));
+        }
+    }
+    __syncthreads();
+    const int nl = min(longs[0].x, kLongCap);
+    for (int i = 0; i < nl; ++i) {
+        const int4 e = longs[1 + i];
+        for (int k = e.x + t; k < e.y; k += 256) {
             const int col = bcol[k];
             atomicOr(&bm[col >> 5], 1u << (col & 31));
         }
@@ -376,20 +599,33 @@ __global__ __launch_bounds__(256) void hub_accumulate_kernel(const HubItem *__re
                                                               const int *__restrict__ prefix, const int *__restrict__ crpt,
                                                               double *__restrict__ cval)
 {
+    __shared__ int4 longs[kLongCap + 1];
     const HubItem it = items[blockIdx.x];
     const unsigned *bm = bitmap + (size_t)it.slot * W;
     const int *pf = prefix + (size_t)it.slot * W;
     double *out = cval + crpt[it.row];
     const int t = threadIdx.x;
+    if (t == 0) longs[0].x = 0;
+    __syncthreads();
+    auto add = [&](int k, double av) {
+        const int col = bcol[k];
+        const int w = col >> 5;
+        const int pos = pf[w] + __popc(bm[w] & ((1u << (col & 31)) - 1u));
+        atomicAdd(&out[pos], av * bval[k]);
+    };
     for (int j = it.j0 + (t >> 5); j < it.j1; j += 8) {
         const int c = acol[j];
         const double av = aval[j];
-        for (int k = brpt[c] + (t & 31); k < brpt[c + 1]; k += 32) {
-            const int col = bcol[k];
-            const int w = col >> 5;
-            const int pos = pf[w] + __popc(bm[w] & ((1u << (col & 31)) - 1u));
-            atomicAdd(&out[pos], av * bval[k]);
-        }
+        const int b0 = brpt[c], b1 = brpt[c + 1];
+        if (defer_long_b(longs, b0, b1, av, t & 31, 31, 256)) continue;
+        for (int k = b0 + (t & 31); k < b1; k += 32) add(k, av);
+    }
+    __syncthreads();
+    const int nl = min(longs[0].x, kLongCap);
+    for (int i = 0; i < nl; ++i) {
+        const int4 e = longs[1 + i];
+        const double av = long_b_value(e);
+        for (int k = e.x + t; k < e.y; k += 256) add(k, av);
     }
 }
 
@@ -622,21 +858,21 @@ G4S_API g4s_status g4s_spgemm_symbolic(int32_t M, int32_t K, int32_t N,
 
     if (int n = rc.count[CLS_TINY]) {
         auto k = spgemm_symbolic_lds_kernel<256, 64, 64, false>;
-        hipLaunchKernelGGL(k, dim3((n + 3) / 4), dim3(256), 4 * 64 * sizeof(int), s, rc.list(CLS_TINY), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr);
+        hipLaunchKernelGGL(k, dim3((n + 3) / 4), dim3(256), sym_lds_bytes(4, 64), s, rc.list(CLS_TINY), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr);
     }
     if (int n = rc.count[CLS_SMALL]) {
         auto k = spgemm_symbolic_lds_kernel<256, 256, 1024, false>;
-        hipLaunchKernelGGL(k, dim3(n), dim3(256), 1024 * sizeof(int), s, rc.list(CLS_SMALL), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr);
+        hipLaunchKernelGGL(k, dim3(n), dim3(256), sym_lds_bytes(1, 1024), s, rc.list(CLS_SMALL), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr);
     }
     if (int n = rc.count[CLS_MEDIUM]) {
         auto k = spgemm_symbolic_lds_kernel<256, 256, 16384, false>;
-        G4S_TRY(allow_lds(k, 16384 * sizeof(int)));
-        hipLaunchKernelGGL(k, dim3(n), dim3(256), 16384 * sizeof(int), s, rc.list(CLS_MEDIUM), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr);
+        G4S_TRY(allow_lds(k, sym_lds_bytes(1, 16384)));
+        hipLaunchKernelGGL(k, dim3(n), dim3(256), sym_lds_bytes(1, 16384), s, rc.list(CLS_MEDIUM), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr);
     }
     if (int n = rc.count[CLS_LARGE]) {
         auto k = spgemm_symbolic_lds_kernel<1024, 1024, 32768, true>;
-        G4S_TRY(allow_lds(k, 32768 * sizeof(int)));
-        hipLaunchKernelGGL(k, dim3(n), dim3(1024), 32768 * sizeof(int), s, rc.list(CLS_LARGE), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, ovf_rows.as<int>(),
+        G4S_TRY(allow_lds(k, sym_lds_bytes(1, 32768)));
+        hipLaunchKernelGGL(k, dim3(n), dim3(1024), sym_lds_bytes(1, 32768), s, rc.list(CLS_LARGE), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, ovf_rows.as<int>(),
                            ovf_count.as<int>());
     }
     G4S_HIP_TRY(hipGetLastError());
@@ -690,8 +926,8 @@ G4S_API g4s_status g4s_spgemm_numeric(int32_t M, int32_t K, int32_t N,
     RowClasses rc;
     G4S_TRY(classify_rows(M, row_size.as<long long>(), kNumLimits, 0, rc, s));
     if (getenv("G4S_DEBUG"))
-        fprintf(stderr, "g4s numeric classes: empty %d <=32 %d <=512 %d <=1024 %d <=2048 %d <=4096 %d hub %d\n", rc.count[CLS_EMPTY], rc.count[CLS_TINY],
-                rc.count[CLS_SMALL], rc.count[CLS_MEDIUM], rc.count[CLS_LARGE], rc.count[CLS_M2], rc.count[CLS_HUB]);
+        fprintf(stderr, "g4s numeric classes: empty %d <=32 %d <=512 %d <=1024 %d <=2048 %d <=4096 %d <=32768 %d hub %d\n", rc.count[CLS_EMPTY], rc.count[CLS_TINY],
+                rc.count[CLS_SMALL], rc.count[CLS_MEDIUM], rc.count[CLS_LARGE], rc.count[CLS_M2], rc.count[CLS_M3], rc.count[CLS_HUB]);
 
     if (int n = rc.count[CLS_TINY]) {
         auto k = spgemm_numeric_lds_kernel<256, 64, 64>;
@@ -699,20 +935,26 @@ G4S_API g4s_status g4s_spgemm_numeric(int32_t M, int32_t K, int32_t N,
     }
     if (int n = rc.count[CLS_SMALL]) {
         auto k = spgemm_numeric_lds_kernel<256, 256, 1024>;
-        hipLaunchKernelGGL(k, dim3(n), dim3(256), 1024 * 12, s, rc.list(CLS_SMALL), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
+        hipLaunchKernelGGL(k, dim3(n), dim3(256), 1024 * 12 + kLongListBytes, s, rc.list(CLS_SMALL), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
     if (int n = rc.count[CLS_MEDIUM]) {
         auto k = spgemm_numeric_lds_kernel<256, 256, 2048>;
-        hipLaunchKernelGGL(k, dim3(n), dim3(256), 2048 * 12, s, rc.list(CLS_MEDIUM), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
+        hipLaunchKernelGGL(k, dim3(n), dim3(256), 2048 * 12 + kLongListBytes, s, rc.list(CLS_MEDIUM), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
     if (int n = rc.count[CLS_LARGE]) {
         auto k = spgemm_numeric_lds_kernel<512, 512, 4096>;
-        hipLaunchKernelGGL(k, dim3(n), dim3(512), 4096 * 12, s, rc.list(CLS_LARGE), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
+        hipLaunchKernelGGL(k, dim3(n), dim3(512), 4096 * 12 + kLongListBytes, s, rc.list(CLS_LARGE), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
     if (int n = rc.count[CLS_M2]) {
         auto k = spgemm_numeric_lds_kernel<1024, 1024, 8192>;
-        G4S_TRY(allow_lds(k, 8192 * 12));
-        hipLaunchKernelGGL(k, dim3(n), dim3(1024), 8192 * 12, s, rc.list(CLS_M2), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
+        G4S_TRY(allow_lds(k, 8192 * 12 + kLongListBytes));
+        hipLaunchKernelGGL(k, dim3(n), dim3(1024), 8192 * 12 + kLongListBytes, s, rc.list(CLS_M2), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
+    }
+    if (int n = rc.count[CLS_M3]) {
+        auto k = spgemm_numeric_big_kernel;
+        const size_t lds = sizeof(unsigned) * kBigWindowWords + sizeof(int) * (kBigThreads + 4) + kLongListBytes;   // 128 KiB bitmap (phase 2 reuses 96 KiB of it) + scan scratch + long-B list
+        G4S_TRY(allow_lds(k, lds));
+        hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rc.list(CLS_M3), n, N, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
     G4S_HIP_TRY(hipGetLastError());
     std::vector<int> hub, ranges, hub2, ranges2;
