@@ -153,6 +153,22 @@ __global__ void pb_fill_consumer_kernel(long long nspans, const int *__restrict_
 struct ProducerItem { int cband, s0, s1, pad; };     // spans [s0, s1) of one column band
 struct ConsumerItem { int rband, k0, k1, split; };   // micro-run slots [k0, k1) of one row band (multiples of 4)
 
+// Lane q of a 4-lane quad reads lane q+SHIFT of the same quad (DPP quad_perm: a VALU move, no LDS crossbar like ds_bpermute).
+// Lanes whose source would fall outside the quad read lane 3; the callers ignore those values.
+template <int SHIFT>
+__device__ __forceinline__ int quad_down_i(int v)
+{
+    constexpr int ctrl = SHIFT == 1 ? 0xF9 : (SHIFT == 2 ? 0xFE : 0xFF);   // quad_perm [1,2,3,3] / [2,3,3,3] / [3,3,3,3]
+    return __builtin_amdgcn_update_dpp(0, v, ctrl, 0xF, 0xF, false);
+}
+template <int SHIFT>
+__device__ __forceinline__ double quad_down_d(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = quad_down_i<SHIFT>((int)(b & 0xFFFFFFFFll)), hi = quad_down_i<SHIFT>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
 // Producer: one lane per PAIR of consecutive entries (unit-stride 4-byte / 16-byte loads), four lanes per 8-entry span. The
 // products of a span are summed per micro-run with a backward segmented reduction across the span's four lanes (shuffles), and
 // each lane stores the sums of the micro-runs that START in its pair (0, 1 or 2 stores).
@@ -210,8 +226,8 @@ __global__ __launch_bounds__(kPbThreads) void pb_producer_kernel(const ProducerI
             // open prefix: the part of this pair that continues a micro-run begun in an earlier lane of the span
             const double op = h0 ? 0.0 : (h1 ? p0 : p0 + p1);
             const bool closed = h0 | h1;
-            const double op1 = __shfl_down(op, 1, 4), op2 = __shfl_down(op, 2, 4), op3 = __shfl_down(op, 3, 4);
-            const int cl1 = __shfl_down((int)closed, 1, 4), cl2 = __shfl_down((int)closed, 2, 4);
+            const double op1 = quad_down_d<1>(op), op2 = quad_down_d<2>(op), op3 = quad_down_d<3>(op);
+            const int cl1 = quad_down_i<1>((int)closed), cl2 = quad_down_i<2>((int)closed);
             // ext: what the following lanes of the span add to the micro-run that contains this pair's last entry
             double ext = 0.0;
             if (q < 3) {
