@@ -21,7 +21,7 @@ namespace {
 constexpr int kDotBlocks = 256;   // partial sums per dot product
 constexpr int kThreads = 256;
 
-struct Scalars { double r1z1, r0z0, pAp, rr; };
+struct Scalars { double r1z1, r0z0; };
 
 __device__ __forceinline__ double block_sum(double v, double *sh)
 {
@@ -90,13 +90,25 @@ __global__ __launch_bounds__(kThreads) void cg_strip_kernel(int n_zero, const in
     if (i < n_zero) v[zero_resid[i]] = 0.0;
 }
 
-__global__ __launch_bounds__(kThreads) void cg_pAp_kernel(int n, const double *__restrict__ p2, const double *__restrict__ Ap, double *__restrict__ part)
+// boundary rows of Ap := 0 (strip_bcs_from_residual, through a byte mask built once per solve) fused with the partial p2·Ap
+__global__ __launch_bounds__(kThreads) void cg_pAp_kernel(int n, const unsigned char *__restrict__ bc_mask, const double *__restrict__ p2,
+                                                           double *__restrict__ Ap, double *__restrict__ part)
 {
     __shared__ double sh[4];
     double acc = 0.0;
-    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += kDotBlocks * kThreads) acc += p2[i] * Ap[i];
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += kDotBlocks * kThreads) {
+        double a = Ap[i];
+        if (bc_mask && bc_mask[i]) { a = 0.0; Ap[i] = 0.0; }
+        acc += p2[i] * a;
+    }
     acc = block_sum(acc, sh);
     if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+__global__ void cg_mask_kernel(int n_zero, const int *__restrict__ zero_resid, unsigned char *__restrict__ mask)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_zero) mask[zero_resid[i]] = 1;
 }
 
 // alpha = dotprod == 0 ? 1e-3 : dotr1z1/dotprod; d0 += alpha·p2; r2 = r1 − alpha·Ap; partial r2·r2   (:383-394)
@@ -118,15 +130,7 @@ __global__ __launch_bounds__(kThreads) void cg_update_kernel(int n, const double
     }
     acc = block_sum(acc, sh);
     if (threadIdx.x == 0) part_rr[blockIdx.x] = acc;
-}
-
-// rr = Σ part; dotr0z0 := dotr1z1 (for the next iteration's β)
-__global__ void cg_finish_kernel(const double *__restrict__ part_rr, Scalars *__restrict__ sc)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        sc->rr = sum_partials(part_rr);
-        sc->r0z0 = sc->r1z1;
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc->r0z0 = r1z1;   // dotr0z0 := dotr1z1 for the next iteration's β (nobody reads r0z0 in this kernel)
 }
 
 __global__ __launch_bounds__(kThreads) void elem_inverse_diagonal_finish_kernel(int n, double *__restrict__ BI)
@@ -180,14 +184,29 @@ G4S_API g4s_status g4s_conj_grad(g4s_elem_op_t op, g4s_csr_t A, int32_t neq, con
     double *part_a = part.as<double>(), *part_b = part_a + kDotBlocks, *part_c = part_b + kDotBlocks;
     Scalars *sc = scal.as<Scalars>();
     G4S_HIP_TRY(hipMemsetAsync(sc, 0, sizeof(Scalars), s));
-    const int vec_grid = std::min(kDotBlocks, (neq + kThreads - 1) / kThreads) > 0 ? kDotBlocks : 1;
-    (void)vec_grid;
 
+    DevBuf maskb;
+    unsigned char *bc_mask = nullptr;
+    if (n_zero) {
+        G4S_TRY(maskb.alloc((size_t)neq));
+        bc_mask = maskb.as<unsigned char>();
+        G4S_HIP_TRY(hipMemsetAsync(bc_mask, 0, (size_t)neq, s));
+        hipLaunchKernelGGL(cg_mask_kernel, dim3((n_zero + kThreads - 1) / kThreads), dim3(kThreads), 0, s, n_zero, zero_resid, bc_mask);
+    }
+    // the residual: the kDotBlocks partial sums come to the host (2 KiB) and are added in block order — the order a device-side
+    // finish kernel would use, without its launch
+    double h_part[kDotBlocks];
+    auto fetch_rr = [&](double *rr) -> int {
+        G4S_HIP_TRY(hipMemcpyAsync(h_part, part_c, sizeof(h_part), hipMemcpyDeviceToHost, s));
+        G4S_HIP_TRY(hipStreamSynchronize(s));
+        double t = 0.0;
+        for (int i = 0; i < kDotBlocks; ++i) t += h_part[i];
+        *rr = t;
+        return G4S_OK;
+    };
     hipLaunchKernelGGL(cg_init_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, neq, F, r1, d0, part_c);
-    hipLaunchKernelGGL(cg_finish_kernel, dim3(1), dim3(64), 0, s, part_c, sc);
     double rr = 0.0;
-    G4S_HIP_TRY(hipMemcpyAsync(&rr, &sc->rr, sizeof(double), hipMemcpyDeviceToHost, s));
-    G4S_HIP_TRY(hipStreamSynchronize(s));
+    G4S_TRY(fetch_rr(&rr));
     double residual = std::sqrt(rr);
     const int steps = *cycles;
     int count = 0;
@@ -196,12 +215,9 @@ G4S_API g4s_status g4s_conj_grad(g4s_elem_op_t op, g4s_csr_t A, int32_t neq, con
         hipLaunchKernelGGL(cg_direction_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, neq, count == 0 ? 1 : 0, part_a, sc, z, p1, p2);
         if (op) G4S_TRY(g4s_elem_op_apply(op, p2, Ap, s));
         else G4S_TRY(g4s_spmv(A, p2, Ap, 1.0, 0.0, s));
-        if (n_zero) hipLaunchKernelGGL(cg_strip_kernel, dim3((n_zero + kThreads - 1) / kThreads), dim3(kThreads), 0, s, n_zero, zero_resid, Ap);
-        hipLaunchKernelGGL(cg_pAp_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, neq, p2, Ap, part_b);
+        hipLaunchKernelGGL(cg_pAp_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, neq, bc_mask, p2, Ap, part_b);
         hipLaunchKernelGGL(cg_update_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, neq, part_b, sc, p2, Ap, r1, r2, d0, part_c);
-        hipLaunchKernelGGL(cg_finish_kernel, dim3(1), dim3(64), 0, s, part_c, sc);
-        G4S_HIP_TRY(hipMemcpyAsync(&rr, &sc->rr, sizeof(double), hipMemcpyDeviceToHost, s));
-        G4S_HIP_TRY(hipStreamSynchronize(s));
+        G4S_TRY(fetch_rr(&rr));
         residual = std::sqrt(rr);
         std::swap(r1, r2);      // the pointer rotation of General_matrix_functions.c:398-402
         std::swap(p1, p2);

@@ -14,6 +14,7 @@
 //   SYM_QUADRATIC_FORM      Cantera gather1/apply1, gather2/apply2, cantera/src/thermo/RedlichKwongMFTP.cpp:927-970.
 // An unregistered callback pair is refused (G4S_ERR_UNSUPPORTED): there is no host fallback in this library.
 #include "common.hpp"
+#include <algorithm>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -90,11 +91,71 @@ __global__ __launch_bounds__(256) void elem_matvec_kernel(int nno, int npe, int 
     }
 }
 
+// Fixed-shape fast path (the CitcomS shape: 8-node hexahedra, 3 dof, and at most 8 elements around a node). The generic kernel
+// above pays eight dependent memory latencies per wave (row pointer → terms → 3 × (equation id → u)); here the node's 8 term slots
+// come from a padded table and every lane issues its 3 equation ids and its 9 matrix entries before anything is consumed, so a
+// wave pays three: terms → (ids, K) → u.
+template <int NPE, int DOF>
+__global__ __launch_bounds__(256) void elem_matvec_fixed_kernel(int nno, const int *__restrict__ terms8 /* [nno][8], −1 = none */,
+                                                                 const int *__restrict__ elem_eq, const int *__restrict__ node_eq,
+                                                                 const double *__restrict__ elt_k, const double *__restrict__ u,
+                                                                 double *__restrict__ Au, double beta)
+{
+    constexpr int N = NPE * DOF, CPL = N / 8;                      // columns per lane (3 for N = 24)
+    static_assert(N % 8 == 0, "npe·dof must be a multiple of 8");
+    const int lane = threadIdx.x & 63;
+    const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (node >= nno) return;
+    const int g = lane >> 3, q = lane & 7;
+    const int term = terms8[node * 8 + g];
+    double acc[DOF];
+#pragma unroll
+    for (int i = 0; i < DOF; ++i) acc[i] = 0.0;
+    if (term >= 0) {
+        const int e = term / NPE, a = term - e * NPE;
+        const double *K = elt_k + (size_t)e * N * N + (size_t)(DOF * a) * N;
+        const int *eq = elem_eq + (size_t)e * N;
+        int ids[CPL];
+        double k[DOF][CPL], uc[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) ids[j] = eq[q + 8 * j];
+#pragma unroll
+        for (int i = 0; i < DOF; ++i)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) k[i][j] = __builtin_nontemporal_load(K + i * N + q + 8 * j);
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) uc[j] = u[ids[j]];
+#pragma unroll
+        for (int i = 0; i < DOF; ++i)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) acc[i] += k[i][j] * uc[j];
+    }
+    double tot[DOF];
+#pragma unroll
+    for (int i = 0; i < DOF; ++i) {
+        double v = acc[i];
+        v += __shfl_down(v, 4, 8);
+        v += __shfl_down(v, 2, 8);
+        v += __shfl_down(v, 1, 8);
+        tot[i] = 0.0;
+#pragma unroll
+        for (int gg = 0; gg < 8; ++gg) tot[i] += __shfl(v, gg * 8, 64);   // term sums in term order: reproducible
+    }
+    if (lane < DOF) {
+        const int eqn = node_eq[node * DOF + lane];
+        double r = tot[0];
+#pragma unroll
+        for (int i = 1; i < DOF; ++i) if (lane == i) r = tot[i];
+        Au[eqn] = beta == 0.0 ? r : r + beta * Au[eqn];
+    }
+}
+
 } // namespace
 
 struct g4s_elem_op_s {
     int nel = 0, npe = 0, dof = 0, nno = 0, neq = 0;
-    DevBuf node_ptr, node_terms, elem_eq, node_eq;
+    DevBuf node_ptr, node_terms, elem_eq, node_eq, terms8;
+    bool fixed8 = false;            // every node has <= 8 terms and the shape is (8, 3): use elem_matvec_fixed_kernel
     const double *elt_k = nullptr;  // borrowed device pointer
 };
 
@@ -138,6 +199,16 @@ G4S_API g4s_status g4s_elem_op_create(g4s_elem_op_t *out, int32_t numElems, int3
     if (!terms.empty()) G4S_HIP_TRY(hipMemcpy(op->node_terms.p, terms.data(), sizeof(int) * terms.size(), hipMemcpyHostToDevice));
     if (!eeq.empty()) G4S_HIP_TRY(hipMemcpy(op->elem_eq.p, eeq.data(), sizeof(int) * eeq.size(), hipMemcpyHostToDevice));
     if (nno) G4S_HIP_TRY(hipMemcpy(op->node_eq.p, id, sizeof(int) * (size_t)nno * dof, hipMemcpyHostToDevice));
+    int max_terms = 0;
+    for (int i = 0; i < nno; ++i) max_terms = std::max(max_terms, cnt[i + 1] - cnt[i]);
+    if (npe == 8 && dof == 3 && max_terms <= 8 && nno > 0) {
+        std::vector<int> t8((size_t)nno * 8, -1);
+        for (int i = 0; i < nno; ++i)
+            for (int t = cnt[i]; t < cnt[i + 1]; ++t) t8[(size_t)i * 8 + (t - cnt[i])] = terms[t];
+        G4S_TRY(op->terms8.alloc(sizeof(int) * t8.size()));
+        G4S_HIP_TRY(hipMemcpy(op->terms8.p, t8.data(), sizeof(int) * t8.size(), hipMemcpyHostToDevice));
+        op->fixed8 = true;
+    }
     *out = op.release();
     return G4S_OK;
 }
@@ -180,11 +251,16 @@ G4S_API g4s_status g4s_elem_op_destroy(g4s_elem_op_t op)
 
 static int elem_op_launch(g4s_elem_op_t op, const double *elt_k, const double *u, double *Au, double beta, hipStream_t s)
 {
-    // equations no node owns receive nothing: with beta == 0 they must read 0 (Element_calculations.c:495-496 zeroes Au first)
-    if (beta == 0.0 && op->neq) G4S_HIP_TRY(hipMemsetAsync(Au, 0, sizeof(double) * (size_t)op->neq, s));
+    // equations no node owns receive nothing: with beta == 0 they must read 0 (Element_calculations.c:495-496 zeroes Au first).
+    // When every equation has an owner (neq == nno·dof, the CitcomS numbering) the kernel writes all of Au and the memset is skipped.
+    if (beta == 0.0 && op->neq && (int64_t)op->nno * op->dof != op->neq) G4S_HIP_TRY(hipMemsetAsync(Au, 0, sizeof(double) * (size_t)op->neq, s));
     if (op->nno) {
-        hipLaunchKernelGGL(elem_matvec_kernel, dim3((op->nno + 3) / 4), dim3(256), 0, s, op->nno, op->npe, op->dof, op->node_ptr.as<int>(),
-                           op->node_terms.as<int>(), op->elem_eq.as<int>(), op->node_eq.as<int>(), elt_k, u, Au, beta);
+        if (op->fixed8)
+            hipLaunchKernelGGL((elem_matvec_fixed_kernel<8, 3>), dim3((op->nno + 3) / 4), dim3(256), 0, s, op->nno, op->terms8.as<int>(),
+                               op->elem_eq.as<int>(), op->node_eq.as<int>(), elt_k, u, Au, beta);
+        else
+            hipLaunchKernelGGL(elem_matvec_kernel, dim3((op->nno + 3) / 4), dim3(256), 0, s, op->nno, op->npe, op->dof, op->node_ptr.as<int>(),
+                               op->node_terms.as<int>(), op->elem_eq.as<int>(), op->node_eq.as<int>(), elt_k, u, Au, beta);
         G4S_HIP_TRY(hipGetLastError());
     }
     return G4S_OK;
