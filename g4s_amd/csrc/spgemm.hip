@@ -45,12 +45,6 @@ struct DevBuf {
 
 __device__ __forceinline__ int lds_peek(const int *p) { return *reinterpret_cast<const volatile int *>(p); }
 
-__device__ __forceinline__ int wave_sum_i(int v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
 __device__ __forceinline__ long long wave_sum_ll(long long v)
 {
 #pragma unroll

@@ -3,10 +3,11 @@
 // Why: on R-MAT 10M/1e8 the row-streaming CSR kernel (spmv.hip) is bound by the x gather, not by the matrix stream — every
 // 8-byte gather that misses L2 moves a 128-byte line (PMC: 6.1 GB fetched for 1.4 GB of algorithmic bytes; the gathers alone
 // cost 0.89 ms, tools/gather_probe.hip). Blocking turns both random sides into streams:
-//   producer  — nonzeros regrouped by 16K-column band. A workgroup loads that band of x into LDS (128 KiB); each thread takes a
-//               span of 8 consecutive entries (local column u16, value f64), multiplies, and sums the products of equal rows
-//               (a "micro-run": same row, same cell, same span) before writing them — on R-MAT only ≈0.55 products per nonzero
-//               leave the producer (tools/cell_hist.py: 0.51 distinct (row, column band) pairs per nonzero).
+//   producer  — nonzeros regrouped by 16K-column band. A workgroup loads that band of x into LDS (128 KiB); each lane takes a
+//               pair of consecutive entries (local column u16, value f64; unit-stride loads), multiplies, and the four lanes
+//               of an 8-entry span sum the products of equal rows (a "micro-run": same row, same cell, same span) before
+//               writing them — on R-MAT only ≈0.57 sums per nonzero leave the producer (tools/cell_hist.py: 0.51 distinct
+//               (row, column band) pairs per nonzero).
 //   consumer  — micro-run sums regrouped by 16K-row band. A workgroup keeps that band of y in LDS, streams (sum f64, local row
 //               u16), accumulates with LDS fp64 atomics, and writes the band of y once.
 // HBM traffic ≈ 10.6 B/nonzero read + 4.4 written by the producer and 5.5 read by the consumer, all sequential, instead of
@@ -30,7 +31,7 @@ namespace {
 constexpr int kBandBits = 14;
 constexpr int kBand = 1 << kBandBits;        // 16384 columns / rows per band: 128 KiB of fp64 in LDS
 constexpr int kPbThreads = 1024;
-constexpr int kSpan = 8;                     // consecutive entries per producer thread; cells are padded to a multiple of it
+constexpr int kSpan = 8;                     // entries per span (= 4 lanes × a pair each); cells are padded to a multiple of it
 constexpr int kProducerChunk = 1 << 17;      // entries per producer workgroup (x band load amortised over ≥ 1.3 MiB of stream)
 constexpr int kConsumerChunk = 1 << 17;      // micro-runs per consumer workgroup of a split (heavy) row band
 constexpr unsigned kPadFlag = 0x8000u;       // local-column flag of a pad slot (its product is forced to 0)
@@ -38,6 +39,19 @@ constexpr unsigned kPadFlag = 0x8000u;       // local-column flag of a pad slot 
 typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
 typedef unsigned short ushort4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
+
+#ifndef G4S_PB_NT
+#define G4S_PB_NT 1
+#endif
+template <typename T>
+__device__ __forceinline__ T pb_stream_load(const T *p)
+{
+#if G4S_PB_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
 
 struct DevBuf {
     void *p = nullptr;
@@ -172,7 +186,10 @@ __device__ __forceinline__ double quad_down_d(double v)
 // Producer: one lane per PAIR of consecutive entries (unit-stride 4-byte / 16-byte loads), four lanes per 8-entry span. The
 // products of a span are summed per micro-run with a backward segmented reduction across the span's four lanes (shuffles), and
 // each lane stores the sums of the micro-runs that START in its pair (0, 1 or 2 stores).
-constexpr int kPairUnroll = 4;
+#ifndef G4S_PB_PAIR_UNROLL
+#define G4S_PB_PAIR_UNROLL 4
+#endif
+constexpr int kPairUnroll = G4S_PB_PAIR_UNROLL;
 
 __global__ __launch_bounds__(kPbThreads) void pb_producer_kernel(const ProducerItem *__restrict__ items, int cols, int RB,
                                                                   const unsigned short *__restrict__ p_lcol, const double *__restrict__ p_val,
@@ -194,8 +211,8 @@ __global__ __launch_bounds__(kPbThreads) void pb_producer_kernel(const ProducerI
 #pragma unroll
     for (int u = 0; u < kPairUnroll; ++u) {
         const long long p = min(base + u * kPbThreads, p_last);
-        lc[u] = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(p_lcol) + p);
-        v[u] = __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(p_val) + p);
+        lc[u] = pb_stream_load(reinterpret_cast<const unsigned *>(p_lcol) + p);
+        v[u] = pb_stream_load(reinterpret_cast<const double2_t *>(p_val) + p);
         mk[u] = masks[p >> 2];
         mb[u] = mbase[p >> 2];
     }
@@ -208,8 +225,8 @@ __global__ __launch_bounds__(kPbThreads) void pb_producer_kernel(const ProducerI
 #pragma unroll
             for (int u = 0; u < kPairUnroll; ++u) {
                 const long long p = min(base + STEP + u * kPbThreads, p_last);
-                lc_n[u] = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(p_lcol) + p);
-                v_n[u] = __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(p_val) + p);
+                lc_n[u] = pb_stream_load(reinterpret_cast<const unsigned *>(p_lcol) + p);
+                v_n[u] = pb_stream_load(reinterpret_cast<const double2_t *>(p_val) + p);
                 mk_n[u] = masks[p >> 2];
                 mb_n[u] = mbase[p >> 2];
             }
@@ -257,7 +274,10 @@ __global__ void pb_scale_rows_kernel(const int *__restrict__ split_bands, int ro
     if (i < rows && i < r0 + kBand) y[i] = beta == 0.0 ? 0.0 : beta * y[i];
 }
 
-constexpr int kPbUnroll = 2;   // consumer: groups of 4 consecutive slots per thread per iteration
+#ifndef G4S_PB_CONS_UNROLL
+#define G4S_PB_CONS_UNROLL 2
+#endif
+constexpr int kPbUnroll = G4S_PB_CONS_UNROLL;   // consumer: groups of 4 consecutive slots per thread per iteration
 
 __global__ __launch_bounds__(kPbThreads) void pb_consumer_kernel(const ConsumerItem *__restrict__ items, int rows,
                                                                   const unsigned short *__restrict__ c_lrow, const double *__restrict__ prod,
@@ -275,9 +295,9 @@ __global__ __launch_bounds__(kPbThreads) void pb_consumer_kernel(const ConsumerI
 #pragma unroll
         for (int u = 0; u < kPbUnroll; ++u) {
             const int k = min(base + u * 4 * kPbThreads, last_group);
-            lr[u] = __builtin_nontemporal_load(reinterpret_cast<const ushort4_t *>(c_lrow + k));
-            pa[u] = __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(prod + k));
-            pb[u] = __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(prod + k + 2));
+            lr[u] = pb_stream_load(reinterpret_cast<const ushort4_t *>(c_lrow + k));
+            pa[u] = pb_stream_load(reinterpret_cast<const double2_t *>(prod + k));
+            pb[u] = pb_stream_load(reinterpret_cast<const double2_t *>(prod + k + 2));
         }
     }
     for (int i = threadIdx.x; i < kBand; i += kPbThreads) ys[i] = 0.0;
@@ -288,9 +308,9 @@ __global__ __launch_bounds__(kPbThreads) void pb_consumer_kernel(const ConsumerI
 #pragma unroll
             for (int u = 0; u < kPbUnroll; ++u) {
                 const int k = min(base + STEP + u * 4 * kPbThreads, last_group);
-                lr_n[u] = __builtin_nontemporal_load(reinterpret_cast<const ushort4_t *>(c_lrow + k));
-                pa_n[u] = __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(prod + k));
-                pb_n[u] = __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(prod + k + 2));
+                lr_n[u] = pb_stream_load(reinterpret_cast<const ushort4_t *>(c_lrow + k));
+                pa_n[u] = pb_stream_load(reinterpret_cast<const double2_t *>(prod + k));
+                pb_n[u] = pb_stream_load(reinterpret_cast<const double2_t *>(prod + k + 2));
             }
         }
 #pragma unroll
