@@ -28,8 +28,16 @@ def power_law_csr(rows, cols, seed, max_len):
     rowptr = np.zeros(rows + 1, np.int64)
     rowptr[1:] = np.cumsum(lens)
     colids = np.empty(rowptr[-1], np.int32)
-    for r in range(rows):
-        colids[rowptr[r]:rowptr[r + 1]] = np.sort(rng.choice(cols, lens[r], replace=False))
+    for r in np.nonzero(lens)[0]:
+        k = int(lens[r])
+        if 4 * k < cols:                      # rejection sampling: O(k), not the O(cols) permutation of rng.choice
+            u = np.unique(rng.integers(0, cols, size=k + k // 2 + 8))
+            while len(u) < k:
+                u = np.unique(np.concatenate([u, rng.integers(0, cols, size=k)]))
+            u = u[np.sort(rng.permutation(len(u))[:k])]
+        else:
+            u = np.sort(rng.choice(cols, k, replace=False))
+        colids[rowptr[r]:rowptr[r + 1]] = u
     values = rng.uniform(-1, 1, rowptr[-1])
     return rowptr.astype(np.int32), colids, values
 

@@ -196,3 +196,22 @@ def test_spmv_path_selection():
     assert host.banded_csr(6_000_000, 5, 1).info()["spmv_path"] == 0
     A = host.rmat_csr(6_000_000, 23, 30_000_000, 5)
     assert A.info()["spmv_path"] == 1
+
+
+@pytest.mark.parametrize("flags", [16, 8])
+def test_spmv_nonfinite_inputs_propagate_like_the_oracle(oracle, flags):
+    """Inf / NaN in x reach exactly the rows the oracle says they reach (pad slots and tail lanes must not leak 0·Inf = NaN)."""
+    from g4s_amd import host
+    rows, cols = 40000, 40000
+    rp, ci, va = power_law_csr(rows, cols, 41, 5000)
+    x = np.random.default_rng(4).uniform(-1, 1, cols)
+    x[[5, 16383, 16384, 39999]] = [np.inf, -np.inf, np.nan, np.inf]
+    A = host.CSR.from_host(rp, ci, va, rows, cols, spmv_flags=flags)
+    y = A.spmv(torch.from_numpy(x).cuda()).cpu().numpy()
+    want = oracle.spmv(rp, ci, va, x)
+    assert np.array_equal(np.isnan(y), np.isnan(want))
+    assert np.array_equal(np.isposinf(y), np.isposinf(want)) and np.array_equal(np.isneginf(y), np.isneginf(want))
+    fin = np.isfinite(want)
+    xf = np.where(np.isfinite(x), x, 0.0)
+    _, asum = oracle.spmv_ld(rp, ci, va, xf)
+    assert np.all(np.abs(y[fin] - want[fin]) <= TOL * asum[fin] + 1e-300)
