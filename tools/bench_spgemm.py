@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--ef", type=float, default=3.0)
 ap.add_argument("--scale", type=int, default=21)
 ap.add_argument("--runs", type=int, default=3)
+ap.add_argument("--cpu-sample-ef", type=float, default=0.0, help="also time the oracle's hash SpGEMM (1 host thread) on this smaller edge factor")
 args = ap.parse_args()
 lib = capi.load()
 n = 1 << args.scale
@@ -49,7 +50,20 @@ def run():
 run()
 sym, num = zip(*[run() for _ in range(args.runs)])
 s, m = sum(sym) / len(sym), sum(num) / len(num)
-print(json.dumps({"metric": "fp64 SpGEMM A*A GFLOPS (2*flop/t)", "value": round(2 * flop / ((s + m) * 1e-3) / 1e9, 3), "unit": "GFLOPS",
+cpu = None
+if args.cpu_sample_ef > 0:
+    from tests import oracle_lib
+    o = oracle_lib.load()
+    As = host.rmat_csr(n, args.scale, int(args.cpu_sample_ef * n), 20240522)
+    As.values.abs_()
+    fs = host.get_flop(As, As)
+    rp, ci, va = As.to_host()
+    t0 = time.perf_counter()
+    crp, cci, cva = o.spgemm((rp, ci, va), (rp, ci, va), n)
+    dt = time.perf_counter() - t0
+    cpu = {"value": round(2 * fs / dt / 1e9, 3), "unit": "GFLOPS", "cores": 1, "kind": "port",
+           "sample": f"R-MAT scale {args.scale}, edge factor {args.cpu_sample_ef}: flop {fs}, nnz(C) {len(cci)}, {dt:.1f} s (oracle_spgemm_symbolic + numeric)"}
+print(json.dumps({"cpu_baseline": cpu, "metric": "fp64 SpGEMM A*A GFLOPS (2*flop/t)", "value": round(2 * flop / ((s + m) * 1e-3) / 1e9, 3), "unit": "GFLOPS",
                   "config": {"workload": f"R-MAT scale {args.scale}, edge factor {args.ef}, C = A*A", "rows": n, "nnz_A": A.nnz, "flop": flop, "nnz_C": cnnz.value,
                              "compression": round(flop / max(cnnz.value, 1), 3)},
                   "symbolic_ms": round(s, 2), "numeric_ms": round(m, 2), "runs": args.runs,
