@@ -399,6 +399,8 @@ G4S_API g4s_status g4s_spmv_csr_i32_f64(int32_t rows, int32_t cols, const int32_
     else nnz32 = rowptr[rows];
     G4S_REQUIRE(nnz32 >= 0, "rowptr[rows] is negative");
     g4s_csr_t A = nullptr;
+    // one call, one product: the blocked path's regrouping (tens of ms) cannot pay off — stay on the streaming path unless asked
+    if (!(flags & G4S_SPMV_BLOCKED)) flags |= G4S_SPMV_STREAM;
     G4S_TRY(g4s_csr_create(&A, rows, cols, nnz32, rowptr, colids, values, flags));
     int st = G4S_OK;
     if (dev) {
