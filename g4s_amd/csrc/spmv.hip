@@ -23,7 +23,10 @@ namespace {
 
 constexpr int WG = 256;
 constexpr int TILE_NNZ = 2048;            // fp64 products staged in LDS per workgroup (16 KiB)
-constexpr int TILE_ROWS = 1024;           // row cap per stream block (4 KiB of staged row pointers)
+#ifndef G4S_TILE_ROWS
+#define G4S_TILE_ROWS 1024
+#endif
+constexpr int TILE_ROWS = G4S_TILE_ROWS;  // row cap per stream block (4 KiB of staged row pointers)
 constexpr int LONG_CHUNK = 8192;          // nonzeros per long-row chunk
 constexpr int UNROLL = TILE_NNZ / WG;     // independent loads in flight per lane
 

@@ -85,7 +85,10 @@ typedef struct g4s_csr_info {
 /* Create a handle. rowptr has rows+1 entries, zero-based, non-decreasing, rowptr[rows] == nnz; colids in [0,cols).
  * With G4S_HOST_POINTERS the three arrays are copied to the device (the handle owns the copies);
  * with G4S_DEVICE_POINTERS they are borrowed and must outlive the handle. Replaces the container role of
- * CSR<int,double> (mm/inc/CSR.h:22-113) for device residency. */
+ * CSR<int,double> (mm/inc/CSR.h:22-113) for device residency.
+ * The handle is a SNAPSHOT of the matrix: the execution plan (and, on the blocked path, a regrouped copy of the values) is
+ * built here; changing the arrays afterwards requires a new handle. One g4s_spmv at a time per handle (the blocked path owns a
+ * product buffer); different handles are independent. */
 g4s_status g4s_csr_create(g4s_csr_t *out, int32_t rows, int32_t cols, int64_t nnz,
                           const int32_t *rowptr, const int32_t *colids, const double *values, unsigned flags);
 g4s_status g4s_csr_destroy(g4s_csr_t A);
