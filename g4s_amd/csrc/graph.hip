@@ -293,24 +293,37 @@ __global__ __launch_bounds__(256) void dense_rows_times_matrix_kernel(int M, int
     const int arow = row0 + (lane & 15), kk = lane >> 4;
     const bool arow_ok = arow < M;
     for (int c0 = 0; c0 < K; c0 += kGemmNC) {
+        const int ntiles = min(8, (K - c0 + 15) / 16);             // column tiles that hold real columns (uniform)
         double4_t acc[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
         for (int k0 = 0; k0 < N; k0 += kGemmKC) {
+            // this wave's A fragments of the whole 64-deep panel go out first (16 independent loads per lane): their latency
+            // hides under the staging of the w panel instead of stalling every MFMA group
+            double afrag[kGemmKC / 4];
+#pragma unroll
+            for (int sidx = 0; sidx < kGemmKC / 4; ++sidx) {
+                const int k = k0 + 4 * sidx + kk;
+                afrag[sidx] = (arow_ok && k < N) ? xx[(size_t)arow * N + k] : 0.0;
+            }
             __syncthreads();
             for (int idx = threadIdx.x; idx < kGemmKC * kGemmNC; idx += 256) {
                 const int r = idx / kGemmNC, c = idx - r * kGemmNC;
                 ws[idx] = (k0 + r < N && c0 + c < K) ? w[(size_t)(k0 + r) * K + c0 + c] : 0.0;
             }
             __syncthreads();
-#pragma unroll 4
-            for (int ks = 0; ks < kGemmKC; ks += 4) {
-                const int k = k0 + ks + kk;
-                const double a = (arow_ok && k < N) ? xx[(size_t)arow * N + k] : 0.0;
+            const int ksteps = min(kGemmKC, N - k0 + 3) / 4;       // k-steps that hold real rows of w (uniform)
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const double b = ws[(ks + kk) * kGemmNC + t * 16 + (lane & 15)];
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+            for (int sidx = 0; sidx < kGemmKC / 4; ++sidx) {
+                if (sidx < ksteps) {
+                    const double a = afrag[sidx];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        if (t < ntiles) {
+                            const double b = ws[(4 * sidx + kk) * kGemmNC + t * 16 + (lane & 15)];
+                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
