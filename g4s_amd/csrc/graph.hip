@@ -339,6 +339,63 @@ __global__ __launch_bounds__(256) void dense_rows_times_matrix_kernel(int M, int
     }
 }
 
+// Persistent variant for the embedding-net sizes (N·roundup(K,16)·8 ≤ 96 KiB): w is staged in LDS ONCE per workgroup and stays
+// there; the 8 waves of a workgroup walk 16-row strips of xx in a grid-stride loop, and a wave loads the A fragments of its NEXT
+// strip while the MFMAs of the current one run. KT = column tiles of 16 (K ≤ 16·KT ≤ 128); NS = k-steps of 4 (N ≤ 4·NS).
+template <int KT>
+__global__ __launch_bounds__(512) void dense_rows_times_matrix_resident_kernel(int M, int N, int K, int NS, const double *__restrict__ xx,
+                                                                                const double *__restrict__ w, double *__restrict__ result)
+{
+    extern __shared__ double wres[];                               // [4·NS][16·KT], zero padded
+    constexpr int KP = 16 * KT;
+    constexpr int MAXS = 32;                                       // N ≤ 128
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kk = lane >> 4, cl = lane & 15;
+    for (int idx = threadIdx.x; idx < 4 * NS * KP; idx += 512) {
+        const int r = idx / KP, c = idx - r * KP;
+        wres[idx] = (r < N && c < K) ? w[(size_t)r * K + c] : 0.0;
+    }
+    __syncthreads();
+    const int nstrips = (M + 15) / 16, stride = gridDim.x * 8;
+    int strip = blockIdx.x * 8 + wave;
+    double a_cur[MAXS], a_nxt[MAXS];
+    auto load_a = [&](int sp, double (&a)[MAXS]) {
+        const int row = sp * 16 + cl;
+        const bool ok = sp < nstrips && row < M;
+#pragma unroll
+        for (int sidx = 0; sidx < MAXS; ++sidx) {
+            const int k = 4 * sidx + kk;
+            a[sidx] = (sidx < NS && ok && k < N) ? xx[(size_t)row * N + k] : 0.0;
+        }
+    };
+    load_a(strip, a_cur);
+    for (; strip < nstrips; strip += stride) {
+        load_a(strip + stride, a_nxt);
+        double4_t acc[KT];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int sidx = 0; sidx < MAXS; ++sidx) {
+            if (sidx < NS) {
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[sidx], wres[(4 * sidx + kk) * KP + t * 16 + cl], acc[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            const int col = t * 16 + cl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = strip * 16 + kk + 4 * r;
+                if (row < M && col < K) result[(size_t)row * K + col] = acc[t][r];
+            }
+        }
+#pragma unroll
+        for (int sidx = 0; sidx < MAXS; ++sidx) a_cur[sidx] = a_nxt[sidx];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ symmetric quadratic form
 // result[0] += Σ_i Σ_{j<i} x_i x_j (a[num·(i+m·j)] + a[num·(j+m·i)]) + Σ_i x_i² a[num·(i+m·i)];  result[1]: see g4s.h.
 // One workgroup; thread t owns rows t, t+256, …; workgroup tree reduction in a fixed shape.
@@ -377,7 +434,31 @@ G4S_API g4s_status g4s_dense_rows_times_matrix(int32_t M, int32_t N, int32_t K, 
     G4S_REQUIRE(M >= 0 && N >= 0 && K >= 0, "negative dimension");
     if (M == 0 || K == 0) return G4S_OK;
     G4S_REQUIRE(result_dev && (N == 0 || (xx_dev && w_dev)), "NULL argument");
-    hipLaunchKernelGGL(dense_rows_times_matrix_kernel, dim3((M + 63) / 64), dim3(256), 0, g4s::as_stream(stream), M, N, K, xx_dev, w_dev, result_dev);
+    const int KT = (K + 15) / 16, NS = (N + 3) / 4;
+    const size_t lds = sizeof(double) * 4 * (size_t)NS * 16 * KT;
+    if (N >= 1 && N <= 128 && K <= 128 && lds <= 96 * 1024 && M >= 4096) {
+        // embedding-net shapes: w resident in LDS, persistent strips
+        const int strips = (M + 15) / 16, grid = std::min(256 * 1, (strips + 7) / 8);
+        auto launch = [&](auto kern) -> int {
+            G4S_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, g4s::as_stream(stream), M, N, K, NS, xx_dev, w_dev, result_dev);
+            return G4S_OK;
+        };
+        int st = G4S_OK;
+        switch (KT) {
+        case 1: st = launch(dense_rows_times_matrix_resident_kernel<1>); break;
+        case 2: st = launch(dense_rows_times_matrix_resident_kernel<2>); break;
+        case 3: st = launch(dense_rows_times_matrix_resident_kernel<3>); break;
+        case 4: st = launch(dense_rows_times_matrix_resident_kernel<4>); break;
+        case 5: st = launch(dense_rows_times_matrix_resident_kernel<5>); break;
+        case 6: st = launch(dense_rows_times_matrix_resident_kernel<6>); break;
+        case 7: st = launch(dense_rows_times_matrix_resident_kernel<7>); break;
+        default: st = launch(dense_rows_times_matrix_resident_kernel<8>); break;
+        }
+        G4S_TRY(st);
+    } else {
+        hipLaunchKernelGGL(dense_rows_times_matrix_kernel, dim3((M + 63) / 64), dim3(256), 0, g4s::as_stream(stream), M, N, K, xx_dev, w_dev, result_dev);
+    }
     G4S_HIP_TRY(hipGetLastError());
     return G4S_OK;
 }

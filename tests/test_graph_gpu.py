@@ -26,7 +26,9 @@ def test_dense_rows_times_matrix_device(oracle):
     from g4s_amd import capi
     lib = capi.load()
     rng = np.random.default_rng(0)
-    for (M, N, K) in [(1, 1, 1), (29, 13, 7), (64, 4, 16), (100, 100, 100), (1000, 50, 25), (333, 70, 130), (5000, 1, 100)]:
+    # M >= 4096 with N, K <= 128 takes the LDS-resident persistent kernel, everything else the panel kernel
+    for (M, N, K) in [(1, 1, 1), (29, 13, 7), (64, 4, 16), (100, 100, 100), (1000, 50, 25), (333, 70, 130), (5000, 1, 100),
+                      (4096, 100, 100), (10007, 37, 50), (5000, 128, 128), (7001, 3, 17), (4100, 129, 20), (4100, 20, 129)]:
         xx, w = rng.uniform(-1, 1, (M, N)), rng.uniform(-1, 1, (N, K))
         # asymmetric integer data catches a transposed fragment map exactly
         xi = rng.integers(-3, 4, (M, N)).astype(np.float64)
