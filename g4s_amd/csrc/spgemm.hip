@@ -53,21 +53,24 @@ __device__ __forceinline__ long long wave_sum_ll(long long v)
 }
 
 // ------------------------------------------------------------------------------------------------ flop per row (a4)
-// One wavefront per row: lanes stride the row's A-entries. BIN::set_intprod_num (BIN.h:78-95) / compute_flop (mkl_mult.h:8-38).
+// Eight lanes per row (most rows of a power-law graph hold a handful of entries; hubs just loop longer): lanes stride the row's
+// A-entries. BIN::set_intprod_num (BIN.h:78-95) / compute_flop (mkl_mult.h:8-38).
 __global__ __launch_bounds__(256) void row_flop_kernel(int M, const int *__restrict__ arpt, const int *__restrict__ acol,
                                                         const int *__restrict__ brpt, long long *__restrict__ row_flop,
                                                         unsigned long long *__restrict__ total)
 {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    const int sub = threadIdx.x & 7;
+    const int row = blockIdx.x * 32 + (threadIdx.x >> 3);
     long long f = 0;
-    for (int j = arpt[row] + lane; j < arpt[row + 1]; j += 64) {
-        const int c = acol[j];
-        f += brpt[c + 1] - brpt[c];
-    }
-    f = wave_sum_ll(f);
-    if (lane == 0) {
+    if (row < M)
+        for (int j = arpt[row] + sub; j < arpt[row + 1]; j += 8) {
+            const int c = acol[j];
+            f += brpt[c + 1] - brpt[c];
+        }
+    f += __shfl_down(f, 4, 8);
+    f += __shfl_down(f, 2, 8);
+    f += __shfl_down(f, 1, 8);
+    if (row < M && sub == 0) {
         row_flop[row] = f;
         if (f) atomicAdd(total, (unsigned long long)f);
     }
@@ -94,7 +97,10 @@ struct ClassLimits { long long lim[6]; int raw[6]; };
 // more than the bitmap path, so only rows whose raw bound is within 4/3 of the table's 24 K-entry limit try it.
 constexpr ClassLimits kSymLimits{{32, 512, 8192, 32768, -1, -1}, {0, 0, 0, 1, 0, 0}};
 // numeric: by the exact nz of the output row; tables hold keys + fp64 at <= 50 % fill: TINY 64, SMALL 1 K, MEDIUM 2 K, LARGE 4 K, M2 8 K slots.
-constexpr ClassLimits kNumLimits{{32, 512, 1024, 2048, 4096, 32768}, {0, 0, 0, 0, 0, 0}};   // M3 (<= 32 K): the all-LDS big-row kernel
+#ifndef G4S_SPGEMM_BIG_LIMIT
+#define G4S_SPGEMM_BIG_LIMIT 65536
+#endif
+constexpr ClassLimits kNumLimits{{32, 512, 1024, 2048, 4096, G4S_SPGEMM_BIG_LIMIT}, {0, 0, 0, 0, 0, 0}};   // M3: the all-LDS big-row kernel
 
 __global__ void classify_kernel(int M, const long long *__restrict__ size, ClassLimits lim, int cols_clip,
                                 int *__restrict__ cls, int *__restrict__ hist)
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(WGSIZE) void spgemm_numeric_lds_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------ big rows, all in LDS
-// Rows with 4 K < nz <= 32 K do not fit a keys+fp64 table in LDS, and the HBM bitmap path pays a global atomic per product.
+// Rows with 4 K < nz <= 64 K do not fit a keys+fp64 table in LDS, and the HBM bitmap path pays a global atomic per product.
 // Instead, one 1024-thread workgroup per row:
 //   phase 1 — the row's distinct columns, SORTED, without a sort: per window of 2^20 columns, mark the window's columns in an LDS
 //             bitmap (128 KiB), popcount-prefix it and emit the set bits in order into ccol;
@@ -784,7 +790,7 @@ int compute_row_flop(int M, const int *arpt, const int *acol, const int *brpt, l
     DevBuf tot;
     G4S_TRY(tot.alloc(sizeof(unsigned long long)));
     G4S_HIP_TRY(hipMemsetAsync(tot.p, 0, sizeof(unsigned long long), s));
-    if (M > 0) hipLaunchKernelGGL(row_flop_kernel, dim3((M + 3) / 4), dim3(256), 0, s, M, arpt, acol, brpt, d_row_flop, tot.as<unsigned long long>());
+    if (M > 0) hipLaunchKernelGGL(row_flop_kernel, dim3((M + 31) / 32), dim3(256), 0, s, M, arpt, acol, brpt, d_row_flop, tot.as<unsigned long long>());
     G4S_HIP_TRY(hipGetLastError());
     unsigned long long h = 0;
     G4S_HIP_TRY(hipMemcpyAsync(&h, tot.p, sizeof(h), hipMemcpyDeviceToHost, s));
