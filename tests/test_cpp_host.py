@@ -91,3 +91,22 @@ def test_cpp_mkl_spgemm_cli(tmp_path, oracle):
             _, r, c, v = line.split()
             got[int(r), int(c)] = float(v)
     assert np.allclose(got, want, rtol=1e-12, atol=1e-14)
+
+
+def _build_c_example(out):
+    lib = os.path.join(ROOT, "g4s_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "citcoms_like.c"),
+                           "-L" + lib, "-lg4s_hip", "-Wl,-rpath," + lib, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", out])
+
+
+def test_c_linkage_of_spmm_dense(tmp_path):
+    """A plain C99 translation unit declares the reference's `extern void spmm_dense(...)` prototype and links (citcoms/bin/Citcom.c:45-48)."""
+    _build_c_example(str(tmp_path / "citcoms_like"))
+
+
+@pytest.mark.gpu
+def test_citcoms_shaped_c_caller_runs_on_gpu(tmp_path):
+    exe = str(tmp_path / "citcoms_like")
+    _build_c_example(exe)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "CHECK OK" in out.stdout, out.stdout + out.stderr
