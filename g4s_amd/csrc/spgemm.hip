@@ -94,8 +94,9 @@ enum { CLS_EMPTY = 0, CLS_TINY, CLS_SMALL, CLS_MEDIUM, CLS_LARGE, CLS_M2, CLS_M3
 // raw[i-1] is set (the unclipped bound decides). Beyond the last limit: hub.
 struct ClassLimits { long long lim[6]; int raw[6]; };
 // symbolic: tables are keys only. TINY 64 slots, SMALL 1 K, MEDIUM 16 K, LARGE = optimistic 32 K-slot table — a failed attempt costs
-// more than the bitmap path, so only rows whose raw bound is within 4/3 of the table's 24 K-entry limit try it.
-constexpr ClassLimits kSymLimits{{32, 512, 8192, 32768, -1, -1}, {0, 0, 0, 1, 0, 0}};
+// more than the bitmap path, so only rows whose raw bound is within 4/3 of the table's 24 K-entry limit try it. M2 (raw flop <= 2 M):
+// LDS bitmap windows (spgemm_symbolic_window_kernel), which also takes the rows whose optimistic table filled up. Beyond: hub.
+constexpr ClassLimits kSymLimits{{32, 512, 8192, 32768, 2097152, -1}, {0, 0, 0, 1, 1, 0}};
 // numeric: by the exact nz of the output row; tables hold keys + fp64 at <= 50 % fill: TINY 64, SMALL 1 K, MEDIUM 2 K, LARGE 4 K, M2 8 K slots.
 #ifndef G4S_SPGEMM_BIG_LIMIT
 #define G4S_SPGEMM_BIG_LIMIT 65536
@@ -384,6 +385,51 @@ constexpr int kBigThreads = 1024;
 constexpr int kBigWindowBits = 20;                    // columns per bitmap window
 constexpr int kBigWindowWords = 1 << (kBigWindowBits - 5);
 constexpr int kBigChunk = 8192;                       // output entries per value pass
+
+// Symbolic twin of phase 1 below: the number of distinct columns of a row whose key table would not fit LDS, counted with the
+// same LDS bitmap windows (no hash table that can overflow, no HBM bitmap, no global atomics). One workgroup per row.
+__global__ __launch_bounds__(kBigThreads) void spgemm_symbolic_window_kernel(
+    const int *__restrict__ rows, int nrows, int N, const int *__restrict__ arpt, const int *__restrict__ acol,
+    const int *__restrict__ brpt, const int *__restrict__ bcol, const long long *__restrict__ row_flop, int *__restrict__ row_nz)
+{
+    extern __shared__ int lds_i[];                                 // dynamic only (Guideline 17): [bitmap][count][pad][long-B list]
+    unsigned *bm = reinterpret_cast<unsigned *>(lds_i);
+    int &s_total = lds_i[kBigWindowWords];
+    int4 *longs = reinterpret_cast<int4 *>(lds_i + kBigWindowWords + 4);
+    const int t = threadIdx.x;
+    const int row = rows[blockIdx.x];
+    (void)nrows;
+    const int a0 = arpt[row], a1 = arpt[row + 1];
+    const int gs = group_shift(row_flop[row], a1 - a0, kBigThreads), gmask = (1 << gs) - 1;
+    const int long_thr = long_b_threshold(kBigThreads);
+    if (t == 0) s_total = 0;
+    for (int w0 = 0; w0 < N; w0 += (1 << kBigWindowBits)) {
+        for (int i = t; i < kBigWindowWords; i += kBigThreads) bm[i] = 0u;
+        if (t == 0) longs[0].x = 0;
+        __syncthreads();
+        const int w1 = min(N, w0 + (1 << kBigWindowBits));
+        auto mark = [&](int col) { if (col >= w0 && col < w1) atomicOr(&bm[(col - w0) >> 5], 1u << ((col - w0) & 31)); };
+        walk_a_entries<false>(a0, a1, t >> gs, kBigThreads >> gs, acol, nullptr, brpt, [&](int b0, int b1, double) {
+            if (defer_long_b(longs, b0, b1, 0.0, t & gmask, gmask, long_thr)) return true;
+            for (int k = b0 + (t & gmask); k < b1; k += gmask + 1) mark(bcol[k]);
+            return true;
+        });
+        __syncthreads();
+        const int nl = min(longs[0].x, kLongCap);
+        for (int i = 0; i < nl; ++i) {
+            const int4 e = longs[1 + i];
+            for (int k = e.x + t; k < e.y; k += kBigThreads) mark(bcol[k]);
+        }
+        __syncthreads();
+        int cnt = 0;
+        for (int i = t; i < kBigWindowWords; i += kBigThreads) cnt += __popc(bm[i]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+        if ((t & 63) == 0 && cnt) atomicAdd(&s_total, cnt);
+        __syncthreads();
+    }
+    if (t == 0) row_nz[row] = s_total;
+}
 
 __global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
     const int *__restrict__ rows, int nrows, int N, const int *__restrict__ arpt, const int *__restrict__ acol, const double *__restrict__ aval,
@@ -877,16 +923,23 @@ G4S_API g4s_status g4s_spgemm_symbolic(int32_t M, int32_t K, int32_t N,
     }
     G4S_HIP_TRY(hipGetLastError());
 
-    // hub rows = class HUB + the rows whose optimistic table filled up
+    // rows too wide for a key table in LDS: the rows whose optimistic table filled up, and the window class → LDS bitmap windows
     int n_ovf = 0;
     G4S_HIP_TRY(hipMemcpyAsync(&n_ovf, ovf_count.p, sizeof(int), hipMemcpyDeviceToHost, s));
     G4S_HIP_TRY(hipStreamSynchronize(s));
-    if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s symbolic: %d optimistic tables overflowed\n", n_ovf);
-    std::vector<int> hub, hub2, ranges, ranges2;
+    if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s symbolic: %d optimistic tables overflowed, %d window-class rows\n", n_ovf, rc.count[CLS_M2]);
+    {
+        auto k = spgemm_symbolic_window_kernel;
+        const size_t lds = sizeof(unsigned) * kBigWindowWords + sizeof(int) * 4 + kLongListBytes;
+        G4S_TRY(allow_lds(k, lds));
+        if (n_ovf) hipLaunchKernelGGL(k, dim3(n_ovf), dim3(kBigThreads), lds, s, ovf_rows.as<int>(), n_ovf, N, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz);
+        if (int n = rc.count[CLS_M2])
+            hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rc.list(CLS_M2), n, N, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz);
+        G4S_HIP_TRY(hipGetLastError());
+    }
+    // hub rows (flop > 2 M): many workgroups per row on a bitmap in HBM
+    std::vector<int> hub, ranges;
     G4S_TRY(fetch_rows_and_ranges(rc.list(CLS_HUB), rc.count[CLS_HUB], arpt, hub, ranges, s));
-    G4S_TRY(fetch_rows_and_ranges(ovf_rows.as<int>(), n_ovf, arpt, hub2, ranges2, s));
-    hub.insert(hub.end(), hub2.begin(), hub2.end());
-    ranges.insert(ranges.end(), ranges2.begin(), ranges2.end());
     G4S_TRY(run_hub_rows(false, hub, ranges, N, arpt, acol, nullptr, brpt, bcol, nullptr, nz, nullptr, nullptr, nullptr, s));
 
     // scan(bin.row_nz, crpt, nrow+1); *nnz = crpt[nrow]   (hash_mult.h:506-507)
