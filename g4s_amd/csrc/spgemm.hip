@@ -385,6 +385,22 @@ constexpr int kBigThreads = 1024;
 constexpr int kBigWindowBits = 20;                    // columns per bitmap window
 constexpr int kBigWindowWords = 1 << (kBigWindowBits - 5);
 constexpr int kBigChunk = 8192;                       // output entries per value pass
+constexpr int kWindowMaxN = 4 << kBigWindowBits;      // widest B for which the window kernels take the mid-size rows too
+inline int window_max_n() { const char *e = getenv("G4S_SPGEMM_WINDOW_MAX_N"); return e ? atoi(e) : kWindowMaxN; }   // tests force the table kernels with 0
+constexpr size_t kBigLdsBytes = sizeof(unsigned) * kBigWindowWords + sizeof(int) * (kBigThreads + 4) + kLongListBytes;
+
+// Inclusive prefix sum over the 64 lanes of a wave on the DPP datapath (row shifts inside each 16-lane row, then the row totals
+// broadcast down): six full-rate VALU adds, no LDS crossbar traffic as with ds_bpermute-based shuffles.
+__device__ __forceinline__ unsigned wave_inclusive_sum(unsigned x)
+{
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);    // row_shr:1
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);    // row_shr:2
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);    // row_shr:4
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);    // row_shr:8
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 → rows 1 and 3
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 → rows 2 and 3
+    return x;
+}
 
 // Symbolic twin of phase 1 below: the number of distinct columns of a row whose key table would not fit LDS, counted with the
 // same LDS bitmap windows (no hash table that can overflow, no HBM bitmap, no global atomics). One workgroup per row.
@@ -454,7 +470,7 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
     unsigned *bm = reinterpret_cast<unsigned *>(lds_i);
     if (t == 0) s_base = 0;
     for (int w0 = 0; w0 < N; w0 += (1 << kBigWindowBits)) {
-        for (int i = t; i < kBigWindowWords; i += kBigThreads) bm[i] = 0u;
+        for (int i = t; i < kBigWindowWords / 4; i += kBigThreads) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
         if (t == 0) longs[0].x = 0;
         __syncthreads();
         const int w1 = min(N, w0 + (1 << kBigWindowBits));
@@ -473,47 +489,89 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
             }
         }
         __syncthreads();
-        constexpr int WPT = kBigWindowWords / kBigThreads;   // 32 consecutive words per thread
-        int cnt = 0;
-#pragma unroll 8
-        for (int i = 0; i < WPT; ++i) cnt += __popc(bm[t * WPT + i]);
-        s_scan[t] = cnt;
-        __syncthreads();
-        for (int d = 1; d < kBigThreads; d <<= 1) {
-            const int v = t >= d ? s_scan[t - d] : 0;
-            __syncthreads();
-            s_scan[t] += v;
-            __syncthreads();
+        // Emit the set bits in column order. Thread t owns word t of each of the 32 rounds of 1024 consecutive words (not 32
+        // consecutive words: in a power-law row the first few hundred columns are all present, and one thread would emit a thousand
+        // entries while the rest emit a handful). Output position = window base + prefix over (round, wave) totals + prefix in the wave.
+        constexpr int ROUNDS = kBigWindowWords / kBigThreads;
+        static_assert(ROUNDS == 32 && kBigThreads == 1024, "emit layout");
+        const int lane = t & 63, wave = t >> 6;
+        // two rounds per scan: a wave holds <= 2048 bits per round, so two inclusive sums fit one register
+        auto packed_counts = [&](int i) { return (unsigned)__popc(bm[i * kBigThreads + t]) | ((unsigned)__popc(bm[(i + 1) * kBigThreads + t]) << 16); };
+#pragma unroll 4
+        for (int i = 0; i < ROUNDS; i += 2) {
+            const unsigned incl = wave_inclusive_sum(packed_counts(i));
+            if (lane == 63) { s_scan[i * 16 + wave] = (int)(incl & 0xffffu); s_scan[(i + 1) * 16 + wave] = (int)(incl >> 16); }
         }
-        int pos = off + s_base + s_scan[t] - cnt;
-        for (int i = 0; i < WPT; ++i) {
-            unsigned bits = bm[t * WPT + i];
-            while (bits) {
-                const int b = __ffs(bits) - 1;
-                bits &= bits - 1;
-                ccol[pos++] = w0 + ((t * WPT + i) << 5) + b;
+        __syncthreads();
+        if (wave == 0) {                                           // exclusive scan of the 512 (round, wave) totals, 8 per lane
+            int v[8], sum = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { v[u] = s_scan[lane * 8 + u]; sum += v[u]; }
+            const int incl = (int)wave_inclusive_sum((unsigned)sum);
+            int run = incl - sum;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s_scan[lane * 8 + u] = run; run += v[u]; }
+            if (lane == 63) s_scan[512] = incl;                    // bits in this window
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int i = 0; i < ROUNDS; i += 2) {
+            const unsigned c = packed_counts(i);
+            const unsigned incl = wave_inclusive_sum(c);           // recomputed rather than kept: 16 live registers per thread cost more
+            const unsigned excl = incl - c;
+            const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int E = (int)((tot >> (16 * h)) & 0xffffu);  // entries of this wave in this round (wave-uniform)
+                if (E == 0) continue;
+                unsigned b = bm[(i + h) * kBigThreads + t];
+                int p = (int)((excl >> (16 * h)) & 0xffffu);
+                const int gbase = off + s_base + s_scan[(i + h) * 16 + wave];
+                const int col0 = w0 + (((i + h) * kBigThreads + t) << 5);
+                p += gbase;
+                while (b) {
+                    const int bit = __ffs(b) - 1;
+                    b &= b - 1;
+                    ccol[p++] = col0 + bit;
+                }
             }
         }
         __syncthreads();
-        if (t == kBigThreads - 1) s_base += s_scan[t];
+        if (t == 0) s_base += s_scan[512];
         __syncthreads();
     }
     __threadfence_block();
     __syncthreads();
 
     // ---- phase 2: values, one chunk of the sorted columns at a time
+    // A product finds its slot through a bucket index over the chunk's column span: bucket b = (col - first) >> shift holds
+    // (first slot << 16 | last slot) of the columns that fall in it, so the binary search runs over one bucket (0–2 steps where the
+    // row is dense or evenly spread) instead of the whole chunk (13 steps).
     double *V = reinterpret_cast<double *>(lds_i);                 // kBigChunk doubles
     int *K = lds_i + 2 * kBigChunk;                                // kBigChunk ints
+    unsigned *IDX = reinterpret_cast<unsigned *>(lds_i + 3 * kBigChunk);   // kBigChunk buckets: 4·kBigChunk ints = the bitmap's 128 KiB
+    static_assert(4 * kBigChunk <= kBigWindowWords && kBigChunk <= 65536, "phase 2 reuses the bitmap region; slots are packed in 16 bits");
     for (int q0 = 0; q0 < nz; q0 += kBigChunk) {
         const int qn = min(kBigChunk, nz - q0);
         for (int i = t; i < qn; i += kBigThreads) { K[i] = ccol[off + q0 + i]; V[i] = 0.0; }
+        for (int i = t; i < kBigChunk; i += kBigThreads) IDX[i] = 0u;
         if (t == 0) longs[0].x = 0;
         __syncthreads();
         const int kfirst = K[0], klast = K[qn - 1];
+        const int span = klast - kfirst;                           // < 2^31
+        const int shift = span < kBigChunk ? 0 : 32 - __clz(span) - 13;   // (span >> shift) < kBigChunk = 2^13
+        static_assert(kBigChunk == 8192, "bucket shift assumes 2^13 buckets");
+        for (int i = t; i < qn; i += kBigThreads) {
+            const int b = (K[i] - kfirst) >> shift;
+            if (i == 0 || ((K[i - 1] - kfirst) >> shift) != b) atomicOr(&IDX[b], (unsigned)i << 16);
+            if (i == qn - 1 || ((K[i + 1] - kfirst) >> shift) != b) atomicOr(&IDX[b], (unsigned)i);
+        }
+        __syncthreads();
         auto add = [&](int k, double av) {
             const int col = bcol[k];
             if (col < kfirst || col > klast) return;
-            int lo = 0, hi = qn - 1;                               // col is present: find its slot
+            const unsigned w = IDX[(col - kfirst) >> shift];       // col is present, so its bucket is not empty
+            int lo = (int)(w >> 16), hi = (int)(w & 0xffffu);
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
                 if (K[mid] < col) lo = mid + 1; else hi = mid;
@@ -910,12 +968,24 @@ G4S_API g4s_status g4s_spgemm_symbolic(int32_t M, int32_t K, int32_t N,
         auto k = spgemm_symbolic_lds_kernel<256, 256, 1024, false>;
         hipLaunchKernelGGL(k, dim3(n), dim3(256), sym_lds_bytes(1, 1024), s, rc.list(CLS_SMALL), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr);
     }
-    if (int n = rc.count[CLS_MEDIUM]) {
+    // Up to kWindowMaxN columns (4 bitmap windows) the window kernel beats the key tables for every row past 512 products (it has no
+    // probe chains and cannot overflow); with more windows each row would re-walk its products once per window, so tables take over.
+    const bool x_med = N <= window_max_n(), x_large = x_med;
+    auto window = [&](const int *rows, int n) -> int {
+        auto k = spgemm_symbolic_window_kernel;
+        const size_t lds = sizeof(unsigned) * kBigWindowWords + sizeof(int) * 4 + kLongListBytes;
+        G4S_TRY(allow_lds(k, lds));
+        if (n) hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rows, n, N, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz);
+        return G4S_OK;
+    };
+    if (x_med) { G4S_TRY(window(rc.list(CLS_MEDIUM), rc.count[CLS_MEDIUM])); }
+    else if (int n = rc.count[CLS_MEDIUM]) {
         auto k = spgemm_symbolic_lds_kernel<256, 256, 16384, false>;
         G4S_TRY(allow_lds(k, sym_lds_bytes(1, 16384)));
         hipLaunchKernelGGL(k, dim3(n), dim3(256), sym_lds_bytes(1, 16384), s, rc.list(CLS_MEDIUM), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr);
     }
-    if (int n = rc.count[CLS_LARGE]) {
+    if (x_large) { G4S_TRY(window(rc.list(CLS_LARGE), rc.count[CLS_LARGE])); }
+    else if (int n = rc.count[CLS_LARGE]) {
         auto k = spgemm_symbolic_lds_kernel<1024, 1024, 32768, true>;
         G4S_TRY(allow_lds(k, sym_lds_bytes(1, 32768)));
         hipLaunchKernelGGL(k, dim3(n), dim3(1024), sym_lds_bytes(1, 32768), s, rc.list(CLS_LARGE), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, ovf_rows.as<int>(),
@@ -990,22 +1060,33 @@ G4S_API g4s_status g4s_spgemm_numeric(int32_t M, int32_t K, int32_t N,
         auto k = spgemm_numeric_lds_kernel<256, 256, 1024>;
         hipLaunchKernelGGL(k, dim3(n), dim3(256), 1024 * 12 + kLongListBytes, s, rc.list(CLS_SMALL), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
+    // Rows past 1 K entries: bitmap windows + bucketed slots beat table + in-LDS bitonic sort while the column range is <= 4 windows.
+    const bool xn_large = N <= window_max_n(), xn_m2 = xn_large;
+    auto big = [&](const int *rows, int n) -> int {
+        auto k = spgemm_numeric_big_kernel;
+        const size_t lds = kBigLdsBytes;
+        G4S_TRY(allow_lds(k, lds));
+        if (n) hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rows, n, N, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
+        return G4S_OK;
+    };
     if (int n = rc.count[CLS_MEDIUM]) {
         auto k = spgemm_numeric_lds_kernel<256, 256, 2048>;
         hipLaunchKernelGGL(k, dim3(n), dim3(256), 2048 * 12 + kLongListBytes, s, rc.list(CLS_MEDIUM), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
-    if (int n = rc.count[CLS_LARGE]) {
+    if (xn_large) { G4S_TRY(big(rc.list(CLS_LARGE), rc.count[CLS_LARGE])); }
+    else if (int n = rc.count[CLS_LARGE]) {
         auto k = spgemm_numeric_lds_kernel<512, 512, 4096>;
         hipLaunchKernelGGL(k, dim3(n), dim3(512), 4096 * 12 + kLongListBytes, s, rc.list(CLS_LARGE), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
-    if (int n = rc.count[CLS_M2]) {
+    if (xn_m2) { G4S_TRY(big(rc.list(CLS_M2), rc.count[CLS_M2])); }
+    else if (int n = rc.count[CLS_M2]) {
         auto k = spgemm_numeric_lds_kernel<1024, 1024, 8192>;
         G4S_TRY(allow_lds(k, 8192 * 12 + kLongListBytes));
         hipLaunchKernelGGL(k, dim3(n), dim3(1024), 8192 * 12 + kLongListBytes, s, rc.list(CLS_M2), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
     if (int n = rc.count[CLS_M3]) {
         auto k = spgemm_numeric_big_kernel;
-        const size_t lds = sizeof(unsigned) * kBigWindowWords + sizeof(int) * (kBigThreads + 4) + kLongListBytes;   // 128 KiB bitmap (phase 2 reuses 96 KiB of it) + scan scratch + long-B list
+        const size_t lds = kBigLdsBytes;   // 128 KiB bitmap (phase 2 reuses it) + scan scratch + long-B list
         G4S_TRY(allow_lds(k, lds));
         hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rc.list(CLS_M3), n, N, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }

@@ -53,8 +53,17 @@ def test_spgemm_golden_fixture(oracle):
     assert np.allclose(cval, g["cval"], rtol=1e-12, atol=1e-12)
 
 
-def test_spgemm_all_row_classes(oracle):
-    """Rows that land in every class: empty, tiny, small, medium, large (optimistic table), overflow → hub, flop-hub."""
+@pytest.fixture(params=["windows", "tables"])
+def mid_row_kernels(request, monkeypatch):
+    """Mid-size rows go to the bitmap-window kernels while B has <= 4 M columns and to the LDS key tables beyond; "tables" forces
+    the latter at test sizes (the library reads the variable on every call)."""
+    if request.param == "tables":
+        monkeypatch.setenv("G4S_SPGEMM_WINDOW_MAX_N", "0")
+    return request.param
+
+
+def test_spgemm_all_row_classes(oracle, mid_row_kernels):
+    """Rows that land in every class: empty, tiny, small, medium, large (optimistic table), overflow → windows, window class."""
     rng = np.random.default_rng(7)
     K, N = 3000, 60000
     # B: 3000 rows × 60000 cols, 100 entries per row (row 0 empty)
@@ -81,22 +90,46 @@ def test_spgemm_all_row_classes(oracle):
 
 
 def test_spgemm_flop_hub_path(oracle):
-    # flop > 393216 for one row → straight to the bitmap-rank path in symbolic; small N so that distinct ≪ flop
+    # flop > 2 M for one row → straight to the HBM bitmap-rank path in symbolic; small N so that distinct ≪ flop
     rng = np.random.default_rng(11)
     K, N = 2000, 9000
-    brp = (np.arange(K + 1) * 300).astype(np.int32)
-    bci = np.concatenate([np.sort(rng.choice(N, 300, replace=False)) for _ in range(K)]).astype(np.int32)
+    brp = (np.arange(K + 1) * 1100).astype(np.int32)
+    bci = np.concatenate([np.sort(rng.choice(N, 1100, replace=False)) for _ in range(K)]).astype(np.int32)
     bva = rng.uniform(0, 1, brp[-1])
-    arp = np.array([0, 1500, 1503, 1503], np.int32)
-    aci = np.concatenate([np.sort(rng.choice(K, 1500, replace=False)), [3, 7, 9]]).astype(np.int32)
+    arp = np.array([0, 1950, 1953, 1953], np.int32)
+    aci = np.concatenate([np.sort(rng.choice(K, 1950, replace=False)), [3, 7, 9]]).astype(np.int32)
     ava = rng.uniform(0, 1, arp[-1])
     c = _check(oracle, (arp, aci, ava), (brp, bci, bva), 3, K, N)
     assert np.diff(c.to_host()[0])[0] > 8000
 
 
-def test_spgemm_power_law_square(oracle):
+def test_spgemm_power_law_square(oracle, mid_row_kernels):
     rp, ci, va = power_law_csr(6000, 6000, 23, 1500)
     _check(oracle, (rp, ci, va), (rp, ci, va), 6000, 6000, 6000)
+
+
+def test_spgemm_three_windows(oracle):
+    """B with 2.6 M columns: the window kernels make three passes per row; rows of 600–9000 products, columns bunched at the
+    window seams (2^20, 2^21) and at both ends."""
+    rng = np.random.default_rng(29)
+    K, N = 400, 2_600_000
+    seams = np.array([0, 1 << 20, 1 << 21, N - 64])
+    brows = []
+    for k in range(K):
+        spread = rng.choice(N, 40, replace=False)
+        near = (seams[rng.integers(0, 4, 24)] + rng.integers(-40, 64, 24)).clip(0, N - 1)
+        brows.append(np.unique(np.concatenate([spread, near])))
+    brp = np.concatenate([[0], np.cumsum([len(r) for r in brows])]).astype(np.int32)
+    bci = np.concatenate(brows).astype(np.int32)
+    bva = rng.uniform(-1, 1, brp[-1])
+    lens = [10, 20, 40, 70, 150, 399, 0, 3]
+    rows = [np.sort(rng.choice(K, l, replace=False)) for l in lens]
+    arp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    aci = np.concatenate(rows).astype(np.int32)
+    ava = rng.uniform(-1, 1, arp[-1])
+    c = _check(oracle, (arp, aci, ava), (brp, bci, bva), len(lens), K, N)
+    nz = np.diff(c.to_host()[0])
+    assert nz[5] > 8192 and 1024 < nz[2] <= 4096                  # one row needs two value chunks; mid rows use the window kernel
 
 
 def test_spgemm_raw_pointer_host_call(oracle, g4s):
