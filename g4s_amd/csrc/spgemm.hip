@@ -99,7 +99,7 @@ struct ClassLimits { long long lim[6]; int raw[6]; };
 constexpr ClassLimits kSymLimits{{32, 512, 8192, 32768, 2097152, -1}, {0, 0, 0, 1, 1, 0}};
 // numeric: by the exact nz of the output row; tables hold keys + fp64 at <= 50 % fill: TINY 64, SMALL 1 K, MEDIUM 2 K, LARGE 4 K, M2 8 K slots.
 #ifndef G4S_SPGEMM_BIG_LIMIT
-#define G4S_SPGEMM_BIG_LIMIT 65536
+#define G4S_SPGEMM_BIG_LIMIT 131072
 #endif
 constexpr ClassLimits kNumLimits{{32, 512, 1024, 2048, 4096, G4S_SPGEMM_BIG_LIMIT}, {0, 0, 0, 0, 0, 0}};   // M3: the all-LDS big-row kernel
 
@@ -222,6 +222,37 @@ __device__ __forceinline__ bool defer_long_b(int4 *list, int b0, int b1, double 
     return true;
 }
 __device__ __forceinline__ double long_b_value(const int4 &e) { return __longlong_as_double(((long long)e.w << 32) | (unsigned)e.z); }
+
+// The cooperative phase. The deferred rows are cut into segments of 256 entries (64 lanes × 4 independent loads in flight per
+// lane) and the segments are dealt round-robin to the waves of the workgroup, continuing across rows: a few rows of tens of
+// thousands of entries (hub columns) and a few hundred rows of a few hundred entries both keep every wave busy, and no wave waits
+// a memory round trip per row. body(col, b_value, a_value).
+template <bool WITH_VAL, typename Body>
+__device__ __forceinline__ void for_deferred_rows(const int4 *list, int t, int threads, const int *__restrict__ bcol,
+                                                  const double *__restrict__ bval, Body body)
+{
+    const int nl = min(list[0].x, kLongCap);
+    const int lane = t & 63, wave = t >> 6, waves = threads >> 6;   // waves is a power of two (256, 512 or 1024 threads)
+    int dealt = 0;
+    for (int i = 0; i < nl; ++i) {
+        const int4 e = list[1 + i];
+        const double av = WITH_VAL ? long_b_value(e) : 0.0;
+        const int last = e.y - 1, nseg = (e.y - e.x + 255) >> 8;
+        for (int sg = (wave - dealt) & (waves - 1); sg < nseg; sg += waves) {
+            const int k = e.x + (sg << 8) + lane;
+            if (k >= e.y) continue;
+            const int k1 = min(k + 64, last), k2 = min(k + 128, last), k3 = min(k + 192, last);
+            const int c0 = bcol[k], c1 = bcol[k1], c2 = bcol[k2], c3 = bcol[k3];
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+            if (WITH_VAL) { v0 = bval[k]; v1 = bval[k1]; v2 = bval[k2]; v3 = bval[k3]; }
+            body(c0, v0, av);
+            if (k + 64 < e.y) body(c1, v1, av);
+            if (k + 128 < e.y) body(c2, v2, av);
+            if (k + 192 < e.y) body(c3, v3, av);
+        }
+        dealt += nseg;
+    }
+}
 
 // Lanes per A-entry: a power of two near a quarter of the row's average B-row length (flop_i / nnz(A_i)), at most 64 and at most
 // the cooperating thread count. These kernels are bound by the number of sequential acol → brpt → bcol rounds, so the more
@@ -385,9 +416,13 @@ constexpr int kBigThreads = 1024;
 constexpr int kBigWindowBits = 20;                    // columns per bitmap window
 constexpr int kBigWindowWords = 1 << (kBigWindowBits - 5);
 constexpr int kBigChunk = 8192;                       // output entries per value pass
+constexpr int kBigStage = 4096;                        // sorted column ids staged in LDS per coalesced store burst
+// Word w of a window lives at LDS slot w ^ ((w >> 6) & 31): the emit step gives each thread 32 consecutive words, and unswizzled
+// the 64 lanes of a wave would read 2 banks (a 32-way conflict); swizzled they read 64.
+__device__ __forceinline__ int bm_slot(int w) { return w ^ ((w >> 6) & 31); }
 constexpr int kWindowMaxN = 4 << kBigWindowBits;      // widest B for which the window kernels take the mid-size rows too
 inline int window_max_n() { const char *e = getenv("G4S_SPGEMM_WINDOW_MAX_N"); return e ? atoi(e) : kWindowMaxN; }   // tests force the table kernels with 0
-constexpr size_t kBigLdsBytes = sizeof(unsigned) * kBigWindowWords + sizeof(int) * (kBigThreads + 4) + kLongListBytes;
+constexpr size_t kBigLdsBytes = sizeof(unsigned) * kBigWindowWords + sizeof(int) * (kBigThreads + 4) + kLongListBytes + sizeof(int) * kBigStage;
 
 // Inclusive prefix sum over the 64 lanes of a wave on the DPP datapath (row shifts inside each 16-lane row, then the row totals
 // broadcast down): six full-rate VALU adds, no LDS crossbar traffic as with ds_bpermute-based shuffles.
@@ -447,6 +482,15 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_symbolic_window_kernel(
     if (t == 0) row_nz[row] = s_total;
 }
 
+#ifdef G4S_PROFILE_BIG
+__device__ unsigned long long g_big_prof[16];
+#define BIG_PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime()
+#define BIG_PROF(slot) do { if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_big_prof[slot], n_ - prof_t); prof_t = n_; } } while (0)
+#else
+#define BIG_PROF_DECL
+#define BIG_PROF(slot)
+#endif
+
 __global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
     const int *__restrict__ rows, int nrows, int N, const int *__restrict__ arpt, const int *__restrict__ acol, const double *__restrict__ aval,
     const int *__restrict__ brpt, const int *__restrict__ bcol, const double *__restrict__ bval, const long long *__restrict__ row_flop,
@@ -458,6 +502,7 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
     int *s_scan = lds_i + kBigWindowWords;                         // kBigThreads ints
     int &s_base = s_scan[kBigThreads];
     int4 *longs = reinterpret_cast<int4 *>(s_scan + kBigThreads + 4);   // 16-byte aligned: (32768 + 1024 + 4) ints
+    int *stage = reinterpret_cast<int *>(longs + kLongCap + 1);          // kBigStage ints
     const int long_thr = long_b_threshold(kBigThreads);
     const int t = threadIdx.x;
     const int row = rows[blockIdx.x];
@@ -466,6 +511,7 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
     const int off = crpt[row], nz = crpt[row + 1] - off;
     const int gs = group_shift(row_flop[row], a1 - a0, kBigThreads), gmask = (1 << gs) - 1;
 
+    BIG_PROF_DECL;
     // ---- phase 1: sorted distinct columns
     unsigned *bm = reinterpret_cast<unsigned *>(lds_i);
     if (t == 0) s_base = 0;
@@ -473,71 +519,80 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
         for (int i = t; i < kBigWindowWords / 4; i += kBigThreads) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
         if (t == 0) longs[0].x = 0;
         __syncthreads();
+        BIG_PROF(0);
         const int w1 = min(N, w0 + (1 << kBigWindowBits));
-        auto mark = [&](int col) { if (col >= w0 && col < w1) atomicOr(&bm[(col - w0) >> 5], 1u << ((col - w0) & 31)); };
+        auto mark = [&](int col) { if (col >= w0 && col < w1) atomicOr(&bm[bm_slot((col - w0) >> 5)], 1u << ((col - w0) & 31)); };
         walk_a_entries<false>(a0, a1, t >> gs, kBigThreads >> gs, acol, nullptr, brpt, [&](int b0, int b1, double) {
             if (defer_long_b(longs, b0, b1, 0.0, t & gmask, gmask, long_thr)) return true;
             for (int k = b0 + (t & gmask); k < b1; k += gmask + 1) mark(bcol[k]);
             return true;
         });
         __syncthreads();
-        {
-            const int nl = min(longs[0].x, kLongCap);
-            for (int i = 0; i < nl; ++i) {
-                const int4 e = longs[1 + i];
-                for (int k = e.x + t; k < e.y; k += kBigThreads) mark(bcol[k]);
-            }
-        }
+        BIG_PROF(1);
+        for_deferred_rows<false>(longs, t, kBigThreads, bcol, nullptr, [&](int col, double, double) { mark(col); });
         __syncthreads();
-        // Emit the set bits in column order. Thread t owns word t of each of the 32 rounds of 1024 consecutive words (not 32
-        // consecutive words: in a power-law row the first few hundred columns are all present, and one thread would emit a thousand
-        // entries while the rest emit a handful). Output position = window base + prefix over (round, wave) totals + prefix in the wave.
-        constexpr int ROUNDS = kBigWindowWords / kBigThreads;
-        static_assert(ROUNDS == 32 && kBigThreads == 1024, "emit layout");
+        BIG_PROF(2);
+        // Emit the set bits in column order. Thread t owns the 32 consecutive words [32t, 32t + 32): a block scan of the per-thread
+        // (set bits, non-empty words) places its columns and its words. The bits themselves are then written word by word from a
+        // list of the non-empty words, one word per thread: in a power-law row the first few hundred columns are all present, and
+        // a thread emitting its own 32 words would write a thousand ids while the rest write a handful (measured: 38 % of the kernel).
+        static_assert(kBigWindowWords / kBigThreads == 32 && kBigThreads == 1024, "emit layout");
+        static_assert(G4S_SPGEMM_BIG_LIMIT <= (1 << 17), "a list item packs the output position in 17 bits");
         const int lane = t & 63, wave = t >> 6;
-        // two rounds per scan: a wave holds <= 2048 bits per round, so two inclusive sums fit one register
-        auto packed_counts = [&](int i) { return (unsigned)__popc(bm[i * kBigThreads + t]) | ((unsigned)__popc(bm[(i + 1) * kBigThreads + t]) << 16); };
-#pragma unroll 4
-        for (int i = 0; i < ROUNDS; i += 2) {
-            const unsigned incl = wave_inclusive_sum(packed_counts(i));
-            if (lane == 63) { s_scan[i * 16 + wave] = (int)(incl & 0xffffu); s_scan[(i + 1) * 16 + wave] = (int)(incl >> 16); }
+        unsigned nonempty = 0;
+        int cnt = 0;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {
+            const unsigned w = bm[bm_slot(t * 32 + i)];
+            cnt += __popc(w);
+            nonempty |= (w != 0u ? 1u : 0u) << i;
         }
+        const int nw = __popc(nonempty);
+        const int incl_c = (int)wave_inclusive_sum((unsigned)cnt), incl_w = (int)wave_inclusive_sum((unsigned)nw);
+        if (lane == 63) { s_scan[wave] = incl_c; s_scan[16 + wave] = incl_w; }
         __syncthreads();
-        if (wave == 0) {                                           // exclusive scan of the 512 (round, wave) totals, 8 per lane
-            int v[8], sum = 0;
+        BIG_PROF(3);
+        int p = incl_c - cnt, wq = incl_w - nw, total = 0, total_w = 0;   // first column / first word of this thread within the window
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { v[u] = s_scan[lane * 8 + u]; sum += v[u]; }
-            const int incl = (int)wave_inclusive_sum((unsigned)sum);
-            int run = incl - sum;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { s_scan[lane * 8 + u] = run; run += v[u]; }
-            if (lane == 63) s_scan[512] = incl;                    // bits in this window
+        for (int u = 0; u < kBigThreads / 64; ++u) {
+            const int vc = s_scan[u], vw = s_scan[16 + u];
+            if (u < wave) { p += vc; wq += vw; }
+            total += vc;
+            total_w += vw;
         }
-        __syncthreads();
-#pragma unroll 2
-        for (int i = 0; i < ROUNDS; i += 2) {
-            const unsigned c = packed_counts(i);
-            const unsigned incl = wave_inclusive_sum(c);           // recomputed rather than kept: 16 live registers per thread cost more
-            const unsigned excl = incl - c;
-            const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int E = (int)((tot >> (16 * h)) & 0xffffu);  // entries of this wave in this round (wave-uniform)
-                if (E == 0) continue;
-                unsigned b = bm[(i + h) * kBigThreads + t];
-                int p = (int)((excl >> (16 * h)) & 0xffffu);
-                const int gbase = off + s_base + s_scan[(i + h) * 16 + wave];
-                const int col0 = w0 + (((i + h) * kBigThreads + t) << 5);
-                p += gbase;
-                while (b) {
-                    const int bit = __ffs(b) - 1;
-                    b &= b - 1;
-                    ccol[p++] = col0 + bit;
+        for (int tile0 = 0; tile0 < total_w; tile0 += kBigStage) {
+            const int tile1 = tile0 + kBigStage;
+            if (wq < tile1 && wq + nw > tile0) {
+                int q = p, j = wq;
+                unsigned m = nonempty;
+                while (m) {
+                    const int i = __ffs(m) - 1;
+                    m &= m - 1;
+                    if (j >= tile0 && j < tile1) stage[j - tile0] = ((t * 32 + i) << 17) | q;
+                    q += __popc(bm[bm_slot(t * 32 + i)]);
+                    ++j;
                 }
             }
+            __syncthreads();
+            BIG_PROF(4);
+            const int n = min(kBigStage, total_w - tile0);
+            for (int e = t; e < n; e += kBigThreads) {
+                const unsigned item = (unsigned)stage[e];
+                const int w = (int)(item >> 17);
+                unsigned bits = bm[bm_slot(w)];
+                int pos = off + s_base + (int)(item & 0x1ffffu);
+                const int col0 = w0 + (w << 5);
+                while (bits) {
+                    const int bit = __ffs(bits) - 1;
+                    bits &= bits - 1;
+                    ccol[pos++] = col0 + bit;
+                }
+            }
+            __syncthreads();
+            BIG_PROF(5);
         }
         __syncthreads();
-        if (t == 0) s_base += s_scan[512];
+        if (t == 0) s_base += total;
         __syncthreads();
     }
     __threadfence_block();
@@ -557,6 +612,7 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
         for (int i = t; i < kBigChunk; i += kBigThreads) IDX[i] = 0u;
         if (t == 0) longs[0].x = 0;
         __syncthreads();
+        BIG_PROF(6);
         const int kfirst = K[0], klast = K[qn - 1];
         const int span = klast - kfirst;                           // < 2^31
         const int shift = span < kBigChunk ? 0 : 32 - __clz(span) - 13;   // (span >> shift) < kBigChunk = 2^13
@@ -567,8 +623,8 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
             if (i == qn - 1 || ((K[i + 1] - kfirst) >> shift) != b) atomicOr(&IDX[b], (unsigned)i);
         }
         __syncthreads();
-        auto add = [&](int k, double av) {
-            const int col = bcol[k];
+        BIG_PROF(7);
+        auto add = [&](int col, double prod) {
             if (col < kfirst || col > klast) return;
             const unsigned w = IDX[(col - kfirst) >> shift];       // col is present, so its bucket is not empty
             int lo = (int)(w >> 16), hi = (int)(w & 0xffffu);
@@ -576,25 +632,21 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
                 const int mid = (lo + hi) >> 1;
                 if (K[mid] < col) lo = mid + 1; else hi = mid;
             }
-            atomicAdd(&V[lo], av * bval[k]);
+            atomicAdd(&V[lo], prod);
         };
         walk_a_entries<true>(a0, a1, t >> gs, kBigThreads >> gs, acol, aval, brpt, [&](int b0, int b1, double av) {
             if (defer_long_b(longs, b0, b1, av, t & gmask, gmask, long_thr)) return true;
-            for (int k = b0 + (t & gmask); k < b1; k += gmask + 1) add(k, av);
+            for (int k = b0 + (t & gmask); k < b1; k += gmask + 1) add(bcol[k], av * bval[k]);
             return true;
         });
         __syncthreads();
-        {
-            const int nl = min(longs[0].x, kLongCap);
-            for (int i = 0; i < nl; ++i) {
-                const int4 e = longs[1 + i];
-                const double av = long_b_value(e);
-                for (int k = e.x + t; k < e.y; k += kBigThreads) add(k, av);
-            }
-        }
+        BIG_PROF(8);
+        for_deferred_rows<true>(longs, t, kBigThreads, bcol, bval, [&](int col, double bv, double av) { add(col, av * bv); });
         __syncthreads();
+        BIG_PROF(9);
         for (int i = t; i < qn; i += kBigThreads) cval[off + q0 + i] = V[i];
         __syncthreads();
+        BIG_PROF(10);
     }
 }
 
@@ -1211,3 +1263,12 @@ G4S_API g4s_status g4s_spgemm_csr_i32_f64(const int32_t *arpt, const int32_t *ac
     if (timings) *timings = t;
     return G4S_OK;
 }
+
+#ifdef G4S_PROFILE_BIG
+extern "C" __attribute__((visibility("default"))) int g4s_debug_big_prof(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_big_prof), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
