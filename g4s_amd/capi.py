@@ -75,6 +75,7 @@ SIGNATURES = {
     "g4s_elem_op_inverse_diagonal": (C.c_int, [vp, vp, vp]),
     "g4s_conj_grad": (C.c_int, [vp, vp, C.c_int32, vp, vp, C.c_int32, vp, vp, C.c_double, C.POINTER(C.c_int32), f64p, vp]),
     "g4s_dense_rows_times_matrix": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]),
+    "g4s_dense_rows_times_matrix_grad": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp]),
     "g4s_sym_quadratic_form": (C.c_int, [C.c_int32, C.c_int32, vp, vp, vp, vp]),
     # include/g4s_synth.h
     "g4s_synth_rmat_keys": (C.c_int, [C.c_uint64, C.c_int32, C.c_int64, C.c_int64, C.c_int64, vp, vp]),

@@ -284,6 +284,9 @@ constexpr int kGemmNC = 128;   // columns of w / result per workgroup pass (8 MF
 // of v_mfma_f64_16x16x4_f64: A lane map row = lane&15, k = lane>>4; B k = lane>>4, col = lane&15; D col = lane&15,
 // row = (lane>>4) + 4·reg — cdna_hip_programming.md §3). w is staged through LDS in 64×128 panels (64 KiB); xx fragments are
 // read straight from global (each 16×N strip is private to one wave and stays in L1 across the k loop).
+// WT: w is stored transposed (K×N row-major, i.e. element (r, c) of the N×K operand is w[c·N + r]) — the dxx = grad·wᵀ product of
+// the op's gradient reads the forward weights in place.
+template <bool WT>
 __global__ __launch_bounds__(256) void dense_rows_times_matrix_kernel(int M, int N, int K, const double *__restrict__ xx,
                                                                        const double *__restrict__ w, double *__restrict__ result)
 {
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(256) void dense_rows_times_matrix_kernel(int M, int
             __syncthreads();
             for (int idx = threadIdx.x; idx < kGemmKC * kGemmNC; idx += 256) {
                 const int r = idx / kGemmNC, c = idx - r * kGemmNC;
-                ws[idx] = (k0 + r < N && c0 + c < K) ? w[(size_t)(k0 + r) * K + c0 + c] : 0.0;
+                ws[idx] = (k0 + r < N && c0 + c < K) ? (WT ? w[(size_t)(c0 + c) * N + k0 + r] : w[(size_t)(k0 + r) * K + c0 + c]) : 0.0;
             }
             __syncthreads();
             const int ksteps = min(kGemmKC, N - k0 + 3) / 4;       // k-steps that hold real rows of w (uniform)
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(256) void dense_rows_times_matrix_kernel(int M, int
 // Persistent variant for the embedding-net sizes (N·roundup(K,16)·8 ≤ 96 KiB): w is staged in LDS ONCE per workgroup and stays
 // there; the 8 waves of a workgroup walk 16-row strips of xx in a grid-stride loop, and a wave loads the A fragments of its NEXT
 // strip while the MFMAs of the current one run. KT = column tiles of 16 (K ≤ 16·KT ≤ 128); NS = k-steps of 4 (N ≤ 4·NS).
-template <int KT>
+template <int KT, bool WT>
 __global__ __launch_bounds__(512) void dense_rows_times_matrix_resident_kernel(int M, int N, int K, int NS, const double *__restrict__ xx,
                                                                                 const double *__restrict__ w, double *__restrict__ result)
 {
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(512) void dense_rows_times_matrix_resident_kernel(i
     const int kk = lane >> 4, cl = lane & 15;
     for (int idx = threadIdx.x; idx < 4 * NS * KP; idx += 512) {
         const int r = idx / KP, c = idx - r * KP;
-        wres[idx] = (r < N && c < K) ? w[(size_t)r * K + c] : 0.0;
+        wres[idx] = (r < N && c < K) ? (WT ? w[(size_t)c * N + r] : w[(size_t)r * K + c]) : 0.0;
     }
     __syncthreads();
     const int nstrips = (M + 15) / 16, stride = gridDim.x * 8;
@@ -396,6 +399,115 @@ __global__ __launch_bounds__(512) void dense_rows_times_matrix_resident_kernel(i
     }
 }
 
+// dw[N×K] = xxᵀ·grad: a reduction over the M rows (1e5–1e6) into a small matrix. One workgroup per (row range, 128×128 block
+// of dw). The rows go through LDS in slabs of 32 — [32][128 xx columns | 128 grad columns | 8 pad] doubles — double buffered:
+// thread t owns LDS column t and fetches its 32 rows of slab s+1 into registers (one base pointer + row stride per thread, all 32
+// loads in flight, no dependent instruction until they are parked) before the MFMAs of slab s, and parks them in the other buffer
+// afterwards; one barrier per slab. Columns past N / K and rows past the range are parked as zeros, so the MFMA loop has no
+// conditions: wave w owns the 16-row tiles w and w+4 of the block × all eight 16-column tiles (16 accumulators of
+// v_mfma_f64_16x16x4_f64: A[i][kk] = xx[m+kk][n0+i], B[kk][j] = grad[m+kk][k0+j]). The pad makes the four kk rows of an operand
+// read fall on different banks. Two earlier versions: operands straight from HBM one 4-row step ahead — latency-bound, 11 TFLOP/s;
+// LDS slabs with the out-of-range mask applied at the load — the compiler put an s_waitcnt after every load, 9 TFLOP/s.
+// Range results go to partials[range][N][K]; dense_reduce_slabs_kernel adds them in order (no atomics).
+#ifndef G4S_DW_SLAB
+#define G4S_DW_SLAB 16
+#endif
+#ifndef G4S_DW_WGS
+#define G4S_DW_WGS 512
+#endif
+constexpr int kDwSlab = G4S_DW_SLAB, kDwLd = 264;
+template <int KT>                                                  // 16-column tiles of the block that hold real columns of dw
+__global__ __launch_bounds__(256) void dense_rows_transposed_times_rows_kernel(int M, int N, int K, int rows_per_wg,
+                                                                                const double *__restrict__ xx, const double *__restrict__ g,
+                                                                                double *__restrict__ partials)
+{
+    extern __shared__ double slab[];                               // 2 × [kDwSlab][kDwLd]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int il = lane & 15, kk = lane >> 4;
+    const int nb = blockIdx.y * 128, kb = blockIdx.z * 128;
+    const int m0 = blockIdx.x * rows_per_wg, m1 = min(M, m0 + rows_per_wg);
+    // this thread's column of the slab: an xx column (t < 128) or a grad column
+    const bool in_x = t < 128;
+    const int col = in_x ? nb + t : kb + t - 128, width = in_x ? N : K;
+    const bool col_ok = col < width;
+    const double *src = (in_x ? xx : g) + min(col, width - 1);
+    const int ntl = min(2, max(0, (min(N - nb, 128) - 16 * wave + 63) / 64));   // row tiles w, w+4 of this wave that hold real rows of dw
+    for (int i = t; i < 2 * kDwSlab * 8; i += 256) {               // the pad columns are read by no one but keep them defined
+        const int b = i / (kDwSlab * 8), r = (i / 8) % kDwSlab;
+        slab[b * kDwSlab * kDwLd + r * kDwLd + 256 + (i & 7)] = 0.0;
+    }
+    double4_t acc[2][KT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < KT; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
+    double stage[kDwSlab];
+    auto fetch = [&](int m) {                                      // clamped rows: always in bounds, masked when parked
+#pragma unroll
+        for (int u = 0; u < kDwSlab; ++u) stage[u] = src[(size_t)min(m + u, m1 - 1) * width];
+    };
+    auto park = [&](double *buf, int m) {
+#pragma unroll
+        for (int u = 0; u < kDwSlab; ++u) buf[u * kDwLd + t] = (col_ok && m + u < m1) ? stage[u] : 0.0;
+    };
+    if (m0 < m1) { fetch(m0); park(slab, m0); }
+    __syncthreads();
+    int cur = 0;
+    for (int m = m0; m < m1; m += kDwSlab) {
+        const bool more = m + kDwSlab < m1;
+        if (more) fetch(m + kDwSlab);
+        const double *buf = slab + cur * (kDwSlab * kDwLd);
+#pragma unroll
+        for (int st = 0; st < kDwSlab / 4; ++st) {
+            const double *rowp = buf + (4 * st + kk) * kDwLd + il;
+            double b[KT];
+#pragma unroll
+            for (int j = 0; j < KT; ++j) b[j] = rowp[128 + 16 * j];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (i < ntl) {                                     // wave-uniform: one scalar branch per row tile, none per MFMA
+                    const double a = rowp[16 * (wave + 4 * i)];
+#pragma unroll
+                    for (int j = 0; j < KT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) park(slab + (cur ^ 1) * (kDwSlab * kDwLd), m + kDwSlab);
+        cur ^= 1;
+        __syncthreads();
+    }
+    double *out = partials + (size_t)blockIdx.x * N * K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            const int k = kb + 16 * j + il;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = nb + 16 * (wave + 4 * i) + kk + 4 * r;
+                if (n < N && k < K) out[(size_t)n * K + k] = acc[i][j][r];
+            }
+        }
+}
+
+// out[i] = Σ_b partials[b][i], b ascending within each of 16 interleaved groups, groups combined in a fixed tree: the same bits
+// every run. 64 elements × 16 groups per workgroup (one thread summing all ranges alone is a chain of dependent loads).
+__global__ __launch_bounds__(1024) void dense_reduce_slabs_kernel(int slabs, size_t elems, const double *__restrict__ partials, double *__restrict__ out)
+{
+    __shared__ double part[16][64];
+    const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + e;
+    double s = 0.0;
+    if (i < elems)
+        for (int b = grp; b < slabs; b += 16) s += partials[(size_t)b * elems + i];
+    part[grp][e] = s;
+    __syncthreads();
+    for (int half = 8; half > 0; half >>= 1) {
+        if (grp < half) part[grp][e] += part[grp + half][e];
+        __syncthreads();
+    }
+    if (grp == 0 && i < elems) out[i] = part[0][e];
+}
+
 // ------------------------------------------------------------------------------------------------ symmetric quadratic form
 // result[0] += Σ_i Σ_{j<i} x_i x_j (a[num·(i+m·j)] + a[num·(j+m·i)]) + Σ_i x_i² a[num·(i+m·i)];  result[1]: see g4s.h.
 // One workgroup; thread t owns rows t, t+256, …; workgroup tree reduction in a fixed shape.
@@ -428,12 +540,10 @@ __global__ __launch_bounds__(256) void sym_quadratic_form_kernel(int m, int numb
 
 } // namespace
 
-G4S_API g4s_status g4s_dense_rows_times_matrix(int32_t M, int32_t N, int32_t K, const double *xx_dev, const double *w_dev,
-                                               double *result_dev, void *stream)
+namespace {
+template <bool WT>
+int dense_rows_times_matrix_launch(int32_t M, int32_t N, int32_t K, const double *xx_dev, const double *w_dev, double *result_dev, void *stream)
 {
-    G4S_REQUIRE(M >= 0 && N >= 0 && K >= 0, "negative dimension");
-    if (M == 0 || K == 0) return G4S_OK;
-    G4S_REQUIRE(result_dev && (N == 0 || (xx_dev && w_dev)), "NULL argument");
     const int KT = (K + 15) / 16, NS = (N + 3) / 4;
     const size_t lds = sizeof(double) * 4 * (size_t)NS * 16 * KT;
     if (N >= 1 && N <= 128 && K <= 128 && lds <= 96 * 1024 && M >= 4096) {
@@ -446,20 +556,75 @@ G4S_API g4s_status g4s_dense_rows_times_matrix(int32_t M, int32_t N, int32_t K, 
         };
         int st = G4S_OK;
         switch (KT) {
-        case 1: st = launch(dense_rows_times_matrix_resident_kernel<1>); break;
-        case 2: st = launch(dense_rows_times_matrix_resident_kernel<2>); break;
-        case 3: st = launch(dense_rows_times_matrix_resident_kernel<3>); break;
-        case 4: st = launch(dense_rows_times_matrix_resident_kernel<4>); break;
-        case 5: st = launch(dense_rows_times_matrix_resident_kernel<5>); break;
-        case 6: st = launch(dense_rows_times_matrix_resident_kernel<6>); break;
-        case 7: st = launch(dense_rows_times_matrix_resident_kernel<7>); break;
-        default: st = launch(dense_rows_times_matrix_resident_kernel<8>); break;
+        case 1: st = launch(dense_rows_times_matrix_resident_kernel<1, WT>); break;
+        case 2: st = launch(dense_rows_times_matrix_resident_kernel<2, WT>); break;
+        case 3: st = launch(dense_rows_times_matrix_resident_kernel<3, WT>); break;
+        case 4: st = launch(dense_rows_times_matrix_resident_kernel<4, WT>); break;
+        case 5: st = launch(dense_rows_times_matrix_resident_kernel<5, WT>); break;
+        case 6: st = launch(dense_rows_times_matrix_resident_kernel<6, WT>); break;
+        case 7: st = launch(dense_rows_times_matrix_resident_kernel<7, WT>); break;
+        default: st = launch(dense_rows_times_matrix_resident_kernel<8, WT>); break;
         }
         G4S_TRY(st);
     } else {
-        hipLaunchKernelGGL(dense_rows_times_matrix_kernel, dim3((M + 63) / 64), dim3(256), 0, g4s::as_stream(stream), M, N, K, xx_dev, w_dev, result_dev);
+        hipLaunchKernelGGL(dense_rows_times_matrix_kernel<WT>, dim3((M + 63) / 64), dim3(256), 0, g4s::as_stream(stream), M, N, K, xx_dev, w_dev, result_dev);
     }
     G4S_HIP_TRY(hipGetLastError());
+    return G4S_OK;
+}
+} // namespace
+
+G4S_API g4s_status g4s_dense_rows_times_matrix(int32_t M, int32_t N, int32_t K, const double *xx_dev, const double *w_dev,
+                                               double *result_dev, void *stream)
+{
+    G4S_REQUIRE(M >= 0 && N >= 0 && K >= 0, "negative dimension");
+    if (M == 0 || K == 0) return G4S_OK;
+    G4S_REQUIRE(result_dev && (N == 0 || (xx_dev && w_dev)), "NULL argument");
+    return dense_rows_times_matrix_launch<false>(M, N, K, xx_dev, w_dev, result_dev, stream);
+}
+
+G4S_API g4s_status g4s_dense_rows_times_matrix_grad(int32_t M, int32_t N, int32_t K, const double *xx_dev, const double *w_dev,
+                                                    const double *grad_dev, double *dxx_dev, double *dw_dev, void *stream)
+{
+    G4S_REQUIRE(M >= 0 && N >= 0 && K >= 0, "negative dimension");
+    hipStream_t s = g4s::as_stream(stream);
+    // dxx[M×N] = grad[M×K]·wᵀ: the forward kernels with the roles of N and K swapped and w read transposed in place
+    if (dxx_dev && M > 0 && N > 0) {
+        G4S_REQUIRE(K == 0 || (grad_dev && w_dev), "NULL argument");
+        G4S_TRY(dense_rows_times_matrix_launch<true>(M, K, N, grad_dev, w_dev, dxx_dev, stream));
+    }
+    // dw[N×K] = xxᵀ·grad
+    if (dw_dev && N > 0 && K > 0) {
+        if (M == 0) { G4S_HIP_TRY(hipMemsetAsync(dw_dev, 0, sizeof(double) * (size_t)N * K, s)); return G4S_OK; }
+        G4S_REQUIRE(xx_dev && grad_dev, "NULL argument");
+        const int wgs = std::min(G4S_DW_WGS, (M + kDwSlab - 1) / kDwSlab);
+        const int rows_per_wg = ((M + wgs - 1) / wgs + kDwSlab - 1) / kDwSlab * kDwSlab;
+        const int used = (M + rows_per_wg - 1) / rows_per_wg;
+        const size_t elems = (size_t)N * K, lds = sizeof(double) * 2 * kDwSlab * kDwLd;
+        double *partials = nullptr;                                // stream-ordered scratch: no host sync, the pool keeps the pages
+        G4S_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&partials), sizeof(double) * elems * used, s));
+        auto launch = [&](auto kern) -> int {
+            G4S_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(used, (N + 127) / 128, (K + 127) / 128), dim3(256), lds, s, M, N, K, rows_per_wg, xx_dev, grad_dev, partials);
+            return G4S_OK;
+        };
+        int st = G4S_OK;
+        switch (K > 128 ? 8 : (K + 15) / 16) {                     // blocks of a wider dw all run the 8-tile kernel (the last one masks its tail)
+        case 1: st = launch(dense_rows_transposed_times_rows_kernel<1>); break;
+        case 2: st = launch(dense_rows_transposed_times_rows_kernel<2>); break;
+        case 3: st = launch(dense_rows_transposed_times_rows_kernel<3>); break;
+        case 4: st = launch(dense_rows_transposed_times_rows_kernel<4>); break;
+        case 5: st = launch(dense_rows_transposed_times_rows_kernel<5>); break;
+        case 6: st = launch(dense_rows_transposed_times_rows_kernel<6>); break;
+        case 7: st = launch(dense_rows_transposed_times_rows_kernel<7>); break;
+        default: st = launch(dense_rows_transposed_times_rows_kernel<8>); break;
+        }
+        if (st != G4S_OK) { (void)hipFreeAsync(partials, s); return st; }
+        hipLaunchKernelGGL(dense_reduce_slabs_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(1024), 0, s, used, elems, partials, dw_dev);
+        const hipError_t launch_err = hipGetLastError();
+        G4S_HIP_TRY(hipFreeAsync(partials, s));
+        G4S_HIP_TRY(launch_err);
+    }
     return G4S_OK;
 }
 

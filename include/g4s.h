@@ -214,6 +214,14 @@ g4s_status g4s_conj_grad(g4s_elem_op_t op, g4s_csr_t A, int32_t neq, const doubl
 g4s_status g4s_dense_rows_times_matrix(int32_t M, int32_t N, int32_t K, const double *xx_dev, const double *w_dev,
                                        double *result_dev, void *stream);
 
+/* Gradient of the op above — _opt_matmul_grad (deepmd/source/op/_opt_matmul_grad.py:6-12):
+ *   dxx[M×N] = grad[M×K] · wᵀ      (tf.matmul(grad, w, False, True))
+ *   dw[N×K]  = xxᵀ · grad[M×K]     (tf.matmul(xx, grad, True, False))
+ * Row-major fp64 device pointers. dxx_dev or dw_dev may be NULL to skip that product. dw is reduced over the M rows in a fixed
+ * slab order (no atomics): the same inputs give the same bits. */
+g4s_status g4s_dense_rows_times_matrix_grad(int32_t M, int32_t N, int32_t K, const double *xx_dev, const double *w_dev,
+                                            const double *grad_dev, double *dxx_dev, double *dw_dev, void *stream);
+
 /* result[0] += Σ_i Σ_{j<i} x_i x_j (a[num·(i+m·j)] + a[num·(j+m·i)]) + Σ_i x_i² a[num·(i+m·i)];
  * numbers == 1: result[1] += Σ_i x_i·b_i (apply1); numbers > 1: result[1] likewise on a[…+1] (gather2/apply2).
  * Host pointers (the operands are ~100×100); result is a host double[2] that is accumulated into. */

@@ -357,6 +357,25 @@ ORACLE_API void oracle_dense_rows_times_matrix(int32_t M, int32_t N, int32_t K, 
         }
 }
 
+/* Gradient of OptMatmul — deepmd/source/op/_opt_matmul_grad.py:6-12: dxx = matmul(grad, w, transpose_b) [M×N],
+ * dw = matmul(xx, grad, transpose_a) [N×K]. Plain triple loops, sums accumulated from 0 in index order. */
+ORACLE_API void oracle_dense_rows_times_matrix_grad(int32_t M, int32_t N, int32_t K, const double *xx, const double *w,
+                                                    const double *grad, double *dxx, double *dw)
+{
+    for (int32_t i = 0; i < M; ++i)
+        for (int32_t n = 0; n < N; ++n) {
+            double s = 0.0;
+            for (int32_t k = 0; k < K; ++k) { double p = grad[(size_t)i * K + k] * w[(size_t)n * K + k]; s = s + p; }
+            dxx[(size_t)i * N + n] = s;
+        }
+    for (int32_t n = 0; n < N; ++n)
+        for (int32_t k = 0; k < K; ++k) {
+            double s = 0.0;
+            for (int32_t i = 0; i < M; ++i) { double p = xx[(size_t)i * N + n] * grad[(size_t)i * K + k]; s = s + p; }
+            dw[(size_t)n * K + k] = s;
+        }
+}
+
 /* Cantera mixing rule: strictly-lower-triangle gather plus diagonal apply
  * — gather1/apply1/GraphProcess1 and gather2/apply2/GraphProcess2, cantera/src/thermo/RedlichKwongMFTP.cpp:927-983,
  * single rank (myid=0, numprocs=1), sequential. numbers==1 → form 1 (result[1] += x_i·b_i), else form 2. */

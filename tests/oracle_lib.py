@@ -42,6 +42,7 @@ class Oracle:
         L.oracle_spmm_dense.argtypes = [C.c_uint32, C.c_uint32, vp, vp, vp, vp, FUN_GATHER, FUN_APPLY, vp, C.c_int]
         L.oracle_element_matvec.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i32, _i32, vp, C.c_int32, _f64, _f64, C.c_int32]
         L.oracle_dense_rows_times_matrix.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, _f64, _f64]
+        L.oracle_dense_rows_times_matrix_grad.argtypes = [C.c_int32, C.c_int32, C.c_int32, _f64, _f64, _f64, _f64, _f64]
         L.oracle_sym_quadratic_form.argtypes = [C.c_int32, C.c_int32, _f64, _f64, vp, _f64]
         L.oracle_element_inverse_diagonal.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i32, _i32, _f64, _f64, C.c_int32]
         L.oracle_conj_grad_elem.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i32, _i32, _f64, C.c_int32, _f64, vp, C.c_int32, _f64, _f64,
@@ -160,6 +161,13 @@ class Oracle:
         res = np.zeros((M, K))
         self.lib.oracle_dense_rows_times_matrix(M, N, K, C.cast(rows, vp), np.ascontiguousarray(w), res)
         return res
+
+    def dense_rows_times_matrix_grad(self, xx, w, grad):
+        M, N = xx.shape
+        K = w.shape[1]
+        dxx, dw = np.zeros((M, N)), np.zeros((N, K))
+        self.lib.oracle_dense_rows_times_matrix_grad(M, N, K, np.ascontiguousarray(xx), np.ascontiguousarray(w), np.ascontiguousarray(grad), dxx, dw)
+        return dxx, dw
 
     def sym_quadratic_form(self, m, numbers, a, x, b=None):
         res = np.zeros(2)

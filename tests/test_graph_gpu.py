@@ -46,6 +46,38 @@ def test_dense_rows_times_matrix_device(oracle):
                 assert np.all(np.abs(got - want) <= 1e-10 * scale + 1e-300), (M, N, K)
 
 
+def test_dense_rows_times_matrix_grad_device(oracle):
+    """dxx = grad·wᵀ and dw = xxᵀ·grad (_opt_matmul_grad.py:6-12) against the oracle's triple loops; integer data must be exact."""
+    from g4s_amd import capi
+    lib = capi.load()
+    rng = np.random.default_rng(5)
+    for (M, N, K) in [(1, 1, 1), (3, 2, 5), (29, 13, 7), (64, 16, 16), (100, 100, 100), (1000, 50, 25), (333, 70, 130), (4096, 100, 100),
+                      (10007, 37, 50), (5000, 128, 128), (4100, 129, 20), (4100, 20, 129), (70000, 100, 100)]:
+        for exact in (True, False):
+            if exact:
+                xx, w, g = (rng.integers(-3, 4, sh).astype(np.float64) for sh in ((M, N), (N, K), (M, K)))
+            else:
+                xx, w, g = rng.uniform(-1, 1, (M, N)), rng.uniform(-1, 1, (N, K)), rng.uniform(-1, 1, (M, K))
+            xd, wd, gd = torch.from_numpy(xx).cuda(), torch.from_numpy(w).cuda(), torch.from_numpy(g).cuda()
+            dxx = torch.full((M, N), float("nan"), dtype=torch.float64, device="cuda")
+            dw = torch.full((N, K), float("nan"), dtype=torch.float64, device="cuda")
+            capi.check(lib.g4s_dense_rows_times_matrix_grad(M, N, K, xd.data_ptr(), wd.data_ptr(), gd.data_ptr(), dxx.data_ptr(), dw.data_ptr(), None))
+            want_dxx, want_dw = oracle.dense_rows_times_matrix_grad(xx, w, g)
+            got_dxx, got_dw = dxx.cpu().numpy(), dw.cpu().numpy()
+            if exact:
+                assert np.array_equal(got_dxx, want_dxx) and np.array_equal(got_dw, want_dw), (M, N, K)
+            else:
+                assert np.all(np.abs(got_dxx - want_dxx) <= 1e-10 * (np.abs(g) @ np.abs(w).T) + 1e-300), (M, N, K)
+                assert np.all(np.abs(got_dw - want_dw) <= 1e-10 * (np.abs(xx).T @ np.abs(g)) + 1e-300), (M, N, K)
+    # either output may be skipped; the reduction over rows is reproducible
+    M, N, K = 20000, 100, 100
+    xd, wd, gd = (torch.from_numpy(rng.uniform(-1, 1, sh)).cuda() for sh in ((M, N), (N, K), (M, K)))
+    a, b = torch.zeros((N, K), dtype=torch.float64, device="cuda"), torch.zeros((N, K), dtype=torch.float64, device="cuda")
+    capi.check(lib.g4s_dense_rows_times_matrix_grad(M, N, K, xd.data_ptr(), wd.data_ptr(), gd.data_ptr(), None, a.data_ptr(), None))
+    capi.check(lib.g4s_dense_rows_times_matrix_grad(M, N, K, xd.data_ptr(), wd.data_ptr(), gd.data_ptr(), None, b.data_ptr(), None))
+    assert torch.equal(a, b)
+
+
 def test_dense_golden_from_reference_graphprocess():
     from g4s_amd import capi
     lib = capi.load()

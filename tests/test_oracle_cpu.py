@@ -287,3 +287,12 @@ def test_conj_grad_solves_the_system(oracle):
     sol = np.linalg.solve(A[np.ix_(free, free)], F[free])
     assert np.allclose(d0[free], sol, rtol=1e-6, atol=1e-9)
     assert np.all(np.diff(np.log(hist + 1e-300))[-3:] < 0)        # converging at the end
+
+
+def test_dense_grad_matches_numpy(oracle):
+    """_opt_matmul_grad.py:6-12: dxx = grad·wᵀ, dw = xxᵀ·grad."""
+    rng = np.random.default_rng(3)
+    for (M, N, K) in [(1, 1, 1), (7, 3, 5), (50, 20, 30)]:
+        xx, w, g = rng.integers(-4, 5, (M, N)).astype(float), rng.integers(-4, 5, (N, K)).astype(float), rng.integers(-4, 5, (M, K)).astype(float)
+        dxx, dw = oracle.dense_rows_times_matrix_grad(xx, w, g)
+        assert np.array_equal(dxx, g @ w.T) and np.array_equal(dw, xx.T @ g)

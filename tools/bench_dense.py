@@ -23,3 +23,22 @@ for (M, N, K) in [(100000, 25, 50), (100000, 50, 100), (100000, 100, 100), (1000
     byt = 8 * (M * N + N * K + M * K)
     print(json.dumps({"M": M, "N": N, "K": K, "ms": round(ms, 4), "TFLOPs": round(2 * M * N * K / ms / 1e9, 2), "GBps": round(byt / ms / 1e6, 1),
                       "frac_hbm_8TBps": round(byt / ms / 1e6 / 8000, 3), "max_abs_diff_vs_torch": err}))
+
+    # gradient (_opt_matmul_grad.py): dxx = grad·wᵀ, dw = xxᵀ·grad
+    g = torch.rand(M, K, dtype=torch.float64, device="cuda") - 0.5
+    dxx = torch.empty(M, N, dtype=torch.float64, device="cuda")
+    dw = torch.empty(N, K, dtype=torch.float64, device="cuda")
+    for which, (pa, pb) in {"dxx": (dxx.data_ptr(), None), "dw": (None, dw.data_ptr())}.items():
+        for _ in range(3):
+            lib.g4s_dense_rows_times_matrix_grad(M, N, K, xx.data_ptr(), w.data_ptr(), g.data_ptr(), pa, pb, st)
+        e0.record()
+        for _ in range(20):
+            lib.g4s_dense_rows_times_matrix_grad(M, N, K, xx.data_ptr(), w.data_ptr(), g.data_ptr(), pa, pb, st)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        if which == "dxx":
+            err, byt = (dxx - g @ w.T).abs().max().item(), 8 * (M * K + N * K + M * N)
+        else:
+            err, byt = (dw - xx.T @ g).abs().max().item(), 8 * (M * N + M * K + N * K)
+        print(json.dumps({"grad": which, "M": M, "N": N, "K": K, "ms": round(ms, 4), "TFLOPs": round(2 * M * N * K / ms / 1e9, 2),
+                          "GBps": round(byt / ms / 1e6, 1), "max_abs_diff_vs_torch": err}))
