@@ -6,8 +6,11 @@
 // The reference's own CUDA attempt copied p and Ap across PCIe every iteration and kept the dot products on the host
 // (citcoms/lib/cgrad_kernel.cu:419-467); here every vector stays in HBM and each iteration is the mat-vec plus three fused
 // vector kernels. Dot products are two-level (fixed grid → partials → serial sum in a fixed order): reproducible.
-// Scalars (dot products, α, β) never leave the device; only the residual (8 bytes) goes to the host loop that owns the
-// termination test of the source.
+// Scalars (dot products, α, β, the residual, the iteration count) never leave the device, and neither does the termination test of
+// the source: `cg_direction_kernel` evaluates `(residual > acc && count < steps) || count == 0` from the partial sums and, when it
+// fails, raises a `done` flag that turns the rest of the enqueued iterations into no-ops. The host enqueues iterations in batches
+// (4, 8, 16, 16, …) and reads 32 bytes of state after each batch, so the GPU runs launches back to back instead of idling across a
+// D2H round trip per iteration (62 → see DESIGN.md §4.4 µs per Cookbook2 iteration).
 #include "common.hpp"
 #include <algorithm>
 #include <cmath>
@@ -21,7 +24,7 @@ namespace {
 constexpr int kDotBlocks = 256;   // partial sums per dot product
 constexpr int kThreads = 256;
 
-struct Scalars { double r1z1, r0z0; };
+struct CgState { double r1z1, r0z0, residual, residual0; int count, done; };   // residual0 = |F|, kept for the host's batch-size fit
 
 __device__ __forceinline__ double block_sum(double v, double *sh)
 {
@@ -34,56 +37,68 @@ __device__ __forceinline__ double block_sum(double v, double *sh)
     return s;
 }
 
-__device__ __forceinline__ double sum_partials(const double *__restrict__ part)
+// Σ of the kDotBlocks partial sums, identical in every workgroup: thread t takes partial t, then the fixed-shape block reduction
+// (a serial loop per thread, the first version, is 256 dependent L2 round trips: ≈15 µs per dot product on an idle GPU)
+__device__ __forceinline__ double sum_partials(const double *__restrict__ part, double *sh)
 {
-    // every thread adds the kDotBlocks partials in the same order: identical value everywhere, no broadcast needed
-    double s = 0.0;
-    for (int i = 0; i < kDotBlocks; ++i) s += part[i];
-    return s;
+    static_assert(kDotBlocks == kThreads, "one partial per thread");
+    return block_sum(part[threadIdx.x], sh);
 }
 
-// r1 = F; d0 = 0; partial r1·r1
-__global__ __launch_bounds__(kThreads) void cg_init_kernel(int n, const double *__restrict__ F, double *__restrict__ r1, double *__restrict__ d0,
-                                                            double *__restrict__ part)
-{
-    __shared__ double sh[4];
-    double acc = 0.0;
-    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += kDotBlocks * kThreads) {
-        const double f = F[i];
-        r1[i] = f; d0[i] = 0.0;
-        acc += f * f;
-    }
-    acc = block_sum(acc, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = acc;
-}
-
-// z = BI∘r1; partial r1·z
-__global__ __launch_bounds__(kThreads) void cg_precond_kernel(int n, const double *__restrict__ BI, const double *__restrict__ r1,
-                                                               double *__restrict__ z, double *__restrict__ part)
+// r1 = F; d0 = 0; z = BI∘r1; partial r1·r1 and r1·z   (General_matrix_functions.c:345-362, first pass of :365-367)
+__global__ __launch_bounds__(kThreads) void cg_init_kernel(int n, const double *__restrict__ F, const double *__restrict__ BI, double *__restrict__ r1,
+                                                            double *__restrict__ d0, double *__restrict__ z, double *__restrict__ part_rr,
+                                                            double *__restrict__ part_rz)
 {
     __shared__ double sh[4];
-    double acc = 0.0;
+    double rr = 0.0, rz = 0.0;
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += kDotBlocks * kThreads) {
-        const double zi = BI[i] * r1[i];
-        z[i] = zi;
-        acc += r1[i] * zi;
+        const double f = F[i], zi = BI[i] * f;
+        r1[i] = f; d0[i] = 0.0; z[i] = zi;
+        rr += f * f;
+        rz += f * zi;
     }
-    acc = block_sum(acc, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+    rr = block_sum(rr, sh);
+    rz = block_sum(rz, sh);
+    if (threadIdx.x == 0) { part_rr[blockIdx.x] = rr; part_rz[blockIdx.x] = rz; }
 }
 
-// dotr1z1 = Σ part; p2 = z (first) | z + (dotr1z1/dotr0z0)·p1; dotr0z0 := dotr1z1   (General_matrix_functions.c:365-379)
-__global__ __launch_bounds__(kThreads) void cg_direction_kernel(int n, int first, const double *__restrict__ part, Scalars *__restrict__ sc,
+// The loop head of :364 and the direction update of :369-379, on the device:
+//   residual = sqrt(Σ part_rr); if !((residual > acc && count < steps) || count == 0) → done (every block reaches the same verdict
+//   from the same sums; one thread records it); else dotr1z1 = Σ part_rz; p2 = z (count == 0) | z + (dotr1z1/dotr0z0)·p1.
+__global__ __launch_bounds__(kThreads) void cg_direction_kernel(int n, int steps, double acc, const double *__restrict__ part_rr,
+                                                                 const double *__restrict__ part_rz, CgState *__restrict__ st,
                                                                  const double *__restrict__ z, const double *__restrict__ p1, double *__restrict__ p2)
 {
-    const double r1z1 = sum_partials(part);
-    const double beta = first ? 0.0 : r1z1 / sc->r0z0;
+    __shared__ double sh[4];
+    if (st->done) return;
+    const double residual = sqrt(sum_partials(part_rr, sh));
+    const int count = st->count;
+    const bool run = (residual > acc && count < steps) || count == 0;
+    if (!run) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { st->residual = residual; st->done = 1; }
+        return;
+    }
+    const double r1z1 = sum_partials(part_rz, sh);
+    const bool first = count == 0;
+    const double beta = first ? 0.0 : r1z1 / st->r0z0;
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) p2[i] = first ? z[i] : z[i] + beta * p1[i];
     __syncthreads();
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) sc->r1z1 = r1z1;   // r0z0 is overwritten by cg_update_kernel, after every block has read it
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { st->r1z1 = r1z1; st->residual = residual; if (first) st->residual0 = residual; }   // r0z0 is overwritten by cg_update_kernel, after every block has read it
 }
 
-// boundary rows of Ap := 0 (strip_bcs_from_residual); partial p2·Ap
+// the verdict alone, once per batch, so that the host reads a final (residual, done) without enqueuing another iteration
+__global__ __launch_bounds__(kThreads) void cg_peek_kernel(int steps, double acc, const double *__restrict__ part_rr, CgState *__restrict__ st)
+{
+    __shared__ double sh[4];
+    if (st->done) return;
+    const double residual = sqrt(sum_partials(part_rr, sh));
+    if (threadIdx.x == 0) {
+        st->residual = residual;
+        if (!((residual > acc && st->count < steps) || st->count == 0)) st->done = 1;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void cg_strip_kernel(int n_zero, const int *__restrict__ zero_resid, double *__restrict__ v)
 {
     const int i = blockIdx.x * kThreads + threadIdx.x;
@@ -91,10 +106,11 @@ __global__ __launch_bounds__(kThreads) void cg_strip_kernel(int n_zero, const in
 }
 
 // boundary rows of Ap := 0 (strip_bcs_from_residual, through a byte mask built once per solve) fused with the partial p2·Ap
-__global__ __launch_bounds__(kThreads) void cg_pAp_kernel(int n, const unsigned char *__restrict__ bc_mask, const double *__restrict__ p2,
-                                                           double *__restrict__ Ap, double *__restrict__ part)
+__global__ __launch_bounds__(kThreads) void cg_pAp_kernel(int n, const CgState *__restrict__ st, const unsigned char *__restrict__ bc_mask,
+                                                           const double *__restrict__ p2, double *__restrict__ Ap, double *__restrict__ part)
 {
     __shared__ double sh[4];
+    if (st->done) return;
     double acc = 0.0;
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += kDotBlocks * kThreads) {
         double a = Ap[i];
@@ -111,26 +127,35 @@ __global__ void cg_mask_kernel(int n_zero, const int *__restrict__ zero_resid, u
     if (i < n_zero) mask[zero_resid[i]] = 1;
 }
 
-// alpha = dotprod == 0 ? 1e-3 : dotr1z1/dotprod; d0 += alpha·p2; r2 = r1 − alpha·Ap; partial r2·r2   (:383-394)
-__global__ __launch_bounds__(kThreads) void cg_update_kernel(int n, const double *__restrict__ part_pAp, Scalars *__restrict__ sc,
-                                                              const double *__restrict__ p2, const double *__restrict__ Ap,
-                                                              const double *__restrict__ r1, double *__restrict__ r2, double *__restrict__ d0,
-                                                              double *__restrict__ part_rr)
+// alpha = dotprod == 0 ? 1e-3 : dotr1z1/dotprod; d0 += alpha·p2; r2 = r1 − alpha·Ap; partial r2·r2   (:383-394), and — so that
+// the next iteration starts at its direction update — z = BI∘r2 with the partial r2·z of :365-367; count++, dotr0z0 := dotr1z1.
+__global__ __launch_bounds__(kThreads) void cg_update_kernel(int n, const double *__restrict__ part_pAp, CgState *__restrict__ st,
+                                                              const double *__restrict__ BI, const double *__restrict__ p2,
+                                                              const double *__restrict__ Ap, const double *__restrict__ r1, double *__restrict__ r2,
+                                                              double *__restrict__ d0, double *__restrict__ z, double *__restrict__ part_rr,
+                                                              double *__restrict__ part_rz)
 {
     __shared__ double sh[4];
-    const double pAp = sum_partials(part_pAp);
-    const double r1z1 = sc->r1z1;
+    if (st->done) return;
+    const double pAp = sum_partials(part_pAp, sh);
+    const double r1z1 = st->r1z1;
     const double alpha = (pAp == 0.0) ? 1.0e-3 : r1z1 / pAp;
-    double acc = 0.0;
+    double rr = 0.0, rz = 0.0;
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += kDotBlocks * kThreads) {
         d0[i] += alpha * p2[i];
         const double r = r1[i] - alpha * Ap[i];
+        const double zi = BI[i] * r;
         r2[i] = r;
-        acc += r * r;
+        z[i] = zi;
+        rr += r * r;
+        rz += r * zi;
     }
-    acc = block_sum(acc, sh);
-    if (threadIdx.x == 0) part_rr[blockIdx.x] = acc;
-    if (blockIdx.x == 0 && threadIdx.x == 0) sc->r0z0 = r1z1;   // dotr0z0 := dotr1z1 for the next iteration's β (nobody reads r0z0 in this kernel)
+    rr = block_sum(rr, sh);
+    rz = block_sum(rz, sh);
+    if (threadIdx.x == 0) { part_rr[blockIdx.x] = rr; part_rz[blockIdx.x] = rz; }
+    __syncthreads();
+    // count and r0z0 are read by every block of this kernel only through `st->done` / `st->r1z1` above: safe to write here
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->r0z0 = r1z1; st->count = st->count + 1; }
 }
 
 __global__ __launch_bounds__(kThreads) void elem_inverse_diagonal_finish_kernel(int n, double *__restrict__ BI)
@@ -156,6 +181,7 @@ struct DevBuf {
 // defined in graph.hip (needs the operator's node→term map)
 extern "C" g4s_status g4s_elem_op_diagonal_sum(g4s_elem_op_t op, double *diag_dev, void *stream);
 int g4s_elem_op_neq(g4s_elem_op_t op);
+int g4s_elem_op_apply_unless(g4s_elem_op_t op, const double *u_dev, double *Au_dev, const int *skip_dev, void *stream);
 
 G4S_API g4s_status g4s_elem_op_inverse_diagonal(g4s_elem_op_t op, double *BI_dev, void *stream)
 {
@@ -176,54 +202,61 @@ G4S_API g4s_status g4s_conj_grad(g4s_elem_op_t op, g4s_csr_t A, int32_t neq, con
     G4S_REQUIRE(n_zero >= 0 && (n_zero == 0 || zero_resid), "zero_resid is NULL");
     hipStream_t s = g4s::as_stream(stream);
     const size_t nb = sizeof(double) * (size_t)neq;
-    DevBuf r1b, r2b, zb, p1b, p2b, Apb, part, scal;
-    G4S_TRY(r1b.alloc(nb)); G4S_TRY(r2b.alloc(nb)); G4S_TRY(zb.alloc(nb)); G4S_TRY(p1b.alloc(nb)); G4S_TRY(p2b.alloc(nb)); G4S_TRY(Apb.alloc(nb));
-    G4S_TRY(part.alloc(sizeof(double) * 3 * kDotBlocks));
-    G4S_TRY(scal.alloc(sizeof(Scalars)));
-    double *r1 = r1b.as<double>(), *r2 = r2b.as<double>(), *z = zb.as<double>(), *p1 = p1b.as<double>(), *p2 = p2b.as<double>(), *Ap = Apb.as<double>();
-    double *part_a = part.as<double>(), *part_b = part_a + kDotBlocks, *part_c = part_b + kDotBlocks;
-    Scalars *sc = scal.as<Scalars>();
-    G4S_HIP_TRY(hipMemsetAsync(sc, 0, sizeof(Scalars), s));
-
-    DevBuf maskb;
+    // one stream-ordered arena for the six work vectors, the partial sums, the state and the boundary mask: after the first solve
+    // the pool hands the same pages back without a driver call (nine hipMalloc/hipFree pairs cost more than a short solve)
+    const size_t nbp = (nb + 255) / 256 * 256;
+    const size_t arena_bytes = 6 * nbp + sizeof(double) * 3 * kDotBlocks + 256 + (n_zero ? ((size_t)neq + 255) / 256 * 256 : 0);
+    struct Arena {
+        void *p = nullptr; hipStream_t s = nullptr;
+        ~Arena() { if (p) (void)hipFreeAsync(p, s); }
+    } arena;
+    arena.s = s;
+    G4S_HIP_TRY(hipMallocAsync(&arena.p, arena_bytes, s));
+    char *base = static_cast<char *>(arena.p);
+    double *r1 = reinterpret_cast<double *>(base), *r2 = reinterpret_cast<double *>(base + nbp), *z = reinterpret_cast<double *>(base + 2 * nbp),
+           *p1 = reinterpret_cast<double *>(base + 3 * nbp), *p2 = reinterpret_cast<double *>(base + 4 * nbp), *Ap = reinterpret_cast<double *>(base + 5 * nbp);
+    double *part_rz = reinterpret_cast<double *>(base + 6 * nbp), *part_pAp = part_rz + kDotBlocks, *part_rr = part_pAp + kDotBlocks;
+    CgState *st = reinterpret_cast<CgState *>(part_rr + kDotBlocks);
+    static_assert(sizeof(CgState) <= 256, "state slot");
+    G4S_HIP_TRY(hipMemsetAsync(st, 0, sizeof(CgState), s));
     unsigned char *bc_mask = nullptr;
     if (n_zero) {
-        G4S_TRY(maskb.alloc((size_t)neq));
-        bc_mask = maskb.as<unsigned char>();
+        bc_mask = reinterpret_cast<unsigned char *>(st) + 256;
         G4S_HIP_TRY(hipMemsetAsync(bc_mask, 0, (size_t)neq, s));
         hipLaunchKernelGGL(cg_mask_kernel, dim3((n_zero + kThreads - 1) / kThreads), dim3(kThreads), 0, s, n_zero, zero_resid, bc_mask);
     }
-    // the residual: the kDotBlocks partial sums come to the host (2 KiB) and are added in block order — the order a device-side
-    // finish kernel would use, without its launch
-    double h_part[kDotBlocks];
-    auto fetch_rr = [&](double *rr) -> int {
-        G4S_HIP_TRY(hipMemcpyAsync(h_part, part_c, sizeof(h_part), hipMemcpyDeviceToHost, s));
-        G4S_HIP_TRY(hipStreamSynchronize(s));
-        double t = 0.0;
-        for (int i = 0; i < kDotBlocks; ++i) t += h_part[i];
-        *rr = t;
-        return G4S_OK;
-    };
-    hipLaunchKernelGGL(cg_init_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, neq, F, r1, d0, part_c);
-    double rr = 0.0;
-    G4S_TRY(fetch_rr(&rr));
-    double residual = std::sqrt(rr);
     const int steps = *cycles;
-    int count = 0;
-    while ((residual > acc && count < steps) || count == 0) {
-        hipLaunchKernelGGL(cg_precond_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, neq, BI, r1, z, part_a);
-        hipLaunchKernelGGL(cg_direction_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, neq, count == 0 ? 1 : 0, part_a, sc, z, p1, p2);
-        if (op) G4S_TRY(g4s_elem_op_apply(op, p2, Ap, s));
-        else G4S_TRY(g4s_spmv(A, p2, Ap, 1.0, 0.0, s));
-        hipLaunchKernelGGL(cg_pAp_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, neq, bc_mask, p2, Ap, part_b);
-        hipLaunchKernelGGL(cg_update_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, neq, part_b, sc, p2, Ap, r1, r2, d0, part_c);
-        G4S_TRY(fetch_rr(&rr));
-        residual = std::sqrt(rr);
-        std::swap(r1, r2);      // the pointer rotation of General_matrix_functions.c:398-402
-        std::swap(p1, p2);
-        ++count;
+    hipLaunchKernelGGL(cg_init_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, neq, F, BI, r1, d0, z, part_rr, part_rz);
+    CgState h{};
+    int batch = 4, enqueued = 0;
+    while (!h.done) {
+        // iterations past the one that meets the test are no-ops on the device (and the pointer rotation of :398-402 below is then
+        // irrelevant: nothing reads r1/r2/p1/p2 again)
+        const int todo = std::max(1, std::min(batch, steps - enqueued + 1));
+        for (int it = 0; it < todo; ++it) {
+            hipLaunchKernelGGL(cg_direction_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, neq, steps, acc, part_rr, part_rz, st, z, p1, p2);
+            if (op) G4S_TRY(g4s_elem_op_apply_unless(op, p2, Ap, &st->done, s));
+            else G4S_TRY(g4s_spmv(A, p2, Ap, 1.0, 0.0, s));
+            hipLaunchKernelGGL(cg_pAp_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, neq, st, bc_mask, p2, Ap, part_pAp);
+            hipLaunchKernelGGL(cg_update_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, neq, part_pAp, st, BI, p2, Ap, r1, r2, d0, z, part_rr, part_rz);
+            std::swap(r1, r2);
+            std::swap(p1, p2);
+        }
+        enqueued += todo;
+        hipLaunchKernelGGL(cg_peek_kernel, dim3(1), dim3(kThreads), 0, s, steps, acc, part_rr, st);
+        G4S_HIP_TRY(hipGetLastError());
+        G4S_HIP_TRY(hipMemcpyAsync(&h, st, sizeof(CgState), hipMemcpyDeviceToHost, s));
+        G4S_HIP_TRY(hipStreamSynchronize(s));
+        // next batch: the iterations a geometric fit of the residual history says are left (+1), between 2 and 32
+        batch = std::min(32, batch * 2);
+        if (!h.done && h.count > 0 && h.residual > acc && acc > 0.0 && h.residual0 > h.residual) {
+            const double rate = std::log(h.residual / h.residual0) / h.count;        // < 0
+            const double left = std::log(acc / h.residual) / rate;
+            if (left > 0.0 && left < 1e6) batch = std::max(2, std::min(32, (int)std::ceil(left) + 1));
+        }
     }
-    *cycles = count;
+    const double residual = h.residual;
+    *cycles = h.count;
     if (n_zero) hipLaunchKernelGGL(cg_strip_kernel, dim3((n_zero + kThreads - 1) / kThreads), dim3(kThreads), 0, s, n_zero, zero_resid, d0);   // :409
     G4S_HIP_TRY(hipGetLastError());
     G4S_HIP_TRY(hipStreamSynchronize(s));

@@ -50,11 +50,12 @@ constexpr int kMaxDof = 4;
 __global__ __launch_bounds__(256) void elem_matvec_kernel(int nno, int npe, int dof, const int *__restrict__ node_ptr,
                                                            const int *__restrict__ node_terms, const int *__restrict__ elem_eq,
                                                            const int *__restrict__ node_eq, const double *__restrict__ elt_k,
-                                                           const double *__restrict__ u, double *__restrict__ Au, double beta)
+                                                           const double *__restrict__ u, double *__restrict__ Au, double beta,
+                                                           const int *__restrict__ skip)
 {
     const int lane = threadIdx.x & 63;
     const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (node >= nno) return;
+    if (node >= nno || (skip && *skip)) return;                   // skip: the `done` flag of a solver that enqueues iterations ahead
     const int n = npe * dof;
     const int t0 = node_ptr[node], t1 = node_ptr[node + 1];
     const int g = lane >> 3, q = lane & 7;
@@ -99,13 +100,13 @@ template <int NPE, int DOF>
 __global__ __launch_bounds__(256) void elem_matvec_fixed_kernel(int nno, const int *__restrict__ terms8 /* [nno][8], −1 = none */,
                                                                  const int *__restrict__ elem_eq, const int *__restrict__ node_eq,
                                                                  const double *__restrict__ elt_k, const double *__restrict__ u,
-                                                                 double *__restrict__ Au, double beta)
+                                                                 double *__restrict__ Au, double beta, const int *__restrict__ skip)
 {
     constexpr int N = NPE * DOF, CPL = N / 8;                      // columns per lane (3 for N = 24)
     static_assert(N % 8 == 0, "npe·dof must be a multiple of 8");
     const int lane = threadIdx.x & 63;
     const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (node >= nno) return;
+    if (node >= nno || (skip && *skip)) return;
     const int g = lane >> 3, q = lane & 7;
     const int term = terms8[node * 8 + g];
     double acc[DOF];
@@ -249,7 +250,7 @@ G4S_API g4s_status g4s_elem_op_destroy(g4s_elem_op_t op)
     return G4S_OK;
 }
 
-static int elem_op_launch(g4s_elem_op_t op, const double *elt_k, const double *u, double *Au, double beta, hipStream_t s)
+static int elem_op_launch(g4s_elem_op_t op, const double *elt_k, const double *u, double *Au, double beta, hipStream_t s, const int *skip = nullptr)
 {
     // equations no node owns receive nothing: with beta == 0 they must read 0 (Element_calculations.c:495-496 zeroes Au first).
     // When every equation has an owner (neq == nno·dof, the CitcomS numbering) the kernel writes all of Au and the memset is skipped.
@@ -257,13 +258,21 @@ static int elem_op_launch(g4s_elem_op_t op, const double *elt_k, const double *u
     if (op->nno) {
         if (op->fixed8)
             hipLaunchKernelGGL((elem_matvec_fixed_kernel<8, 3>), dim3((op->nno + 3) / 4), dim3(256), 0, s, op->nno, op->terms8.as<int>(),
-                               op->elem_eq.as<int>(), op->node_eq.as<int>(), elt_k, u, Au, beta);
+                               op->elem_eq.as<int>(), op->node_eq.as<int>(), elt_k, u, Au, beta, skip);
         else
             hipLaunchKernelGGL(elem_matvec_kernel, dim3((op->nno + 3) / 4), dim3(256), 0, s, op->nno, op->npe, op->dof, op->node_ptr.as<int>(),
-                               op->node_terms.as<int>(), op->elem_eq.as<int>(), op->node_eq.as<int>(), elt_k, u, Au, beta);
+                               op->node_terms.as<int>(), op->elem_eq.as<int>(), op->node_eq.as<int>(), elt_k, u, Au, beta, skip);
         G4S_HIP_TRY(hipGetLastError());
     }
     return G4S_OK;
+}
+
+// g4s_elem_op_apply that returns at once when *skip_dev != 0 (cg.hip: iterations enqueued past the one that converged)
+int g4s_elem_op_apply_unless(g4s_elem_op_t op, const double *u_dev, double *Au_dev, const int *skip_dev, void *stream)
+{
+    G4S_REQUIRE(op && u_dev && Au_dev, "NULL argument");
+    G4S_REQUIRE(op->elt_k || op->nel == 0, "no element matrices bound");
+    return elem_op_launch(op, op->elt_k, u_dev, Au_dev, 0.0, g4s::as_stream(stream), skip_dev);
 }
 
 G4S_API g4s_status g4s_elem_op_apply(g4s_elem_op_t op, const double *u_dev, double *Au_dev, void *stream)
