@@ -40,6 +40,18 @@ class PatternDesc(C.Structure):
                 ("static_weights", C.c_int32), ("inner", C.c_int32), ("numbers", C.c_int32)]
 
 
+class StokesParams(C.Structure):
+    """g4s_stokes_params — the controls solve_Ahat_p_fhat_CG reads (citcoms/lib/Stokes_flow_Incomp.c:188-452)."""
+    _fields_ = [("imp", C.c_double), ("inner_accuracy_scale", C.c_double), ("v_res", C.c_double), ("v_steps_low", C.c_int32),
+                ("steps_max", C.c_int32), ("check_continuity_convergence", C.c_int32), ("check_pressure_convergence", C.c_int32)]
+
+
+class StokesResult(C.Structure):
+    _fields_ = [("outer_iterations", C.c_int32), ("last_solve_valid", C.c_int32), ("inner_iterations", C.c_int64),
+                ("incompressibility", C.c_double), ("v_norm", C.c_double), ("p_norm", C.c_double), ("dvelocity", C.c_double),
+                ("dpressure", C.c_double)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/*.h appears here (tests check the export list).
 SIGNATURES = {
     "g4s_version": (C.c_char_p, []),
@@ -74,6 +86,11 @@ SIGNATURES = {
     "g4s_elem_op_apply": (C.c_int, [vp, vp, vp, vp]),
     "g4s_elem_op_inverse_diagonal": (C.c_int, [vp, vp, vp]),
     "g4s_conj_grad": (C.c_int, [vp, vp, C.c_int32, vp, vp, C.c_int32, vp, vp, C.c_double, C.POINTER(C.c_int32), f64p, vp]),
+    "g4s_elem_op_div_u": (C.c_int, [vp, vp, vp, vp, vp]),
+    "g4s_elem_op_grad_p": (C.c_int, [vp, vp, vp, vp, vp, C.c_int32, vp]),
+    "g4s_elem_op_pressure_preconditioner": (C.c_int, [vp, vp, vp, vp, vp]),
+    "g4s_stokes_uzawa_cg": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_double, vp, C.c_int32, vp, vp, vp, C.POINTER(StokesParams),
+                                      C.POINTER(StokesResult), vp, C.c_int32, vp]),
     "g4s_dense_rows_times_matrix": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]),
     "g4s_dense_rows_times_matrix_grad": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp]),
     "g4s_sym_quadratic_form": (C.c_int, [C.c_int32, C.c_int32, vp, vp, vp, vp]),

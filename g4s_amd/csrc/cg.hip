@@ -208,10 +208,10 @@ G4S_API g4s_status g4s_conj_grad(g4s_elem_op_t op, g4s_csr_t A, int32_t neq, con
     const size_t arena_bytes = 6 * nbp + sizeof(double) * 3 * kDotBlocks + 256 + (n_zero ? ((size_t)neq + 255) / 256 * 256 : 0);
     struct Arena {
         void *p = nullptr; hipStream_t s = nullptr;
-        ~Arena() { if (p) (void)hipFreeAsync(p, s); }
+        ~Arena() { g4s::scratch_free(p, s); }
     } arena;
     arena.s = s;
-    G4S_HIP_TRY(hipMallocAsync(&arena.p, arena_bytes, s));
+    G4S_TRY(g4s::scratch_alloc(&arena.p, arena_bytes, s));
     char *base = static_cast<char *>(arena.p);
     double *r1 = reinterpret_cast<double *>(base), *r2 = reinterpret_cast<double *>(base + nbp), *z = reinterpret_cast<double *>(base + 2 * nbp),
            *p1 = reinterpret_cast<double *>(base + 3 * nbp), *p2 = reinterpret_cast<double *>(base + 4 * nbp), *Ap = reinterpret_cast<double *>(base + 5 * nbp);

@@ -18,10 +18,23 @@ int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// stream-ordered scratch from the library's own never-trimming memory pool (runtime.cpp)
+int scratch_alloc(void **p, size_t bytes, hipStream_t s);
+void scratch_free(void *p, hipStream_t s);
+int scratch_shutdown();
+
 // 8 XCDs, each with its own L2: block b and b+8 share one (MI355X_MICROARCH.md, Workgroup dispatch).
 constexpr int kXcds = 8;
 
+// Device-side tables of an element operator (graph.hip owns them): node → (element, local node) terms in ascending element
+// order, equation ids per element unknown and per (node, dof).
+struct ElemOpView {
+    int nel, npe, dof, nno, neq;
+    const int *node_ptr, *node_terms, *elem_eq, *node_eq;
+};
+
 } // namespace g4s
+int g4s_elem_op_view(g4s_elem_op_t op, g4s::ElemOpView *out);   // graph.hip
 
 #define G4S_HIP_TRY(expr)                                                                            \
     do {                                                                                             \

@@ -243,6 +243,12 @@ extern "C" g4s_status g4s_elem_op_diagonal_sum(g4s_elem_op_t op, double *diag_de
     return G4S_OK;
 }
 int g4s_elem_op_neq(g4s_elem_op_t op) { return op ? op->neq : 0; }
+int g4s_elem_op_view(g4s_elem_op_t op, g4s::ElemOpView *out)
+{
+    G4S_REQUIRE(op && out, "NULL argument");
+    *out = g4s::ElemOpView{op->nel, op->npe, op->dof, op->nno, op->neq, op->node_ptr.as<int>(), op->node_terms.as<int>(), op->elem_eq.as<int>(), op->node_eq.as<int>()};
+    return G4S_OK;
+}
 
 G4S_API g4s_status g4s_elem_op_destroy(g4s_elem_op_t op)
 {
@@ -611,7 +617,7 @@ G4S_API g4s_status g4s_dense_rows_times_matrix_grad(int32_t M, int32_t N, int32_
         const int used = (M + rows_per_wg - 1) / rows_per_wg;
         const size_t elems = (size_t)N * K, lds = sizeof(double) * 2 * kDwSlab * kDwLd;
         double *partials = nullptr;                                // stream-ordered scratch: no host sync, the pool keeps the pages
-        G4S_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&partials), sizeof(double) * elems * used, s));
+        G4S_TRY(g4s::scratch_alloc(reinterpret_cast<void **>(&partials), sizeof(double) * elems * used, s));
         auto launch = [&](auto kern) -> int {
             G4S_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3(used, (N + 127) / 128, (K + 127) / 128), dim3(256), lds, s, M, N, K, rows_per_wg, xx_dev, grad_dev, partials);
@@ -628,10 +634,10 @@ G4S_API g4s_status g4s_dense_rows_times_matrix_grad(int32_t M, int32_t N, int32_
         case 7: st = launch(dense_rows_transposed_times_rows_kernel<7>); break;
         default: st = launch(dense_rows_transposed_times_rows_kernel<8>); break;
         }
-        if (st != G4S_OK) { (void)hipFreeAsync(partials, s); return st; }
+        if (st != G4S_OK) { g4s::scratch_free(partials, s); return st; }
         hipLaunchKernelGGL(dense_reduce_slabs_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(1024), 0, s, used, elems, partials, dw_dev);
         const hipError_t launch_err = hipGetLastError();
-        G4S_HIP_TRY(hipFreeAsync(partials, s));
+        g4s::scratch_free(partials, s);
         G4S_HIP_TRY(launch_err);
     }
     return G4S_OK;

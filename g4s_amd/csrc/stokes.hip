@@ -1,0 +1,311 @@
+// stokes.hip — the incompressibility (Uzawa / Schur-complement CG) iteration of CitcomS around the velocity solve.
+//
+// Follows solve_Ahat_p_fhat_CG, citcoms/lib/Stokes_flow_Incomp.c:188-452, in its update order, for the incompressible case
+// (inv_gruneisen == 0, so initial_vel_residual :839-881 runs) with solve_del2_u's conjugate-gradient branch
+// (General_matrix_functions.c:89-94) as the velocity solve — that is g4s_conj_grad (cg.hip) on the element-by-element operator.
+// Operators: assemble_div_u / assemble_grad_p (Element_calculations.c:701-779) on the per-element gradient vectors
+// g[e][p] = elt_del[e].g[p][0]; norms: global_v_norm2 / global_p_norm2 / global_div_norm2 / global_pdot
+// (Global_operations.c:565-656), one process. Every vector stays in HBM; the host owns the outer loop's scalar logic
+// (keep_iterating :150-162, the "two consecutive converging iterations" rule) and reads a few doubles per outer iteration — the
+// inner solve between two reads is tens of mat-vecs.
+#include "common.hpp"
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace {
+
+constexpr int kBlocks = 256, kThreads = 256;
+
+__device__ __forceinline__ double block_sum(double v, double *sh)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double s = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    __syncthreads();
+    return s;
+}
+
+struct Sum3 { double a, b, c; };
+
+// f(i) does the element-wise work of index i and returns up to three terms to be summed over i. Two-level sums with a fixed
+// shape (grid-stride partials per workgroup → finish_sums_kernel): reproducible.
+template <typename F>
+__global__ __launch_bounds__(kThreads) void map_sum_kernel(int n, F f, double *__restrict__ part)
+{
+    __shared__ double sh[4];
+    Sum3 acc{0.0, 0.0, 0.0};
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += kBlocks * kThreads) {
+        const Sum3 v = f(i);
+        acc.a += v.a; acc.b += v.b; acc.c += v.c;
+    }
+    const double a = block_sum(acc.a, sh), b = block_sum(acc.b, sh), c = block_sum(acc.c, sh);
+    if (threadIdx.x == 0) { part[blockIdx.x] = a; part[kBlocks + blockIdx.x] = b; part[2 * kBlocks + blockIdx.x] = c; }
+}
+
+__global__ __launch_bounds__(kThreads) void finish_sums_kernel(const double *__restrict__ part, double *__restrict__ out3)
+{
+    __shared__ double sh[4];
+    static_assert(kBlocks == kThreads, "one partial per thread");
+    for (int k = 0; k < 3; ++k) {
+        const double s = block_sum(part[k * kBlocks + threadIdx.x], sh);
+        if (threadIdx.x == 0) out3[k] = s;
+    }
+}
+
+template <typename F>
+__global__ __launch_bounds__(kThreads) void map_kernel(int n, F f)
+{
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < n) f(i);
+}
+
+// divU[e] = Σ_a (g0·U[j1] + g1·U[j2] + g2·U[j3]) in a order — the per-element sequence of assemble_div_u (bit-identical)
+__global__ __launch_bounds__(kThreads) void div_u_kernel(int nel, int npe, int dof, const int *__restrict__ elem_eq, const double *__restrict__ g,
+                                                          const double *__restrict__ U, double *__restrict__ divU)
+{
+    const int e = blockIdx.x * kThreads + threadIdx.x;
+    if (e >= nel) return;
+    const int n = npe * dof;
+    double s = 0.0;
+    for (int a = 0; a < npe; ++a) {
+        double t = 0.0;
+        for (int d = 0; d < dof; ++d) {
+            const double q = g[(size_t)e * n + a * dof + d] * U[elem_eq[(size_t)e * n + a * dof + d]];
+            t = d == 0 ? q : t + q;
+        }
+        s = s + t;
+    }
+    divU[e] = s;
+}
+
+// gradP[eq(node, d)] = Σ over the node's (element, local node) terms, ascending element, of g·P[e], elements with P == 0 skipped:
+// the sequence of additions assemble_grad_p makes into that equation (bit-identical). A gather: no atomics.
+__global__ __launch_bounds__(kThreads) void grad_p_kernel(int nno, int npe, int dof, const int *__restrict__ node_ptr,
+                                                           const int *__restrict__ node_terms, const int *__restrict__ node_eq,
+                                                           const double *__restrict__ g, const double *__restrict__ P, double *__restrict__ gradP)
+{
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= nno * dof) return;
+    const int node = idx / dof, d = idx - node * dof, n = npe * dof;
+    double s = 0.0;
+    for (int t = node_ptr[node]; t < node_ptr[node + 1]; ++t) {
+        const int term = node_terms[t], e = term / npe, a = term - e * npe;
+        const double pe = P[e];
+        if (pe == 0.0) continue;
+        const double q = g[(size_t)e * n + a * dof + d] * pe;
+        s = s + q;
+    }
+    gradP[node_eq[idx]] = s;
+}
+
+__global__ __launch_bounds__(kThreads) void zero_rows_kernel(int n_zero, const int *__restrict__ rows, double *__restrict__ v)
+{
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < n_zero) v[rows[i]] = 0.0;
+}
+
+// BPI[e] = 1 / Σ_p g[e][p]·(BI[eq(e,p)]·g[e][p])  (assemble_dAhatp_entry + build_diagonal_of_Ahat)
+__global__ __launch_bounds__(kThreads) void pressure_precond_kernel(int nel, int n, const int *__restrict__ elem_eq, const double *__restrict__ g,
+                                                                     const double *__restrict__ BI, double *__restrict__ BPI)
+{
+    const int e = blockIdx.x * kThreads + threadIdx.x;
+    if (e >= nel) return;
+    double divU = 0.0;
+    for (int p = 0; p < n; ++p) {
+        const double ge = g[(size_t)e * n + p];
+        const double gradP = BI[elem_eq[(size_t)e * n + p]] * ge;
+        const double q = ge * gradP;
+        divU = divU + q;
+    }
+    BPI[e] = divU != 0.0 ? 1.0 / divU : 1.0;
+}
+
+inline int grid_for(int n) { return (n + kThreads - 1) / kThreads; }
+
+struct Scratch {
+    void *p = nullptr; hipStream_t s = nullptr;
+    ~Scratch() { g4s::scratch_free(p, s); }
+};
+
+} // namespace
+
+G4S_API g4s_status g4s_elem_op_div_u(g4s_elem_op_t op, const double *g_dev, const double *U_dev, double *divU_dev, void *stream)
+{
+    g4s::ElemOpView v;
+    G4S_TRY(g4s_elem_op_view(op, &v));
+    G4S_REQUIRE(v.nel == 0 || (g_dev && U_dev && divU_dev), "NULL argument");
+    if (v.nel) hipLaunchKernelGGL(div_u_kernel, dim3(grid_for(v.nel)), dim3(kThreads), 0, g4s::as_stream(stream), v.nel, v.npe, v.dof, v.elem_eq, g_dev, U_dev, divU_dev);
+    G4S_HIP_TRY(hipGetLastError());
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_elem_op_grad_p(g4s_elem_op_t op, const double *g_dev, const double *P_dev, double *gradP_dev,
+                                      const int32_t *zero_resid_dev, int32_t n_zero, void *stream)
+{
+    g4s::ElemOpView v;
+    G4S_TRY(g4s_elem_op_view(op, &v));
+    G4S_REQUIRE(v.neq == 0 || gradP_dev, "NULL argument");
+    G4S_REQUIRE(v.nel == 0 || (g_dev && P_dev), "NULL argument");
+    G4S_REQUIRE(n_zero >= 0 && (n_zero == 0 || zero_resid_dev), "zero_resid is NULL");
+    hipStream_t s = g4s::as_stream(stream);
+    // equations no node owns receive nothing and must read 0 (the source zeroes gradP first)
+    if (v.neq && (int64_t)v.nno * v.dof != v.neq) G4S_HIP_TRY(hipMemsetAsync(gradP_dev, 0, sizeof(double) * (size_t)v.neq, s));
+    if (v.nno) hipLaunchKernelGGL(grad_p_kernel, dim3(grid_for(v.nno * v.dof)), dim3(kThreads), 0, s, v.nno, v.npe, v.dof, v.node_ptr, v.node_terms, v.node_eq, g_dev, P_dev, gradP_dev);
+    if (n_zero) hipLaunchKernelGGL(zero_rows_kernel, dim3(grid_for(n_zero)), dim3(kThreads), 0, s, n_zero, zero_resid_dev, gradP_dev);
+    G4S_HIP_TRY(hipGetLastError());
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_elem_op_pressure_preconditioner(g4s_elem_op_t op, const double *g_dev, const double *BI_dev, double *BPI_dev, void *stream)
+{
+    g4s::ElemOpView v;
+    G4S_TRY(g4s_elem_op_view(op, &v));
+    G4S_REQUIRE(v.nel == 0 || (g_dev && BI_dev && BPI_dev), "NULL argument");
+    if (v.nel) hipLaunchKernelGGL(pressure_precond_kernel, dim3(grid_for(v.nel)), dim3(kThreads), 0, g4s::as_stream(stream), v.nel, v.npe * v.dof, v.elem_eq, g_dev, BI_dev, BPI_dev);
+    G4S_HIP_TRY(hipGetLastError());
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, const double *g, const double *BI, const double *BPI, const double *nmass,
+                                       const double *area, double volume, const int32_t *zero_resid, int32_t n_zero, const double *FF,
+                                       double *V, double *P, const g4s_stokes_params *prm, g4s_stokes_result *res, double *hist,
+                                       int32_t hist_lines, void *stream)
+{
+    g4s::ElemOpView v;
+    G4S_TRY(g4s_elem_op_view(op, &v));
+    G4S_REQUIRE(prm && res, "params / result is NULL");
+    G4S_REQUIRE(v.nel > 0 && v.neq > 0 && v.nno > 0, "empty operator");
+    G4S_REQUIRE(g && BI && BPI && nmass && area && FF && V && P, "NULL argument");
+    G4S_REQUIRE(volume > 0.0, "volume must be positive");
+    G4S_REQUIRE(n_zero >= 0 && (n_zero == 0 || zero_resid), "zero_resid is NULL");
+    G4S_REQUIRE(hist_lines >= 0 && (hist_lines == 0 || hist), "hist is NULL");
+    hipStream_t s = g4s::as_stream(stream);
+    const int neq = v.neq, nel = v.nel, nno = v.nno, dof = v.dof;
+    const size_t nq = ((size_t)neq * 8 + 255) / 256 * 256, np = ((size_t)nel * 8 + 255) / 256 * 256;
+    Scratch scr; scr.s = s;
+    G4S_TRY(g4s::scratch_alloc(&scr.p, 3 * nq + 6 * np + sizeof(double) * (3 * kBlocks + 8), s));
+    char *base = static_cast<char *>(scr.p);
+    double *F = reinterpret_cast<double *>(base), *u1 = reinterpret_cast<double *>(base + nq), *tmp = reinterpret_cast<double *>(base + 2 * nq);
+    double *r1 = reinterpret_cast<double *>(base + 3 * nq), *r2 = reinterpret_cast<double *>(base + 3 * nq + np),
+           *z1 = reinterpret_cast<double *>(base + 3 * nq + 2 * np), *s1 = reinterpret_cast<double *>(base + 3 * nq + 3 * np),
+           *s2 = reinterpret_cast<double *>(base + 3 * nq + 4 * np), *Fp = reinterpret_cast<double *>(base + 3 * nq + 5 * np);
+    double *part = reinterpret_cast<double *>(base + 3 * nq + 6 * np), *sums_dev = part + 3 * kBlocks;
+    const int *node_eq = v.node_eq;
+
+    double h3[3];
+    auto sums = [&](int n, auto f) -> int {                        // launch, finish, bring the three sums to the host
+        hipLaunchKernelGGL(map_sum_kernel, dim3(kBlocks), dim3(kThreads), 0, s, n, f, part);
+        hipLaunchKernelGGL(finish_sums_kernel, dim3(1), dim3(kThreads), 0, s, part, sums_dev);
+        G4S_HIP_TRY(hipGetLastError());
+        G4S_HIP_TRY(hipMemcpyAsync(h3, sums_dev, sizeof(h3), hipMemcpyDeviceToHost, s));
+        G4S_HIP_TRY(hipStreamSynchronize(s));
+        return G4S_OK;
+    };
+    auto each = [&](int n, auto f) { hipLaunchKernelGGL(map_kernel, dim3(grid_for(n)), dim3(kThreads), 0, s, n, f); };
+    auto strip = [&](double *x) { if (n_zero) hipLaunchKernelGGL(zero_rows_kernel, dim3(grid_for(n_zero)), dim3(kThreads), 0, s, n_zero, zero_resid, x); };
+    auto v_terms = [=] __device__(const double *X, int i) {        // (Σ_d X[eq(i,d)]²)·NMass[i], the summand of global_v_norm2
+        double t = 0.0;
+        for (int d = 0; d < dof; ++d) { const double x = X[node_eq[i * dof + d]]; const double q = x * x; t = d == 0 ? q : t + q; }
+        return t * nmass[i];
+    };
+    int64_t inner_total = 0;
+    const double inner_acc = prm->imp * prm->inner_accuracy_scale * prm->v_res;
+    auto solve_del2_u = [&](const double *rhs, double *d0, int *valid) -> int {   // General_matrix_functions.c:48-146, CG branch
+        int32_t cycles = prm->v_steps_low;
+        double residual = 0.0;
+        G4S_TRY(g4s_conj_grad(op, nullptr, neq, BI, zero_resid, n_zero, rhs, d0, inner_acc, &cycles, &residual, s));
+        inner_total += cycles;
+        *valid = residual < inner_acc ? 1 : 0;
+        return G4S_OK;
+    };
+
+    // ---- initial_vel_residual (:839-881): F = FF − grad(P) − K·V, stripped; K·u1 = F; V += u1
+    int valid = 0;
+    G4S_TRY(g4s_elem_op_grad_p(op, g, P, u1, zero_resid, n_zero, s));
+    each(neq, [=] __device__(int i) { F[i] = FF[i] - u1[i]; });
+    G4S_TRY(g4s_elem_op_apply(op, V, u1, s));
+    strip(u1);
+    each(neq, [=] __device__(int i) { F[i] = F[i] - u1[i]; });
+    strip(F);
+    G4S_TRY(solve_del2_u(F, u1, &valid));
+    strip(u1);
+    each(neq, [=] __device__(int i) { V[i] = V[i] + u1[i]; });
+
+    // ---- r1 = div(V); incompressibility = sqrt(|r1|²_div / (1e-32 + |V|²))
+    G4S_TRY(g4s_elem_op_div_u(op, g, V, r1, s));
+    G4S_TRY(sums(std::max(nno, nel), [=] __device__(int i) {
+        Sum3 o{0.0, 0.0, 0.0};
+        if (i < nno) o.a = v_terms(V, i);
+        if (i < nel) { o.b = r1[i] * r1[i] / area[i]; o.c = P[i] * P[i] * area[i]; }
+        return o;
+    }));
+    double vdotv = h3[0] / volume, pdotp = h3[2] / volume;
+    double incompressibility = std::sqrt(h3[1] / volume / (1e-32 + vdotv));
+    double dvelocity = 1.0, dpressure = 1.0;
+    int count = 0, converging = 0, lines = 0;
+    auto record = [&]() {
+        if (lines < hist_lines) { double *h = hist + 5 * (size_t)lines; h[0] = std::sqrt(vdotv); h[1] = std::sqrt(pdotp); h[2] = dvelocity; h[3] = dpressure; h[4] = incompressibility; }
+        ++lines;
+    };
+    record();
+    double r0dotz0 = 0.0;
+    for (;;) {
+        const bool keep = prm->check_continuity_convergence ? (incompressibility > prm->imp || converging < 2)
+                                                            : (incompressibility > prm->imp && converging < 2);   // keep_iterating :150-162
+        if (!(count < prm->steps_max && keep)) break;
+        // z1 = BPI∘r1; r1dotz1 = <r1, z1>
+        G4S_TRY(sums(nel, [=] __device__(int i) { const double z = BPI[i] * r1[i]; z1[i] = z; return Sum3{r1[i] * z, 0.0, 0.0}; }));
+        const double r1dotz1 = h3[0];
+        if (r1dotz1 == 0.0) return g4s::set_error(G4S_ERR_INVALID, "g4s_stokes_uzawa_cg: <r1, z1> = 0 at the head of iteration %d (the source asserts)", count);
+        if (count == 0) each(nel, [=] __device__(int i) { s2[i] = z1[i]; });
+        else {
+            const double delta = r1dotz1 / r0dotz0;
+            each(nel, [=] __device__(int i) { s2[i] = z1[i] + delta * s1[i]; });
+        }
+        // K·u1 = grad(s2)
+        G4S_TRY(g4s_elem_op_grad_p(op, g, s2, tmp, zero_resid, n_zero, s));
+        G4S_TRY(solve_del2_u(tmp, u1, &valid));
+        strip(u1);
+        G4S_TRY(g4s_elem_op_div_u(op, g, u1, Fp, s));
+        G4S_TRY(sums(nel, [=] __device__(int i) { return Sum3{s2[i] * Fp[i], 0.0, 0.0}; }));
+        const double alpha = r1dotz1 / h3[0];
+        each(nel, [=] __device__(int i) { r2[i] = r1[i] - alpha * Fp[i]; P[i] += alpha * s2[i]; });
+        each(neq, [=] __device__(int i) { V[i] -= alpha * u1[i]; });
+        G4S_TRY(g4s_elem_op_div_u(op, g, V, z1, s));
+        G4S_TRY(sums(std::max(nno, nel), [=] __device__(int i) {
+            Sum3 o{0.0, 0.0, 0.0};
+            if (i < nno) { o.a = v_terms(V, i); o.b = v_terms(u1, i); }
+            if (i < nel) o.c = P[i] * P[i] * area[i];
+            return o;
+        }));
+        vdotv = h3[0] / volume;
+        const double u1dotu1 = h3[1] / volume;
+        pdotp = h3[2] / volume;
+        G4S_TRY(sums(nel, [=] __device__(int i) { return Sum3{s2[i] * s2[i] * area[i], z1[i] * z1[i] / area[i], 0.0}; }));
+        dvelocity = alpha * std::sqrt(u1dotu1 / (1e-32 + vdotv));
+        dpressure = alpha * std::sqrt(h3[0] / volume / (1e-32 + pdotp));
+        incompressibility = std::sqrt(h3[1] / volume / (1e-32 + vdotv));
+        ++count;
+        record();
+        if (!valid) converging = 0;
+        else if (prm->check_pressure_convergence) converging = (dvelocity < prm->imp && dpressure < prm->imp) ? converging + 1 : 0;
+        else converging = dvelocity < prm->imp ? converging + 1 : 0;
+        std::swap(s1, s2);
+        std::swap(r1, r2);
+        r0dotz0 = r1dotz1;
+    }
+    G4S_HIP_TRY(hipGetLastError());
+    G4S_HIP_TRY(hipStreamSynchronize(s));
+    res->outer_iterations = count;
+    res->inner_iterations = inner_total;
+    res->last_solve_valid = valid;
+    res->incompressibility = incompressibility;
+    res->v_norm = std::sqrt(vdotv);
+    res->p_norm = std::sqrt(pdotp);
+    res->dvelocity = dvelocity;
+    res->dpressure = dpressure;
+    return G4S_OK;
+}

@@ -210,6 +210,47 @@ g4s_status g4s_elem_op_inverse_diagonal(g4s_elem_op_t op, double *BI_dev, void *
 g4s_status g4s_conj_grad(g4s_elem_op_t op, g4s_csr_t A, int32_t neq, const double *BI_dev, const int32_t *zero_resid_dev, int32_t n_zero,
                          const double *F_dev, double *d0_dev, double acc, int32_t *cycles, double *residual, void *stream);
 
+/* ---- The incompressibility (Uzawa) iteration of CitcomS around the velocity solve — SURVEY.md §8 f1.
+ * g_dev[e·npe·dof + p] = elt_del[e].g[p][0], the per-element divergence / gradient vector; pressure unknowns are elements. */
+
+/* divU[e] = Σ_a (g[3a]·U[eq1] + g[3a+1]·U[eq2] + g[3a+2]·U[eq3]) — assemble_div_u, citcoms/lib/Element_calculations.c:701-729. */
+g4s_status g4s_elem_op_div_u(g4s_elem_op_t op, const double *g_dev, const double *U_dev, double *divU_dev, void *stream);
+/* gradP = Σ_e g·P[e] scattered to the equations (here: gathered per node, no atomics), then the boundary rows zeroed —
+ * assemble_grad_p, Element_calculations.c:737-779 (strip_bcs_from_residual, BC_util.c:89-102). */
+g4s_status g4s_elem_op_grad_p(g4s_elem_op_t op, const double *g_dev, const double *P_dev, double *gradP_dev,
+                              const int32_t *zero_resid_dev, int32_t n_zero, void *stream);
+/* BPI[e] = 1 / Σ_p g[e][p]·BI[eq(e,p)]·g[e][p] (1 where that is 0) — build_diagonal_of_Ahat / assemble_dAhatp_entry,
+ * Element_calculations.c:613-644, 785-830. */
+g4s_status g4s_elem_op_pressure_preconditioner(g4s_elem_op_t op, const double *g_dev, const double *BI_dev, double *BPI_dev, void *stream);
+
+typedef struct g4s_stokes_params {
+    double imp;                            /* accuracy of the outer iteration (control.accuracy) */
+    double inner_accuracy_scale;           /* control.inner_accuracy_scale */
+    double v_res;                          /* monitor.fdotf: the inner solves run to imp·inner_accuracy_scale·v_res */
+    int32_t v_steps_low;                   /* iteration cap of one velocity solve (control.v_steps_low) */
+    int32_t steps_max;                     /* cap of the outer iteration */
+    int32_t check_continuity_convergence;  /* keep_iterating: || instead of && (Stokes_flow_Incomp.c:150-162) */
+    int32_t check_pressure_convergence;    /* "converging" also needs dpressure < imp */
+} g4s_stokes_params;
+
+typedef struct g4s_stokes_result {
+    int32_t outer_iterations;              /* *steps_max on return */
+    int32_t last_solve_valid;              /* the last velocity solve reached its accuracy */
+    int64_t inner_iterations;              /* CG iterations of all velocity solves */
+    double incompressibility, v_norm, p_norm, dvelocity, dpressure;   /* the quantities of print_convergence_progress */
+} g4s_stokes_result;
+
+/* solve_Ahat_p_fhat_CG, citcoms/lib/Stokes_flow_Incomp.c:188-452, incompressible case (initial_vel_residual :839-881 included),
+ * velocity solves by g4s_conj_grad on the element-by-element operator (solve_del2_u's CG branch, General_matrix_functions.c:89-94).
+ * V_dev[neq] and P_dev[nel] are updated in place; F_dev is not modified. nmass_dev[nno] = NMass, area_dev[nel] = eco[].area,
+ * volume = mesh.volume (the weights of global_v_norm2 / global_p_norm2 / global_div_norm2, Global_operations.c:591-656).
+ * hist (host, may be NULL): 5 doubles per printed line — v_norm, p_norm, dvelocity, dpressure, incompressibility — line 0 before
+ * the loop, at most hist_lines lines. Every vector stays on the device; a few scalars per outer iteration cross PCIe. */
+g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, const double *g_dev, const double *BI_dev, const double *BPI_dev, const double *nmass_dev,
+                               const double *area_dev, double volume, const int32_t *zero_resid_dev, int32_t n_zero, const double *F_dev,
+                               double *V_dev, double *P_dev, const g4s_stokes_params *params, g4s_stokes_result *result,
+                               double *hist, int32_t hist_lines, void *stream);
+
 /* result[M×K] = xx[M×N] · w[N×K], row-major fp64, device pointers (opt_matmul.cc:24-62). */
 g4s_status g4s_dense_rows_times_matrix(int32_t M, int32_t N, int32_t K, const double *xx_dev, const double *w_dev,
                                        double *result_dev, void *stream);

@@ -621,3 +621,186 @@ ORACLE_API double oracle_conj_grad_elem(int32_t nel, int32_t npe, int32_t dof, c
     free(r1); free(r2); free(z1); free(p1); free(p2); free(Ap); free(rows);
     return residual;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * CitcomS incompressibility (Uzawa) iteration around the velocity solve — SURVEY.md §8 f1.
+ * Single cap (m = 1), 0-based arrays, pressure unknowns = elements (npno = nel), g[e][p] = elt_del[e].g[p][0].
+ * ---------------------------------------------------------------------------------------------------------------------------- */
+
+/* assemble_div_u, citcoms/lib/Element_calculations.c:701-729: a outer, e inner; each term is (g0·U1 + g1·U2 + g2·U3) added to divU[e]. */
+ORACLE_API void oracle_assemble_div_u(int32_t nel, int32_t npe, int32_t dof, const int32_t *ien, const int32_t *id, const double *g,
+                                      const double *U, double *divU)
+{
+    const int32_t n = npe * dof;
+    for (int32_t e = 0; e < nel; ++e) divU[e] = 0.0;
+    for (int32_t a = 0; a < npe; ++a) {
+        const int32_t p = a * dof;
+        for (int32_t e = 0; e < nel; ++e) {
+            const int32_t b = ien[e * npe + a];
+            double t = 0.0;
+            for (int32_t d = 0; d < dof; ++d) { double q = g[(size_t)e * n + p + d] * U[id[b * dof + d]]; t = (d == 0) ? q : t + q; }
+            divU[e] = divU[e] + t;
+        }
+    }
+}
+
+/* assemble_grad_p, Element_calculations.c:737-779: zero, skip elements with P == 0, scatter g·P in element order, strip boundary rows. */
+ORACLE_API void oracle_assemble_grad_p(int32_t nel, int32_t npe, int32_t dof, const int32_t *ien, const int32_t *id, const double *g,
+                                       int32_t neq, const int32_t *zero_resid, int32_t n_zero, const double *P, double *gradP)
+{
+    const int32_t n = npe * dof;
+    for (int32_t i = 0; i < neq; ++i) gradP[i] = 0.0;
+    for (int32_t e = 0; e < nel; ++e) {
+        if (0.0 == P[e]) continue;
+        for (int32_t a = 0; a < npe; ++a) {
+            const int32_t b = ien[e * npe + a];
+            for (int32_t d = 0; d < dof; ++d) {
+                double q = g[(size_t)e * n + a * dof + d] * P[e];
+                gradP[id[b * dof + d]] = gradP[id[b * dof + d]] + q;
+            }
+        }
+    }
+    for (int32_t i = 0; i < n_zero; ++i) gradP[zero_resid[i]] = 0.0;
+}
+
+/* build_diagonal_of_Ahat + assemble_dAhatp_entry, Element_calculations.c:613-644, 785-830 (control.precondition on). */
+ORACLE_API void oracle_build_diagonal_of_Ahat(int32_t nel, int32_t npe, int32_t dof, const int32_t *ien, const int32_t *id, const double *g,
+                                              const double *BI, double *BPI)
+{
+    const int32_t n = npe * dof;
+    for (int32_t e = 0; e < nel; ++e) {
+        double divU = 0.0;
+        for (int32_t a = 0; a < npe; ++a) {
+            const int32_t node = ien[e * npe + a];
+            for (int32_t d = 0; d < dof; ++d) {
+                const double ge = g[(size_t)e * n + a * dof + d];
+                const double gradP = BI[id[node * dof + d]] * ge;     /* gradP[p] starts at 0 and receives one term */
+                double q = ge * gradP;
+                divU = divU + q;
+            }
+        }
+        BPI[e] = (divU != 0.0) ? 1.0 / divU : 1.0;
+    }
+}
+
+/* global_v_norm2 / global_p_norm2 / global_div_norm2 / global_pdot, citcoms/lib/Global_operations.c:565-656 (one process). */
+static double uz_v_norm2(int32_t nno, int32_t dof, const int32_t *id, const double *nmass, double volume, const double *V)
+{
+    double temp = 0.0;
+    for (int32_t i = 0; i < nno; ++i) {
+        double s = 0.0;
+        for (int32_t d = 0; d < dof; ++d) { double q = V[id[i * dof + d]] * V[id[i * dof + d]]; s = (d == 0) ? q : s + q; }
+        double w = s * nmass[i];
+        temp = temp + w;
+    }
+    return temp / volume;
+}
+static double uz_p_norm2(int32_t nel, const double *area, double volume, const double *P)
+{
+    double temp = 0.0;
+    for (int32_t i = 0; i < nel; ++i) { double q = P[i] * P[i] * area[i]; temp = temp + q; }
+    return temp / volume;
+}
+static double uz_div_norm2(int32_t nel, const double *area, double volume, const double *A)
+{
+    double temp = 0.0;
+    for (int32_t i = 0; i < nel; ++i) { double q = A[i] * A[i] / area[i]; temp = temp + q; }
+    return temp / volume;
+}
+static double uz_pdot(int32_t nel, const double *A, const double *B)
+{
+    double temp = 0.0;
+    for (int32_t i = 0; i < nel; ++i) { double q = A[i] * B[i]; temp = temp + q; }
+    return temp;
+}
+
+/* solve_del2_u with the conjugate-gradient branch, General_matrix_functions.c:48-146: d0 = 0; residual = conj_grad(...,
+ * cycles = v_steps_low); valid = residual < acc. */
+static int uz_solve_del2_u(int32_t nel, int32_t npe, int32_t dof, const int32_t *ien, const int32_t *id, const double *elt_k, int32_t neq,
+                           const double *BI, const int32_t *zero_resid, int32_t n_zero, const double *F, double *d0, double acc,
+                           int32_t v_steps_low, int64_t *inner_total)
+{
+    int32_t cycles = v_steps_low;
+    double residual = oracle_conj_grad_elem(nel, npe, dof, ien, id, elt_k, neq, BI, zero_resid, n_zero, F, d0, acc, &cycles, NULL);
+    if (inner_total) *inner_total += cycles;
+    return residual < acc ? 1 : 0;
+}
+
+/* solve_Ahat_p_fhat_CG, citcoms/lib/Stokes_flow_Incomp.c:188-452, incompressible (inv_gruneisen == 0: initial_vel_residual
+ * :839-881 runs), no rigid-rotation removal. hist (may be NULL) receives 5 doubles per printed line (v_norm, p_norm, dvelocity,
+ * dpressure, incompressibility), line 0 = before the loop. Returns the final incompressibility; *steps_max: in cap, out count. */
+ORACLE_API double oracle_solve_Ahat_p_fhat_CG(int32_t nel, int32_t npe, int32_t dof, const int32_t *ien, const int32_t *id, int32_t nno,
+                                              int32_t neq, const double *elt_k, const double *g, const double *BI, const double *BPI,
+                                              const double *nmass, const double *area, double volume,
+                                              const int32_t *zero_resid, int32_t n_zero, const double *FF, double *V, double *P,
+                                              double imp, double inner_accuracy_scale, double v_res, int32_t v_steps_low,
+                                              int32_t check_continuity_convergence, int32_t check_pressure_convergence,
+                                              int32_t *steps_max, double *hist, int64_t *inner_iterations)
+{
+    const int32_t n = npe * dof;
+    const double **rows = (const double **)malloc(sizeof(double *) * (size_t)(nel > 0 ? nel : 1));
+    for (int32_t e = 0; e < nel; ++e) rows[e] = elt_k + (size_t)e * n * n;
+    double *F = malloc(sizeof(double) * neq), *u1 = malloc(sizeof(double) * neq), *tmp = malloc(sizeof(double) * neq);
+    double *r1 = malloc(sizeof(double) * nel), *r2 = malloc(sizeof(double) * nel), *z1 = malloc(sizeof(double) * nel);
+    double *s1 = malloc(sizeof(double) * nel), *s2 = malloc(sizeof(double) * nel), *Fp = malloc(sizeof(double) * (nel > neq ? nel : neq));
+    const double inner_imp = imp * inner_accuracy_scale;
+    int32_t count = 0, converging = 0, valid;
+    double alpha, delta, r0dotz0 = 0.0, r1dotz1, vdotv, pdotp = 0.0, incompressibility, dvelocity = 1.0, dpressure = 1.0;
+    if (inner_iterations) *inner_iterations = 0;
+    for (int32_t j = 0; j < neq; ++j) F[j] = FF[j];
+    for (int32_t j = 0; j < nel; ++j) s1[j] = 0.0;
+
+    /* initial_vel_residual: F = F − grad(P) − K·V, stripped; solve K·u1 = F; strip; V += u1 */
+    oracle_assemble_grad_p(nel, npe, dof, ien, id, g, neq, zero_resid, n_zero, P, u1);
+    for (int32_t i = 0; i < neq; ++i) F[i] = F[i] - u1[i];
+    oracle_element_matvec(nel, npe, dof, ien, id, rows, 0, V, u1, neq);
+    for (int32_t i = 0; i < n_zero; ++i) u1[zero_resid[i]] = 0.0;
+    for (int32_t i = 0; i < neq; ++i) F[i] = F[i] - u1[i];
+    for (int32_t i = 0; i < n_zero; ++i) F[zero_resid[i]] = 0.0;
+    valid = uz_solve_del2_u(nel, npe, dof, ien, id, elt_k, neq, BI, zero_resid, n_zero, F, u1, inner_imp * v_res, v_steps_low, inner_iterations);
+    for (int32_t i = 0; i < n_zero; ++i) u1[zero_resid[i]] = 0.0;
+    for (int32_t i = 0; i < neq; ++i) V[i] = V[i] + u1[i];
+
+    oracle_assemble_div_u(nel, npe, dof, ien, id, g, V, r1);
+    vdotv = uz_v_norm2(nno, dof, id, nmass, volume, V);
+    incompressibility = sqrt(uz_div_norm2(nel, area, volume, r1) / (1e-32 + vdotv));
+    if (hist) { hist[0] = sqrt(vdotv); hist[1] = sqrt(uz_p_norm2(nel, area, volume, P)); hist[2] = dvelocity; hist[3] = dpressure; hist[4] = incompressibility; }
+
+    for (;;) {
+        /* keep_iterating, Stokes_flow_Incomp.c:150-162 */
+        const int keep = check_continuity_convergence ? ((incompressibility > imp) || (converging < 2)) : ((incompressibility > imp) && (converging < 2));
+        if (!(count < *steps_max && keep)) break;
+        for (int32_t j = 0; j < nel; ++j) z1[j] = BPI[j] * r1[j];
+        r1dotz1 = uz_pdot(nel, r1, z1);
+        if (count == 0) for (int32_t j = 0; j < nel; ++j) s2[j] = z1[j];
+        else {
+            delta = r1dotz1 / r0dotz0;
+            for (int32_t j = 0; j < nel; ++j) s2[j] = z1[j] + delta * s1[j];
+        }
+        /* solve K·u1 = grad(s2) */
+        oracle_assemble_grad_p(nel, npe, dof, ien, id, g, neq, zero_resid, n_zero, s2, tmp);
+        valid = uz_solve_del2_u(nel, npe, dof, ien, id, elt_k, neq, BI, zero_resid, n_zero, tmp, u1, inner_imp * v_res, v_steps_low, inner_iterations);
+        for (int32_t i = 0; i < n_zero; ++i) u1[zero_resid[i]] = 0.0;
+        oracle_assemble_div_u(nel, npe, dof, ien, id, g, u1, Fp);
+        alpha = r1dotz1 / uz_pdot(nel, s2, Fp);
+        for (int32_t j = 0; j < nel; ++j) r2[j] = r1[j] - alpha * Fp[j];
+        for (int32_t j = 0; j < nel; ++j) P[j] += alpha * s2[j];
+        for (int32_t j = 0; j < neq; ++j) V[j] -= alpha * u1[j];
+        vdotv = uz_v_norm2(nno, dof, id, nmass, volume, V);
+        pdotp = uz_p_norm2(nel, area, volume, P);
+        dvelocity = alpha * sqrt(uz_v_norm2(nno, dof, id, nmass, volume, u1) / (1e-32 + vdotv));
+        dpressure = alpha * sqrt(uz_p_norm2(nel, area, volume, s2) / (1e-32 + pdotp));
+        oracle_assemble_div_u(nel, npe, dof, ien, id, g, V, z1);
+        incompressibility = sqrt(uz_div_norm2(nel, area, volume, z1) / (1e-32 + vdotv));
+        count++;
+        if (hist) { double *h = hist + 5 * count; h[0] = sqrt(vdotv); h[1] = sqrt(pdotp); h[2] = dvelocity; h[3] = dpressure; h[4] = incompressibility; }
+        if (!valid) converging = 0;
+        else if (check_pressure_convergence) converging = (dvelocity < imp && dpressure < imp) ? converging + 1 : 0;
+        else converging = (dvelocity < imp) ? converging + 1 : 0;
+        { double *sh = s1; s1 = s2; s2 = sh; sh = r1; r1 = r2; r2 = sh; }
+        r0dotz0 = r1dotz1;
+    }
+    *steps_max = count;
+    free(F); free(u1); free(tmp); free(r1); free(r2); free(z1); free(s1); free(s2); free(Fp); free(rows);
+    return incompressibility;
+}

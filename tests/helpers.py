@@ -64,3 +64,21 @@ def spd_blocks(nel, n, seed):
     a = rng.uniform(-1, 1, (nel, n, n))
     k = a @ a.transpose(0, 2, 1) + n * np.eye(n)[None]
     return np.ascontiguousarray(k.reshape(nel, n * n))
+
+
+def stokes_problem(ex, ey, ez, seed):
+    """A synthetic saddle-point problem on the hexahedral mesh of hex_mesh: SPD 24×24 element stiffness blocks, a random per-element
+    divergence vector g (elt_del[e].g[p][0]), boundary equations on a ninth of the nodes, positive node masses and element volumes
+    (the weights of CitcomS's global norms). Sizes follow SURVEY.md §8d C5; the data are seeded, not physical."""
+    ien, idmap, nno, neq = hex_mesh(ex, ey, ez)
+    nel = len(ien)
+    rng = np.random.default_rng(1000 + seed)
+    K = spd_blocks(nel, 24, seed)
+    g = rng.uniform(-1, 1, (nel, 24))
+    bc = np.array(sorted(set(idmap[rng.choice(nno, max(1, nno // 9), replace=False)].ravel().tolist())), np.int32)
+    F = rng.uniform(-1, 1, neq)
+    F[bc] = 0.0
+    nmass = rng.uniform(0.5, 1.5, nno)
+    area = rng.uniform(0.5, 1.5, nel)
+    return {"ien": ien, "id": idmap, "nno": nno, "neq": neq, "K": K, "g": np.ascontiguousarray(g), "bc": bc, "F": F, "nmass": nmass, "area": area,
+            "volume": float(area.sum())}

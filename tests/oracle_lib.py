@@ -42,6 +42,13 @@ class Oracle:
         L.oracle_spmm_dense.argtypes = [C.c_uint32, C.c_uint32, vp, vp, vp, vp, FUN_GATHER, FUN_APPLY, vp, C.c_int]
         L.oracle_element_matvec.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i32, _i32, vp, C.c_int32, _f64, _f64, C.c_int32]
         L.oracle_dense_rows_times_matrix.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, _f64, _f64]
+        L.oracle_assemble_div_u.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i32, _i32, _f64, _f64, _f64]
+        L.oracle_assemble_grad_p.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i32, _i32, _f64, C.c_int32, vp, C.c_int32, _f64, _f64]
+        L.oracle_build_diagonal_of_Ahat.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i32, _i32, _f64, _f64, _f64]
+        L.oracle_solve_Ahat_p_fhat_CG.restype = C.c_double
+        L.oracle_solve_Ahat_p_fhat_CG.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i32, _i32, C.c_int32, C.c_int32, _f64, _f64, _f64, _f64, _f64, _f64,
+                                                  C.c_double, vp, C.c_int32, _f64, _f64, _f64, C.c_double, C.c_double, C.c_double, C.c_int32,
+                                                  C.c_int32, C.c_int32, C.POINTER(C.c_int32), vp, C.POINTER(C.c_int64)]
         L.oracle_dense_rows_times_matrix_grad.argtypes = [C.c_int32, C.c_int32, C.c_int32, _f64, _f64, _f64, _f64, _f64]
         L.oracle_sym_quadratic_form.argtypes = [C.c_int32, C.c_int32, _f64, _f64, vp, _f64]
         L.oracle_element_inverse_diagonal.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i32, _i32, _f64, _f64, C.c_int32]
@@ -151,6 +158,47 @@ class Oracle:
                                              np.ascontiguousarray(BI), zr.ctypes.data if len(zr) else None, len(zr), np.ascontiguousarray(F), d0,
                                              acc, C.byref(cyc), hist.ctypes.data)
         return d0, cyc.value, res, hist[:cyc.value]
+
+    # ---- Uzawa iteration (Stokes_flow_Incomp.c) and its operators
+    @staticmethod
+    def _mesh(ien, idmap):
+        return np.ascontiguousarray(ien, np.int32).ravel(), np.ascontiguousarray(idmap, np.int32).ravel()
+
+    def assemble_div_u(self, ien, idmap, g, U, npe=8, dof=3):
+        ie, idm = self._mesh(ien, idmap)
+        out = np.zeros(len(ien))
+        self.lib.oracle_assemble_div_u(len(ien), npe, dof, ie, idm, np.ascontiguousarray(g).ravel(), np.ascontiguousarray(U), out)
+        return out
+
+    def assemble_grad_p(self, ien, idmap, g, neq, zero_resid, P, npe=8, dof=3):
+        ie, idm = self._mesh(ien, idmap)
+        zr = np.ascontiguousarray(zero_resid, np.int32)
+        out = np.zeros(neq)
+        self.lib.oracle_assemble_grad_p(len(ien), npe, dof, ie, idm, np.ascontiguousarray(g).ravel(), neq, zr.ctypes.data if len(zr) else None, len(zr),
+                                        np.ascontiguousarray(P), out)
+        return out
+
+    def build_diagonal_of_Ahat(self, ien, idmap, g, BI, npe=8, dof=3):
+        ie, idm = self._mesh(ien, idmap)
+        out = np.zeros(len(ien))
+        self.lib.oracle_build_diagonal_of_Ahat(len(ien), npe, dof, ie, idm, np.ascontiguousarray(g).ravel(), np.ascontiguousarray(BI), out)
+        return out
+
+    def solve_Ahat_p_fhat_CG(self, ien, idmap, nno, neq, elt_k, g, BI, BPI, nmass, area, volume, zero_resid, F, V, P, imp, inner_scale, v_res,
+                             v_steps_low, steps_max, check_continuity=0, check_pressure=0, npe=8, dof=3):
+        """Returns (V, P, outer count, incompressibility, hist[count+1, 5], inner iterations); V and P are copies."""
+        ie, idm = self._mesh(ien, idmap)
+        zr = np.ascontiguousarray(zero_resid, np.int32)
+        V, P = np.array(V, dtype=np.float64), np.array(P, dtype=np.float64)
+        steps = C.c_int32(steps_max)
+        hist = np.zeros((steps_max + 1, 5))
+        inner = C.c_int64(0)
+        inc = self.lib.oracle_solve_Ahat_p_fhat_CG(len(ien), npe, dof, ie, idm, nno, neq, np.ascontiguousarray(elt_k).ravel(), np.ascontiguousarray(g).ravel(),
+                                                   np.ascontiguousarray(BI), np.ascontiguousarray(BPI), np.ascontiguousarray(nmass),
+                                                   np.ascontiguousarray(area), volume, zr.ctypes.data if len(zr) else None, len(zr),
+                                                   np.ascontiguousarray(F), V, P, imp, inner_scale, v_res, v_steps_low, check_continuity, check_pressure,
+                                                   C.byref(steps), hist.ctypes.data, C.byref(inner))
+        return V, P, steps.value, inc, hist[:steps.value + 1], inner.value
 
     def dense_rows_times_matrix(self, xx, w):
         M, N = xx.shape

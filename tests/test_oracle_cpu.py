@@ -296,3 +296,33 @@ def test_dense_grad_matches_numpy(oracle):
         xx, w, g = rng.integers(-4, 5, (M, N)).astype(float), rng.integers(-4, 5, (N, K)).astype(float), rng.integers(-4, 5, (M, K)).astype(float)
         dxx, dw = oracle.dense_rows_times_matrix_grad(xx, w, g)
         assert np.array_equal(dxx, g @ w.T) and np.array_equal(dw, xx.T @ g)
+
+
+def test_uzawa_operators_and_iteration(oracle):
+    """assemble_div_u and assemble_grad_p are transposes of each other (before the boundary strip); build_diagonal_of_Ahat is the
+    diagonal of G·diag(BI)·Gᵀ; solve_Ahat_p_fhat_CG drives div(V) to the requested accuracy and solves the momentum equation."""
+    from tests.helpers import stokes_problem
+    pr = stokes_problem(4, 3, 2, 5)
+    ien, idmap, nno, neq, nel = pr["ien"], pr["id"], pr["nno"], pr["neq"], len(pr["ien"])
+    rng = np.random.default_rng(0)
+    U, P = rng.uniform(-1, 1, neq), rng.uniform(-1, 1, nel)
+    none = np.zeros(0, np.int32)
+    assert abs(oracle.assemble_div_u(ien, idmap, pr["g"], U) @ P - U @ oracle.assemble_grad_p(ien, idmap, pr["g"], neq, none, P)) < 1e-10
+    # dense G: row e holds g[e] at the equations of the element's nodes
+    G = np.zeros((nel, neq))
+    for e in range(nel):
+        for a in range(8):
+            for d in range(3):
+                G[e, idmap[ien[e, a], d]] += pr["g"][e, 3 * a + d]
+    assert np.allclose(oracle.assemble_div_u(ien, idmap, pr["g"], U), G @ U, rtol=1e-12)
+    BI = oracle.element_inverse_diagonal(ien, idmap, pr["K"], neq)
+    BPI = oracle.build_diagonal_of_Ahat(ien, idmap, pr["g"], BI)
+    assert np.allclose(1.0 / BPI, np.einsum("ej,j,ej->e", G, BI, G), rtol=1e-12)
+    v_res = float(np.linalg.norm(pr["F"]))
+    V, Pn, cnt, inc, hist, inner = oracle.solve_Ahat_p_fhat_CG(ien, idmap, nno, neq, pr["K"], pr["g"], BI, BPI, pr["nmass"], pr["area"], pr["volume"],
+                                                              pr["bc"], pr["F"], np.zeros(neq), np.zeros(nel), 1e-7, 1.0, v_res, 500, 60)
+    assert 2 <= cnt < 60 and inc <= 1e-7 and hist.shape == (cnt + 1, 5) and inner > cnt
+    assert np.all(np.diff(hist[1:, 4]) < 0) or hist[-1, 4] < hist[1, 4]
+    mom = pr["F"] - oracle.assemble_grad_p(ien, idmap, pr["g"], neq, pr["bc"], Pn) - oracle.element_matvec(ien, idmap, pr["K"], V, neq)
+    mom[pr["bc"]] = 0.0
+    assert np.linalg.norm(mom) <= 50 * 1e-7 * v_res
