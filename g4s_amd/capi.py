@@ -86,6 +86,10 @@ SIGNATURES = {
     "g4s_elem_op_apply": (C.c_int, [vp, vp, vp, vp]),
     "g4s_elem_op_inverse_diagonal": (C.c_int, [vp, vp, vp]),
     "g4s_conj_grad": (C.c_int, [vp, vp, C.c_int32, vp, vp, C.c_int32, vp, vp, C.c_double, C.POINTER(C.c_int32), f64p, vp]),
+    "g4s_node_op_create": (C.c_int, [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp]),
+    "g4s_node_op_destroy": (C.c_int, [vp]),
+    "g4s_node_op_apply": (C.c_int, [vp, vp, vp, vp, C.c_int32, vp]),
+    "g4s_conj_grad_node": (C.c_int, [vp, C.c_int32, vp, vp, C.c_int32, vp, vp, C.c_double, C.POINTER(C.c_int32), f64p, vp]),
     "g4s_elem_op_div_u": (C.c_int, [vp, vp, vp, vp, vp]),
     "g4s_elem_op_grad_p": (C.c_int, [vp, vp, vp, vp, vp, C.c_int32, vp]),
     "g4s_elem_op_pressure_preconditioner": (C.c_int, [vp, vp, vp, vp, vp]),

@@ -14,6 +14,7 @@
 #include "common.hpp"
 #include <algorithm>
 #include <cmath>
+#include <functional>
 
 // opaque handle types of the two operators, defined in graph.hip / spmv.hip
 extern "C" g4s_status g4s_elem_op_apply(g4s_elem_op_t op, const double *u_dev, double *Au_dev, void *stream);
@@ -182,6 +183,7 @@ struct DevBuf {
 extern "C" g4s_status g4s_elem_op_diagonal_sum(g4s_elem_op_t op, double *diag_dev, void *stream);
 int g4s_elem_op_neq(g4s_elem_op_t op);
 int g4s_elem_op_apply_unless(g4s_elem_op_t op, const double *u_dev, double *Au_dev, const int *skip_dev, void *stream);
+int g4s_node_op_apply_unless(g4s_node_op_t op, const double *u_dev, double *Au_dev, const int32_t *zero_resid_dev, int32_t n_zero, const int *skip_dev, void *stream);   // nodeop.hip
 
 G4S_API g4s_status g4s_elem_op_inverse_diagonal(g4s_elem_op_t op, double *BI_dev, void *stream)
 {
@@ -194,10 +196,13 @@ G4S_API g4s_status g4s_elem_op_inverse_diagonal(g4s_elem_op_t op, double *BI_dev
     return G4S_OK;
 }
 
-G4S_API g4s_status g4s_conj_grad(g4s_elem_op_t op, g4s_csr_t A, int32_t neq, const double *BI, const int32_t *zero_resid, int32_t n_zero,
-                                 const double *F, double *d0, double acc, int32_t *cycles, double *residual_out, void *stream)
+namespace {
+// matvec(p, Ap, done_flag, stream): Ap = K·p, free to return at once when *done_flag != 0
+using MatVec = std::function<int(const double *, double *, const int *, hipStream_t)>;
+
+int conj_grad_impl(const MatVec &matvec, int32_t neq, const double *BI, const int32_t *zero_resid, int32_t n_zero,
+                   const double *F, double *d0, double acc, int32_t *cycles, double *residual_out, void *stream)
 {
-    G4S_REQUIRE((op != nullptr) != (A != nullptr), "exactly one of op / A must be given");
     G4S_REQUIRE(neq > 0 && BI && F && d0 && cycles, "bad argument");
     G4S_REQUIRE(n_zero >= 0 && (n_zero == 0 || zero_resid), "zero_resid is NULL");
     hipStream_t s = g4s::as_stream(stream);
@@ -235,8 +240,7 @@ G4S_API g4s_status g4s_conj_grad(g4s_elem_op_t op, g4s_csr_t A, int32_t neq, con
         const int todo = std::max(1, std::min(batch, steps - enqueued + 1));
         for (int it = 0; it < todo; ++it) {
             hipLaunchKernelGGL(cg_direction_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, neq, steps, acc, part_rr, part_rz, st, z, p1, p2);
-            if (op) G4S_TRY(g4s_elem_op_apply_unless(op, p2, Ap, &st->done, s));
-            else G4S_TRY(g4s_spmv(A, p2, Ap, 1.0, 0.0, s));
+            G4S_TRY(matvec(p2, Ap, &st->done, s));
             hipLaunchKernelGGL(cg_pAp_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, neq, st, bc_mask, p2, Ap, part_pAp);
             hipLaunchKernelGGL(cg_update_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, neq, part_pAp, st, BI, p2, Ap, r1, r2, d0, z, part_rr, part_rz);
             std::swap(r1, r2);
@@ -262,4 +266,24 @@ G4S_API g4s_status g4s_conj_grad(g4s_elem_op_t op, g4s_csr_t A, int32_t neq, con
     G4S_HIP_TRY(hipStreamSynchronize(s));
     if (residual_out) *residual_out = residual;
     return G4S_OK;
+}
+} // namespace
+
+G4S_API g4s_status g4s_conj_grad(g4s_elem_op_t op, g4s_csr_t A, int32_t neq, const double *BI, const int32_t *zero_resid, int32_t n_zero,
+                                 const double *F, double *d0, double acc, int32_t *cycles, double *residual_out, void *stream)
+{
+    G4S_REQUIRE((op != nullptr) != (A != nullptr), "exactly one of op / A must be given");
+    MatVec mv;
+    if (op) mv = [op](const double *p, double *Ap, const int *done, hipStream_t s) { return g4s_elem_op_apply_unless(op, p, Ap, done, s); };
+    else mv = [A](const double *p, double *Ap, const int *, hipStream_t s) { return g4s_spmv(A, p, Ap, 1.0, 0.0, s); };
+    return conj_grad_impl(mv, neq, BI, zero_resid, n_zero, F, d0, acc, cycles, residual_out, stream);
+}
+
+G4S_API g4s_status g4s_conj_grad_node(g4s_node_op_t op, int32_t neq, const double *BI, const int32_t *zero_resid, int32_t n_zero,
+                                      const double *F, double *d0, double acc, int32_t *cycles, double *residual_out, void *stream)
+{
+    G4S_REQUIRE(op, "op is NULL");
+    // the boundary rows of Ap are zeroed by cg_pAp_kernel's mask, as for the other operators
+    MatVec mv = [op](const double *p, double *Ap, const int *done, hipStream_t s) { return g4s_node_op_apply_unless(op, p, Ap, nullptr, 0, done, s); };
+    return conj_grad_impl(mv, neq, BI, zero_resid, n_zero, F, d0, acc, cycles, residual_out, stream);
 }

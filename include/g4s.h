@@ -187,6 +187,7 @@ g4s_status g4s_spmm_dense(uint32_t numNodes, uint32_t degree, const double **edg
 /* Device-resident forms of the three patterns (what spmm_dense dispatches to; solvers call these directly
  * to keep vectors on the device between iterations). */
 typedef struct g4s_elem_op_s *g4s_elem_op_t;
+typedef struct g4s_node_op_s *g4s_node_op_t;
 /* elt_k_dev: numElems × (npe·dof)² doubles, contiguous, device memory (borrowed). ien/id host arrays as in the descriptor. */
 g4s_status g4s_elem_op_create(g4s_elem_op_t *out, int32_t numElems, int32_t nodes_per_elem, int32_t dof,
                               const int32_t *ien_host, const int32_t *id_host, int32_t nno, int32_t neq,
@@ -209,6 +210,22 @@ g4s_status g4s_elem_op_inverse_diagonal(g4s_elem_op_t op, double *BI_dev, void *
  * Exactly one of op / A selects the operator (element-by-element or assembled CSR). */
 g4s_status g4s_conj_grad(g4s_elem_op_t op, g4s_csr_t A, int32_t neq, const double *BI_dev, const int32_t *zero_resid_dev, int32_t n_zero,
                          const double *F_dev, double *d0_dev, double acc, int32_t *cycles, double *residual, void *stream);
+
+/* ---- CitcomS's node-assembled stiffness operator (the other mat-vec format of assemble_del2_u) — SURVEY.md §8 f1.
+ * node_map[nno·max_eqn] = E->Node_map[lev][m] (slot group 0: the node's own three equations, groups 1..13: lower-numbered
+ * neighbours, unused slots = neq; citcoms/lib/Construct_arrays.c:254-328), eqn_k1..3[nno·max_eqn] = E->Eqn_k1..3[lev][m]
+ * (construct_node_ks :335-470), id[nno·3] = E->ID .doff[1..3]; all host pointers, 0-based nodes, copied. The stored symmetric half
+ * is expanded once into per-node 3×3 neighbour blocks so that the mat-vec is a gather. */
+g4s_status g4s_node_op_create(g4s_node_op_t *out, int32_t nno, int32_t neq, int32_t max_eqn, const int32_t *node_map,
+                              const int32_t *id, const double *eqn_k1, const double *eqn_k2, const double *eqn_k3);
+g4s_status g4s_node_op_destroy(g4s_node_op_t op);
+/* Au = K·u, then the listed rows zeroed (strip_bcs) — n_assemble_del2_u, citcoms/lib/Element_calculations.c:516-577.
+ * u_dev / Au_dev hold neq doubles (the reference's dummy entry [neq] is not needed: unused slots are dropped at create). */
+g4s_status g4s_node_op_apply(g4s_node_op_t op, const double *u_dev, double *Au_dev, const int32_t *zero_resid_dev, int32_t n_zero,
+                             void *stream);
+/* g4s_conj_grad (below) on the node-assembled operator. */
+g4s_status g4s_conj_grad_node(g4s_node_op_t op, int32_t neq, const double *BI_dev, const int32_t *zero_resid_dev, int32_t n_zero,
+                              const double *F_dev, double *d0_dev, double acc, int32_t *cycles, double *residual, void *stream);
 
 /* ---- The incompressibility (Uzawa) iteration of CitcomS around the velocity solve — SURVEY.md §8 f1.
  * g_dev[e·npe·dof + p] = elt_del[e].g[p][0], the per-element divergence / gradient vector; pressure unknowns are elements. */

@@ -804,3 +804,70 @@ ORACLE_API double oracle_solve_Ahat_p_fhat_CG(int32_t nel, int32_t npe, int32_t 
     free(F); free(u1); free(tmp); free(r1); free(r2); free(z1); free(s1); free(s2); free(Fp); free(rows);
     return incompressibility;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * CitcomS node-assembled stiffness operator: Node_map / Eqn_k1..3 — SURVEY.md §8 f1.
+ * max_eqn = 14·dims slots per node: slot group 0 = the node's own 3 equations, groups 1..13 = lower-numbered neighbours;
+ * unused slots hold the dummy equation `neq` (Construct_arrays.c:254-328). 0-based nodes, dims = dof = 3.
+ * ---------------------------------------------------------------------------------------------------------------------------- */
+
+/* construct_node_ks, citcoms/lib/Construct_arrays.c:335-470: Eqn_k from the element matrices, symmetric half (node1 <= node),
+ * boundary dofs weighted out (bcw[node·3 + d] = 0 where NODE & VBX/VBZ/VBY is set, 1 otherwise). Returns -1 if a slot is missing
+ * (the source asserts). */
+ORACLE_API int oracle_construct_node_ks(int32_t nel, int32_t npe, const int32_t *ien, const int32_t *id, int32_t nno, int32_t neq,
+                                        int32_t max_eqn, const int32_t *node_map, const double *elt_k, const double *bcw,
+                                        double *k1, double *k2, double *k3)
+{
+    const int32_t dims = 3, lms = npe * dims;
+    (void)neq;
+    for (int64_t i = 0; i < (int64_t)nno * max_eqn; ++i) { k1[i] = 0.0; k2[i] = 0.0; k3[i] = 0.0; }
+    for (int32_t element = 0; element < nel; ++element) {
+        const double *elt_K = elt_k + (size_t)element * lms * lms;
+        for (int32_t i = 0; i < npe; ++i) {                /* i: the node we are storing to */
+            const int32_t node = ien[element * npe + i], pp = i * dims;
+            const int64_t loc0 = (int64_t)node * max_eqn;
+            const double w1 = bcw[node * 3 + 0], w2 = bcw[node * 3 + 1], w3 = bcw[node * 3 + 2];
+            for (int32_t j = 0; j < npe; ++j) {            /* j: the node we are receiving from */
+                const int32_t node1 = ien[element * npe + j];
+                if (node1 > node) continue;                /* only half of the matrix, because of the symmetry */
+                const int32_t qq = j * dims;
+                for (int32_t dir = 0; dir < 3; ++dir) {
+                    const int32_t eqn = id[node1 * 3 + dir];
+                    const double ww = bcw[node1 * 3 + dir];
+                    int32_t index = -1;
+                    for (int32_t k = 0; k < max_eqn; ++k)
+                        if (node_map[loc0 + k] == eqn) { index = k; break; }
+                    if (index < 0) return -1;
+                    k1[loc0 + index] += w1 * ww * elt_K[pp * lms + qq + dir];
+                    k2[loc0 + index] += w2 * ww * elt_K[(pp + 1) * lms + qq + dir];
+                    k3[loc0 + index] += w3 * ww * elt_K[(pp + 2) * lms + qq + dir];
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+/* n_assemble_del2_u, citcoms/lib/Element_calculations.c:516-577: Au = K·u from the stored half, node by node; u and Au have
+ * neq + 1 entries (index neq is the dummy equation). strip_bcs: zero the listed rows afterwards. */
+ORACLE_API void oracle_n_assemble_del2_u(int32_t nno, int32_t neq, int32_t max_eqn, const int32_t *node_map, const int32_t *id,
+                                         const double *k1, const double *k2, const double *k3, double *u /* [neq+1], u[neq] := 0 */,
+                                         double *Au /* [neq+1] */, const int32_t *zero_resid, int32_t n_zero)
+{
+    for (int32_t e = 0; e <= neq; ++e) Au[e] = 0.0;
+    u[neq] = 0.0;
+    for (int32_t e = 0; e < nno; ++e) {
+        const int32_t eqn1 = id[e * 3], eqn2 = id[e * 3 + 1], eqn3 = id[e * 3 + 2];
+        const double U1 = u[eqn1], U2 = u[eqn2], U3 = u[eqn3];
+        const int32_t *C = node_map + (int64_t)e * max_eqn;
+        const double *B1 = k1 + (int64_t)e * max_eqn, *B2 = k2 + (int64_t)e * max_eqn, *B3 = k3 + (int64_t)e * max_eqn;
+        for (int32_t i = 3; i < max_eqn; ++i) {
+            const double UU = u[C[i]];
+            Au[eqn1] += B1[i] * UU;
+            Au[eqn2] += B2[i] * UU;
+            Au[eqn3] += B3[i] * UU;
+        }
+        for (int32_t i = 0; i < max_eqn; ++i) Au[C[i]] += B1[i] * U1 + B2[i] * U2 + B3[i] * U3;
+    }
+    for (int32_t i = 0; i < n_zero; ++i) Au[zero_resid[i]] = 0.0;
+}

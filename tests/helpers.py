@@ -82,3 +82,28 @@ def stokes_problem(ex, ey, ez, seed):
     area = rng.uniform(0.5, 1.5, nel)
     return {"ien": ien, "id": idmap, "nno": nno, "neq": neq, "K": K, "g": np.ascontiguousarray(g), "bc": bc, "F": F, "nmass": nmass, "area": area,
             "volume": float(area.sum())}
+
+
+def hex_node_map(ex, ey, ez, idmap):
+    """CitcomS's Node_map for the mesh of hex_mesh (construct_node_maps, citcoms/lib/Construct_arrays.c:254-328): 14·3 slots per
+    node — the node's own three equations, then those of every lower-numbered neighbour of the 3×3×3 stencil — unused slots = neq."""
+    nx, ny, nz = ex + 1, ey + 1, ez + 1
+    nno, neq, max_eqn = nx * ny * nz, 3 * nx * ny * nz, 42
+    nm = np.full((nno, max_eqn), neq, np.int32)
+    for k in range(nz):
+        for j in range(ny):
+            for i in range(nx):
+                nn = (k * ny + j) * nx + i
+                nm[nn, 0:3] = idmap[nn]
+                ia = 0
+                for dk in (-1, 0, 1):
+                    for dj in (-1, 0, 1):
+                        for di in (-1, 0, 1):
+                            ii, jj, kk = i + di, j + dj, k + dk
+                            if not (0 <= ii < nx and 0 <= jj < ny and 0 <= kk < nz):
+                                continue
+                            ja = (kk * ny + jj) * nx + ii
+                            if ja < nn:
+                                ia += 1
+                                nm[nn, 3 * ia:3 * ia + 3] = idmap[ja]
+    return nm, max_eqn

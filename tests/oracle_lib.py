@@ -42,6 +42,9 @@ class Oracle:
         L.oracle_spmm_dense.argtypes = [C.c_uint32, C.c_uint32, vp, vp, vp, vp, FUN_GATHER, FUN_APPLY, vp, C.c_int]
         L.oracle_element_matvec.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i32, _i32, vp, C.c_int32, _f64, _f64, C.c_int32]
         L.oracle_dense_rows_times_matrix.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, _f64, _f64]
+        L.oracle_construct_node_ks.restype = C.c_int
+        L.oracle_construct_node_ks.argtypes = [C.c_int32, C.c_int32, _i32, _i32, C.c_int32, C.c_int32, C.c_int32, _i32, _f64, _f64, _f64, _f64, _f64]
+        L.oracle_n_assemble_del2_u.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i32, _i32, _f64, _f64, _f64, _f64, _f64, vp, C.c_int32]
         L.oracle_assemble_div_u.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i32, _i32, _f64, _f64, _f64]
         L.oracle_assemble_grad_p.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i32, _i32, _f64, C.c_int32, vp, C.c_int32, _f64, _f64]
         L.oracle_build_diagonal_of_Ahat.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i32, _i32, _f64, _f64, _f64]
@@ -158,6 +161,23 @@ class Oracle:
                                              np.ascontiguousarray(BI), zr.ctypes.data if len(zr) else None, len(zr), np.ascontiguousarray(F), d0,
                                              acc, C.byref(cyc), hist.ctypes.data)
         return d0, cyc.value, res, hist[:cyc.value]
+
+    # ---- node-assembled operator (Construct_arrays.c, n_assemble_del2_u)
+    def construct_node_ks(self, ien, idmap, nno, neq, node_map, elt_k, bcw, npe=8):
+        ie, idm = np.ascontiguousarray(ien, np.int32).ravel(), np.ascontiguousarray(idmap, np.int32).ravel()
+        max_eqn = node_map.shape[1]
+        k1, k2, k3 = (np.zeros(nno * max_eqn) for _ in range(3))
+        rc = self.lib.oracle_construct_node_ks(len(ien), npe, ie, idm, nno, neq, max_eqn, np.ascontiguousarray(node_map, np.int32).ravel(),
+                                               np.ascontiguousarray(elt_k).ravel(), np.ascontiguousarray(bcw, np.float64).ravel(), k1, k2, k3)
+        assert rc == 0, "a Node_map slot is missing"
+        return k1, k2, k3
+
+    def n_assemble_del2_u(self, nno, neq, node_map, idmap, k1, k2, k3, u, zero_resid):
+        zr = np.ascontiguousarray(zero_resid, np.int32)
+        uu, Au = np.concatenate([np.asarray(u, np.float64), [0.0]]), np.zeros(neq + 1)
+        self.lib.oracle_n_assemble_del2_u(nno, neq, node_map.shape[1], np.ascontiguousarray(node_map, np.int32).ravel(),
+                                          np.ascontiguousarray(idmap, np.int32).ravel(), k1, k2, k3, uu, Au, zr.ctypes.data if len(zr) else None, len(zr))
+        return Au[:neq]
 
     # ---- Uzawa iteration (Stokes_flow_Incomp.c) and its operators
     @staticmethod

@@ -13,7 +13,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from g4s_amd import capi  # noqa: E402
 from tests import oracle_lib  # noqa: E402
-from tests.helpers import hex_mesh, spd_blocks  # noqa: E402
+from tests.helpers import hex_mesh, hex_node_map, spd_blocks  # noqa: E402
 
 ez = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 lib, o = capi.load(), oracle_lib.load()
@@ -80,4 +80,35 @@ long_ms = (time.perf_counter() - t0) / reps * 1e3
 d_or2, cyc_or2, _, _ = o.conj_grad_elem(ien, idmap, K, neq, BI, bc, F, acc2, 250)
 print(json.dumps({"workload": "same operator, accuracy 1e-13*|F|", "cg_iterations": cyc.value, "cg_iterations_oracle": cyc_or2, "gpu_cg_ms": round(long_ms, 3),
                   "gpu_us_per_iteration": round(long_ms * 1e3 / cyc.value, 2), "max_rel_diff": float(np.max(np.abs(d0.cpu().numpy() - d_or2)) / np.max(np.abs(d_or2)))}))
+# the same operator in CitcomS's node-assembled form (Node_map / Eqn_k → per-node 3×3 neighbour blocks)
+nm, max_eqn = hex_node_map(32, 32, ez, idmap)
+bcw = np.ones((nno, 3))
+bcw.reshape(-1)[np.searchsorted(idmap.ravel(), bc)] = 0.0
+ks = o.construct_node_ks(ien, idmap, nno, neq, nm, K, bcw)
+hn = C.c_void_p()
+capi.check(lib.g4s_node_op_create(C.byref(hn), nno, neq, max_eqn, np.ascontiguousarray(nm).ctypes.data, np.ascontiguousarray(idmap).ctypes.data,
+                                  ks[0].ctypes.data, ks[1].ctypes.data, ks[2].ctypes.data))
+for _ in range(20):
+    lib.g4s_node_op_apply(hn, u.data_ptr(), Au.data_ptr(), None, 0, st)
+e0.record()
+for _ in range(200):
+    lib.g4s_node_op_apply(hn, u.data_ptr(), Au.data_ptr(), None, 0, st)
+e1.record()
+torch.cuda.synchronize()
+nmv_us = e0.elapsed_time(e1) / 200 * 1e3
+for _ in range(2):
+    cyc.value = 250
+    capi.check(lib.g4s_conj_grad_node(hn, neq, BId.data_ptr(), bcd.data_ptr(), len(bc), Fd.data_ptr(), d0.data_ptr(), acc2, C.byref(cyc), C.byref(res), None))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(reps):
+    cyc.value = 250
+    capi.check(lib.g4s_conj_grad_node(hn, neq, BId.data_ptr(), bcd.data_ptr(), len(bc), Fd.data_ptr(), d0.data_ptr(), acc2, C.byref(cyc), C.byref(res), None))
+torch.cuda.synchronize()
+node_ms = (time.perf_counter() - t0) / reps * 1e3
+nalg = nno * 27 * (72 + 4) + 16 * neq
+print(json.dumps({"workload": "same operator, node-assembled form, accuracy 1e-13*|F|", "cg_iterations": cyc.value, "gpu_cg_ms": round(node_ms, 3),
+                  "gpu_us_per_iteration": round(node_ms * 1e3 / cyc.value, 2), "gpu_matvec_us": round(nmv_us, 2), "matvec_algorithmic_bytes": nalg,
+                  "matvec_GBps": round(nalg / (nmv_us * 1e-6) / 1e9, 1), "max_rel_diff_vs_elem_oracle": float(np.max(np.abs(d0.cpu().numpy() - d_or2)) / np.max(np.abs(d_or2)))}))
+lib.g4s_node_op_destroy(hn)
 lib.g4s_elem_op_destroy(h)
