@@ -215,3 +215,28 @@ def test_spmv_nonfinite_inputs_propagate_like_the_oracle(oracle, flags):
     xf = np.where(np.isfinite(x), x, 0.0)
     _, asum = oracle.spmv_ld(rp, ci, va, xf)
     assert np.all(np.abs(y[fin] - want[fin]) <= TOL * asum[fin] + 1e-300)
+
+
+def test_row_slabs_reproduce_the_full_product():
+    """The multi-GPU bench gives every rank a row slab (all columns) chosen by the equal-work rule and its own SpMV plan. On one
+    GPU: the slabs of a 6 M-vertex R-MAT (each takes the blocked path on its own) stacked equal the product of the whole matrix."""
+    from g4s_amd import dist as gdist, host
+    n = 6_000_000
+    A = host.rmat_csr(n, 23, 30_000_000, 11)
+    x = host.synth_vector(3, n)
+    y_full = A.spmv(x)
+    Aabs = host.CSR(A.rowptr, A.colids, A.values.abs(), n, n)
+    scale = Aabs.spmv(x.abs())
+    for parts in (2, 3):
+        offs = gdist.row_partition(A.rowptr, parts)
+        assert offs[0] == 0 and offs[-1] == n and all(b > a for a, b in zip(offs, offs[1:]))
+        work = [int(A.rowptr[b].item()) - int(A.rowptr[a].item()) + (b - a) for a, b in zip(offs, offs[1:])]   # nnz + rows (dist.row_partition)
+        assert max(work) - min(work) <= 0.02 * (A.nnz + n)                          # equal work, up to one hub row
+        ys = []
+        for a, b in zip(offs, offs[1:]):
+            rp, ci, va = gdist.slice_rows(A.rowptr, A.colids, A.values, a, b)
+            S = host.CSR(rp, ci, va, b - a, n)
+            assert S.info()["spmv_path"] == 1
+            ys.append(S.spmv(x))
+        y = torch.cat(ys)
+        assert torch.all((y - y_full).abs() <= 1e-10 * scale + 1e-300)
