@@ -166,7 +166,7 @@ __device__ __forceinline__ int hash_of(int key) { return (key * kHashScal) & (TA
 // (128 KiB tables) are bound by exactly that chain. body(b0, b1, av) returns false to stop early.
 template <bool WITH_VAL, typename Body>
 __device__ __forceinline__ void walk_a_entries(int a0, int a1, int first, int stride, const int *__restrict__ acol,
-                                               const double *__restrict__ aval, const int *__restrict__ brpt, Body body)
+                                               const double *__restrict__ aval, const int *__restrict__ blo, const int *__restrict__ bhi, Body body)
 {
     int j = a0 + first;
     int c1 = 0, b0 = 0, b1 = 0;
@@ -174,8 +174,8 @@ __device__ __forceinline__ void walk_a_entries(int a0, int a1, int first, int st
     if (j < a1) {
         const int c0 = acol[j];
         if (WITH_VAL) av0 = aval[j];
-        b0 = brpt[c0];
-        b1 = brpt[c0 + 1];
+        b0 = blo[c0];
+        b1 = bhi[c0];
     }
     if (j + stride < a1) {
         c1 = acol[j + stride];
@@ -190,8 +190,8 @@ __device__ __forceinline__ void walk_a_entries(int a0, int a1, int first, int st
             if (WITH_VAL) av2 = aval[j2];
         }
         if (j1 < a1) {
-            nb0 = brpt[c1];
-            nb1 = brpt[c1 + 1];
+            nb0 = blo[c1];
+            nb1 = bhi[c1];
         }
         if (!body(b0, b1, av0)) return;
         b0 = nb0; b1 = nb1; av0 = av1; c1 = c2; av1 = av2; j = j1;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(WGSIZE) void spgemm_symbolic_lds_kernel(
             }
             if (OPTIMISTIC && probes >= MAX_PROBES) { s_ovf[sub] = 1; stop = true; }   // the table is filling up: give the row to the bitmap path
         };
-        walk_a_entries<false>(a0, a1, t >> gs, THREADS >> gs, acol, nullptr, brpt, [&](int b0, int b1, double) {
+        walk_a_entries<false>(a0, a1, t >> gs, THREADS >> gs, acol, nullptr, brpt, brpt + 1, [&](int b0, int b1, double) {
             // the abort flag is read by all lanes of the wave in one instruction: the lanes of a group leave together, so the
             // shuffle inside defer_long_b never reads a lane that has already left
             if (OPTIMISTIC && lds_peek(&s_ovf[sub])) return false;
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(WGSIZE) void spgemm_numeric_lds_kernel(
                 h = (h + 1) & (TABLE - 1);
             }
         };
-        walk_a_entries<true>(a0, a1, t >> gs, THREADS >> gs, acol, aval, brpt, [&](int b0, int b1, double av) {
+        walk_a_entries<true>(a0, a1, t >> gs, THREADS >> gs, acol, aval, brpt, brpt + 1, [&](int b0, int b1, double av) {
             if (RPB == 1 && defer_long_b(longs, b0, b1, av, t & gmask, gmask, long_thr)) return true;
             for (int k = b0 + (t & gmask); k < b1; k += gmask + 1) insert(bcol[k], av * bval[k]);   // multop, hash_mult.h:583
             return true;
@@ -437,10 +437,38 @@ __device__ __forceinline__ unsigned wave_inclusive_sum(unsigned x)
     return x;
 }
 
+// Window splits. B's rows are sorted by column, so the entries of row c that fall into bitmap window w are one contiguous piece:
+// wsplit[(j − 1)·K + c] = first position of row c whose column is >= j·2^20 (j = 1 … W − 1), computed once per product by
+// window_splits_kernel. A window pass (and a value chunk, which spans one or a few windows) then walks only that piece of every B
+// row instead of reading the whole row and discarding what is outside — with two windows that halves the products visited.
+__global__ void window_splits_kernel(int K, int W, const int *__restrict__ brpt, const int *__restrict__ bcol, int *__restrict__ wsplit)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)K * (W - 1)) return;
+    const int j = (int)(idx / K) + 1, c = (int)(idx - (long long)(j - 1) * K);
+    const int bound = j << kBigWindowBits;
+    int lo = brpt[c], hi = brpt[c + 1];
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (bcol[mid] < bound) lo = mid + 1; else hi = mid;
+    }
+    wsplit[idx] = lo;
+}
+
+// lo/hi arrays (indexed by B row) that bracket the columns [cfirst, clast]; without splits the whole row
+__device__ __forceinline__ void window_bounds(const int *brpt, const int *wsplit, int K, int N, int cfirst, int clast, const int *&lo, const int *&hi)
+{
+    lo = brpt; hi = brpt + 1;
+    if (!wsplit) return;
+    const int wf = cfirst >> kBigWindowBits, wl = clast >> kBigWindowBits, W = (N + (1 << kBigWindowBits) - 1) >> kBigWindowBits;
+    if (wf > 0) lo = wsplit + (size_t)(wf - 1) * K;
+    if (wl < W - 1) hi = wsplit + (size_t)wl * K;
+}
+
 // Symbolic twin of phase 1 below: the number of distinct columns of a row whose key table would not fit LDS, counted with the
 // same LDS bitmap windows (no hash table that can overflow, no HBM bitmap, no global atomics). One workgroup per row.
 __global__ __launch_bounds__(kBigThreads) void spgemm_symbolic_window_kernel(
-    const int *__restrict__ rows, int nrows, int N, const int *__restrict__ arpt, const int *__restrict__ acol,
+    const int *__restrict__ rows, int nrows, int N, int K, const int *__restrict__ wsplit, const int *__restrict__ arpt, const int *__restrict__ acol,
     const int *__restrict__ brpt, const int *__restrict__ bcol, const long long *__restrict__ row_flop, int *__restrict__ row_nz)
 {
     extern __shared__ int lds_i[];                                 // dynamic only (Guideline 17): [bitmap][count][pad][long-B list]
@@ -459,8 +487,10 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_symbolic_window_kernel(
         if (t == 0) longs[0].x = 0;
         __syncthreads();
         const int w1 = min(N, w0 + (1 << kBigWindowBits));
+        const int *wlo, *whi;
+        window_bounds(brpt, wsplit, K, N, w0, w1 - 1, wlo, whi);
         auto mark = [&](int col) { if (col >= w0 && col < w1) atomicOr(&bm[(col - w0) >> 5], 1u << ((col - w0) & 31)); };
-        walk_a_entries<false>(a0, a1, t >> gs, kBigThreads >> gs, acol, nullptr, brpt, [&](int b0, int b1, double) {
+        walk_a_entries<false>(a0, a1, t >> gs, kBigThreads >> gs, acol, nullptr, wlo, whi, [&](int b0, int b1, double) {
             if (defer_long_b(longs, b0, b1, 0.0, t & gmask, gmask, long_thr)) return true;
             for (int k = b0 + (t & gmask); k < b1; k += gmask + 1) mark(bcol[k]);
             return true;
@@ -492,7 +522,7 @@ __device__ unsigned long long g_big_prof[16];
 #endif
 
 __global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
-    const int *__restrict__ rows, int nrows, int N, const int *__restrict__ arpt, const int *__restrict__ acol, const double *__restrict__ aval,
+    const int *__restrict__ rows, int nrows, int N, int K, const int *__restrict__ wsplit, const int *__restrict__ arpt, const int *__restrict__ acol, const double *__restrict__ aval,
     const int *__restrict__ brpt, const int *__restrict__ bcol, const double *__restrict__ bval, const long long *__restrict__ row_flop,
     const int *__restrict__ crpt, int *__restrict__ ccol, double *__restrict__ cval)
 {
@@ -521,8 +551,10 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
         __syncthreads();
         BIG_PROF(0);
         const int w1 = min(N, w0 + (1 << kBigWindowBits));
+        const int *wlo, *whi;
+        window_bounds(brpt, wsplit, K, N, w0, w1 - 1, wlo, whi);
         auto mark = [&](int col) { if (col >= w0 && col < w1) atomicOr(&bm[bm_slot((col - w0) >> 5)], 1u << ((col - w0) & 31)); };
-        walk_a_entries<false>(a0, a1, t >> gs, kBigThreads >> gs, acol, nullptr, brpt, [&](int b0, int b1, double) {
+        walk_a_entries<false>(a0, a1, t >> gs, kBigThreads >> gs, acol, nullptr, wlo, whi, [&](int b0, int b1, double) {
             if (defer_long_b(longs, b0, b1, 0.0, t & gmask, gmask, long_thr)) return true;
             for (int k = b0 + (t & gmask); k < b1; k += gmask + 1) mark(bcol[k]);
             return true;
@@ -603,24 +635,26 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
     // (first slot << 16 | last slot) of the columns that fall in it, so the binary search runs over one bucket (0–2 steps where the
     // row is dense or evenly spread) instead of the whole chunk (13 steps).
     double *V = reinterpret_cast<double *>(lds_i);                 // kBigChunk doubles
-    int *K = lds_i + 2 * kBigChunk;                                // kBigChunk ints
+    int *KC = lds_i + 2 * kBigChunk;                                // kBigChunk ints
     unsigned *IDX = reinterpret_cast<unsigned *>(lds_i + 3 * kBigChunk);   // kBigChunk buckets: 4·kBigChunk ints = the bitmap's 128 KiB
     static_assert(4 * kBigChunk <= kBigWindowWords && kBigChunk <= 65536, "phase 2 reuses the bitmap region; slots are packed in 16 bits");
     for (int q0 = 0; q0 < nz; q0 += kBigChunk) {
         const int qn = min(kBigChunk, nz - q0);
-        for (int i = t; i < qn; i += kBigThreads) { K[i] = ccol[off + q0 + i]; V[i] = 0.0; }
+        for (int i = t; i < qn; i += kBigThreads) { KC[i] = ccol[off + q0 + i]; V[i] = 0.0; }
         for (int i = t; i < kBigChunk; i += kBigThreads) IDX[i] = 0u;
         if (t == 0) longs[0].x = 0;
         __syncthreads();
         BIG_PROF(6);
-        const int kfirst = K[0], klast = K[qn - 1];
+        const int kfirst = KC[0], klast = KC[qn - 1];
+        const int *clo, *chi;
+        window_bounds(brpt, wsplit, K, N, kfirst, klast, clo, chi);   // the part of each B row inside the windows this chunk spans
         const int span = klast - kfirst;                           // < 2^31
         const int shift = span < kBigChunk ? 0 : 32 - __clz(span) - 13;   // (span >> shift) < kBigChunk = 2^13
         static_assert(kBigChunk == 8192, "bucket shift assumes 2^13 buckets");
         for (int i = t; i < qn; i += kBigThreads) {
-            const int b = (K[i] - kfirst) >> shift;
-            if (i == 0 || ((K[i - 1] - kfirst) >> shift) != b) atomicOr(&IDX[b], (unsigned)i << 16);
-            if (i == qn - 1 || ((K[i + 1] - kfirst) >> shift) != b) atomicOr(&IDX[b], (unsigned)i);
+            const int b = (KC[i] - kfirst) >> shift;
+            if (i == 0 || ((KC[i - 1] - kfirst) >> shift) != b) atomicOr(&IDX[b], (unsigned)i << 16);
+            if (i == qn - 1 || ((KC[i + 1] - kfirst) >> shift) != b) atomicOr(&IDX[b], (unsigned)i);
         }
         __syncthreads();
         BIG_PROF(7);
@@ -630,11 +664,11 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
             int lo = (int)(w >> 16), hi = (int)(w & 0xffffu);
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
-                if (K[mid] < col) lo = mid + 1; else hi = mid;
+                if (KC[mid] < col) lo = mid + 1; else hi = mid;
             }
             atomicAdd(&V[lo], prod);
         };
-        walk_a_entries<true>(a0, a1, t >> gs, kBigThreads >> gs, acol, aval, brpt, [&](int b0, int b1, double av) {
+        walk_a_entries<true>(a0, a1, t >> gs, kBigThreads >> gs, acol, aval, clo, chi, [&](int b0, int b1, double av) {
             if (defer_long_b(longs, b0, b1, av, t & gmask, gmask, long_thr)) return true;
             for (int k = b0 + (t & gmask); k < b1; k += gmask + 1) add(bcol[k], av * bval[k]);
             return true;
@@ -980,6 +1014,23 @@ int read_last(const int *d_rpt, int n, int *out, hipStream_t s)
 } // namespace
 
 // ================================================================================================ C-ABI
+namespace {
+// wsplit for the window kernels (see window_splits_kernel); left empty (kernels then read whole rows) for a single window or when
+// the table would be large (more than 16 windows).
+int build_window_splits(int K, int N, const int *brpt, const int *bcol, DevBuf &buf, const int **out, hipStream_t s)
+{
+    *out = nullptr;
+    const int W = (N + (1 << kBigWindowBits) - 1) >> kBigWindowBits;
+    if (W < 2 || W > 16 || K <= 0 || getenv("G4S_SPGEMM_NO_SPLITS")) return G4S_OK;
+    const long long total = (long long)K * (W - 1);
+    G4S_TRY(buf.alloc(sizeof(int) * (size_t)total));
+    hipLaunchKernelGGL(window_splits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, K, W, brpt, bcol, buf.as<int>());
+    G4S_HIP_TRY(hipGetLastError());
+    *out = buf.as<int>();
+    return G4S_OK;
+}
+} // namespace
+
 G4S_API g4s_status g4s_spgemm_symbolic(int32_t M, int32_t K, int32_t N,
                                        const int32_t *arpt, const int32_t *acol, const int32_t *brpt, const int32_t *bcol,
                                        int32_t *crpt, int64_t *cnnz, void *stream)
@@ -1007,6 +1058,9 @@ G4S_API g4s_status g4s_spgemm_symbolic(int32_t M, int32_t K, int32_t N,
     if (getenv("G4S_DEBUG"))
         fprintf(stderr, "g4s symbolic classes: empty %d tiny %d small %d medium %d large %d hub %d (flop %lld)\n", rc.count[CLS_EMPTY], rc.count[CLS_TINY],
                 rc.count[CLS_SMALL], rc.count[CLS_MEDIUM], rc.count[CLS_LARGE], rc.count[CLS_HUB], (long long)flop);
+    DevBuf wsplit_buf;
+    const int *wsplit = nullptr;
+    G4S_TRY(build_window_splits(K, N, brpt, bcol, wsplit_buf, &wsplit, s));
     G4S_TRY(ovf_rows.alloc(sizeof(int) * (size_t)std::max(1, rc.count[CLS_LARGE])));
     G4S_TRY(ovf_count.alloc(sizeof(int)));
     G4S_HIP_TRY(hipMemsetAsync(ovf_count.p, 0, sizeof(int), s));
@@ -1027,7 +1081,7 @@ G4S_API g4s_status g4s_spgemm_symbolic(int32_t M, int32_t K, int32_t N,
         auto k = spgemm_symbolic_window_kernel;
         const size_t lds = sizeof(unsigned) * kBigWindowWords + sizeof(int) * 4 + kLongListBytes;
         G4S_TRY(allow_lds(k, lds));
-        if (n) hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rows, n, N, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz);
+        if (n) hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rows, n, N, K, wsplit, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz);
         return G4S_OK;
     };
     if (x_med) { G4S_TRY(window(rc.list(CLS_MEDIUM), rc.count[CLS_MEDIUM])); }
@@ -1054,9 +1108,9 @@ G4S_API g4s_status g4s_spgemm_symbolic(int32_t M, int32_t K, int32_t N,
         auto k = spgemm_symbolic_window_kernel;
         const size_t lds = sizeof(unsigned) * kBigWindowWords + sizeof(int) * 4 + kLongListBytes;
         G4S_TRY(allow_lds(k, lds));
-        if (n_ovf) hipLaunchKernelGGL(k, dim3(n_ovf), dim3(kBigThreads), lds, s, ovf_rows.as<int>(), n_ovf, N, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz);
+        if (n_ovf) hipLaunchKernelGGL(k, dim3(n_ovf), dim3(kBigThreads), lds, s, ovf_rows.as<int>(), n_ovf, N, K, wsplit, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz);
         if (int n = rc.count[CLS_M2])
-            hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rc.list(CLS_M2), n, N, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz);
+            hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rc.list(CLS_M2), n, N, K, wsplit, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz);
         G4S_HIP_TRY(hipGetLastError());
     }
     // hub rows (flop > 2 M): many workgroups per row on a bitmap in HBM
@@ -1088,7 +1142,7 @@ G4S_API g4s_status g4s_spgemm_numeric(int32_t M, int32_t K, int32_t N,
                                       const int32_t *brpt, const int32_t *bcol, const double *bval,
                                       const int32_t *crpt, int32_t *ccol, double *cval, unsigned flags, void *stream)
 {
-    (void)K; (void)flags; // rows always come out sorted by column: the sorted form is the only ordering contract (hash_mult.h:530-551)
+    (void)flags; // rows always come out sorted by column: the sorted form is the only ordering contract (hash_mult.h:530-551)
     G4S_REQUIRE(M >= 0 && N >= 0, "negative dimension");
     G4S_REQUIRE(arpt && brpt && crpt, "NULL argument");
     hipStream_t s = g4s::as_stream(stream);
@@ -1112,13 +1166,16 @@ G4S_API g4s_status g4s_spgemm_numeric(int32_t M, int32_t K, int32_t N,
         auto k = spgemm_numeric_lds_kernel<256, 256, 1024>;
         hipLaunchKernelGGL(k, dim3(n), dim3(256), 1024 * 12 + kLongListBytes, s, rc.list(CLS_SMALL), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
+    DevBuf wsplit_buf;
+    const int *wsplit = nullptr;
+    G4S_TRY(build_window_splits(K, N, brpt, bcol, wsplit_buf, &wsplit, s));
     // Rows past 1 K entries: bitmap windows + bucketed slots beat table + in-LDS bitonic sort while the column range is <= 4 windows.
     const bool xn_large = N <= window_max_n(), xn_m2 = xn_large;
     auto big = [&](const int *rows, int n) -> int {
         auto k = spgemm_numeric_big_kernel;
         const size_t lds = kBigLdsBytes;
         G4S_TRY(allow_lds(k, lds));
-        if (n) hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rows, n, N, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
+        if (n) hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rows, n, N, K, wsplit, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
         return G4S_OK;
     };
     if (int n = rc.count[CLS_MEDIUM]) {
@@ -1140,7 +1197,7 @@ G4S_API g4s_status g4s_spgemm_numeric(int32_t M, int32_t K, int32_t N,
         auto k = spgemm_numeric_big_kernel;
         const size_t lds = kBigLdsBytes;   // 128 KiB bitmap (phase 2 reuses it) + scan scratch + long-B list
         G4S_TRY(allow_lds(k, lds));
-        hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rc.list(CLS_M3), n, N, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
+        hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rc.list(CLS_M3), n, N, K, wsplit, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
     G4S_HIP_TRY(hipGetLastError());
     std::vector<int> hub, ranges, hub2, ranges2;
