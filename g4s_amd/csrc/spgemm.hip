@@ -7,12 +7,15 @@
 // probing, empty = −1 (hash_mult.h:89,100; define.h:12). Rows are classified by the same flop upper bound the reference
 // bins by (BIN::set_intprod_num / set_bin_id, BIN.h:78-95,158-177: min(Σ_j nnz(B(acol_j,:)), cols)).
 //
-// MI355X mapping (one table per ROW in LDS instead of one table per THREAD in cache):
+// MI355X mapping (one accumulator per ROW in LDS instead of one table per THREAD in cache); DESIGN.md §4.2 has the class table:
 //   * tiny rows  (bound ≤ 32)     one wavefront per row, 64-slot table, 8 lanes per A-entry
-//   * small rows (bound ≤ 512)    one 256-thread workgroup per row, 1024-slot table
-//   * medium rows                 one workgroup per row, 16K-slot (symbolic, keys only) / 8K-slot (numeric, keys+fp64) table
-//   * large rows                  symbolic: optimistic 32K-slot key table (128 KiB LDS) that aborts when it fills up;
-//   * hub rows (table > LDS)      bitmap-rank path in HBM: mark columns in a per-row bitmap, popcount-prefix it; a column's
+//   * small rows (bound ≤ 512)    one 256-thread workgroup per row, 1024-slot table (numeric: + in-LDS bitonic sort)
+//   * mid-size rows, B ≤ 4 M cols LDS bitmap windows of 2^20 columns instead of a table: symbolic marks and popcounts
+//                                 (spgemm_symbolic_window_kernel); numeric emits the sorted columns from the bitmap and adds the
+//                                 values per 8 K-entry chunk through a bucketed slot index (spgemm_numeric_big_kernel)
+//   * mid-size rows, wider B      key tables up to 32 K slots (the largest one optimistic: it hands the row to the window kernel
+//                                 when a probe sequence gets long)
+//   * hub rows                    bitmap-rank path in HBM: mark columns in a per-row bitmap, popcount-prefix it; a column's
 //                                 rank is its position in the sorted output row, so products are atomically added straight
 //                                 into C (no table, no sort).
 // Numeric classes use the EXACT row sizes known from symbolic, so the tables are at most half full.
@@ -1200,9 +1203,8 @@ G4S_API g4s_status g4s_spgemm_numeric(int32_t M, int32_t K, int32_t N,
         hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rc.list(CLS_M3), n, N, K, wsplit, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
     G4S_HIP_TRY(hipGetLastError());
-    std::vector<int> hub, ranges, hub2, ranges2;
+    std::vector<int> hub, ranges;
     G4S_TRY(fetch_rows_and_ranges(rc.list(CLS_HUB), rc.count[CLS_HUB], arpt, hub, ranges, s));
-    (void)hub2; (void)ranges2;
     G4S_TRY(run_hub_rows(true, hub, ranges, N, arpt, acol, aval, brpt, bcol, bval, nullptr, crpt, ccol, cval, s));
     G4S_HIP_TRY(hipStreamSynchronize(s));
     return G4S_OK;
