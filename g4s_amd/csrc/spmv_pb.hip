@@ -30,6 +30,8 @@ namespace {
 
 constexpr int kBandBits = 14;
 constexpr int kBand = 1 << kBandBits;        // 16384 columns / rows per band: 128 KiB of fp64 in LDS
+constexpr int kMaxHotBands = 64;             // popularity-ranked column bands in front of the natural ones
+constexpr double kHotFactor = 4.0;           // a hot band must hold this many times the nonzeros of an average natural band
 constexpr int kPbThreads = 1024;
 constexpr int kSpan = 8;                     // entries per span (= 4 lanes × a pair each); cells are padded to a multiple of it
 constexpr int kProducerChunk = 1 << 17;      // entries per producer workgroup (x band load amortised over ≥ 1.3 MiB of stream)
@@ -72,9 +74,43 @@ struct DevBuf {
 inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 65536 ? 65536 : g)); }
 
 // ================================================================================================ plan construction kernels
+// Hot column bands. In a power-law graph a few thousand columns hold a third of the nonzeros, but their ids are scattered over
+// the natural 16 K bands (R-MAT: ids with few 1-bits), so a row's entries in popular columns land in different bands and each
+// costs its own partial sum. Columns are therefore ranked by degree; the top H·16 K go to H extra "hot" bands in rank order (a row
+// now merges all its entries of one hot band into one micro-run), the rest keep their natural band. On C2 the distinct
+// (row, band) pairs per nonzero drop from 0.512 to 0.324 (tools/hot_band_probe.py). colmap[col] = (band' << 14) | local column;
+// the x values of the hot columns are gathered into a dense hot_x (H·128 KiB) at the start of every product.
+__global__ void pb_col_degree_kernel(long long nnz, const int *__restrict__ colids, int *__restrict__ deg)
+{
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long long)gridDim.x * blockDim.x) atomicAdd(&deg[colids[k]], 1);
+}
+__global__ void pb_iota_kernel(int n, int *__restrict__ v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+__global__ void pb_colmap_kernel(int cols, int H, const int *__restrict__ order /* columns by descending degree */, unsigned *__restrict__ colmap)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cols) return;
+    if (H == 0) { colmap[i] = (unsigned)i; return; }
+    // natural position first (every thread writes its own column), hot columns are overwritten by pb_colmap_hot_kernel afterwards
+    colmap[i] = (((unsigned)i >> kBandBits) + (unsigned)H) << kBandBits | ((unsigned)i & (kBand - 1));
+}
+__global__ void pb_colmap_hot_kernel(int nhot, const int *__restrict__ order, unsigned *__restrict__ colmap)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nhot) colmap[order[r]] = (unsigned)r;                   // band' = r >> 14 < H, local = r & 16383
+}
+__global__ void pb_gather_hot_kernel(int nhot, const int *__restrict__ hot_cols, const double *__restrict__ x, double *__restrict__ hot_x)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nhot) hot_x[r] = x[hot_cols[r]];
+}
+
 // key = (column band << bits) | row band; rowid[k] = row of CSR entry k; idx[k] = k
-__global__ void pb_keys_kernel(int rows, long long nnz, const int *__restrict__ rowptr, const int *__restrict__ colids, int band_key_bits,
-                               unsigned *__restrict__ key, int *__restrict__ rowid, unsigned *__restrict__ idx)
+__global__ void pb_keys_kernel(int rows, long long nnz, const int *__restrict__ rowptr, const int *__restrict__ colids, const unsigned *__restrict__ colmap,
+                               int band_key_bits, unsigned *__restrict__ key, int *__restrict__ rowid, unsigned *__restrict__ idx)
 {
     for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long long)gridDim.x * blockDim.x) {
         int lo = 0, hi = rows;                       // last r with rowptr[r] <= k
@@ -82,7 +118,7 @@ __global__ void pb_keys_kernel(int rows, long long nnz, const int *__restrict__ 
             const int mid = lo + ((hi - lo) >> 1);
             if (rowptr[mid] <= k) lo = mid; else hi = mid;
         }
-        key[k] = (((unsigned)colids[k] >> kBandBits) << band_key_bits) | ((unsigned)lo >> kBandBits);
+        key[k] = ((colmap[colids[k]] >> kBandBits) << band_key_bits) | ((unsigned)lo >> kBandBits);
         rowid[k] = lo;
         idx[k] = (unsigned)k;
     }
@@ -105,7 +141,7 @@ __global__ void pb_cell_starts_kernel(long long nnz, const unsigned *__restrict_
 }
 
 // Padded producer layout: sorted entry i of cell q lives at i + shift[q] (cells start at multiples of kSpan).
-__global__ void pb_fill_producer_kernel(long long nnz, const int *__restrict__ colids, const double *__restrict__ values, const int *__restrict__ rowid,
+__global__ void pb_fill_producer_kernel(long long nnz, const int *__restrict__ colids, const unsigned *__restrict__ colmap, const double *__restrict__ values, const int *__restrict__ rowid,
                                         const unsigned *__restrict__ perm, const unsigned *__restrict__ sorted_keys, int band_key_bits, int RB,
                                         const int *__restrict__ shift, unsigned short *__restrict__ p_lcol, double *__restrict__ p_val,
                                         int *__restrict__ t_row, int *__restrict__ t_cell)
@@ -114,7 +150,7 @@ __global__ void pb_fill_producer_kernel(long long nnz, const int *__restrict__ c
         const unsigned k = perm[i], key = sorted_keys[i];
         const int q = (int)((long long)(key >> band_key_bits) * RB + (key & ((1u << band_key_bits) - 1u)));
         const long long pos = i + shift[q];
-        p_lcol[pos] = (unsigned short)(colids[k] & (kBand - 1));
+        p_lcol[pos] = (unsigned short)(colmap[colids[k]] & (kBand - 1));
         p_val[pos] = values[k];
         t_row[pos] = rowid[k];
         t_cell[pos] = q;
@@ -191,7 +227,7 @@ __device__ __forceinline__ double quad_down_d(double v)
 #endif
 constexpr int kPairUnroll = G4S_PB_PAIR_UNROLL;
 
-__global__ __launch_bounds__(kPbThreads) void pb_producer_kernel(const ProducerItem *__restrict__ items, int cols, int RB,
+__global__ __launch_bounds__(kPbThreads) void pb_producer_kernel(const ProducerItem *__restrict__ items, int cols, int RB, int H, const double *__restrict__ hot_x,
                                                                   const unsigned short *__restrict__ p_lcol, const double *__restrict__ p_val,
                                                                   const unsigned char *__restrict__ masks, const int *__restrict__ mbase /* consumer slot of each span's first micro-run */,
                                                                   const double *__restrict__ x, double *__restrict__ prod)
@@ -200,7 +236,10 @@ __global__ __launch_bounds__(kPbThreads) void pb_producer_kernel(const ProducerI
     double *xs = pb_lds;                                           // kBand doubles
     (void)RB;
     const ProducerItem it = items[blockIdx.x];
-    const int c0 = it.cband << kBandBits;
+    const bool hot = it.cband < H;                                 // hot bands read the gathered copy; the others a natural 16 K slice of x
+    const int c0 = hot ? it.cband << kBandBits : (it.cband - H) << kBandBits;
+    const double *xsrc = hot ? hot_x : x;
+    const int xlimit = hot ? H << kBandBits : cols;
     const int p_end = it.s1 * 4, p_last = p_end - 1;               // pair indices: pair p = entries 2p, 2p+1; span = p >> 2
     constexpr int STEP = kPbThreads * kPairUnroll;
     int base = it.s0 * 4 + (int)threadIdx.x;
@@ -216,7 +255,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_producer_kernel(const ProducerI
         mk[u] = masks[p >> 2];
         mb[u] = mbase[p >> 2];
     }
-    for (int i = threadIdx.x; i < kBand; i += kPbThreads) xs[i] = (c0 + i < cols) ? x[c0 + i] : 0.0;
+    for (int i = threadIdx.x; i < kBand; i += kPbThreads) xs[i] = (c0 + i < xlimit) ? xsrc[c0 + i] : 0.0;
     __syncthreads();
     const int q = threadIdx.x & 3;                                 // position of this lane's pair inside its span
     for (; base - (int)threadIdx.x < p_end; base += STEP) {        // uniform trip count per workgroup: every lane takes part in the shuffles
@@ -344,8 +383,8 @@ __global__ __launch_bounds__(kPbThreads) void pb_consumer_kernel(const ConsumerI
 struct PbPlan {
     int rows = 0, cols = 0, CB = 0, RB = 0;
     long long nnz = 0, micro_runs = 0;
-    DevBuf p_lcol, p_val, masks, mbase, c_lrow, prod, delta, pitems, citems, split_bands;
-    int n_pitems = 0, n_citems = 0, n_split = 0;
+    DevBuf p_lcol, p_val, masks, mbase, c_lrow, prod, delta, pitems, citems, split_bands, hot_cols, hot_x;
+    int n_pitems = 0, n_citems = 0, n_split = 0, H = 0;
     size_t lds_producer = 0, lds_consumer = 0;
     long long bytes = 0;
 };
@@ -358,7 +397,54 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     if (!P) return set_error(G4S_ERR_NOMEM, "host allocation failed");
     std::unique_ptr<PbPlan> guard(P);
     P->rows = rows; P->cols = cols; P->nnz = nnz;
-    const int CB = P->CB = (cols + kBand - 1) >> kBandBits;
+    // 0. hot column bands: rank the columns by degree, take the leading 16 K-column groups that are much denser than a natural band
+    const int CBnat = (cols + kBand - 1) >> kBandBits;
+    DevBuf colmap, deg, deg_s, order_in, order, tmp0;
+    G4S_TRY(colmap.alloc(sizeof(unsigned) * (size_t)cols));
+    int H = 0;
+    {
+        const char *e = getenv("G4S_PB_HOT_BANDS");
+        const int want = e ? atoi(e) : -1;                          // -1 = decide from the degree distribution
+        const int Hmax = std::min(kMaxHotBands, cols / (2 * kBand));
+        if (want != 0 && Hmax > 0) {
+            G4S_TRY(deg.alloc(sizeof(int) * (size_t)cols)); G4S_TRY(deg_s.alloc(sizeof(int) * (size_t)cols));
+            G4S_TRY(order_in.alloc(sizeof(int) * (size_t)cols)); G4S_TRY(order.alloc(sizeof(int) * (size_t)cols));
+            G4S_HIP_TRY(hipMemset(deg.p, 0, deg.bytes));
+            hipLaunchKernelGGL(pb_col_degree_kernel, dim3(grid_for(nnz)), dim3(256), 0, nullptr, nnz, d_colids, deg.as<int>());
+            hipLaunchKernelGGL(pb_iota_kernel, dim3((cols + 255) / 256), dim3(256), 0, nullptr, cols, order_in.as<int>());
+            G4S_HIP_TRY(hipGetLastError());
+            size_t tb = 0;
+            G4S_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, deg.as<int>(), deg_s.as<int>(), order_in.as<int>(), order.as<int>(), cols, 0, 32, nullptr));
+            G4S_TRY(tmp0.alloc(tb));
+            G4S_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp0.p, tb, deg.as<int>(), deg_s.as<int>(), order_in.as<int>(), order.as<int>(), cols, 0, 32, nullptr));
+            std::vector<int> top((size_t)Hmax * kBand);
+            G4S_HIP_TRY(hipMemcpy(top.data(), deg_s.p, sizeof(int) * top.size(), hipMemcpyDeviceToHost));
+            if (want > 0) H = std::min(want, Hmax);
+            else {
+                // band h of the ranking is worth its 128 KiB gather while it holds kHotFactor times the nonzeros of an average natural band
+                const double avg = (double)nnz / CBnat;
+                for (int h = 0; h < Hmax; ++h) {
+                    long long in_band = 0;
+                    for (int i = 0; i < kBand; ++i) in_band += top[(size_t)h * kBand + i];
+                    if ((double)in_band < kHotFactor * avg) break;
+                    H = h + 1;
+                }
+            }
+        }
+    }
+    hipLaunchKernelGGL(pb_colmap_kernel, dim3((cols + 255) / 256), dim3(256), 0, nullptr, cols, H, order.as<int>(), colmap.as<unsigned>());
+    if (H) {
+        const int nhot = H * kBand;
+        hipLaunchKernelGGL(pb_colmap_hot_kernel, dim3((nhot + 255) / 256), dim3(256), 0, nullptr, nhot, order.as<int>(), colmap.as<unsigned>());
+        G4S_TRY(P->hot_cols.alloc(sizeof(int) * (size_t)nhot));
+        G4S_TRY(P->hot_x.alloc(sizeof(double) * (size_t)nhot));
+        G4S_HIP_TRY(hipMemcpy(P->hot_cols.p, order.p, sizeof(int) * (size_t)nhot, hipMemcpyDeviceToDevice));
+    }
+    G4S_HIP_TRY(hipGetLastError());
+    G4S_HIP_TRY(hipDeviceSynchronize());
+    deg.release(); deg_s.release(); order_in.release(); order.release(); tmp0.release();
+    P->H = H;
+    const int CB = P->CB = CBnat + H;
     const int RB = P->RB = (rows + kBand - 1) >> kBandBits;
     int bits = 1;
     while ((1 << bits) < std::max(CB, RB)) ++bits;
@@ -371,7 +457,7 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     DevBuf key, key_s, idx, perm, rowid, tmp, startP;
     const size_t n4 = sizeof(unsigned) * (size_t)nnz;
     G4S_TRY(key.alloc(n4)); G4S_TRY(key_s.alloc(n4)); G4S_TRY(idx.alloc(n4)); G4S_TRY(perm.alloc(n4)); G4S_TRY(rowid.alloc(n4));
-    hipLaunchKernelGGL(pb_keys_kernel, dim3(grid_for(nnz)), dim3(256), 0, nullptr, rows, nnz, d_rowptr, d_colids, bits, key.as<unsigned>(),
+    hipLaunchKernelGGL(pb_keys_kernel, dim3(grid_for(nnz)), dim3(256), 0, nullptr, rows, nnz, d_rowptr, d_colids, colmap.as<unsigned>(), bits, key.as<unsigned>(),
                        rowid.as<int>(), idx.as<unsigned>());
     G4S_HIP_TRY(hipGetLastError());
     size_t tmp_bytes = 0;
@@ -411,11 +497,11 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     G4S_HIP_TRY(hipMemset(P->p_val.p, 0, P->p_val.bytes));
     G4S_HIP_TRY(hipMemset(t_row.p, 0xFF, t_row.bytes));           // −1 = pad
     G4S_HIP_TRY(hipMemset(t_cell.p, 0, t_cell.bytes));
-    hipLaunchKernelGGL(pb_fill_producer_kernel, dim3(grid_for(nnz)), dim3(256), 0, nullptr, nnz, d_colids, d_values, rowid.as<int>(), perm.as<unsigned>(),
+    hipLaunchKernelGGL(pb_fill_producer_kernel, dim3(grid_for(nnz)), dim3(256), 0, nullptr, nnz, d_colids, colmap.as<unsigned>(), d_values, rowid.as<int>(), perm.as<unsigned>(),
                        key_s.as<unsigned>(), bits, RB, d_shP.as<int>(), P->p_lcol.as<unsigned short>(), P->p_val.as<double>(), t_row.as<int>(), t_cell.as<int>());
     G4S_HIP_TRY(hipGetLastError());
     G4S_HIP_TRY(hipDeviceSynchronize());
-    key_s.release(); perm.release(); rowid.release(); startP.release();
+    key_s.release(); perm.release(); rowid.release(); startP.release(); colmap.release();
 
     // 3. micro-runs: head mask per span, exclusive scan → index of each span's first micro-run
     G4S_TRY(P->masks.alloc((size_t)nspans + 64));
@@ -491,10 +577,10 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     G4S_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pb_consumer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_consumer));
     G4S_HIP_TRY(hipDeviceSynchronize());
     P->bytes = (long long)(P->p_lcol.bytes + P->p_val.bytes + P->masks.bytes + P->mbase.bytes + P->c_lrow.bytes + P->prod.bytes + P->delta.bytes +
-                           P->pitems.bytes + P->citems.bytes + P->split_bands.bytes);
+                           P->pitems.bytes + P->citems.bytes + P->split_bands.bytes + P->hot_cols.bytes + P->hot_x.bytes);
     if (getenv("G4S_DEBUG"))
-        fprintf(stderr, "g4s blocked SpMV plan: %d x %d bands, nnz %lld, padded %lld, micro-runs %lld (%.3f per nonzero), %d producer / %d consumer items, %d split bands, %.2f GB\n",
-                CB, RB, nnz, totP, P->micro_runs, (double)P->micro_runs / (double)nnz, P->n_pitems, P->n_citems, P->n_split, P->bytes / 1e9);
+        fprintf(stderr, "g4s blocked SpMV plan: %d x %d bands (%d hot), nnz %lld, padded %lld, micro-runs %lld (%.3f per nonzero), %d producer / %d consumer items, %d split bands, %.2f GB\n",
+                CB, RB, H, nnz, totP, P->micro_runs, (double)P->micro_runs / (double)nnz, P->n_pitems, P->n_citems, P->n_split, P->bytes / 1e9);
     *out = guard.release();
     return G4S_OK;
 }
@@ -507,8 +593,10 @@ int pb_spmv(PbPlan *P, const double *x, double *y, double alpha, double beta, hi
 {
     if (P->n_split)
         hipLaunchKernelGGL(pb_scale_rows_kernel, dim3(kBand / 256, P->n_split), dim3(256), 0, s, P->split_bands.as<int>(), P->rows, y, beta);
+    if (P->H)
+        hipLaunchKernelGGL(pb_gather_hot_kernel, dim3(P->H * kBand / 256), dim3(256), 0, s, P->H * kBand, P->hot_cols.as<int>(), x, P->hot_x.as<double>());
     if (P->n_pitems)
-        hipLaunchKernelGGL(pb_producer_kernel, dim3(P->n_pitems), dim3(kPbThreads), P->lds_producer, s, P->pitems.as<ProducerItem>(), P->cols, P->RB,
+        hipLaunchKernelGGL(pb_producer_kernel, dim3(P->n_pitems), dim3(kPbThreads), P->lds_producer, s, P->pitems.as<ProducerItem>(), P->cols, P->RB, P->H, P->hot_x.as<double>(),
                            P->p_lcol.as<unsigned short>(), P->p_val.as<double>(), P->masks.as<unsigned char>(), P->mbase.as<int>(), x, P->prod.as<double>());
     if (P->n_citems)
         hipLaunchKernelGGL(pb_consumer_kernel, dim3(P->n_citems), dim3(kPbThreads), P->lds_consumer, s, P->citems.as<ConsumerItem>(), P->rows,

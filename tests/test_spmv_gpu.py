@@ -240,3 +240,38 @@ def test_row_slabs_reproduce_the_full_product():
             ys.append(S.spmv(x))
         y = torch.cat(ys)
         assert torch.all((y - y_full).abs() <= 1e-10 * scale + 1e-300)
+
+
+@pytest.mark.parametrize("hot", ["0", "1", "3"])
+def test_spmv_blocked_hot_column_bands(oracle, monkeypatch, hot):
+    """The blocked path ranks columns by degree and gives the most popular ones their own bands (G4S_PB_HOT_BANDS forces how many;
+    the default decides from the degree distribution). Same parity bar with none, one and three hot bands, on a matrix whose hot
+    columns are scattered over the natural bands, with empty rows, a hub row and a rectangular shape."""
+    from g4s_amd import capi, host
+    monkeypatch.setenv("G4S_PB_HOT_BANDS", hot)
+    rows, cols = 90000, 120000
+    rng = np.random.default_rng(41)
+    popular = rng.choice(cols, 3000, replace=False)
+    lens = rng.integers(0, 12, rows)
+    lens[5] = 40000                                                   # hub row
+    lens[[0, 1000, rows - 1]] = 0
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = np.empty(rp[-1], np.int32)
+    for r in range(rows):
+        n = lens[r]
+        if n == 0:
+            continue
+        k = min(n, cols)
+        if n > 64:
+            c = rng.choice(cols, k, replace=False)
+        else:
+            c = np.unique(np.where(rng.random(k) < 0.6, popular[rng.integers(0, len(popular), k)], rng.integers(0, cols, k)))
+            while len(c) < k:                                         # top up after duplicates were merged
+                c = np.unique(np.concatenate([c, rng.integers(0, cols, k - len(c))]))
+        ci[rp[r]:rp[r + 1]] = np.sort(c)
+    va = rng.uniform(-1, 1, rp[-1])
+    A = host.CSR.from_host(rp, ci, va, rows, cols, spmv_flags=capi.SPMV_BLOCKED)
+    assert A.info()["spmv_path"] == 1
+    x = rng.uniform(-1, 1, cols)
+    _check(oracle, A, rp, ci, va, x)
+    _check(oracle, A, rp, ci, va, x, alpha=0.75, beta=-2.0, y0=rng.uniform(-1, 1, rows))
