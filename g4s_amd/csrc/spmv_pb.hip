@@ -34,6 +34,8 @@ constexpr int kMaxHotBands = 64;             // popularity-ranked column bands i
 constexpr double kHotFactor = 4.0;           // a hot band must hold this many times the nonzeros of an average natural band
 constexpr int kPbThreads = 1024;
 constexpr int kSpan = 8;                     // entries per span (= 4 lanes × a pair each); cells are padded to a multiple of it
+constexpr int kWindow = 32;                  // entries per merge window (= the 16 lanes of a DPP row × a pair each = 4 spans): a micro-run
+                                             // is a run of one row inside one cell and one window; column bands start at multiples of it
 constexpr int kProducerChunk = 1 << 17;      // entries per producer workgroup (x band load amortised over ≥ 1.3 MiB of stream)
 constexpr int kConsumerChunk = 1 << 17;      // micro-runs per consumer workgroup of a split (heavy) row band
 constexpr unsigned kPadFlag = 0x8000u;       // local-column flag of a pad slot (its product is forced to 0)
@@ -158,11 +160,16 @@ __global__ void pb_fill_producer_kernel(long long nnz, const int *__restrict__ c
 }
 
 // Micro-run heads of a span: a real entry whose row differs from the previous entry's (or that opens the span). t_row < 0 marks pads.
-__global__ void pb_span_heads_kernel(long long nspans, const int *__restrict__ t_row, unsigned char *__restrict__ masks, int *__restrict__ counts)
+__global__ void pb_span_heads_kernel(long long nspans, const int *__restrict__ t_row, const int *__restrict__ t_cell,
+                                     unsigned char *__restrict__ masks, int *__restrict__ counts)
 {
     for (long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x; s < nspans; s += (long long)gridDim.x * blockDim.x) {
         unsigned m = 0;
+        // a run continues from the previous span when that span is in the same window and the same cell (pads exist only at the
+        // end of a cell, so the previous span of a cell is full and its last entry is real)
         int prev = -2;
+        if ((s * kSpan) % kWindow != 0 && t_row[s * kSpan] >= 0 && t_row[s * kSpan - 1] >= 0 && t_cell[s * kSpan] == t_cell[s * kSpan - 1])
+            prev = t_row[s * kSpan - 1];
         for (int j = 0; j < kSpan; ++j) {
             const int r = t_row[s * kSpan + j];
             if (r >= 0 && r != prev) m |= 1u << j;
@@ -203,25 +210,24 @@ __global__ void pb_fill_consumer_kernel(long long nspans, const int *__restrict_
 struct ProducerItem { int cband, s0, s1, pad; };     // spans [s0, s1) of one column band
 struct ConsumerItem { int rband, k0, k1, split; };   // micro-run slots [k0, k1) of one row band (multiples of 4)
 
-// Lane q of a 4-lane quad reads lane q+SHIFT of the same quad (DPP quad_perm: a VALU move, no LDS crossbar like ds_bpermute).
-// Lanes whose source would fall outside the quad read lane 3; the callers ignore those values.
+// Lane i of a 16-lane DPP row reads lane i+SHIFT of the same row (row_shl: a VALU move, no LDS crossbar like ds_bpermute); lanes
+// whose source falls past the row read 0.
 template <int SHIFT>
-__device__ __forceinline__ int quad_down_i(int v)
+__device__ __forceinline__ int row_down_i(int v)
 {
-    constexpr int ctrl = SHIFT == 1 ? 0xF9 : (SHIFT == 2 ? 0xFE : 0xFF);   // quad_perm [1,2,3,3] / [2,3,3,3] / [3,3,3,3]
-    return __builtin_amdgcn_update_dpp(0, v, ctrl, 0xF, 0xF, false);
+    return __builtin_amdgcn_update_dpp(0, v, 0x100 + SHIFT, 0xF, 0xF, true);
 }
 template <int SHIFT>
-__device__ __forceinline__ double quad_down_d(double v)
+__device__ __forceinline__ double row_down_d(double v)
 {
     const long long b = __double_as_longlong(v);
-    const int lo = quad_down_i<SHIFT>((int)(b & 0xFFFFFFFFll)), hi = quad_down_i<SHIFT>((int)(b >> 32));
+    const int lo = row_down_i<SHIFT>((int)(b & 0xFFFFFFFFll)), hi = row_down_i<SHIFT>((int)(b >> 32));
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
-// Producer: one lane per PAIR of consecutive entries (unit-stride 4-byte / 16-byte loads), four lanes per 8-entry span. The
-// products of a span are summed per micro-run with a backward segmented reduction across the span's four lanes (shuffles), and
-// each lane stores the sums of the micro-runs that START in its pair (0, 1 or 2 stores).
+// Producer: one lane per PAIR of consecutive entries (unit-stride 4-byte / 16-byte loads), four lanes per 8-entry span, sixteen
+// per 32-entry window. The products of a window are summed per micro-run with a backward segmented scan across the window's
+// sixteen lanes (four DPP row shifts), and each lane stores the sums of the micro-runs that START in its pair (0, 1 or 2 stores).
 #ifndef G4S_PB_PAIR_UNROLL
 #define G4S_PB_PAIR_UNROLL 4
 #endif
@@ -282,17 +288,14 @@ __global__ __launch_bounds__(kPbThreads) void pb_producer_kernel(const ProducerI
             // open prefix: the part of this pair that continues a micro-run begun in an earlier lane of the span
             const double op = h0 ? 0.0 : (h1 ? p0 : p0 + p1);
             const bool closed = h0 | h1;
-            const double op1 = quad_down_d<1>(op), op2 = quad_down_d<2>(op), op3 = quad_down_d<3>(op);
-            const int cl1 = quad_down_i<1>((int)closed), cl2 = quad_down_i<2>((int)closed);
-            // ext: what the following lanes of the span add to the micro-run that contains this pair's last entry
-            double ext = 0.0;
-            if (q < 3) {
-                ext = op1;
-                if (!cl1 && q < 2) {
-                    ext += op2;
-                    if (!cl2 && q < 1) ext += op3;
-                }
-            }
+            // S_j = op_j + (closed_j ? 0 : S_{j+1}) over the 16 lanes of the window, by doubling; ext = S of the next lane = what the
+            // following lanes add to the micro-run that contains this pair's last entry
+            double S = op;
+            int f = (int)closed;
+#define G4S_PB_SCAN_STEP(D) { const double sv = row_down_d<D>(S); const int sf = row_down_i<D>(f); if (!f) S += sv; f |= sf; }
+            G4S_PB_SCAN_STEP(1) G4S_PB_SCAN_STEP(2) G4S_PB_SCAN_STEP(4) G4S_PB_SCAN_STEP(8)
+#undef G4S_PB_SCAN_STEP
+            const double ext = row_down_d<1>(S);
             if (live && closed) {
                 const int d0 = mb[u];
                 if (h0) prod[d0 + __popc(m & ((1u << (2 * q)) - 1u))] = h1 ? p0 : p0 + p1 + ext;
@@ -495,11 +498,13 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     std::vector<int> padP((size_t)ncells + 1), shP((size_t)ncells);
     long long totP = 0;
     for (long long q = 0; q < ncells; ++q) {
+        if (q % RB == 0) totP = (totP + kWindow - 1) & ~(long long)(kWindow - 1);   // a column band starts on a window boundary
         padP[q] = (int)totP;
         shP[q] = (int)(totP - hP[q]);
         totP += hP[q + 1] - hP[q];
         totP = (totP + kSpan - 1) & ~(long long)(kSpan - 1);
     }
+    totP = (totP + kWindow - 1) & ~(long long)(kWindow - 1);
     padP[ncells] = (int)totP;
     if (totP + 64 > INT32_MAX) return set_error(G4S_ERR_UNSUPPORTED, "pb_build: padded length exceeds int32");
     const long long nspans = totP / kSpan;
@@ -525,7 +530,7 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     G4S_TRY(counts.alloc(sizeof(int) * ((size_t)nspans + 1)));
     G4S_TRY(P->mbase.alloc(sizeof(int) * ((size_t)nspans + 64)));
     G4S_HIP_TRY(hipMemset(counts.p, 0, counts.bytes));
-    hipLaunchKernelGGL(pb_span_heads_kernel, dim3(grid_for(nspans)), dim3(256), 0, nullptr, nspans, t_row.as<int>(), P->masks.as<unsigned char>(), counts.as<int>());
+    hipLaunchKernelGGL(pb_span_heads_kernel, dim3(grid_for(nspans)), dim3(256), 0, nullptr, nspans, t_row.as<int>(), t_cell.as<int>(), P->masks.as<unsigned char>(), counts.as<int>());
     G4S_HIP_TRY(hipGetLastError());
     G4S_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, counts.as<int>(), P->mbase.as<int>(), (int)nspans + 1, nullptr));
     G4S_TRY(tmp.alloc(tmp_bytes));
@@ -564,7 +569,7 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
                        P->masks.as<unsigned char>(), P->mbase.as<int>(), P->c_lrow.as<unsigned short>());
     G4S_HIP_TRY(hipGetLastError());
     // 5. work items, heaviest first (the tail of each launch is then made of light bands)
-    const int kPC = std::max(kSpan * kPbThreads, (getenv("G4S_PB_PCHUNK") ? atoi(getenv("G4S_PB_PCHUNK")) : kProducerChunk)) / kSpan;   // spans per item
+    const int kPC = (std::max(kSpan * kPbThreads, (getenv("G4S_PB_PCHUNK") ? atoi(getenv("G4S_PB_PCHUNK")) : kProducerChunk)) / kWindow) * (kWindow / kSpan);   // spans per item, whole windows
     const int kCC = std::max(4, (getenv("G4S_PB_CCHUNK") ? atoi(getenv("G4S_PB_CCHUNK")) : kConsumerChunk) & ~3);
     std::vector<ProducerItem> pit;
     for (int c = 0; c < CB; ++c) {
