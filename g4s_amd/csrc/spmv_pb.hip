@@ -104,11 +104,6 @@ __global__ void pb_colmap_hot_kernel(int nhot, const int *__restrict__ order, un
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < nhot) colmap[order[r]] = (unsigned)r;                   // band' = r >> 14 < H, local = r & 16383
 }
-__global__ void pb_gather_hot_kernel(int nhot, const int *__restrict__ hot_cols, const double *__restrict__ x, double *__restrict__ hot_x)
-{
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < nhot) hot_x[r] = x[hot_cols[r]];
-}
 
 // key = (column band << bits) | row band; rowid[k] = row of CSR entry k; idx[k] = k
 __global__ void pb_keys_kernel(int rows, long long nnz, const int *__restrict__ rowptr, const int *__restrict__ colids, const unsigned *__restrict__ colmap,
@@ -309,11 +304,21 @@ __global__ __launch_bounds__(kPbThreads) void pb_producer_kernel(const ProducerI
     }
 }
 
-__global__ void pb_scale_rows_kernel(const int *__restrict__ split_bands, int rows, double *__restrict__ y, double beta)
+// One launch ahead of the producer: blocks [0, n_split·64) pre-scale y for the row bands whose sums arrive from several consumer
+// workgroups (those add into y with atomics), the remaining blocks gather the x values of the hot columns into hot_x.
+__global__ void pb_prepare_kernel(int n_split, const int *__restrict__ split_bands, int rows, double *__restrict__ y, double beta,
+                                  int nhot, const int *__restrict__ hot_cols, const double *__restrict__ x, double *__restrict__ hot_x)
 {
-    const int r0 = split_bands[blockIdx.y] << kBandBits;
-    const int i = r0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < rows && i < r0 + kBand) y[i] = beta == 0.0 ? 0.0 : beta * y[i];
+    constexpr int kBlocksPerBand = kBand / 256;
+    const int b = blockIdx.x;
+    if (b < n_split * kBlocksPerBand) {
+        const int r0 = split_bands[b / kBlocksPerBand] << kBandBits;
+        const int i = r0 + (b % kBlocksPerBand) * 256 + (int)threadIdx.x;
+        if (i < rows) y[i] = beta == 0.0 ? 0.0 : beta * y[i];
+    } else {
+        const int r = (b - n_split * kBlocksPerBand) * 256 + (int)threadIdx.x;
+        if (r < nhot) hot_x[r] = x[hot_cols[r]];
+    }
 }
 
 #ifndef G4S_PB_CONS_UNROLL
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_consumer_kernel(const ConsumerI
         const int r = r0 + i;
         if (r >= rows) break;
         if (it.split) {
-            if (ys[i] != 0.0) atomicAdd(&y[r], alpha * ys[i]);     // y was pre-scaled by beta (pb_scale_rows_kernel)
+            if (ys[i] != 0.0) atomicAdd(&y[r], alpha * ys[i]);     // y was pre-scaled by beta (pb_prepare_kernel)
         } else {
             y[r] = beta == 0.0 ? alpha * ys[i] : alpha * ys[i] + beta * y[r];
         }
@@ -613,10 +618,9 @@ long long pb_bytes(const PbPlan *P) { return P ? P->bytes : 0; }
 
 int pb_spmv(PbPlan *P, const double *x, double *y, double alpha, double beta, hipStream_t s)
 {
-    if (P->n_split)
-        hipLaunchKernelGGL(pb_scale_rows_kernel, dim3(kBand / 256, P->n_split), dim3(256), 0, s, P->split_bands.as<int>(), P->rows, y, beta);
-    if (P->H)
-        hipLaunchKernelGGL(pb_gather_hot_kernel, dim3(P->H * kBand / 256), dim3(256), 0, s, P->H * kBand, P->hot_cols.as<int>(), x, P->hot_x.as<double>());
+    if (P->n_split || P->H)
+        hipLaunchKernelGGL(pb_prepare_kernel, dim3((P->n_split + P->H) * (kBand / 256)), dim3(256), 0, s, P->n_split, P->split_bands.as<int>(), P->rows, y, beta,
+                           P->H * kBand, P->hot_cols.as<int>(), x, P->hot_x.as<double>());
     if (P->n_pitems)
         hipLaunchKernelGGL(pb_producer_kernel, dim3(P->n_pitems), dim3(kPbThreads), P->lds_producer, s, P->pitems.as<ProducerItem>(), P->cols, P->RB, P->H, P->hot_x.as<double>(),
                            P->p_lcol.as<unsigned short>(), P->p_val.as<double>(), P->masks.as<unsigned char>(), P->mbase.as<int>(), x, P->prod.as<double>());
