@@ -207,6 +207,8 @@ __device__ __forceinline__ void walk_a_entries(int a0, int a1, int first, int st
 // processed afterwards by the whole workgroup, lanes striding it coalesced. A full list falls back to in-group processing.
 constexpr int kLongCap = 255;                        // entries; slot 0 of the int4 array holds the counter
 constexpr size_t kLongListBytes = sizeof(int4) * (kLongCap + 1);
+// numeric tables of the one-row-per-workgroup kernels: keys + fp64 (12 B per slot), the long-B list, the dense copy for the sort
+constexpr size_t num_lds_bytes(int table) { return (size_t)table * 12 + kLongListBytes + (size_t)table / 2 * 12 + 16; }
 constexpr size_t sym_lds_bytes(int rpb, int table) { return sizeof(int) * ((size_t)rpb * table + 2 * rpb) + (rpb == 1 ? kLongListBytes : 0); }
 __device__ __forceinline__ int long_b_threshold(int threads) { return threads >= 256 ? threads / 4 : 1 << 30; }
 
@@ -373,37 +375,71 @@ __global__ __launch_bounds__(WGSIZE) void spgemm_numeric_lds_kernel(
         });
         if (RPB == 1) {
             __syncthreads();                                        // uniform: with RPB == 1 every thread of the workgroup has this row
-            const int nl = min(longs[0].x, kLongCap);
-            for (int i = 0; i < nl; ++i) {
-                const int4 e = longs[1 + i];
-                const double av = long_b_value(e);
-                for (int k = e.x + t; k < e.y; k += THREADS) insert(bcol[k], av * bval[k]);
-            }
+            for_deferred_rows<true>(longs, t, THREADS, bcol, bval, [&](int col, double bv, double av) { insert(col, av * bv); });
         }
     }
     __syncthreads();
-    // sort_and_store_table2mat (hash_mult.h:526-553): empties to the end, ascending keys, then store the first nz slots
-    for (int s = t; s < TABLE; s += THREADS) if (K[s] == kEmpty) K[s] = INT_MAX;
-    __syncthreads();
-    for (int k = 2; k <= TABLE; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = t; i < TABLE; i += THREADS) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const int ki = K[i], kj = K[ixj];
-                    const bool asc = (i & k) == 0;
-                    if ((ki > kj) == asc) {
-                        K[i] = kj; K[ixj] = ki;
-                        const double vi = V[i]; V[i] = V[ixj]; V[ixj] = vi;
+    // sort_and_store_table2mat (hash_mult.h:526-553): compact the occupied slots, ascending keys, store.
+    const int off = row >= 0 ? crpt[row] : 0, nz = row >= 0 ? crpt[row + 1] - off : 0;
+    if constexpr (RPB == 1) {
+        // The table is at most half full and often far emptier (the class spans a 16× range of row sizes): the occupied slots are
+        // first gathered into a dense array (order irrelevant before the sort) and only next_pow2(nz) entries are sorted — a
+        // 1024-slot table with 50 entries costs 21 compare-exchange rounds of 64 instead of 55 rounds of 1024.
+        double *V2 = reinterpret_cast<double *>(lds_i + TABLE * 3 + 4 * (kLongCap + 1));
+        int *K2 = reinterpret_cast<int *>(V2 + TABLE / 2);
+        int *cnt = K2 + TABLE / 2;
+        if (t == 0) *cnt = 0;
+        __syncthreads();
+        for (int s2 = t; s2 < TABLE; s2 += THREADS) {
+            const int key = K[s2];
+            if (key != kEmpty) {
+                const int pos = atomicAdd(cnt, 1);
+                if (pos < TABLE / 2) { K2[pos] = key; V2[pos] = V[s2]; }   // pos >= TABLE/2 only with a wrong crpt from the caller
+            }
+        }
+        int n2 = 1;
+        while (n2 < nz) n2 <<= 1;
+        n2 = min(n2, TABLE / 2);
+        __syncthreads();
+        for (int s2 = min(*cnt, TABLE / 2) + t; s2 < n2; s2 += THREADS) K2[s2] = INT_MAX;
+        __syncthreads();
+        for (int k = 2; k <= n2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = t; i < n2; i += THREADS) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const int ki = K2[i], kj = K2[ixj];
+                        const bool asc = (i & k) == 0;
+                        if ((ki > kj) == asc) {
+                            K2[i] = kj; K2[ixj] = ki;
+                            const double vi = V2[i]; V2[i] = V2[ixj]; V2[ixj] = vi;
+                        }
                     }
                 }
+                __syncthreads();
             }
-            __syncthreads();
         }
-    }
-    if (row >= 0) {
-        const int off = crpt[row], nz = crpt[row + 1] - off;
-        for (int s = t; s < nz; s += THREADS) { ccol[off + s] = K[s]; cval[off + s] = V[s]; }
+        for (int s2 = t; s2 < min(nz, n2); s2 += THREADS) { ccol[off + s2] = K2[s2]; cval[off + s2] = V2[s2]; }
+    } else {
+        for (int s2 = t; s2 < TABLE; s2 += THREADS) if (K[s2] == kEmpty) K[s2] = INT_MAX;
+        __syncthreads();
+        for (int k = 2; k <= TABLE; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = t; i < TABLE; i += THREADS) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const int ki = K[i], kj = K[ixj];
+                        const bool asc = (i & k) == 0;
+                        if ((ki > kj) == asc) {
+                            K[i] = kj; K[ixj] = ki;
+                            const double vi = V[i]; V[i] = V[ixj]; V[ixj] = vi;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int s2 = t; s2 < nz; s2 += THREADS) { ccol[off + s2] = K[s2]; cval[off + s2] = V[s2]; }
     }
 }
 
@@ -1167,7 +1203,7 @@ G4S_API g4s_status g4s_spgemm_numeric(int32_t M, int32_t K, int32_t N,
     }
     if (int n = rc.count[CLS_SMALL]) {
         auto k = spgemm_numeric_lds_kernel<256, 256, 1024>;
-        hipLaunchKernelGGL(k, dim3(n), dim3(256), 1024 * 12 + kLongListBytes, s, rc.list(CLS_SMALL), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
+        hipLaunchKernelGGL(k, dim3(n), dim3(256), num_lds_bytes(1024), s, rc.list(CLS_SMALL), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
     DevBuf wsplit_buf;
     const int *wsplit = nullptr;
@@ -1183,18 +1219,19 @@ G4S_API g4s_status g4s_spgemm_numeric(int32_t M, int32_t K, int32_t N,
     };
     if (int n = rc.count[CLS_MEDIUM]) {
         auto k = spgemm_numeric_lds_kernel<256, 256, 2048>;
-        hipLaunchKernelGGL(k, dim3(n), dim3(256), 2048 * 12 + kLongListBytes, s, rc.list(CLS_MEDIUM), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
+        hipLaunchKernelGGL(k, dim3(n), dim3(256), num_lds_bytes(2048), s, rc.list(CLS_MEDIUM), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
     if (xn_large) { G4S_TRY(big(rc.list(CLS_LARGE), rc.count[CLS_LARGE])); }
     else if (int n = rc.count[CLS_LARGE]) {
         auto k = spgemm_numeric_lds_kernel<512, 512, 4096>;
-        hipLaunchKernelGGL(k, dim3(n), dim3(512), 4096 * 12 + kLongListBytes, s, rc.list(CLS_LARGE), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
+        G4S_TRY(allow_lds(k, num_lds_bytes(4096)));
+        hipLaunchKernelGGL(k, dim3(n), dim3(512), num_lds_bytes(4096), s, rc.list(CLS_LARGE), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
     if (xn_m2) { G4S_TRY(big(rc.list(CLS_M2), rc.count[CLS_M2])); }
     else if (int n = rc.count[CLS_M2]) {
         auto k = spgemm_numeric_lds_kernel<1024, 1024, 8192>;
-        G4S_TRY(allow_lds(k, 8192 * 12 + kLongListBytes));
-        hipLaunchKernelGGL(k, dim3(n), dim3(1024), 8192 * 12 + kLongListBytes, s, rc.list(CLS_M2), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
+        G4S_TRY(allow_lds(k, num_lds_bytes(8192)));
+        hipLaunchKernelGGL(k, dim3(n), dim3(1024), num_lds_bytes(8192), s, rc.list(CLS_M2), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
     if (int n = rc.count[CLS_M3]) {
         auto k = spgemm_numeric_big_kernel;
