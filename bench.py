@@ -171,7 +171,7 @@ def main():
     elapsed = float(t.item())
 
     # ---- roofline of the SpMV launch: HIP events on the launch stream around back-to-back launches. One launch of the hot path is
-    # spmv_csr_adaptive_kernel (+ the few-µs long-row fixup) on the streaming path, or pb_producer_kernel + pb_consumer_kernel on
+    # spmv_csr_adaptive_kernel (+ the few-µs long-row fixup) on the streaming path, or pb_prepare_kernel + pb_producer_kernel + pb_consumer_kernel on
     # the blocked path (their durations add up to kernel_ms; profiles/ holds the rocprofv3 split). At N=1 the timed region above
     # IS that; at N>1 it is re-measured without the exchange, outside the timed region.
     if world == 1:
@@ -214,7 +214,7 @@ def main():
         "hbm_gbs_algorithmic_whole_job": round((12 * nnz_total + 4 * (n_rows + 1) + 8 * n_rows + 8 * n_cols) * args.steps / elapsed / 1e9, 2),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": ("pb_producer_kernel+pb_consumer_kernel (propagation-blocked SpMV)" if info["spmv_path"] == 1
+                     "kernel": ("pb_prepare_kernel+pb_producer_kernel+pb_consumer_kernel (propagation-blocked SpMV)" if info["spmv_path"] == 1
                                 else "spmv_csr_adaptive_kernel"), "kernel_ms": round(kernel_ms, 5),
                      "algorithmic_bytes_per_launch": info["algorithmic_bytes"],
                      "launch_rows": info["rows"], "launch_nnz": info["nnz"]},
