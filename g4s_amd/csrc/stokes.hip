@@ -62,23 +62,29 @@ __global__ __launch_bounds__(kThreads) void map_kernel(int n, F f)
     if (i < n) f(i);
 }
 
-// divU[e] = Σ_a (g0·U[j1] + g1·U[j2] + g2·U[j3]) in a order — the per-element sequence of assemble_div_u (bit-identical)
+// divU[e] = Σ_a (g0·U[j1] + g1·U[j2] + g2·U[j3]) in a order — the per-element sequence of assemble_div_u (bit-identical).
+// Eight lanes per element: lane a forms the term of local node a (its gathers of U are independent of the other lanes'), then the
+// terms are added in a = 0, 1, 2, … order through shuffles, as the source's loop adds them. One thread per element was a chain of
+// 24 dependent gathers (11 µs for 8192 elements).
 __global__ __launch_bounds__(kThreads) void div_u_kernel(int nel, int npe, int dof, const int *__restrict__ elem_eq, const double *__restrict__ g,
                                                           const double *__restrict__ U, double *__restrict__ divU)
 {
-    const int e = blockIdx.x * kThreads + threadIdx.x;
-    if (e >= nel) return;
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    const int e = idx >> 3, sub = idx & 7;
     const int n = npe * dof;
+    const bool ok = e < nel;
     double s = 0.0;
-    for (int a = 0; a < npe; ++a) {
+    for (int a0 = 0; a0 < npe; a0 += 8) {                          // npe = 8 in CitcomS: one round
+        const int a = a0 + sub;
         double t = 0.0;
-        for (int d = 0; d < dof; ++d) {
-            const double q = g[(size_t)e * n + a * dof + d] * U[elem_eq[(size_t)e * n + a * dof + d]];
-            t = d == 0 ? q : t + q;
-        }
-        s = s + t;
+        if (ok && a < npe)
+            for (int d = 0; d < dof; ++d) {
+                const double q = g[(size_t)e * n + a * dof + d] * U[elem_eq[(size_t)e * n + a * dof + d]];
+                t = d == 0 ? q : t + q;
+            }
+        for (int k = 0; k < 8 && a0 + k < npe; ++k) s = s + __shfl(t, (threadIdx.x & ~7) + k, 64);   // every lane of the group keeps the same running sum
     }
-    divU[e] = s;
+    if (ok && sub == 0) divU[e] = s;
 }
 
 // gradP[eq(node, d)] = Σ over the node's (element, local node) terms, ascending element, of g·P[e], elements with P == 0 skipped:
@@ -137,7 +143,7 @@ G4S_API g4s_status g4s_elem_op_div_u(g4s_elem_op_t op, const double *g_dev, cons
     g4s::ElemOpView v;
     G4S_TRY(g4s_elem_op_view(op, &v));
     G4S_REQUIRE(v.nel == 0 || (g_dev && U_dev && divU_dev), "NULL argument");
-    if (v.nel) hipLaunchKernelGGL(div_u_kernel, dim3(grid_for(v.nel)), dim3(kThreads), 0, g4s::as_stream(stream), v.nel, v.npe, v.dof, v.elem_eq, g_dev, U_dev, divU_dev);
+    if (v.nel) hipLaunchKernelGGL(div_u_kernel, dim3(grid_for(v.nel * 8)), dim3(kThreads), 0, g4s::as_stream(stream), v.nel, v.npe, v.dof, v.elem_eq, g_dev, U_dev, divU_dev);
     G4S_HIP_TRY(hipGetLastError());
     return G4S_OK;
 }
