@@ -259,6 +259,7 @@ int conj_grad_impl(const MatVec &matvec, int32_t neq, const double *BI, const in
             if (left > 0.0 && left < 1e6) batch = std::max(2, std::min(32, (int)std::ceil(left) + 1));
         }
     }
+    if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s conj_grad: %d iterations, %d enqueued, residual %.3e (acc %.3e)\n", h.count, enqueued, h.residual, acc);
     const double residual = h.residual;
     *cycles = h.count;
     if (n_zero) hipLaunchKernelGGL(cg_strip_kernel, dim3((n_zero + kThreads - 1) / kThreads), dim3(kThreads), 0, s, n_zero, zero_resid, d0);   // :409
