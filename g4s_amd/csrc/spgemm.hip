@@ -1186,10 +1186,11 @@ G4S_API g4s_status g4s_spgemm_numeric(int32_t M, int32_t K, int32_t N,
     G4S_REQUIRE(arpt && brpt && crpt, "NULL argument");
     hipStream_t s = g4s::as_stream(stream);
     if (M == 0) return G4S_OK;
-    DevBuf row_size, row_flop;
+    // lanes per A-entry are sized from the row's average B-row length; the exact nz of the output row (known here) stands in for
+    // the flop count of the symbolic phase (they differ by the row's compression ratio), which saves a pass over A
+    DevBuf row_size;
+    DevBuf &row_flop = row_size;
     G4S_TRY(row_size.alloc(sizeof(long long) * (size_t)M));
-    G4S_TRY(row_flop.alloc(sizeof(long long) * (size_t)M));
-    G4S_TRY(compute_row_flop(M, arpt, acol, brpt, row_flop.as<long long>(), nullptr, s));
     hipLaunchKernelGGL(nz_to_ll_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, crpt, row_size.as<long long>());
     RowClasses rc;
     G4S_TRY(classify_rows(M, row_size.as<long long>(), kNumLimits, 0, rc, s));
