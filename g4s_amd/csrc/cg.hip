@@ -9,7 +9,7 @@
 // Scalars (dot products, α, β, the residual, the iteration count) never leave the device, and neither does the termination test of
 // the source: `cg_direction_kernel` evaluates `(residual > acc && count < steps) || count == 0` from the partial sums and, when it
 // fails, raises a `done` flag that turns the rest of the enqueued iterations into no-ops. The host enqueues iterations in batches
-// (4, 8, 16, 16, …) and reads 32 bytes of state after each batch, so the GPU runs launches back to back instead of idling across a
+// (sized from the previous solve and a geometric fit of the residual) and reads 40 bytes of state after each batch, so the GPU runs launches back to back instead of idling across a
 // D2H round trip per iteration (62 → see DESIGN.md §4.4 µs per Cookbook2 iteration).
 #include "common.hpp"
 #include <algorithm>
@@ -233,7 +233,10 @@ int conj_grad_impl(const MatVec &matvec, int32_t neq, const double *BI, const in
     const int steps = *cycles;
     hipLaunchKernelGGL(cg_init_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, neq, F, BI, r1, d0, z, part_rr, part_rz);
     CgState h{};
-    int batch = 4, enqueued = 0;
+    // first batch: one more than the previous solve of this thread needed — consecutive velocity solves of an Uzawa iteration take
+    // nearly the same number of iterations, so the whole solve is usually one batch, one read-back and no wasted launches
+    static thread_local int last_iterations = 3;
+    int batch = std::max(2, std::min(32, last_iterations + 1)), enqueued = 0;
     while (!h.done) {
         // iterations past the one that meets the test are no-ops on the device (and the pointer rotation of :398-402 below is then
         // irrelevant: nothing reads r1/r2/p1/p2 again)
@@ -260,6 +263,7 @@ int conj_grad_impl(const MatVec &matvec, int32_t neq, const double *BI, const in
         }
     }
     if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s conj_grad: %d iterations, %d enqueued, residual %.3e (acc %.3e)\n", h.count, enqueued, h.residual, acc);
+    last_iterations = h.count;
     const double residual = h.residual;
     *cycles = h.count;
     if (n_zero) hipLaunchKernelGGL(cg_strip_kernel, dim3((n_zero + kThreads - 1) / kThreads), dim3(kThreads), 0, s, n_zero, zero_resid, d0);   // :409
