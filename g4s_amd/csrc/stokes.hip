@@ -6,8 +6,8 @@
 // Operators: assemble_div_u / assemble_grad_p (Element_calculations.c:701-779) on the per-element gradient vectors
 // g[e][p] = elt_del[e].g[p][0]; norms: global_v_norm2 / global_p_norm2 / global_div_norm2 / global_pdot
 // (Global_operations.c:565-656), one process. Every vector stays in HBM; the host owns the outer loop's scalar logic
-// (keep_iterating :150-162, the "two consecutive converging iterations" rule) and reads a few doubles per outer iteration — the
-// inner solve between two reads is tens of mat-vecs.
+// (keep_iterating :150-162, the "two consecutive converging iterations" rule); δ, α and the norms are computed on the device and
+// nine doubles come back once per outer iteration.
 #include "common.hpp"
 #include <algorithm>
 #include <cmath>
@@ -45,14 +45,16 @@ __global__ __launch_bounds__(kThreads) void map_sum_kernel(int n, F f, double *_
     if (threadIdx.x == 0) { part[blockIdx.x] = a; part[kBlocks + blockIdx.x] = b; part[2 * kBlocks + blockIdx.x] = c; }
 }
 
-__global__ __launch_bounds__(kThreads) void finish_sums_kernel(const double *__restrict__ part, double *__restrict__ out3)
+// One workgroup: the three sums in a fixed shape, then ep(s0, s1, s2) on one thread — the scalar algebra of the outer loop (δ, α,
+// the norms) stays on the device, in the slots of a small scalar array the following kernels read.
+template <typename E>
+__global__ __launch_bounds__(kThreads) void finish_sums_kernel(const double *__restrict__ part, E ep)
 {
     __shared__ double sh[4];
     static_assert(kBlocks == kThreads, "one partial per thread");
-    for (int k = 0; k < 3; ++k) {
-        const double s = block_sum(part[k * kBlocks + threadIdx.x], sh);
-        if (threadIdx.x == 0) out3[k] = s;
-    }
+    double r[3];
+    for (int k = 0; k < 3; ++k) r[k] = block_sum(part[k * kBlocks + threadIdx.x], sh);
+    if (threadIdx.x == 0) ep(r[0], r[1], r[2]);
 }
 
 template <typename F>
@@ -192,7 +194,7 @@ G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, const double *g, const 
     const int neq = v.neq, nel = v.nel, nno = v.nno, dof = v.dof;
     const size_t nq = ((size_t)neq * 8 + 255) / 256 * 256, np = ((size_t)nel * 8 + 255) / 256 * 256;
     Scratch scr; scr.s = s;
-    G4S_TRY(g4s::scratch_alloc(&scr.p, 3 * nq + 6 * np + sizeof(double) * (3 * kBlocks + 8), s));
+    G4S_TRY(g4s::scratch_alloc(&scr.p, 3 * nq + 6 * np + sizeof(double) * (3 * kBlocks + 16), s));
     char *base = static_cast<char *>(scr.p);
     double *F = reinterpret_cast<double *>(base), *u1 = reinterpret_cast<double *>(base + nq), *tmp = reinterpret_cast<double *>(base + 2 * nq);
     double *r1 = reinterpret_cast<double *>(base + 3 * nq), *r2 = reinterpret_cast<double *>(base + 3 * nq + np),
@@ -201,12 +203,19 @@ G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, const double *g, const 
     double *part = reinterpret_cast<double *>(base + 3 * nq + 6 * np), *sums_dev = part + 3 * kBlocks;
     const int *node_eq = v.node_eq;
 
-    double h3[3];
-    auto sums = [&](int n, auto f) -> int {                        // launch, finish, bring the three sums to the host
+    // sc: device scalars of the loop. A reduction = map_sum over the vectors + a one-workgroup finish whose epilogue writes the
+    // derived scalars; nothing comes to the host until fetch() at the end of an outer iteration.
+    enum { R1Z1, R0Z0, DELTA, ALPHA, VDOTV, U1DOTU1, PDOTP, S2S2, DIVN, NSC };
+    static_assert(NSC <= 16, "scalar slots");
+    double *sc = sums_dev;
+    double hsc[NSC] = {0};
+    auto reduce = [&](int n, auto f, auto ep) {
         hipLaunchKernelGGL(map_sum_kernel, dim3(kBlocks), dim3(kThreads), 0, s, n, f, part);
-        hipLaunchKernelGGL(finish_sums_kernel, dim3(1), dim3(kThreads), 0, s, part, sums_dev);
+        hipLaunchKernelGGL(finish_sums_kernel, dim3(1), dim3(kThreads), 0, s, part, ep);
+    };
+    auto fetch = [&]() -> int {
         G4S_HIP_TRY(hipGetLastError());
-        G4S_HIP_TRY(hipMemcpyAsync(h3, sums_dev, sizeof(h3), hipMemcpyDeviceToHost, s));
+        G4S_HIP_TRY(hipMemcpyAsync(hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, s));
         G4S_HIP_TRY(hipStreamSynchronize(s));
         return G4S_OK;
     };
@@ -242,14 +251,16 @@ G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, const double *g, const 
 
     // ---- r1 = div(V); incompressibility = sqrt(|r1|²_div / (1e-32 + |V|²))
     G4S_TRY(g4s_elem_op_div_u(op, g, V, r1, s));
-    G4S_TRY(sums(std::max(nno, nel), [=] __device__(int i) {
+    G4S_HIP_TRY(hipMemsetAsync(sc, 0, sizeof(double) * NSC, s));
+    reduce(std::max(nno, nel), [=] __device__(int i) {
         Sum3 o{0.0, 0.0, 0.0};
         if (i < nno) o.a = v_terms(V, i);
         if (i < nel) { o.b = r1[i] * r1[i] / area[i]; o.c = P[i] * P[i] * area[i]; }
         return o;
-    }));
-    double vdotv = h3[0] / volume, pdotp = h3[2] / volume;
-    double incompressibility = std::sqrt(h3[1] / volume / (1e-32 + vdotv));
+    }, [=] __device__(double a, double b, double c) { sc[VDOTV] = a; sc[DIVN] = b; sc[PDOTP] = c; });
+    G4S_TRY(fetch());
+    double vdotv = hsc[VDOTV] / volume, pdotp = hsc[PDOTP] / volume;
+    double incompressibility = std::sqrt(hsc[DIVN] / volume / (1e-32 + vdotv));
     double dvelocity = 1.0, dpressure = 1.0;
     int count = 0, converging = 0, lines = 0;
     auto record = [&]() {
@@ -257,43 +268,42 @@ G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, const double *g, const 
         ++lines;
     };
     record();
-    double r0dotz0 = 0.0;
     for (;;) {
         const bool keep = prm->check_continuity_convergence ? (incompressibility > prm->imp || converging < 2)
                                                             : (incompressibility > prm->imp && converging < 2);   // keep_iterating :150-162
         if (!(count < prm->steps_max && keep)) break;
-        // z1 = BPI∘r1; r1dotz1 = <r1, z1>
-        G4S_TRY(sums(nel, [=] __device__(int i) { const double z = BPI[i] * r1[i]; z1[i] = z; return Sum3{r1[i] * z, 0.0, 0.0}; }));
-        const double r1dotz1 = h3[0];
-        if (r1dotz1 == 0.0) return g4s::set_error(G4S_ERR_INVALID, "g4s_stokes_uzawa_cg: <r1, z1> = 0 at the head of iteration %d (the source asserts)", count);
-        if (count == 0) each(nel, [=] __device__(int i) { s2[i] = z1[i]; });
-        else {
-            const double delta = r1dotz1 / r0dotz0;
-            each(nel, [=] __device__(int i) { s2[i] = z1[i] + delta * s1[i]; });
-        }
+        // z1 = BPI∘r1; r1dotz1 = <r1, z1>; δ = r1dotz1 / r0dotz0 (:296-318)
+        reduce(nel, [=] __device__(int i) { const double z = BPI[i] * r1[i]; z1[i] = z; return Sum3{r1[i] * z, 0.0, 0.0}; },
+               [=] __device__(double a, double, double) { sc[R1Z1] = a; sc[DELTA] = a / sc[R0Z0]; });
+        const bool first = count == 0;
+        each(nel, [=] __device__(int i) { s2[i] = first ? z1[i] : z1[i] + sc[DELTA] * s1[i]; });
         // K·u1 = grad(s2)
         G4S_TRY(g4s_elem_op_grad_p(op, g, s2, tmp, zero_resid, n_zero, s));
         G4S_TRY(solve_del2_u(tmp, u1, &valid));
         strip(u1);
         G4S_TRY(g4s_elem_op_div_u(op, g, u1, Fp, s));
-        G4S_TRY(sums(nel, [=] __device__(int i) { return Sum3{s2[i] * Fp[i], 0.0, 0.0}; }));
-        const double alpha = r1dotz1 / h3[0];
-        each(nel, [=] __device__(int i) { r2[i] = r1[i] - alpha * Fp[i]; P[i] += alpha * s2[i]; });
-        each(neq, [=] __device__(int i) { V[i] -= alpha * u1[i]; });
+        // α = <r1, z1> / <s2, div(u1)>; r2, P, V (:336-354)
+        reduce(nel, [=] __device__(int i) { return Sum3{s2[i] * Fp[i], 0.0, 0.0}; },
+               [=] __device__(double a, double, double) { sc[ALPHA] = sc[R1Z1] / a; });
+        each(nel, [=] __device__(int i) { const double alpha = sc[ALPHA]; r2[i] = r1[i] - alpha * Fp[i]; P[i] += alpha * s2[i]; });
+        each(neq, [=] __device__(int i) { V[i] -= sc[ALPHA] * u1[i]; });
         G4S_TRY(g4s_elem_op_div_u(op, g, V, z1, s));
-        G4S_TRY(sums(std::max(nno, nel), [=] __device__(int i) {
+        reduce(std::max(nno, nel), [=] __device__(int i) {
             Sum3 o{0.0, 0.0, 0.0};
             if (i < nno) { o.a = v_terms(V, i); o.b = v_terms(u1, i); }
             if (i < nel) o.c = P[i] * P[i] * area[i];
             return o;
-        }));
-        vdotv = h3[0] / volume;
-        const double u1dotu1 = h3[1] / volume;
-        pdotp = h3[2] / volume;
-        G4S_TRY(sums(nel, [=] __device__(int i) { return Sum3{s2[i] * s2[i] * area[i], z1[i] * z1[i] / area[i], 0.0}; }));
-        dvelocity = alpha * std::sqrt(u1dotu1 / (1e-32 + vdotv));
-        dpressure = alpha * std::sqrt(h3[0] / volume / (1e-32 + pdotp));
-        incompressibility = std::sqrt(h3[1] / volume / (1e-32 + vdotv));
+        }, [=] __device__(double a, double b, double c) { sc[VDOTV] = a; sc[U1DOTU1] = b; sc[PDOTP] = c; });
+        reduce(nel, [=] __device__(int i) { return Sum3{s2[i] * s2[i] * area[i], z1[i] * z1[i] / area[i], 0.0}; },
+               [=] __device__(double a, double b, double) { sc[S2S2] = a; sc[DIVN] = b; sc[R0Z0] = sc[R1Z1]; });   // shift <r0, z0> = <r1, z1> (:405)
+        G4S_TRY(fetch());                                          // the one read-back of the iteration: 9 doubles
+        if (hsc[R1Z1] == 0.0) return g4s::set_error(G4S_ERR_INVALID, "g4s_stokes_uzawa_cg: <r1, z1> = 0 at the head of iteration %d (the source asserts)", count);
+        const double alpha = hsc[ALPHA];
+        vdotv = hsc[VDOTV] / volume;
+        pdotp = hsc[PDOTP] / volume;
+        dvelocity = alpha * std::sqrt(hsc[U1DOTU1] / volume / (1e-32 + vdotv));
+        dpressure = alpha * std::sqrt(hsc[S2S2] / volume / (1e-32 + pdotp));
+        incompressibility = std::sqrt(hsc[DIVN] / volume / (1e-32 + vdotv));
         ++count;
         record();
         if (!valid) converging = 0;
@@ -301,7 +311,6 @@ G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, const double *g, const 
         else converging = dvelocity < prm->imp ? converging + 1 : 0;
         std::swap(s1, s2);
         std::swap(r1, r2);
-        r0dotz0 = r1dotz1;
     }
     G4S_HIP_TRY(hipGetLastError());
     G4S_HIP_TRY(hipStreamSynchronize(s));
