@@ -93,7 +93,7 @@ SIGNATURES = {
     "g4s_elem_op_div_u": (C.c_int, [vp, vp, vp, vp, vp]),
     "g4s_elem_op_grad_p": (C.c_int, [vp, vp, vp, vp, vp, C.c_int32, vp]),
     "g4s_elem_op_pressure_preconditioner": (C.c_int, [vp, vp, vp, vp, vp]),
-    "g4s_stokes_uzawa_cg": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_double, vp, C.c_int32, vp, vp, vp, C.POINTER(StokesParams),
+    "g4s_stokes_uzawa_cg": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_double, vp, C.c_int32, vp, vp, vp, C.POINTER(StokesParams),
                                       C.POINTER(StokesResult), vp, C.c_int32, vp]),
     "g4s_dense_rows_times_matrix": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]),
     "g4s_dense_rows_times_matrix_grad": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp]),

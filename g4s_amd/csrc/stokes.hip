@@ -177,7 +177,7 @@ G4S_API g4s_status g4s_elem_op_pressure_preconditioner(g4s_elem_op_t op, const d
     return G4S_OK;
 }
 
-G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, const double *g, const double *BI, const double *BPI, const double *nmass,
+G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, g4s_csr_t K_csr, const double *g, const double *BI, const double *BPI, const double *nmass,
                                        const double *area, double volume, const int32_t *zero_resid, int32_t n_zero, const double *FF,
                                        double *V, double *P, const g4s_stokes_params *prm, g4s_stokes_result *res, double *hist,
                                        int32_t hist_lines, void *stream)
@@ -231,7 +231,7 @@ G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, const double *g, const 
     auto solve_del2_u = [&](const double *rhs, double *d0, int *valid) -> int {   // General_matrix_functions.c:48-146, CG branch
         int32_t cycles = prm->v_steps_low;
         double residual = 0.0;
-        G4S_TRY(g4s_conj_grad(op, nullptr, neq, BI, zero_resid, n_zero, rhs, d0, inner_acc, &cycles, &residual, s));
+        G4S_TRY(g4s_conj_grad(K_csr ? nullptr : op, K_csr, neq, BI, zero_resid, n_zero, rhs, d0, inner_acc, &cycles, &residual, s));
         inner_total += cycles;
         *valid = residual < inner_acc ? 1 : 0;
         return G4S_OK;
@@ -241,7 +241,8 @@ G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, const double *g, const 
     int valid = 0;
     G4S_TRY(g4s_elem_op_grad_p(op, g, P, u1, zero_resid, n_zero, s));
     each(neq, [=] __device__(int i) { F[i] = FF[i] - u1[i]; });
-    G4S_TRY(g4s_elem_op_apply(op, V, u1, s));
+    if (K_csr) G4S_TRY(g4s_spmv(K_csr, V, u1, 1.0, 0.0, s));
+    else G4S_TRY(g4s_elem_op_apply(op, V, u1, s));
     strip(u1);
     each(neq, [=] __device__(int i) { F[i] = F[i] - u1[i]; });
     strip(F);

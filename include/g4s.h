@@ -258,12 +258,15 @@ typedef struct g4s_stokes_result {
 } g4s_stokes_result;
 
 /* solve_Ahat_p_fhat_CG, citcoms/lib/Stokes_flow_Incomp.c:188-452, incompressible case (initial_vel_residual :839-881 included),
- * velocity solves by g4s_conj_grad on the element-by-element operator (solve_del2_u's CG branch, General_matrix_functions.c:89-94).
+ * velocity solves by g4s_conj_grad (solve_del2_u's CG branch, General_matrix_functions.c:89-94) on the element-by-element
+ * operator of `op`, or — K_csr != NULL — on the assembled stiffness matrix through g4s_spmv (BASELINE config 5: "assembled stiffness
+ * matrix driving G4S SpMV inside the CG/Uzawa solver loop"; op then only supplies the mesh maps of div/grad; the boundary rows are
+ * zeroed after every product either way, so K_csr is the plain assembly of the element matrices).
  * V_dev[neq] and P_dev[nel] are updated in place; F_dev is not modified. nmass_dev[nno] = NMass, area_dev[nel] = eco[].area,
  * volume = mesh.volume (the weights of global_v_norm2 / global_p_norm2 / global_div_norm2, Global_operations.c:591-656).
  * hist (host, may be NULL): 5 doubles per printed line — v_norm, p_norm, dvelocity, dpressure, incompressibility — line 0 before
  * the loop, at most hist_lines lines. Every vector stays on the device; a few scalars per outer iteration cross PCIe. */
-g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, const double *g_dev, const double *BI_dev, const double *BPI_dev, const double *nmass_dev,
+g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, g4s_csr_t K_csr, const double *g_dev, const double *BI_dev, const double *BPI_dev, const double *nmass_dev,
                                const double *area_dev, double volume, const int32_t *zero_resid_dev, int32_t n_zero, const double *F_dev,
                                double *V_dev, double *P_dev, const g4s_stokes_params *params, g4s_stokes_result *result,
                                double *hist, int32_t hist_lines, void *stream);

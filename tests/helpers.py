@@ -107,3 +107,15 @@ def hex_node_map(ex, ey, ez, idmap):
                                 ia += 1
                                 nm[nn, 3 * ia:3 * ia + 3] = idmap[ja]
     return nm, max_eqn
+
+
+def assemble_csr(ien, idmap, K, neq):
+    """The element matrices summed into one CSR matrix (scipy): rowptr, colids, values with sorted, duplicate-free rows."""
+    import scipy.sparse as sp
+    n = K.shape[1]
+    m = int(round(n ** 0.5))
+    eq = idmap[ien].reshape(len(ien), m)
+    A = sp.coo_matrix((K.ravel(), (np.repeat(eq, m, axis=1).ravel(), np.tile(eq, (1, m)).ravel())), shape=(neq, neq)).tocsr()
+    A.sum_duplicates()
+    A.sort_indices()
+    return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)

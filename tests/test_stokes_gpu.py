@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import hex_mesh, spd_blocks, stokes_problem
+from tests.helpers import assemble_csr, hex_mesh, spd_blocks, stokes_problem
 
 pytestmark = pytest.mark.gpu
 
@@ -47,9 +47,12 @@ def test_div_grad_preconditioner_bit_exact(oracle, ex, ey, ez, seed):
     lib.g4s_elem_op_destroy(h)
 
 
-@pytest.mark.parametrize("ex,ey,ez,seed,check_cont,check_p", [(3, 3, 2, 0, 0, 0), (6, 6, 4, 1, 1, 1), (16, 16, 8, 2, 0, 1)])
-def test_uzawa_iteration_matches_oracle(oracle, ex, ey, ez, seed, check_cont, check_p):
-    from g4s_amd import capi
+@pytest.mark.parametrize("ex,ey,ez,seed,check_cont,check_p,stiffness", [(3, 3, 2, 0, 0, 0, "elements"), (6, 6, 4, 1, 1, 1, "elements"),
+                                                                           (16, 16, 8, 2, 0, 1, "elements"), (6, 6, 4, 1, 0, 0, "csr"),
+                                                                           (16, 16, 8, 3, 1, 0, "csr")])
+def test_uzawa_iteration_matches_oracle(oracle, ex, ey, ez, seed, check_cont, check_p, stiffness):
+    """stiffness = "csr": the velocity solves and K·V run on the assembled matrix through g4s_spmv (BASELINE config 5)."""
+    from g4s_amd import capi, host
     lib = capi.load()
     pr = stokes_problem(ex, ey, ez, seed)
     ien, idmap, nno, neq, nel = pr["ien"], pr["id"], pr["nno"], pr["neq"], len(pr["ien"])
@@ -66,10 +69,12 @@ def test_uzawa_iteration_matches_oracle(oracle, ex, ey, ez, seed, check_cont, ch
     Kd, gd, BId, BPId, nmd, ard, bcd, Fd = (dev(pr["K"]), dev(pr["g"]), dev(BI), dev(BPI), dev(pr["nmass"]), dev(pr["area"]), dev(pr["bc"]), dev(pr["F"]))
     Vd, Pd = dev(V0), dev(P0)
     h = _op(lib, capi, ien, idmap, nno, neq, Kd)
+    Acsr = host.CSR.from_host(*assemble_csr(ien, idmap, pr["K"], neq), neq, neq) if stiffness == "csr" else None
+    KCSR = Acsr.handle if Acsr is not None else None
     prm = capi.StokesParams(imp, scale, v_res, vlow, steps, check_cont, check_p)
     res = capi.StokesResult()
     hist = np.zeros((steps + 1, 5))
-    capi.check(lib.g4s_stokes_uzawa_cg(h, gd.data_ptr(), BId.data_ptr(), BPId.data_ptr(), nmd.data_ptr(), ard.data_ptr(), pr["volume"], bcd.data_ptr(),
+    capi.check(lib.g4s_stokes_uzawa_cg(h, KCSR, gd.data_ptr(), BId.data_ptr(), BPId.data_ptr(), nmd.data_ptr(), ard.data_ptr(), pr["volume"], bcd.data_ptr(),
                                        len(pr["bc"]), Fd.data_ptr(), Vd.data_ptr(), Pd.data_ptr(), C.byref(prm), C.byref(res), hist.ctypes.data, steps + 1, None))
     lib.g4s_elem_op_destroy(h)
     assert torch.equal(Fd, dev(pr["F"])), "F must not be modified"
