@@ -535,11 +535,7 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_symbolic_window_kernel(
             return true;
         });
         __syncthreads();
-        const int nl = min(longs[0].x, kLongCap);
-        for (int i = 0; i < nl; ++i) {
-            const int4 e = longs[1 + i];
-            for (int k = e.x + t; k < e.y; k += kBigThreads) mark(bcol[k]);
-        }
+        for_deferred_rows<false>(longs, t, kBigThreads, bcol, nullptr, [&](int col, double, double) { mark(col); });
         __syncthreads();
         int cnt = 0;
         for (int i = t; i < kBigWindowWords; i += kBigThreads) cnt += __popc(bm[i]);
