@@ -22,6 +22,11 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 int scratch_alloc(void **p, size_t bytes, hipStream_t s);
 void scratch_free(void *p, hipStream_t s);
 int scratch_shutdown();
+void spgemm_release_cache();   // spgemm.hip
+// caching allocator for large device blocks (runtime.cpp); big_free returns false for a pointer it does not own
+int big_alloc(void **p, size_t bytes);
+bool big_free(void *p);
+void big_release_all();
 
 // 8 XCDs, each with its own L2: block b and b+8 share one (MI355X_MICROARCH.md, Workgroup dispatch).
 constexpr int kXcds = 8;

@@ -1,6 +1,8 @@
 // runtime.cpp — device selection, allocators and error reporting of the C-ABI (include/g4s.h, "runtime").
 #include "common.hpp"
 #include <mutex>
+#include <unordered_map>
+#include <vector>
 
 namespace g4s {
 
@@ -57,6 +59,75 @@ void scratch_free(void *p, hipStream_t s)
     if (p) (void)hipFreeAsync(p, s);
 }
 
+// Large device blocks (product outputs, per-row bitmaps: tens of MB to tens of GB). On this stack a fresh allocation of that size —
+// hipMalloc and hipMallocFromPoolAsync alike — takes anything from under a millisecond to several seconds (measured: 0.5 ms vs
+// 4.1 s for the same 15.5 GB request one call apart), so freed blocks are kept in a small free list and handed out again when a
+// request fits one within 25 % (what a caching allocator does). big_free synchronises the device first, as hipFree would.
+namespace {
+struct BigBlock { void *p; size_t bytes; };
+std::mutex g_big_mutex;
+std::unordered_map<void *, size_t> g_big_live;
+std::vector<BigBlock> g_big_cache;
+void big_drop_cache_locked()
+{
+    for (auto &b : g_big_cache) (void)hipFree(b.p);
+    g_big_cache.clear();
+}
+} // namespace
+
+int big_alloc(void **p, size_t bytes)
+{
+    *p = nullptr;
+    if (bytes == 0) bytes = 1;
+    {
+        std::lock_guard<std::mutex> lock(g_big_mutex);
+        int best = -1;
+        for (int i = 0; i < (int)g_big_cache.size(); ++i)
+            if (g_big_cache[i].bytes >= bytes && g_big_cache[i].bytes - bytes <= bytes / 4 && (best < 0 || g_big_cache[i].bytes < g_big_cache[best].bytes)) best = i;
+        if (best >= 0) {
+            *p = g_big_cache[best].p;
+            g_big_live[*p] = g_big_cache[best].bytes;
+            g_big_cache.erase(g_big_cache.begin() + best);
+            return G4S_OK;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) {                                // give the cached blocks back and try once more
+        (void)hipGetLastError();
+        { std::lock_guard<std::mutex> lock(g_big_mutex); big_drop_cache_locked(); }
+        e = hipMalloc(p, bytes);
+    }
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return set_error(G4S_ERR_NOMEM, "device allocation of %zu bytes: out of memory", bytes); }
+    G4S_HIP_TRY(e);
+    std::lock_guard<std::mutex> lock(g_big_mutex);
+    g_big_live[*p] = bytes;
+    return G4S_OK;
+}
+
+bool big_free(void *p)
+{
+    if (!p) return true;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_big_mutex);
+        auto it = g_big_live.find(p);
+        if (it == g_big_live.end()) return false;
+        bytes = it->second;
+        g_big_live.erase(it);
+    }
+    (void)hipDeviceSynchronize();                                  // nothing in flight may still touch the block when it is handed out again
+    std::lock_guard<std::mutex> lock(g_big_mutex);
+    if (g_big_cache.size() >= 8) { (void)hipFree(p); return true; }
+    g_big_cache.push_back(BigBlock{p, bytes});
+    return true;
+}
+
+void big_release_all()
+{
+    std::lock_guard<std::mutex> lock(g_big_mutex);
+    big_drop_cache_locked();
+}
+
 int scratch_shutdown()
 {
     std::lock_guard<std::mutex> lock(g_pool_mutex);
@@ -90,25 +161,30 @@ G4S_API g4s_status g4s_device_synchronize(void)
     return G4S_OK;
 }
 
-G4S_API g4s_status g4s_shutdown(void) { return g4s::scratch_shutdown(); }
+G4S_API g4s_status g4s_shutdown(void)
+{
+    g4s::spgemm_release_cache();
+    g4s::big_release_all();
+    return g4s::scratch_shutdown();
+}
 
 // Host allocator paired with every callee-allocated host output (mm/inc/utility.h:126-153 pairs my_malloc/my_free).
 G4S_API void *g4s_malloc(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
 G4S_API void g4s_free(void *p) { std::free(p); }
 
+// Device allocations handed to the caller (g4s_dev_alloc, the callee-allocated outputs of g4s_spgemm_csr_i32_f64 with
+// G4S_DEVICE_POINTERS) are blocks of the caching allocator above; g4s_dev_free returns them to it (and still accepts a plain
+// hipMalloc pointer). g4s_shutdown releases what is cached.
 G4S_API g4s_status g4s_dev_alloc(void **dptr, size_t bytes)
 {
     G4S_REQUIRE(dptr, "dptr is NULL");
-    *dptr = nullptr;
-    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
-    if (e == hipErrorOutOfMemory) return g4s::set_error(G4S_ERR_NOMEM, "hipMalloc(%zu) out of memory", bytes);
-    G4S_HIP_TRY(e);
-    return G4S_OK;
+    return g4s::big_alloc(dptr, bytes);
 }
 
 G4S_API g4s_status g4s_dev_free(void *dptr)
 {
-    if (dptr) G4S_HIP_TRY(hipFree(dptr));
+    if (!dptr || g4s::big_free(dptr)) return G4S_OK;               // a block of the library's own allocator
+    G4S_HIP_TRY(hipFree(dptr));                                    // a plain hipMalloc pointer
     return G4S_OK;
 }
 

@@ -22,8 +22,10 @@
 // Integer results (crpt, ccol) are exact; fp64 sums are accumulated with LDS/HBM atomics, i.e. in a different order than
 // the reference's (j outer, k inner): equal within the 1e-10 relative tolerance of the north star, not bit for bit.
 #include "common.hpp"
+#include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -32,17 +34,29 @@ constexpr int kHashScal = 107; // HASH_SCAL, mm/inc/define.h:12
 constexpr int kEmpty = -1;
 
 // ------------------------------------------------------------------------------------------------ small utilities
+// Device memory of a product: small transients from the library's never-trimming pool, large blocks (>= 64 MiB: outputs, column
+// scratch, hub bitmaps) from its caching allocator (runtime.cpp) — plain hipMalloc of gigabytes took anything between 1 ms and 4 s
+// from one call to the next (measured on the one-call form: 95 ms to 2300 ms for the same product).
+thread_local hipStream_t t_stream = nullptr;   // the stream of the API call in progress on this thread: pool allocations and frees are ordered on it
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes)
+    hipStream_t s = nullptr;
+    bool big = false;
+    ~DevBuf() { release(); }
+    int alloc(size_t bytes, bool for_caller = false)              // for_caller: the pointer is handed out and comes back through g4s_dev_free
     {
-        if (p) { (void)hipFree(p); p = nullptr; }
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
-        if (e != hipSuccess) return g4s::set_error(e == hipErrorOutOfMemory ? G4S_ERR_NOMEM : G4S_ERR_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
-        return G4S_OK;
+        release();
+        big = for_caller || bytes >= ((size_t)64 << 20);
+        if (big) return g4s::big_alloc(&p, bytes);
+        s = t_stream;
+        return g4s::scratch_alloc(&p, bytes, s);
     }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; } }
+    void release()
+    {
+        if (!p) return;
+        if (big) (void)g4s::big_free(p); else g4s::scratch_free(p, s);
+        p = nullptr;
+    }
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
@@ -504,31 +518,101 @@ __device__ __forceinline__ void window_bounds(const int *brpt, const int *wsplit
     if (wl < W - 1) hi = wsplit + (size_t)wl * K;
 }
 
+// Emits the set bits of one LDS bitmap window (words swizzled by bm_slot) in ascending column order to out[0 … total) and returns
+// total (the same value in every thread). Thread t owns the 32 consecutive words [32t, 32t + 32): a block scan of the per-thread
+// (set bits, non-empty words) places its columns and its words. The bits themselves are then written word by word from a list of
+// the non-empty words, one word per thread: in a power-law row the first few hundred columns are all present, and a thread emitting
+// its own 32 words would write a thousand ids while the rest write a handful (measured: 38 % of the numeric kernel).
+// s_scan: 34 ints of LDS scratch, stage: kBigStage ints. Contains barriers: call from uniform control flow.
+__device__ __forceinline__ int emit_window_columns(const unsigned *bm, int w0, int *__restrict__ out, int *s_scan, int *stage, int t)
+{
+    static_assert(kBigWindowWords / kBigThreads == 32 && kBigThreads == 1024, "emit layout");
+    static_assert(G4S_SPGEMM_BIG_LIMIT <= (1 << 17), "a list item packs the output position in 17 bits");
+    const int lane = t & 63, wave = t >> 6;
+    unsigned nonempty = 0;
+    int cnt = 0;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) {
+        const unsigned w = bm[bm_slot(t * 32 + i)];
+        cnt += __popc(w);
+        nonempty |= (w != 0u ? 1u : 0u) << i;
+    }
+    const int nw = __popc(nonempty);
+    const int incl_c = (int)wave_inclusive_sum((unsigned)cnt), incl_w = (int)wave_inclusive_sum((unsigned)nw);
+    if (lane == 63) { s_scan[wave] = incl_c; s_scan[16 + wave] = incl_w; }
+    __syncthreads();
+    int p = incl_c - cnt, wq = incl_w - nw, total = 0, total_w = 0;   // first column / first word of this thread within the window
+#pragma unroll
+    for (int u = 0; u < kBigThreads / 64; ++u) {
+        const int vc = s_scan[u], vw = s_scan[16 + u];
+        if (u < wave) { p += vc; wq += vw; }
+        total += vc;
+        total_w += vw;
+    }
+    for (int tile0 = 0; tile0 < total_w; tile0 += kBigStage) {
+        const int tile1 = tile0 + kBigStage;
+        if (wq < tile1 && wq + nw > tile0) {
+            int q = p, j = wq;
+            unsigned m = nonempty;
+            while (m) {
+                const int i = __ffs(m) - 1;
+                m &= m - 1;
+                if (j >= tile0 && j < tile1) stage[j - tile0] = ((t * 32 + i) << 17) | q;
+                q += __popc(bm[bm_slot(t * 32 + i)]);
+                ++j;
+            }
+        }
+        __syncthreads();
+        const int n = min(kBigStage, total_w - tile0);
+        for (int e = t; e < n; e += kBigThreads) {
+            const unsigned item = (unsigned)stage[e];
+            const int w = (int)(item >> 17);
+            unsigned bits = bm[bm_slot(w)];
+            int pos = (int)(item & 0x1ffffu);
+            const int col0 = w0 + (w << 5);
+            while (bits) {
+                const int bit = __ffs(bits) - 1;
+                bits &= bits - 1;
+                out[pos++] = col0 + bit;
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    return total;
+}
+
 // Symbolic twin of phase 1 below: the number of distinct columns of a row whose key table would not fit LDS, counted with the
 // same LDS bitmap windows (no hash table that can overflow, no HBM bitmap, no global atomics). One workgroup per row.
+// pre_off / pre_cols (one-shot call only): rows with pre_off[row] >= 0 also write their sorted distinct columns to
+// pre_cols[pre_off[row] …], so that the numeric phase does not have to mark and emit them a second time.
 __global__ __launch_bounds__(kBigThreads) void spgemm_symbolic_window_kernel(
     const int *__restrict__ rows, int nrows, int N, int K, const int *__restrict__ wsplit, const int *__restrict__ arpt, const int *__restrict__ acol,
-    const int *__restrict__ brpt, const int *__restrict__ bcol, const long long *__restrict__ row_flop, int *__restrict__ row_nz)
+    const int *__restrict__ brpt, const int *__restrict__ bcol, const long long *__restrict__ row_flop, int *__restrict__ row_nz,
+    const long long *__restrict__ pre_off, int *__restrict__ pre_cols)
 {
-    extern __shared__ int lds_i[];                                 // dynamic only (Guideline 17): [bitmap][count][pad][long-B list]
+    extern __shared__ int lds_i[];                                 // dynamic only (Guideline 17): the layout of the numeric big-row kernel
     unsigned *bm = reinterpret_cast<unsigned *>(lds_i);
-    int &s_total = lds_i[kBigWindowWords];
-    int4 *longs = reinterpret_cast<int4 *>(lds_i + kBigWindowWords + 4);
+    int *s_scan = lds_i + kBigWindowWords;                         // kBigThreads ints
+    int &s_total = s_scan[kBigThreads];
+    int4 *longs = reinterpret_cast<int4 *>(s_scan + kBigThreads + 4);
+    int *stage = reinterpret_cast<int *>(longs + kLongCap + 1);
     const int t = threadIdx.x;
     const int row = rows[blockIdx.x];
     (void)nrows;
     const int a0 = arpt[row], a1 = arpt[row + 1];
     const int gs = group_shift(row_flop[row], a1 - a0, kBigThreads), gmask = (1 << gs) - 1;
     const int long_thr = long_b_threshold(kBigThreads);
+    const long long po = pre_off ? pre_off[row] : -1;              // uniform
     if (t == 0) s_total = 0;
     for (int w0 = 0; w0 < N; w0 += (1 << kBigWindowBits)) {
-        for (int i = t; i < kBigWindowWords; i += kBigThreads) bm[i] = 0u;
+        for (int i = t; i < kBigWindowWords / 4; i += kBigThreads) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
         if (t == 0) longs[0].x = 0;
         __syncthreads();
         const int w1 = min(N, w0 + (1 << kBigWindowBits));
         const int *wlo, *whi;
         window_bounds(brpt, wsplit, K, N, w0, w1 - 1, wlo, whi);
-        auto mark = [&](int col) { if (col >= w0 && col < w1) atomicOr(&bm[(col - w0) >> 5], 1u << ((col - w0) & 31)); };
+        auto mark = [&](int col) { if (col >= w0 && col < w1) atomicOr(&bm[bm_slot((col - w0) >> 5)], 1u << ((col - w0) & 31)); };
         walk_a_entries<false>(a0, a1, t >> gs, kBigThreads >> gs, acol, nullptr, wlo, whi, [&](int b0, int b1, double) {
             if (defer_long_b(longs, b0, b1, 0.0, t & gmask, gmask, long_thr)) return true;
             for (int k = b0 + (t & gmask); k < b1; k += gmask + 1) mark(bcol[k]);
@@ -537,11 +621,16 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_symbolic_window_kernel(
         __syncthreads();
         for_deferred_rows<false>(longs, t, kBigThreads, bcol, nullptr, [&](int col, double, double) { mark(col); });
         __syncthreads();
-        int cnt = 0;
-        for (int i = t; i < kBigWindowWords; i += kBigThreads) cnt += __popc(bm[i]);
+        if (po >= 0) {
+            const int total = emit_window_columns(bm, w0, pre_cols + po + s_total, s_scan, stage, t);
+            if (t == 0) s_total += total;
+        } else {
+            int cnt = 0;
+            for (int i = t; i < kBigWindowWords; i += kBigThreads) cnt += __popc(bm[i]);
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
-        if ((t & 63) == 0 && cnt) atomicAdd(&s_total, cnt);
+            for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+            if ((t & 63) == 0 && cnt) atomicAdd(&s_total, cnt);
+        }
         __syncthreads();
     }
     if (t == 0) row_nz[row] = s_total;
@@ -559,7 +648,8 @@ __device__ unsigned long long g_big_prof[16];
 __global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
     const int *__restrict__ rows, int nrows, int N, int K, const int *__restrict__ wsplit, const int *__restrict__ arpt, const int *__restrict__ acol, const double *__restrict__ aval,
     const int *__restrict__ brpt, const int *__restrict__ bcol, const double *__restrict__ bval, const long long *__restrict__ row_flop,
-    const int *__restrict__ crpt, int *__restrict__ ccol, double *__restrict__ cval)
+    const int *__restrict__ crpt, int *__restrict__ ccol, double *__restrict__ cval,
+    const long long *__restrict__ pre_off, const int *__restrict__ pre_cols)
 {
     // No static __shared__ in this kernel: it would sit in front of the dynamic region and push the fp64 table of phase 2 off its
     // 8-byte alignment (cdna_hip_programming.md Guideline 17). Everything is carved from the dynamic region instead.
@@ -577,10 +667,11 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
     const int gs = group_shift(row_flop[row], a1 - a0, kBigThreads), gmask = (1 << gs) - 1;
 
     BIG_PROF_DECL;
-    // ---- phase 1: sorted distinct columns
+    // ---- phase 1: sorted distinct columns — unless the symbolic phase of the one-shot call already left them in pre_cols
+    const long long po = pre_off ? pre_off[row] : -1;              // uniform
     unsigned *bm = reinterpret_cast<unsigned *>(lds_i);
     if (t == 0) s_base = 0;
-    for (int w0 = 0; w0 < N; w0 += (1 << kBigWindowBits)) {
+    for (int w0 = 0; w0 < N && po < 0; w0 += (1 << kBigWindowBits)) {
         for (int i = t; i < kBigWindowWords / 4; i += kBigThreads) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
         if (t == 0) longs[0].x = 0;
         __syncthreads();
@@ -599,65 +690,8 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
         for_deferred_rows<false>(longs, t, kBigThreads, bcol, nullptr, [&](int col, double, double) { mark(col); });
         __syncthreads();
         BIG_PROF(2);
-        // Emit the set bits in column order. Thread t owns the 32 consecutive words [32t, 32t + 32): a block scan of the per-thread
-        // (set bits, non-empty words) places its columns and its words. The bits themselves are then written word by word from a
-        // list of the non-empty words, one word per thread: in a power-law row the first few hundred columns are all present, and
-        // a thread emitting its own 32 words would write a thousand ids while the rest write a handful (measured: 38 % of the kernel).
-        static_assert(kBigWindowWords / kBigThreads == 32 && kBigThreads == 1024, "emit layout");
-        static_assert(G4S_SPGEMM_BIG_LIMIT <= (1 << 17), "a list item packs the output position in 17 bits");
-        const int lane = t & 63, wave = t >> 6;
-        unsigned nonempty = 0;
-        int cnt = 0;
-#pragma unroll 8
-        for (int i = 0; i < 32; ++i) {
-            const unsigned w = bm[bm_slot(t * 32 + i)];
-            cnt += __popc(w);
-            nonempty |= (w != 0u ? 1u : 0u) << i;
-        }
-        const int nw = __popc(nonempty);
-        const int incl_c = (int)wave_inclusive_sum((unsigned)cnt), incl_w = (int)wave_inclusive_sum((unsigned)nw);
-        if (lane == 63) { s_scan[wave] = incl_c; s_scan[16 + wave] = incl_w; }
-        __syncthreads();
+        const int total = emit_window_columns(bm, w0, ccol + off + s_base, s_scan, stage, t);
         BIG_PROF(3);
-        int p = incl_c - cnt, wq = incl_w - nw, total = 0, total_w = 0;   // first column / first word of this thread within the window
-#pragma unroll
-        for (int u = 0; u < kBigThreads / 64; ++u) {
-            const int vc = s_scan[u], vw = s_scan[16 + u];
-            if (u < wave) { p += vc; wq += vw; }
-            total += vc;
-            total_w += vw;
-        }
-        for (int tile0 = 0; tile0 < total_w; tile0 += kBigStage) {
-            const int tile1 = tile0 + kBigStage;
-            if (wq < tile1 && wq + nw > tile0) {
-                int q = p, j = wq;
-                unsigned m = nonempty;
-                while (m) {
-                    const int i = __ffs(m) - 1;
-                    m &= m - 1;
-                    if (j >= tile0 && j < tile1) stage[j - tile0] = ((t * 32 + i) << 17) | q;
-                    q += __popc(bm[bm_slot(t * 32 + i)]);
-                    ++j;
-                }
-            }
-            __syncthreads();
-            BIG_PROF(4);
-            const int n = min(kBigStage, total_w - tile0);
-            for (int e = t; e < n; e += kBigThreads) {
-                const unsigned item = (unsigned)stage[e];
-                const int w = (int)(item >> 17);
-                unsigned bits = bm[bm_slot(w)];
-                int pos = off + s_base + (int)(item & 0x1ffffu);
-                const int col0 = w0 + (w << 5);
-                while (bits) {
-                    const int bit = __ffs(bits) - 1;
-                    bits &= bits - 1;
-                    ccol[pos++] = col0 + bit;
-                }
-            }
-            __syncthreads();
-            BIG_PROF(5);
-        }
         __syncthreads();
         if (t == 0) s_base += total;
         __syncthreads();
@@ -675,7 +709,11 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
     static_assert(4 * kBigChunk <= kBigWindowWords && kBigChunk <= 65536, "phase 2 reuses the bitmap region; slots are packed in 16 bits");
     for (int q0 = 0; q0 < nz; q0 += kBigChunk) {
         const int qn = min(kBigChunk, nz - q0);
-        for (int i = t; i < qn; i += kBigThreads) { KC[i] = ccol[off + q0 + i]; V[i] = 0.0; }
+        for (int i = t; i < qn; i += kBigThreads) {
+            int c;
+            if (po >= 0) { c = pre_cols[po + q0 + i]; ccol[off + q0 + i] = c; } else c = ccol[off + q0 + i];
+            KC[i] = c; V[i] = 0.0;
+        }
         for (int i = t; i < kBigChunk; i += kBigThreads) IDX[i] = 0u;
         if (t == 0) longs[0].x = 0;
         __syncthreads();
@@ -1050,6 +1088,65 @@ int read_last(const int *d_rpt, int n, int *out, hipStream_t s)
 
 // ================================================================================================ C-ABI
 namespace {
+// Sorted columns carried from the symbolic to the numeric phase of the one-shot call (g4s_spgemm_csr_i32_f64): rows counted by the
+// window kernel whose product bound lies in (1 K, 128 K] — the rows the numeric big-row kernel will take — also write their distinct
+// columns, in order, to cols[off[row] …] (off[row] = −1 for every other row); the big-row kernel then skips its own mark-and-emit
+// phase for them. The scratch is sized by the bound Σ min(flop_i, N), so it is only used while that fits comfortably in free HBM.
+struct PreSorted {
+    DevBuf off;                  // long long off[M]
+    const long long *d_off = nullptr;
+    int *d_cols = nullptr;       // int cols[total], borrowed from the cache below
+    bool holds_cache = false;
+    ~PreSorted();
+};
+
+// The column scratch is the largest transient of a product (8 GB on config 3) and has the same size from call to call: one cached
+// block per process, handed to one call at a time (a concurrent call simply runs without the scratch), released by g4s_shutdown.
+// Leaving it to the pool made the allocator split the freed output blocks differently from call to call, and every other call then
+// paid a fresh 15 GB driver allocation (1–2 s).
+struct ColumnScratchCache {
+    std::mutex m;
+    void *p = nullptr;
+    size_t bytes = 0;
+    bool in_use = false;
+} g_col_cache;
+
+int *acquire_column_scratch(size_t bytes)
+{
+    std::lock_guard<std::mutex> lock(g_col_cache.m);
+    if (g_col_cache.in_use) return nullptr;
+    if (g_col_cache.bytes < bytes) {
+        if (g_col_cache.p) { (void)hipFree(g_col_cache.p); g_col_cache.p = nullptr; g_col_cache.bytes = 0; }
+        if (hipMalloc(&g_col_cache.p, bytes) != hipSuccess) { (void)hipGetLastError(); g_col_cache.p = nullptr; return nullptr; }
+        g_col_cache.bytes = bytes;
+    }
+    g_col_cache.in_use = true;
+    return static_cast<int *>(g_col_cache.p);
+}
+void release_column_scratch()
+{
+    std::lock_guard<std::mutex> lock(g_col_cache.m);
+    g_col_cache.in_use = false;
+}
+PreSorted::~PreSorted() { if (holds_cache) release_column_scratch(); }
+
+__global__ void presorted_need_kernel(int M, const int *__restrict__ cls, unsigned class_mask, const long long *__restrict__ row_flop, int N,
+                                      long long *__restrict__ need)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const long long f = row_flop[i];
+    const bool take = ((class_mask >> cls[i]) & 1u) && f > 1024 && f <= G4S_SPGEMM_BIG_LIMIT;
+    need[i] = take ? (f < N ? f : (long long)N) : 0;
+}
+__global__ void presorted_mark_kernel(int M, const long long *__restrict__ need, long long *__restrict__ off)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M && need[i] == 0) off[i] = -1;
+}
+} // namespace
+
+namespace {
 // wsplit for the window kernels (see window_splits_kernel); left empty (kernels then read whole rows) for a single window or when
 // the table would be large (more than 16 windows).
 int build_window_splits(int K, int N, const int *brpt, const int *bcol, DevBuf &buf, const int **out, hipStream_t s)
@@ -1066,13 +1163,14 @@ int build_window_splits(int K, int N, const int *brpt, const int *bcol, DevBuf &
 }
 } // namespace
 
-G4S_API g4s_status g4s_spgemm_symbolic(int32_t M, int32_t K, int32_t N,
-                                       const int32_t *arpt, const int32_t *acol, const int32_t *brpt, const int32_t *bcol,
-                                       int32_t *crpt, int64_t *cnnz, void *stream)
+namespace {
+int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, const int32_t *acol, const int32_t *brpt, const int32_t *bcol,
+                         int32_t *crpt, int64_t *cnnz, void *stream, PreSorted *pre)
 {
     G4S_REQUIRE(M >= 0 && K >= 0 && N >= 0, "negative dimension");
     G4S_REQUIRE(arpt && brpt && crpt && cnnz, "NULL argument");
     hipStream_t s = g4s::as_stream(stream);
+    t_stream = s;
     *cnnz = 0;
     if (M == 0) { G4S_HIP_TRY(hipMemsetAsync(crpt, 0, sizeof(int), s)); return G4S_OK; }
     int annz = 0, bnnz = 0;
@@ -1112,11 +1210,45 @@ G4S_API g4s_status g4s_spgemm_symbolic(int32_t M, int32_t K, int32_t N,
     // Up to kWindowMaxN columns (4 bitmap windows) the window kernel beats the key tables for every row past 512 products (it has no
     // probe chains and cannot overflow); with more windows each row would re-walk its products once per window, so tables take over.
     const bool x_med = N <= window_max_n(), x_large = x_med;
+    const long long *pre_off = nullptr;
+    int *pre_cols = nullptr;
+    if (pre && !getenv("G4S_SPGEMM_NO_PRESORT")) {
+        // which classes the window kernel counts in this call: M2 always, MEDIUM / LARGE while B is narrow enough
+        const unsigned class_mask = (1u << CLS_M2) | (x_med ? (1u << CLS_MEDIUM) : 0u) | (x_large ? (1u << CLS_LARGE) : 0u);
+        DevBuf need, tmp;
+        G4S_TRY(need.alloc(sizeof(long long) * ((size_t)M + 1)));
+        G4S_TRY(pre->off.alloc(sizeof(long long) * ((size_t)M + 1)));
+        G4S_HIP_TRY(hipMemsetAsync(need.p, 0, sizeof(long long) * ((size_t)M + 1), s));
+        hipLaunchKernelGGL(presorted_need_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, rc.cls.as<int>(), class_mask, row_flop.as<long long>(), N, need.as<long long>());
+        size_t tb = 0;
+        G4S_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, need.as<long long>(), pre->off.as<long long>(), M + 1, s));
+        G4S_TRY(tmp.alloc(tb));
+        G4S_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, need.as<long long>(), pre->off.as<long long>(), M + 1, s));
+        long long total_cols = 0;
+        G4S_HIP_TRY(hipMemcpyAsync(&total_cols, pre->off.as<long long>() + M, sizeof(long long), hipMemcpyDeviceToHost, s));
+        G4S_HIP_TRY(hipStreamSynchronize(s));
+        size_t free_b = 0, total_b = 0;
+        G4S_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        int *cols = nullptr;
+        if (total_cols > 0 && ((size_t)total_cols * sizeof(int) <= free_b / 4 || (size_t)total_cols * sizeof(int) <= g_col_cache.bytes))
+            cols = acquire_column_scratch(sizeof(int) * (size_t)total_cols);
+        if (cols) {
+            pre->holds_cache = true;
+            hipLaunchKernelGGL(presorted_mark_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, need.as<long long>(), pre->off.as<long long>());
+            G4S_HIP_TRY(hipGetLastError());
+            G4S_HIP_TRY(hipStreamSynchronize(s));                    // need / tmp die at the end of this block
+            pre->d_off = pre_off = pre->off.as<long long>();
+            pre->d_cols = pre_cols = cols;
+            if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s symbolic: %.2f GB scratch for pre-sorted columns\n", total_cols * 4 / 1e9);
+        } else {
+            G4S_HIP_TRY(hipStreamSynchronize(s));
+        }
+    }
     auto window = [&](const int *rows, int n) -> int {
         auto k = spgemm_symbolic_window_kernel;
-        const size_t lds = sizeof(unsigned) * kBigWindowWords + sizeof(int) * 4 + kLongListBytes;
+        const size_t lds = kBigLdsBytes;
         G4S_TRY(allow_lds(k, lds));
-        if (n) hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rows, n, N, K, wsplit, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz);
+        if (n) hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rows, n, N, K, wsplit, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, pre_off, pre_cols);
         return G4S_OK;
     };
     if (x_med) { G4S_TRY(window(rc.list(CLS_MEDIUM), rc.count[CLS_MEDIUM])); }
@@ -1141,11 +1273,12 @@ G4S_API g4s_status g4s_spgemm_symbolic(int32_t M, int32_t K, int32_t N,
     if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s symbolic: %d optimistic tables overflowed, %d window-class rows\n", n_ovf, rc.count[CLS_M2]);
     {
         auto k = spgemm_symbolic_window_kernel;
-        const size_t lds = sizeof(unsigned) * kBigWindowWords + sizeof(int) * 4 + kLongListBytes;
+        const size_t lds = kBigLdsBytes;
         G4S_TRY(allow_lds(k, lds));
-        if (n_ovf) hipLaunchKernelGGL(k, dim3(n_ovf), dim3(kBigThreads), lds, s, ovf_rows.as<int>(), n_ovf, N, K, wsplit, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz);
+        if (n_ovf) hipLaunchKernelGGL(k, dim3(n_ovf), dim3(kBigThreads), lds, s, ovf_rows.as<int>(), n_ovf, N, K, wsplit, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz,
+                                      (const long long *)nullptr, (int *)nullptr);   // rows of the optimistic table class are not in the scratch
         if (int n = rc.count[CLS_M2])
-            hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rc.list(CLS_M2), n, N, K, wsplit, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz);
+            hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rc.list(CLS_M2), n, N, K, wsplit, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, pre_off, pre_cols);
         G4S_HIP_TRY(hipGetLastError());
     }
     // hub rows (flop > 2 M): many workgroups per row on a bitmap in HBM
@@ -1171,16 +1304,28 @@ G4S_API g4s_status g4s_spgemm_symbolic(int32_t M, int32_t K, int32_t N,
     G4S_HIP_TRY(hipStreamSynchronize(s));
     return G4S_OK;
 }
+} // namespace
 
-G4S_API g4s_status g4s_spgemm_numeric(int32_t M, int32_t K, int32_t N,
-                                      const int32_t *arpt, const int32_t *acol, const double *aval,
-                                      const int32_t *brpt, const int32_t *bcol, const double *bval,
-                                      const int32_t *crpt, int32_t *ccol, double *cval, unsigned flags, void *stream)
+G4S_API g4s_status g4s_spgemm_symbolic(int32_t M, int32_t K, int32_t N,
+                                       const int32_t *arpt, const int32_t *acol, const int32_t *brpt, const int32_t *bcol,
+                                       int32_t *crpt, int64_t *cnnz, void *stream)
 {
+    return spgemm_symbolic_impl(M, K, N, arpt, acol, brpt, bcol, crpt, cnnz, stream, nullptr);
+}
+
+namespace {
+int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
+                        const int32_t *arpt, const int32_t *acol, const double *aval,
+                        const int32_t *brpt, const int32_t *bcol, const double *bval,
+                        const int32_t *crpt, int32_t *ccol, double *cval, unsigned flags, void *stream, const PreSorted *pre)
+{
+    const long long *pre_off = pre ? pre->d_off : nullptr;
+    const int *pre_cols = pre ? pre->d_cols : nullptr;
     (void)flags; // rows always come out sorted by column: the sorted form is the only ordering contract (hash_mult.h:530-551)
     G4S_REQUIRE(M >= 0 && N >= 0, "negative dimension");
     G4S_REQUIRE(arpt && brpt && crpt, "NULL argument");
     hipStream_t s = g4s::as_stream(stream);
+    t_stream = s;
     if (M == 0) return G4S_OK;
     // lanes per A-entry are sized from the row's average B-row length; the exact nz of the output row (known here) stands in for
     // the flop count of the symbolic phase (they differ by the row's compression ratio), which saves a pass over A
@@ -1211,7 +1356,7 @@ G4S_API g4s_status g4s_spgemm_numeric(int32_t M, int32_t K, int32_t N,
         auto k = spgemm_numeric_big_kernel;
         const size_t lds = kBigLdsBytes;
         G4S_TRY(allow_lds(k, lds));
-        if (n) hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rows, n, N, K, wsplit, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
+        if (n) hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rows, n, N, K, wsplit, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols);
         return G4S_OK;
     };
     if (int n = rc.count[CLS_MEDIUM]) {
@@ -1234,7 +1379,7 @@ G4S_API g4s_status g4s_spgemm_numeric(int32_t M, int32_t K, int32_t N,
         auto k = spgemm_numeric_big_kernel;
         const size_t lds = kBigLdsBytes;   // 128 KiB bitmap (phase 2 reuses it) + scan scratch + long-B list
         G4S_TRY(allow_lds(k, lds));
-        hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rc.list(CLS_M3), n, N, K, wsplit, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
+        hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rc.list(CLS_M3), n, N, K, wsplit, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols);
     }
     G4S_HIP_TRY(hipGetLastError());
     std::vector<int> hub, ranges;
@@ -1243,6 +1388,15 @@ G4S_API g4s_status g4s_spgemm_numeric(int32_t M, int32_t K, int32_t N,
     G4S_HIP_TRY(hipStreamSynchronize(s));
     return G4S_OK;
 }
+} // namespace
+
+G4S_API g4s_status g4s_spgemm_numeric(int32_t M, int32_t K, int32_t N,
+                                      const int32_t *arpt, const int32_t *acol, const double *aval,
+                                      const int32_t *brpt, const int32_t *bcol, const double *bval,
+                                      const int32_t *crpt, int32_t *ccol, double *cval, unsigned flags, void *stream)
+{
+    return spgemm_numeric_impl(M, K, N, arpt, acol, aval, brpt, bcol, bval, crpt, ccol, cval, flags, stream, nullptr);
+}
 
 G4S_API g4s_status g4s_spgemm_flop(int32_t M, const int32_t *arpt, const int32_t *acol, const int32_t *brpt,
                                    int64_t *flop, int64_t *row_flop, unsigned flags)
@@ -1250,6 +1404,7 @@ G4S_API g4s_status g4s_spgemm_flop(int32_t M, const int32_t *arpt, const int32_t
     G4S_REQUIRE(M >= 0 && arpt && brpt && flop, "bad argument");
     *flop = 0;
     if (M == 0) return G4S_OK;
+    t_stream = nullptr;
     DevBuf rf;
     if (flags & G4S_DEVICE_POINTERS) {
         long long *d_rf = reinterpret_cast<long long *>(row_flop);
@@ -1288,6 +1443,7 @@ G4S_API g4s_status g4s_spgemm_csr_i32_f64(const int32_t *arpt, const int32_t *ac
     g4s_timings t{};
     const auto t_total = clk::now();
     const bool dev = (flags & G4S_DEVICE_POINTERS) != 0;
+    t_stream = nullptr;                                            // the one-call form runs on the default stream
 
     // ---- create: inputs to the device (mkl_sparse_d_create_csr ×2 in the reference's timed path, mkl_mult.h:50-52)
     auto t0 = clk::now();
@@ -1316,15 +1472,22 @@ G4S_API g4s_status g4s_spgemm_csr_i32_f64(const int32_t *arpt, const int32_t *ac
     // ---- spmm: symbolic + numeric (rows come out sorted: the reference's separate `order` stage is folded in)
     t0 = clk::now();
     DevBuf d_crpt;
-    G4S_TRY(d_crpt.alloc(sizeof(int) * ((size_t)M + 1)));
+    G4S_TRY(d_crpt.alloc(sizeof(int) * ((size_t)M + 1), dev));
     int64_t cnnz = 0;
-    G4S_TRY(g4s_spgemm_symbolic(M, K, N, p_arpt, p_acol, p_brpt, p_bcol, d_crpt.as<int>(), &cnnz, nullptr));
+    const auto t_sym = clk::now();
+    PreSorted pre;
+    G4S_TRY(spgemm_symbolic_impl(M, K, N, p_arpt, p_acol, p_brpt, p_bcol, d_crpt.as<int>(), &cnnz, nullptr, &pre));
     *cnnz_out = cnnz;
     DevBuf d_ccol, d_cval;
-    G4S_TRY(d_ccol.alloc(sizeof(int) * (size_t)cnnz));
-    G4S_TRY(d_cval.alloc(sizeof(double) * (size_t)cnnz));
-    G4S_TRY(g4s_spgemm_numeric(M, K, N, p_arpt, p_acol, p_aval, p_brpt, p_bcol, p_bval, d_crpt.as<int>(), d_ccol.as<int>(), d_cval.as<double>(),
-                               flags, nullptr));
+    const double ms_sym = ms_since(t_sym);
+    const auto t_alloc = clk::now();
+    G4S_TRY(d_cval.alloc(sizeof(double) * (size_t)cnnz, dev));
+    G4S_TRY(d_ccol.alloc(sizeof(int) * (size_t)cnnz, dev));
+    const double ms_alloc = ms_since(t_alloc);
+    const auto t_num = clk::now();
+    G4S_TRY(spgemm_numeric_impl(M, K, N, p_arpt, p_acol, p_aval, p_brpt, p_bcol, p_bval, d_crpt.as<int>(), d_ccol.as<int>(), d_cval.as<double>(),
+                                flags, nullptr, &pre));
+    if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s one-call: symbolic %.1f ms, output allocation %.1f ms, numeric %.1f ms\n", ms_sym, ms_alloc, ms_since(t_num));
     t.spmm = ms_since(t0);
     t.convert = 0.0;
     t.order = 0.0;
@@ -1365,3 +1528,12 @@ extern "C" __attribute__((visibility("default"))) int g4s_debug_big_prof(unsigne
     return 0;
 }
 #endif
+
+// called by g4s_shutdown (runtime.cpp)
+namespace g4s {
+void spgemm_release_cache()
+{
+    std::lock_guard<std::mutex> lock(g_col_cache.m);
+    if (g_col_cache.p && !g_col_cache.in_use) { (void)hipFree(g_col_cache.p); g_col_cache.p = nullptr; g_col_cache.bytes = 0; }
+}
+} // namespace g4s

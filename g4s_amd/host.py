@@ -100,12 +100,52 @@ def get_flop(A, B):
     return flop.value
 
 
-def HashSpGEMM(a, b, sortOutput=True):
-    """C = A·B, two-phase (symbolic → crpt, numeric → ccol/cval) — HashSpGEMM, mm/inc/hash_mult.h:1028-1057."""
+class _LibraryBuffer:
+    """A device array the library allocated for a callee-allocated output (mkl_mult.h:90-92: outputs are allocated by the callee and
+    freed by the caller). torch views it without a copy through __cuda_array_interface__ and keeps this object alive; the memory goes
+    back through g4s_dev_free when the last view is gone."""
+
+    def __init__(self, ptr, count, typestr):
+        self._ptr, self._count, self._typestr = int(ptr or 0), int(count), typestr
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self._count,), "typestr": self._typestr, "data": (self._ptr, False), "version": 2}
+
+    def __del__(self):
+        try:
+            if self._ptr:
+                capi.load().g4s_dev_free(C.c_void_p(self._ptr))
+        except Exception:
+            pass
+
+
+def _view(ptr, count, typestr, dtype, device):
+    if count == 0:
+        if ptr:
+            capi.load().g4s_dev_free(ptr)
+        return torch.empty(0, dtype=dtype, device=device)
+    return torch.as_tensor(_LibraryBuffer(ptr.value if hasattr(ptr, "value") else ptr, count, typestr), device=device)
+
+
+def HashSpGEMM(a, b, sortOutput=True, two_phase=False):
+    """C = A·B — HashSpGEMM, mm/inc/hash_mult.h:1028-1057. One call into the library (symbolic → crpt, numeric → ccol/cval, the sorted
+    columns of the large rows carried from the first phase to the second); `two_phase=True` issues g4s_spgemm_symbolic and
+    g4s_spgemm_numeric separately into torch-owned arrays. The result's `timings` holds the library's stage times (one-call form)."""
     _require_gpu()
     assert a.cols == b.rows
     lib = capi.load()
     dev = a.rowptr.device
+    if not two_phase:
+        crpt_p, ccol_p, cval_p = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        cnnz, tm = C.c_int64(0), capi.Timings()
+        flags = capi.DEVICE_POINTERS | (capi.SORT_OUTPUT if sortOutput else 0)
+        capi.check(lib.g4s_spgemm_csr_i32_f64(_ptr(a.rowptr), _ptr(a.colids), _ptr(a.values), _ptr(b.rowptr), _ptr(b.colids), _ptr(b.values),
+                                              C.byref(crpt_p), C.byref(ccol_p), C.byref(cval_p), a.rows, a.cols, b.cols, C.byref(cnnz), C.byref(tm), flags))
+        c = CSR(_view(crpt_p, a.rows + 1, "<i4", torch.int32, dev), _view(ccol_p, cnnz.value, "<i4", torch.int32, dev),
+                _view(cval_p, cnnz.value, "<f8", torch.float64, dev), a.rows, b.cols)
+        c.timings = {n: getattr(tm, n) for n, _ in capi.Timings._fields_}
+        return c
     crpt = torch.empty(a.rows + 1, dtype=torch.int32, device=dev)
     cnnz = C.c_int64(0)
     capi.check(lib.g4s_spgemm_symbolic(a.rows, a.cols, b.cols, _ptr(a.rowptr), _ptr(a.colids), _ptr(b.rowptr), _ptr(b.colids),

@@ -59,6 +59,9 @@ void       *g4s_malloc(size_t bytes);
 void        g4s_free(void *p);
 
 /* Device buffers for callers without their own HIP code (the bench and the tests use torch tensors instead). */
+/* Device blocks of the library's caching allocator (a freed block is kept and handed out again for a request it fits within 25 %:
+ * fresh multi-GB allocations cost up to seconds on this stack; g4s_shutdown releases what is cached). g4s_dev_free synchronises the
+ * device like hipFree, and also accepts a plain hipMalloc pointer. */
 g4s_status  g4s_dev_alloc(void **dptr, size_t bytes);
 g4s_status  g4s_dev_free(void *dptr);
 g4s_status  g4s_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
