@@ -86,6 +86,15 @@ SIGNATURES = {
     "g4s_elem_op_apply": (C.c_int, [vp, vp, vp, vp]),
     "g4s_elem_op_inverse_diagonal": (C.c_int, [vp, vp, vp]),
     "g4s_conj_grad": (C.c_int, [vp, vp, C.c_int32, vp, vp, C.c_int32, vp, vp, C.c_double, C.POINTER(C.c_int32), f64p, vp]),
+    "g4s_cg_ws_create": (C.c_int, [C.POINTER(vp), C.c_int32]),
+    "g4s_cg_ws_destroy": (C.c_int, [vp]),
+    "g4s_cg_begin": (C.c_int, [vp, vp, vp, vp, vp, C.c_int32, vp]),
+    "g4s_cg_direction": (C.c_int, [vp, C.c_int32, C.c_double, vp]),
+    "g4s_cg_state": (C.c_int, [vp, i32p, i32p, f64p, vp]),
+    "g4s_cg_buffers": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+    "g4s_cg_reduce_pAp": (C.c_int, [vp, vp]),
+    "g4s_cg_update": (C.c_int, [vp, vp, vp, vp]),
+    "g4s_cg_end": (C.c_int, [vp, vp, vp, C.c_int32, vp]),
     "g4s_node_op_create": (C.c_int, [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp]),
     "g4s_node_op_destroy": (C.c_int, [vp]),
     "g4s_node_op_apply": (C.c_int, [vp, vp, vp, vp, C.c_int32, vp]),

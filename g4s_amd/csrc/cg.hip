@@ -292,3 +292,124 @@ G4S_API g4s_status g4s_conj_grad_node(g4s_node_op_t op, int32_t neq, const doubl
     MatVec mv = [op](const double *p, double *Ap, const int *done, hipStream_t s) { return g4s_node_op_apply_unless(op, p, Ap, nullptr, 0, done, s); };
     return conj_grad_impl(mv, neq, BI, zero_resid, n_zero, F, d0, acc, cycles, residual_out, stream);
 }
+
+// ------------------------------------------------------------------------------------------------ step-wise form (multi-GPU)
+// The same kernels with the loop opened up, for a row-partitioned operator: every rank holds its slab of the
+// vectors; the 256 partial sums of each dot product are all-reduced element-wise by the caller between the steps (RCCL / gloo
+// through torch.distributed — one 2 KiB or 4 KiB collective), after which every rank's kernels add the same 256 numbers in the same
+// order and reach the same α, β and verdict. The caller also owns the mat-vec (exchange p, local SpMV into Ap).
+//   begin → [all-reduce rr, rz] → direction → state (done?) → buffers: p → caller: Ap = A·p → reduce_pAp → [all-reduce pAp]
+//   → update → [all-reduce rr, rz] → direction → …  → end
+struct g4s_cg_ws_s {
+    int n = 0;
+    void *arena = nullptr;
+    double *r1 = nullptr, *r2 = nullptr, *z = nullptr, *p1 = nullptr, *p2 = nullptr, *Ap = nullptr;
+    double *part = nullptr;          // [rz | pAp | rr], kDotBlocks each
+    CgState *st = nullptr;
+    unsigned char *mask = nullptr;
+    bool use_mask = false;
+};
+
+G4S_API g4s_status g4s_cg_ws_create(g4s_cg_ws_t *out, int32_t n_local)
+{
+    G4S_REQUIRE(out && n_local > 0, "bad argument");
+    *out = nullptr;
+    auto ws = new (std::nothrow) g4s_cg_ws_s();
+    if (!ws) return g4s::set_error(G4S_ERR_NOMEM, "host allocation failed");
+    ws->n = n_local;
+    const size_t nbp = (sizeof(double) * (size_t)n_local + 255) / 256 * 256, mb = ((size_t)n_local + 255) / 256 * 256;
+    const int rc = g4s::big_alloc(&ws->arena, 6 * nbp + sizeof(double) * 3 * kDotBlocks + 256 + mb);
+    if (rc != G4S_OK) { delete ws; return rc; }
+    char *b = static_cast<char *>(ws->arena);
+    ws->r1 = reinterpret_cast<double *>(b); ws->r2 = reinterpret_cast<double *>(b + nbp); ws->z = reinterpret_cast<double *>(b + 2 * nbp);
+    ws->p1 = reinterpret_cast<double *>(b + 3 * nbp); ws->p2 = reinterpret_cast<double *>(b + 4 * nbp); ws->Ap = reinterpret_cast<double *>(b + 5 * nbp);
+    ws->part = reinterpret_cast<double *>(b + 6 * nbp);
+    ws->st = reinterpret_cast<CgState *>(ws->part + 3 * kDotBlocks);
+    ws->mask = reinterpret_cast<unsigned char *>(ws->st) + 256;
+    *out = ws;
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_cg_ws_destroy(g4s_cg_ws_t ws)
+{
+    if (ws) { (void)g4s::big_free(ws->arena); delete ws; }
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_cg_begin(g4s_cg_ws_t ws, const double *F_dev, const double *BI_dev, double *d0_dev, const int32_t *zero_resid_dev, int32_t n_zero,
+                                void *stream)
+{
+    G4S_REQUIRE(ws && F_dev && BI_dev && d0_dev, "NULL argument");
+    G4S_REQUIRE(n_zero >= 0 && (n_zero == 0 || zero_resid_dev), "zero_resid is NULL");
+    hipStream_t s = g4s::as_stream(stream);
+    G4S_HIP_TRY(hipMemsetAsync(ws->st, 0, sizeof(CgState), s));
+    ws->use_mask = n_zero > 0;
+    if (n_zero) {
+        G4S_HIP_TRY(hipMemsetAsync(ws->mask, 0, (size_t)ws->n, s));
+        hipLaunchKernelGGL(cg_mask_kernel, dim3((n_zero + kThreads - 1) / kThreads), dim3(kThreads), 0, s, n_zero, zero_resid_dev, ws->mask);
+    }
+    hipLaunchKernelGGL(cg_init_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, ws->n, F_dev, BI_dev, ws->r1, d0_dev, ws->z, ws->part + 2 * kDotBlocks, ws->part);
+    G4S_HIP_TRY(hipGetLastError());
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_cg_direction(g4s_cg_ws_t ws, int32_t steps, double acc, void *stream)
+{
+    G4S_REQUIRE(ws, "ws is NULL");
+    hipLaunchKernelGGL(cg_direction_kernel, dim3(kDotBlocks), dim3(kThreads), 0, g4s::as_stream(stream), ws->n, steps, acc, ws->part + 2 * kDotBlocks, ws->part, ws->st,
+                       ws->z, ws->p1, ws->p2);
+    G4S_HIP_TRY(hipGetLastError());
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_cg_state(g4s_cg_ws_t ws, int32_t *count, int32_t *done, double *residual, void *stream)
+{
+    G4S_REQUIRE(ws, "ws is NULL");
+    hipStream_t s = g4s::as_stream(stream);
+    CgState h{};
+    G4S_HIP_TRY(hipMemcpyAsync(&h, ws->st, sizeof(CgState), hipMemcpyDeviceToHost, s));
+    G4S_HIP_TRY(hipStreamSynchronize(s));
+    if (count) *count = h.count;
+    if (done) *done = h.done;
+    if (residual) *residual = h.residual;
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_cg_buffers(g4s_cg_ws_t ws, double **p_dev, double **Ap_dev, double **partials_dev)
+{
+    G4S_REQUIRE(ws, "ws is NULL");
+    if (p_dev) *p_dev = ws->p2;
+    if (Ap_dev) *Ap_dev = ws->Ap;
+    if (partials_dev) *partials_dev = ws->part;
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_cg_reduce_pAp(g4s_cg_ws_t ws, void *stream)
+{
+    G4S_REQUIRE(ws, "ws is NULL");
+    hipLaunchKernelGGL(cg_pAp_kernel, dim3(kDotBlocks), dim3(kThreads), 0, g4s::as_stream(stream), ws->n, ws->st, ws->use_mask ? ws->mask : nullptr, ws->p2, ws->Ap,
+                       ws->part + kDotBlocks);
+    G4S_HIP_TRY(hipGetLastError());
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_cg_update(g4s_cg_ws_t ws, const double *BI_dev, double *d0_dev, void *stream)
+{
+    G4S_REQUIRE(ws && BI_dev && d0_dev, "NULL argument");
+    hipLaunchKernelGGL(cg_update_kernel, dim3(kDotBlocks), dim3(kThreads), 0, g4s::as_stream(stream), ws->n, ws->part + kDotBlocks, ws->st, BI_dev, ws->p2, ws->Ap,
+                       ws->r1, ws->r2, d0_dev, ws->z, ws->part + 2 * kDotBlocks, ws->part);
+    G4S_HIP_TRY(hipGetLastError());
+    std::swap(ws->r1, ws->r2);      // the pointer rotation of General_matrix_functions.c:398-402
+    std::swap(ws->p1, ws->p2);
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_cg_end(g4s_cg_ws_t ws, double *d0_dev, const int32_t *zero_resid_dev, int32_t n_zero, void *stream)
+{
+    G4S_REQUIRE(ws && d0_dev, "NULL argument");
+    hipStream_t s = g4s::as_stream(stream);
+    if (n_zero) hipLaunchKernelGGL(cg_strip_kernel, dim3((n_zero + kThreads - 1) / kThreads), dim3(kThreads), 0, s, n_zero, zero_resid_dev, d0_dev);   // :409
+    G4S_HIP_TRY(hipGetLastError());
+    G4S_HIP_TRY(hipStreamSynchronize(s));
+    return G4S_OK;
+}

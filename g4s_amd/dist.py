@@ -97,3 +97,59 @@ class VectorExchange:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
         return x_full
+
+
+def _all_reduce_sum(t, group=None):
+    """Element-wise sum over the ranks, in place. RCCL reduces device tensors directly; gloo (the CPU rehearsal backend) goes through host memory."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(t, group=group)
+    else:
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+
+
+def dist_conj_grad(A_local, exchange, BI_local, F_local, zero_resid_local, acc, steps, group=None):
+    """Jacobi-CG (conj_grad, citcoms/lib/General_matrix_functions.c:307-424) on a row-partitioned operator: this rank owns the rows
+    [offsets[rank], offsets[rank+1]) of A (a host.CSR with all columns), the matching slabs of BI, F and the solution, and the local
+    indices of its boundary rows. Per iteration: one exchange of the direction vector (`exchange`, a VectorExchange), one local
+    g4s_spmv, two all-reduces of 256 partial sums. The vector kernels and the termination test are the library's
+    (g4s_cg_* step API); torch only moves bytes. Returns (d0_local, iterations, residual)."""
+    import ctypes as C
+    from . import capi, host
+    lib = capi.load()
+    n = A_local.rows
+    dev = F_local.device
+    ws = C.c_void_p()
+    capi.check(lib.g4s_cg_ws_create(C.byref(ws), n))
+    try:
+        d0 = torch.empty(n, dtype=torch.float64, device=dev)
+        zr = zero_resid_local if zero_resid_local is not None and zero_resid_local.numel() else None
+        nz = int(zr.numel()) if zr is not None else 0
+        st = host._stream()
+        capi.check(lib.g4s_cg_begin(ws, host._ptr(F_local), host._ptr(BI_local), host._ptr(d0), host._ptr(zr) if zr is not None else None, nz, st))
+        p_ptr, Ap_ptr, part_ptr = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        capi.check(lib.g4s_cg_buffers(ws, C.byref(p_ptr), C.byref(Ap_ptr), C.byref(part_ptr)))
+        part = host.view_f64(part_ptr, 768, dev)
+        p_full = torch.zeros(A_local.cols, dtype=torch.float64, device=dev)
+        count, done, residual = C.c_int32(0), C.c_int32(0), C.c_double(0.0)
+        _all_reduce_sum(part, group)                              # r·z and r·r of the start vector
+        while True:
+            capi.check(lib.g4s_cg_direction(ws, int(steps), float(acc), st))
+            capi.check(lib.g4s_cg_state(ws, C.byref(count), C.byref(done), C.byref(residual), st))
+            if done.value:
+                break
+            capi.check(lib.g4s_cg_buffers(ws, C.byref(p_ptr), C.byref(Ap_ptr), None))
+            p, Ap = host.view_f64(p_ptr, n, dev), host.view_f64(Ap_ptr, n, dev)
+            exchange(p, p_full)
+            A_local.spmv(p_full, Ap)
+            capi.check(lib.g4s_cg_reduce_pAp(ws, st))
+            _all_reduce_sum(part[256:512], group)
+            capi.check(lib.g4s_cg_update(ws, host._ptr(BI_local), host._ptr(d0), st))
+            _all_reduce_sum(part, group)                          # [0,256) r·z and [512,768) r·r; the middle third is rewritten before its next use
+        capi.check(lib.g4s_cg_end(ws, host._ptr(d0), host._ptr(zr) if zr is not None else None, nz, st))
+        return d0, count.value, residual.value
+    finally:
+        lib.g4s_cg_ws_destroy(ws)

@@ -120,6 +120,18 @@ class _LibraryBuffer:
             pass
 
 
+class _BorrowedBuffer:
+    """A device array owned by a library object (e.g. the vectors of a g4s_cg_ws_t), viewed by torch without a copy."""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def view_f64(ptr, count, device="cuda"):
+    """torch view of `count` doubles at a device pointer the caller keeps alive."""
+    return torch.as_tensor(_BorrowedBuffer(ptr.value if hasattr(ptr, "value") else ptr, count, "<f8"), device=device)
+
+
 def _view(ptr, count, typestr, dtype, device):
     if count == 0:
         if ptr:

@@ -191,6 +191,7 @@ g4s_status g4s_spmm_dense(uint32_t numNodes, uint32_t degree, const double **edg
  * to keep vectors on the device between iterations). */
 typedef struct g4s_elem_op_s *g4s_elem_op_t;
 typedef struct g4s_node_op_s *g4s_node_op_t;
+typedef struct g4s_cg_ws_s *g4s_cg_ws_t;
 /* elt_k_dev: numElems × (npe·dof)² doubles, contiguous, device memory (borrowed). ien/id host arrays as in the descriptor. */
 g4s_status g4s_elem_op_create(g4s_elem_op_t *out, int32_t numElems, int32_t nodes_per_elem, int32_t dof,
                               const int32_t *ien_host, const int32_t *id_host, int32_t nno, int32_t neq,
@@ -273,6 +274,24 @@ g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, g4s_csr_t K_csr, const double *
                                const double *area_dev, double volume, const int32_t *zero_resid_dev, int32_t n_zero, const double *F_dev,
                                double *V_dev, double *P_dev, const g4s_stokes_params *params, g4s_stokes_result *result,
                                double *hist, int32_t hist_lines, void *stream);
+
+/* ---- g4s_conj_grad with the loop opened up, for a row-partitioned operator on several GPUs (1-D row partition,
+ * all-gather / halo exchange of the direction vector, all-reduce of the dot products). Every rank holds its slab of F, BI, d0; the
+ * caller owns the mat-vec (exchange p, local g4s_spmv into Ap) and, between the steps, all-reduces (sum) the partial sums
+ * element-wise: partials[0..256) = r·z, [256..512) = p·Ap, [512..768) = r·r. Sequence:
+ *   g4s_cg_begin → all-reduce [512..768) and [0..256) → g4s_cg_direction → g4s_cg_state (done?) → g4s_cg_buffers: p → Ap = A·p →
+ *   g4s_cg_reduce_pAp → all-reduce [256..512) → g4s_cg_update → all-reduce [512..768), [0..256) → g4s_cg_direction → … → g4s_cg_end.
+ * With one rank and no all-reduce this is g4s_conj_grad step by step. zero_resid indices are local to the slab. */
+g4s_status g4s_cg_ws_create(g4s_cg_ws_t *out, int32_t n_local);
+g4s_status g4s_cg_ws_destroy(g4s_cg_ws_t ws);
+g4s_status g4s_cg_begin(g4s_cg_ws_t ws, const double *F_dev, const double *BI_dev, double *d0_dev, const int32_t *zero_resid_dev, int32_t n_zero,
+                        void *stream);
+g4s_status g4s_cg_direction(g4s_cg_ws_t ws, int32_t steps, double acc, void *stream);   /* loop test + β + p (conj_grad :364-379) */
+g4s_status g4s_cg_state(g4s_cg_ws_t ws, int32_t *count, int32_t *done, double *residual, void *stream);   /* synchronises */
+g4s_status g4s_cg_buffers(g4s_cg_ws_t ws, double **p_dev, double **Ap_dev, double **partials_dev);        /* valid until the next g4s_cg_update */
+g4s_status g4s_cg_reduce_pAp(g4s_cg_ws_t ws, void *stream);                              /* boundary rows of Ap := 0, partial p·Ap */
+g4s_status g4s_cg_update(g4s_cg_ws_t ws, const double *BI_dev, double *d0_dev, void *stream);   /* α, d0, r, z (:383-402) */
+g4s_status g4s_cg_end(g4s_cg_ws_t ws, double *d0_dev, const int32_t *zero_resid_dev, int32_t n_zero, void *stream);   /* d0 boundary rows := 0 (:409) */
 
 /* result[M×K] = xx[M×N] · w[N×K], row-major fp64, device pointers (opt_matmul.cc:24-62). */
 g4s_status g4s_dense_rows_times_matrix(int32_t M, int32_t N, int32_t K, const double *xx_dev, const double *w_dev,

@@ -1,0 +1,80 @@
+"""Multi-rank Jacobi-CG on a row-partitioned assembled stiffness matrix (BASELINE config 5 "1 vs 8 GPUs"): 2 and 3
+ranks share this box's GPU and talk through gloo (the collectives are what is being rehearsed; RCCL takes their place on a multi-GPU
+node). Every rank runs g4s_amd.dist.dist_conj_grad on its slab; the stacked solution must match the single-rank oracle CG."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests.helpers import assemble_csr, hex_mesh, spd_blocks
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem():
+    ien, idmap, nno, neq = hex_mesh(12, 10, 6)
+    K = spd_blocks(len(ien), 24, 11)
+    rng = np.random.default_rng(11)
+    bc = np.array(sorted(set(idmap[rng.choice(nno, nno // 9, replace=False)].ravel().tolist())), np.int32)
+    F = rng.uniform(-1, 1, neq)
+    F[bc] = 0.0
+    return ien, idmap, nno, neq, K, bc, F
+
+
+def _worker(rank, world, port, mode, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from g4s_amd import dist as gdist, host
+    ien, idmap, nno, neq, K, bc, F = _problem()
+    rp, ci, va = assemble_csr(ien, idmap, K, neq)
+    diag = np.zeros(neq)
+    for r in range(neq):
+        k = np.searchsorted(ci[rp[r]:rp[r + 1]], r)
+        diag[r] = va[rp[r] + k]
+    rpt = torch.from_numpy(rp).cuda()
+    offs = gdist.row_partition(rpt, world)
+    r0, r1 = offs[rank], offs[rank + 1]
+    lrp, lci, lva = gdist.slice_rows(rpt, torch.from_numpy(ci).cuda(), torch.from_numpy(va).cuda(), r0, r1)
+    A = host.CSR(lrp, lci, lva, r1 - r0, neq)
+    ex = gdist.VectorExchange(offs, rank, world, colids=lci, mode=mode)
+    bcl = torch.from_numpy((bc[(bc >= r0) & (bc < r1)] - r0).astype(np.int32)).cuda()
+    BI = torch.from_numpy(1.0 / diag[r0:r1]).cuda()
+    Fl = torch.from_numpy(F[r0:r1]).cuda()
+    acc = 1e-8 * float(np.linalg.norm(F))
+    d0, its, res = gdist.dist_conj_grad(A, ex, BI, Fl, bcl, acc, 250)
+    np.save(os.path.join(out_dir, f"d{rank}.npy"), d0.cpu().numpy())
+    np.save(os.path.join(out_dir, f"m{rank}.npy"), np.array([r0, r1, its, res, acc]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(1, "allgatherv"), (2, "needed"), (3, "allgatherv")])
+def test_dist_conj_grad_matches_oracle(tmp_path, oracle, world, mode):
+    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
+    ien, idmap, nno, neq, K, bc, F = _problem()
+    BI = oracle.element_inverse_diagonal(ien, idmap, K, neq)
+    acc = 1e-8 * float(np.linalg.norm(F))
+    d_or, cyc_or, res_or, _ = oracle.conj_grad_elem(ien, idmap, K, neq, BI, bc, F, acc, 250)
+    metas = [np.load(tmp_path / f"m{r}.npy") for r in range(world)]
+    got = np.concatenate([np.load(tmp_path / f"d{r}.npy") for r in range(world)])
+    assert metas[0][0] == 0 and metas[-1][1] == neq
+    its = {int(m[2]) for m in metas}
+    assert len(its) == 1, "every rank must stop at the same iteration"
+    assert abs(its.pop() - cyc_or) <= 1
+    assert all(m[3] <= m[4] for m in metas)
+    assert np.all(got[bc] == 0.0)
+    assert np.allclose(got, d_or, rtol=1e-6, atol=1e-7 * np.abs(d_or).max())
