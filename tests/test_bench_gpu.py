@@ -1,0 +1,53 @@
+"""bench.py end to end on the GPU box: the single-rank JSON contract, and the N > 1 path (row partition, per-step exchange,
+max-over-ranks timing) rehearsed with two ranks sharing the box's one GPU over gloo — exactly the launch line the driver uses for
+N > 1, with `--backend gloo` in place of RCCL. Reduced sizes (`--small`): these are plumbing checks, not measurements."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_rank_contract():
+    r = subprocess.run([sys.executable, "bench.py", "--small", "--steps", "5", "--warmup", "2", "--path", "blocked"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1.5 and d["roofline"]["unit"] == "GB/s"
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    assert d["config"]["spmv_path"] == "blocked" and "model" not in d["config"]
+
+
+@pytest.mark.parametrize("workload,exchange", [("rmat", "allgatherv"), ("lap7", "needed")])
+def test_bench_two_ranks_rehearsal(workload, exchange):
+    env = dict(os.environ, G4S_BENCH_SAME_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_port()),
+           "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--small", "--backend", "gloo", "--workload", workload, "--exchange", exchange,
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["scaling"] == "strong"
+    assert "2 rank(s)" in d["config"]["partition"] and exchange in d["config"]["exchange"]
