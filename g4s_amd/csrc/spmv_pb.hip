@@ -574,8 +574,14 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
                        P->masks.as<unsigned char>(), P->mbase.as<int>(), P->c_lrow.as<unsigned short>());
     G4S_HIP_TRY(hipGetLastError());
     // 5. work items, heaviest first (the tail of each launch is then made of light bands)
-    const int kPC = (std::max(kSpan * kPbThreads, (getenv("G4S_PB_PCHUNK") ? atoi(getenv("G4S_PB_PCHUNK")) : kProducerChunk)) / kWindow) * (kWindow / kSpan);   // spans per item, whole windows
-    const int kCC = std::max(4, (getenv("G4S_PB_CCHUNK") ? atoi(getenv("G4S_PB_CCHUNK")) : kConsumerChunk) & ~3);
+    // Work-item sizes follow the matrix: the full C2 matrix runs best at 128 K entries / 128 K micro-runs per item (sweeps in
+    // profiles/README.md); a row slab of it (the per-rank matrix of the multi-GPU bench, an eighth of the nonzeros) would then have
+    // ~90 heavy producer items and ~20–80 consumer items for 256 CUs, and measured 20–25 % faster at 32 K / 16 K.
+    auto pow2_at_most = [](long long v) { long long p = 1; while (p * 2 <= v) p *= 2; return p; };
+    const long long auto_pc = std::min<long long>(kProducerChunk, std::max<long long>(32768, pow2_at_most(totP / 512)));
+    const long long auto_cc = std::min<long long>(kConsumerChunk, std::max<long long>(16384, pow2_at_most(P->micro_runs / 256)));
+    const int kPC = (std::max<long long>(kSpan * kPbThreads, getenv("G4S_PB_PCHUNK") ? atoll(getenv("G4S_PB_PCHUNK")) : auto_pc) / kWindow) * (kWindow / kSpan);   // spans per item, whole windows
+    const int kCC = (int)std::max<long long>(4, (getenv("G4S_PB_CCHUNK") ? atoll(getenv("G4S_PB_CCHUNK")) : auto_cc) & ~3ll);
     std::vector<ProducerItem> pit;
     for (int c = 0; c < CB; ++c) {
         const int s0 = padP[(size_t)c * RB] / kSpan, s1 = padP[(size_t)(c + 1) * RB] / kSpan;
