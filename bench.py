@@ -7,7 +7,7 @@ are split by equal work (the rule of mm/inc/BIN.h:101-122), every rank owns its 
 {exchange x over RCCL/xGMI, local SpMV} — total work is fixed, so scaling is "strong". Inputs are resident in HBM before
 the timed region. Prints ONE JSON line (rank 0).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload rmat|banded|lap5|lap7] [--exchange allgatherv|needed]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload rmat|banded|lap5|lap7] [--exchange auto|allgatherv|needed|compact]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -92,7 +92,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="rmat", choices=sorted(WORKLOADS))
-    ap.add_argument("--exchange", default="allgatherv", choices=["allgatherv", "needed"])
+    ap.add_argument("--exchange", default="auto", choices=["auto", "allgatherv", "needed", "compact"],
+                    help="auto: compact (only the referenced entries of x travel, columns renumbered) for rmat, needed (halo ranges) otherwise")
     ap.add_argument("--small", action="store_true", help="reduced sizes for plumbing checks (not a valid benchmark)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nt", action="store_true", help="plain loads for the matrix stream (A/B against nontemporal)")
@@ -129,17 +130,26 @@ def main():
     offs = gdist.row_partition(A_full.rowptr, world)
     r0, r1 = offs[rank], offs[rank + 1]
     flags = (capi.SPMV_NO_NT if args.no_nt else 0) | {"auto": 0, "stream": capi.SPMV_STREAM, "blocked": capi.SPMV_BLOCKED}[args.path]
+    mode = args.exchange if args.exchange != "auto" else ("compact" if args.workload == "rmat" else "needed")
     if world > 1:
         rp, ci, va = gdist.slice_rows(A_full.rowptr, A_full.colids, A_full.values, r0, r1)
-        A = host.CSR(rp, ci, va, r1 - r0, n_cols, spmv_flags=flags)
         del A_full
         torch.cuda.empty_cache()
+        if mode == "compact":
+            exchange = gdist.CompactExchange(offs, rank, world, ci)
+            A = host.CSR(rp, exchange.local_colids, va, r1 - r0, exchange.n_ref, spmv_flags=flags)
+            x_cols = exchange.n_ref
+        else:
+            A = host.CSR(rp, ci, va, r1 - r0, n_cols, spmv_flags=flags)
+            exchange = gdist.VectorExchange(offs, rank, world, colids=A.colids, mode=mode)
+            x_cols = n_cols
     else:
         A = host.CSR(A_full.rowptr, A_full.colids, A_full.values, n_rows, n_cols, spmv_flags=flags)
+        exchange = gdist.VectorExchange(offs, rank, world, colids=A.colids, mode="allgatherv")
+        x_cols = n_cols
     x_local = host.synth_vector(7, r1 - r0, i0=r0)
-    x_full = torch.zeros(n_cols, dtype=torch.float64, device="cuda")
+    x_full = torch.zeros(x_cols, dtype=torch.float64, device="cuda")
     y_local = torch.empty(r1 - r0, dtype=torch.float64, device="cuda")
-    exchange = gdist.VectorExchange(offs, rank, world, colids=A.colids, mode=args.exchange)
     exchange(x_local, x_full)
     info = A.info()
 
@@ -207,7 +217,7 @@ def main():
         "config": {"workload": WORKLOADS[args.workload] + (" [--small: NOT the benchmark size]" if args.small else ""),
                    "rows": n_rows, "cols": n_cols, "nnz": nnz_total, "index": "int32",
                    "partition": f"1-D rows by equal nnz+rows over {world} rank(s)",
-                   "exchange": ("none (single GPU)" if world == 1 else f"{args.exchange} over RCCL, {exchange.recv_bytes} B received per rank 0 step"),
+                   "exchange": ("none (single GPU)" if world == 1 else f"{mode} over RCCL, {exchange.recv_bytes} B received per rank 0 step"),
                    "matrix_loads": "plain" if args.no_nt else "nontemporal",
                    "spmv_path": "blocked" if info["spmv_path"] == 1 else "stream",
                    **({"backend": "gloo (rehearsal, not a valid multi-GPU number)"} if args.backend != "nccl" else {})},

@@ -643,7 +643,7 @@ int pb_spmv(PbPlan *P, const double *x, double *y, double alpha, double beta, hi
 bool pb_should_use(int rows, int cols, long long nnz, const int *d_colids)
 {
     (void)rows;
-    if ((long long)cols * 8 < (32ll << 20) || nnz < (4ll << 20)) return false;
+    if ((long long)cols * 8 < (8ll << 20) || nnz < (4ll << 20)) return false;   // x within ~2 L2s: the gathers mostly hit (a 15 MB x still ran 2.3× faster blocked)
     const int W = 2048, S = 64;
     std::vector<int> h(W);
     double ratio = 0.0;

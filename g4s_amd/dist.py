@@ -99,6 +99,74 @@ class VectorExchange:
         return x_full
 
 
+class CompactExchange:
+    """Exchange for matrices without column locality (power-law graphs): a rank's rows reference only part of every peer's slab,
+    scattered all over it, so the slab's columns are renumbered 0 … n_ref−1 in ascending global order (`local_colids`, to build the
+    local CSR with `cols = n_ref`) and only the referenced entries travel: every owner gathers the entries a peer asked for at set-up
+    (`x_local[give_idx]`) and sends them packed; they land in the contiguous segment of `x_compact` that belongs to that owner — no
+    scatter on the receiving side. Against the whole-slab all-gather this moves n_ref·8 bytes per rank instead of cols·8, and the local
+    product stages n_ref/16 K column bands of x instead of cols/16 K.
+
+    offsets: the row partition (rank k owns x[offsets[k]:offsets[k+1]]); colids: the global column ids of this rank's rows."""
+
+    def __init__(self, offsets, rank, world, colids, group=None):
+        self.offsets, self.rank, self.world, self.group = list(offsets), rank, world, group
+        dev = colids.device
+        ref = torch.unique(colids.long())                                        # sorted referenced columns
+        self.n_ref = int(ref.numel())
+        self.local_colids = torch.bucketize(colids.long(), ref).to(torch.int32)   # position of every entry's column in ref
+        bounds = torch.searchsorted(ref, torch.tensor(self.offsets, dtype=torch.int64, device=dev)).tolist()
+        self.seg = [(bounds[k], bounds[k + 1]) for k in range(world)]            # segment of x_compact owned by rank k
+        want_idx = [(ref[lo:hi] - self.offsets[k]).contiguous() for k, (lo, hi) in enumerate(self.seg)]   # local indices at the owner
+        self.own_idx = want_idx[rank]
+        self.give_idx = [None] * world
+        if world > 1:
+            nccl = dist.get_backend(group) == "nccl"
+            cdev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
+            mine = torch.tensor([w.numel() for w in want_idx], dtype=torch.int64, device=cdev)
+            allw = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allw, mine, group=group)
+            give_count = [int(allw[k][rank].item()) for k in range(world)]
+            ops, keep = [], []
+            for k in range(world):
+                if k == rank:
+                    continue
+                if want_idx[k].numel():
+                    buf = want_idx[k].to(cdev)
+                    keep.append(buf)
+                    ops.append(dist.P2POp(dist.isend, buf, k, group=group))
+                if give_count[k]:
+                    self.give_idx[k] = torch.empty(give_count[k], dtype=torch.int64, device=cdev)
+                    ops.append(dist.P2POp(dist.irecv, self.give_idx[k], k, group=group))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            self.give_idx = [g.to(dev) if g is not None else None for g in self.give_idx]
+        self.recv_bytes = sum(8 * (hi - lo) for k, (lo, hi) in enumerate(self.seg) if k != rank)
+        self._send = [torch.empty(g.numel(), dtype=torch.float64, device=dev) if g is not None else None for g in self.give_idx]
+
+    def __call__(self, x_local, x_compact):
+        lo, hi = self.seg[self.rank]
+        if hi > lo:
+            torch.index_select(x_local, 0, self.own_idx, out=x_compact[lo:hi])
+        if self.world == 1:
+            return x_compact
+        ops = []
+        for k in range(self.world):
+            if k == self.rank:
+                continue
+            if self.give_idx[k] is not None:
+                torch.index_select(x_local, 0, self.give_idx[k], out=self._send[k])
+                ops.append(dist.P2POp(dist.isend, self._send[k], k, group=self.group))
+            lo, hi = self.seg[k]
+            if hi > lo:
+                ops.append(dist.P2POp(dist.irecv, x_compact[lo:hi], k, group=self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return x_compact
+
+
 def _all_reduce_sum(t, group=None):
     """Element-wise sum over the ranks, in place. RCCL reduces device tensors directly; gloo (the CPU rehearsal backend) goes through host memory."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:

@@ -49,8 +49,12 @@ def _worker(rank, world, port, mode, out_dir):
     offs = gdist.row_partition(rpt, world)
     r0, r1 = offs[rank], offs[rank + 1]
     lrp, lci, lva = gdist.slice_rows(rpt, torch.from_numpy(ci).cuda(), torch.from_numpy(va).cuda(), r0, r1)
-    A = host.CSR(lrp, lci, lva, r1 - r0, neq)
-    ex = gdist.VectorExchange(offs, rank, world, colids=lci, mode=mode)
+    if mode == "compact":
+        ex = gdist.CompactExchange(offs, rank, world, lci)
+        A = host.CSR(lrp, ex.local_colids, lva, r1 - r0, ex.n_ref)
+    else:
+        A = host.CSR(lrp, lci, lva, r1 - r0, neq)
+        ex = gdist.VectorExchange(offs, rank, world, colids=lci, mode=mode)
     bcl = torch.from_numpy((bc[(bc >= r0) & (bc < r1)] - r0).astype(np.int32)).cuda()
     BI = torch.from_numpy(1.0 / diag[r0:r1]).cuda()
     Fl = torch.from_numpy(F[r0:r1]).cuda()
@@ -62,7 +66,7 @@ def _worker(rank, world, port, mode, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(1, "allgatherv"), (2, "needed"), (3, "allgatherv")])
+@pytest.mark.parametrize("world,mode", [(1, "allgatherv"), (2, "needed"), (3, "allgatherv"), (3, "compact")])
 def test_dist_conj_grad_matches_oracle(tmp_path, oracle, world, mode):
     mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
     ien, idmap, nno, neq, K, bc, F = _problem()

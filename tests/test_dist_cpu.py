@@ -76,3 +76,44 @@ def test_row_partition_balances_work():
     shares = [work[offs[i]:offs[i + 1]].sum() for i in range(4)]
     assert offs[0] == 0 and offs[-1] == 5000
     assert max(shares) <= sum(shares) / 4 + work.max()     # no part exceeds the average by more than one row's work
+
+
+def _compact_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from g4s_amd import dist as gdist
+    from tests import oracle_lib
+    o = oracle_lib.load()
+    rp, ci, va = power_law_csr(4000, 4000, 9, 1200)
+    n = len(rp) - 1
+    rpt, cit, vat = torch.from_numpy(rp), torch.from_numpy(ci), torch.from_numpy(va)
+    offs = gdist.row_partition(rpt, world)
+    r0, r1 = offs[rank], offs[rank + 1]
+    lrp, lci, lva = gdist.slice_rows(rpt, cit, vat, r0, r1)
+    ex = gdist.CompactExchange(offs, rank, world, lci)
+    assert ex.n_ref == len(np.unique(lci.numpy())) and int(ex.local_colids.max()) < ex.n_ref
+    x = torch.from_numpy(o.vector(7, n))
+    xc = torch.full((ex.n_ref,), float("nan"), dtype=torch.float64)
+    for _ in range(2):                                             # twice: the send buffers are reused
+        ex(x[r0:r1].clone(), xc)
+    assert not torch.isnan(xc).any()
+    y_local = o.spmv(lrp.numpy(), ex.local_colids.numpy(), lva.numpy(), xc.numpy())
+    np.save(os.path.join(out_dir, f"y{rank}.npy"), y_local)
+    np.save(os.path.join(out_dir, f"meta{rank}.npy"), np.array([r0, r1, ex.recv_bytes, ex.n_ref]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_compact_exchange_matches_single(tmp_path, oracle, world):
+    """Columns renumbered per rank, only the referenced entries of x travel: same per-row arithmetic → bit-identical product."""
+    mp.spawn(_compact_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    rp, ci, va = power_law_csr(4000, 4000, 9, 1200)
+    want = oracle.spmv(rp, ci, va, oracle.vector(7, 4000))
+    got = np.concatenate([np.load(tmp_path / f"y{r}.npy") for r in range(world)])
+    assert np.array_equal(got, want)
+    metas = [np.load(tmp_path / f"meta{r}.npy") for r in range(world)]
+    assert all(m[3] <= 4000 for m in metas)
+    if world > 1:
+        assert all(m[2] < 8 * 4000 for m in metas)                 # fewer bytes than the whole-slab all-gather

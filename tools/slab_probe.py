@@ -4,7 +4,7 @@ exchange is not included). Usage: python tools/slab_probe.py [N=8]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from g4s_amd import dist as gdist, host
+from g4s_amd import capi, dist as gdist, host
 import bench
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 A = bench.build_matrix("rmat", host, False)
@@ -24,5 +24,16 @@ for r in range(N):
     rp, ci, va = gdist.slice_rows(A.rowptr, A.colids, A.values, a, b)
     S = host.CSR(rp, ci, va, b - a, A.cols)
     ms = t(S, torch.empty(b - a, dtype=torch.float64, device="cuda"))
-    print(f"slab {r}: rows {b - a:9d} nnz {S.nnz:10d} path {S.info()['spmv_path']} {ms:.4f} ms  ({full / N / ms:.2f} of ideal)")
-    del S
+    # the same slab with its columns renumbered to the referenced ones only (g4s_amd.dist.CompactExchange)
+    ref = torch.unique(ci.long())
+    lc = torch.bucketize(ci.long(), ref).to(torch.int32)
+    Sc = host.CSR(rp, lc, va, b - a, int(ref.numel()), spmv_flags=(capi.SPMV_BLOCKED if os.environ.get('SLAB_FORCE_BLOCKED') else 0))
+    xc = x[ref]
+    for _ in range(5): Sc.spmv(xc, ybuf := torch.empty(b - a, dtype=torch.float64, device="cuda"))
+    e0.record()
+    for _ in range(50): Sc.spmv(xc, ybuf)
+    e1.record(); torch.cuda.synchronize()
+    msc = e0.elapsed_time(e1) / 50
+    print(f"slab {r}: rows {b - a:9d} nnz {S.nnz:10d} path {S.info()['spmv_path']} {ms:.4f} ms ({full / N / ms:.2f} of ideal) | compact columns: {ref.numel():8d} of {A.cols} "
+          f"referenced, path {Sc.info()['spmv_path']} {msc:.4f} ms ({full / N / msc:.2f} of ideal), exchange {8 * ref.numel() / 1e6:.0f} MB instead of {8 * A.cols / 1e6:.0f} MB")
+    del S, Sc
