@@ -37,6 +37,13 @@ def slice_rows(rowptr, colids, values, r0, r1):
     return rp, colids[k0:k1].contiguous(), values[k0:k1].contiguous()
 
 
+def _gloo_on_device(t, group=None):
+    """gloo moves device tensors from its own host threads with no regard for the HIP stream that produced them (the rehearsal set-up:
+    several ranks on one GPU). Kernels that wrote the send buffers must have finished before the sends are posted; RCCL is
+    stream-ordered and needs nothing."""
+    return t.is_cuda and dist.is_initialized() and dist.get_backend(group) != "nccl"
+
+
 class VectorExchange:
     """Brings the x entries this rank's rows reference into a full-length local buffer.
 
@@ -94,6 +101,8 @@ class VectorExchange:
             if hi > lo:
                 ops.append(dist.P2POp(dist.irecv, x_full[lo:hi], k, group=self.group))
         if ops:
+            if _gloo_on_device(x_local, self.group):
+                torch.cuda.synchronize()
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
         return x_full
@@ -143,7 +152,14 @@ class CompactExchange:
                     w.wait()
             self.give_idx = [g.to(dev) if g is not None else None for g in self.give_idx]
         self.recv_bytes = sum(8 * (hi - lo) for k, (lo, hi) in enumerate(self.seg) if k != rank)
-        self._send = [torch.empty(g.numel(), dtype=torch.float64, device=dev) if g is not None else None for g in self.give_idx]
+        # one gather per step fills the send buffer of every peer: peer k's packed entries are _send_all[_cut[k]:_cut[k+1]]
+        sizes = [g.numel() if g is not None else 0 for g in self.give_idx]
+        self._cut = [0]
+        for n in sizes:
+            self._cut.append(self._cut[-1] + n)
+        parts = [g for g in self.give_idx if g is not None]
+        self._give_all = torch.cat(parts) if parts else torch.empty(0, dtype=torch.int64, device=dev)
+        self._send_all = torch.empty(self._cut[-1], dtype=torch.float64, device=dev)
 
     def __call__(self, x_local, x_compact):
         lo, hi = self.seg[self.rank]
@@ -151,17 +167,20 @@ class CompactExchange:
             torch.index_select(x_local, 0, self.own_idx, out=x_compact[lo:hi])
         if self.world == 1:
             return x_compact
+        if self._cut[-1]:
+            torch.index_select(x_local, 0, self._give_all, out=self._send_all)
         ops = []
         for k in range(self.world):
             if k == self.rank:
                 continue
-            if self.give_idx[k] is not None:
-                torch.index_select(x_local, 0, self.give_idx[k], out=self._send[k])
-                ops.append(dist.P2POp(dist.isend, self._send[k], k, group=self.group))
+            if self._cut[k + 1] > self._cut[k]:
+                ops.append(dist.P2POp(dist.isend, self._send_all[self._cut[k]:self._cut[k + 1]], k, group=self.group))
             lo, hi = self.seg[k]
             if hi > lo:
                 ops.append(dist.P2POp(dist.irecv, x_compact[lo:hi], k, group=self.group))
         if ops:
+            if _gloo_on_device(x_local, self.group):
+                torch.cuda.synchronize()
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
         return x_compact
