@@ -1092,6 +1092,7 @@ namespace {
 // window kernel whose product bound lies in (1 K, 128 K] — the rows the numeric big-row kernel will take — also write their distinct
 // columns, in order, to cols[off[row] …] (off[row] = −1 for every other row); the big-row kernel then skips its own mark-and-emit
 // phase for them. The scratch is sized by the bound Σ min(flop_i, N), so it is only used while that fits comfortably in free HBM.
+constexpr long long kPresortMinFlop = 1024;   // rows with fewer products cannot reach the numeric big-row class (nz > 1 K)
 struct PreSorted {
     DevBuf off;                  // long long off[M]
     const long long *d_off = nullptr;
@@ -1131,12 +1132,12 @@ void release_column_scratch()
 PreSorted::~PreSorted() { if (holds_cache) release_column_scratch(); }
 
 __global__ void presorted_need_kernel(int M, const int *__restrict__ cls, unsigned class_mask, const long long *__restrict__ row_flop, int N,
-                                      long long *__restrict__ need)
+                                      long long min_flop, long long *__restrict__ need)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const long long f = row_flop[i];
-    const bool take = ((class_mask >> cls[i]) & 1u) && f > 1024 && f <= G4S_SPGEMM_BIG_LIMIT;
+    const bool take = ((class_mask >> cls[i]) & 1u) && f > min_flop && f <= G4S_SPGEMM_BIG_LIMIT;
     need[i] = take ? (f < N ? f : (long long)N) : 0;
 }
 __global__ void presorted_mark_kernel(int M, const long long *__restrict__ need, long long *__restrict__ off)
@@ -1219,7 +1220,8 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
         G4S_TRY(need.alloc(sizeof(long long) * ((size_t)M + 1)));
         G4S_TRY(pre->off.alloc(sizeof(long long) * ((size_t)M + 1)));
         G4S_HIP_TRY(hipMemsetAsync(need.p, 0, sizeof(long long) * ((size_t)M + 1), s));
-        hipLaunchKernelGGL(presorted_need_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, rc.cls.as<int>(), class_mask, row_flop.as<long long>(), N, need.as<long long>());
+        const long long min_flop = getenv("G4S_SPGEMM_PRESORT_MIN") ? atoll(getenv("G4S_SPGEMM_PRESORT_MIN")) : kPresortMinFlop;
+        hipLaunchKernelGGL(presorted_need_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, rc.cls.as<int>(), class_mask, row_flop.as<long long>(), N, min_flop, need.as<long long>());
         size_t tb = 0;
         G4S_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, need.as<long long>(), pre->off.as<long long>(), M + 1, s));
         G4S_TRY(tmp.alloc(tb));
