@@ -33,3 +33,30 @@ def test_vector_laplacian_banded_match_oracle(oracle):
         A = host.banded_csr(n, hb, 99)
         for got, want in zip(A.to_host(), oracle.banded(n, hb, 99)):
             assert np.array_equal(got, want)
+
+
+def test_device_allocator_round_trip():
+    """g4s_dev_alloc / g4s_dev_free: blocks come from the library's caching allocator — a freed block is handed out again for a
+    request it fits within 25 %, a much smaller request gets its own block, a plain hipMalloc pointer (torch's) is not ours to cache,
+    g4s_shutdown drops what is cached, and the memory is usable from torch while it is owned."""
+    import ctypes as C
+    from g4s_amd import capi, host
+    lib = capi.load()
+    a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    n = 64 << 20
+    capi.check(lib.g4s_dev_alloc(C.byref(a), n))
+    t = host.view_f64(a, n // 8)
+    t.fill_(3.0)
+    assert float(t.sum().item()) == 3.0 * (n // 8)
+    del t
+    capi.check(lib.g4s_dev_free(a))
+    capi.check(lib.g4s_dev_alloc(C.byref(b), n - 4096))            # fits the cached block
+    assert b.value == a.value
+    capi.check(lib.g4s_dev_alloc(C.byref(c), 1 << 20))             # far smaller: a block of its own
+    assert c.value not in (0, b.value)
+    capi.check(lib.g4s_dev_free(b))
+    capi.check(lib.g4s_dev_free(c))
+    capi.check(lib.g4s_dev_free(None))
+    capi.check(lib.g4s_shutdown())
+    capi.check(lib.g4s_dev_alloc(C.byref(a), 4096))                # the library keeps working after a shutdown
+    capi.check(lib.g4s_dev_free(a))
