@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="rmat", choices=sorted(WORKLOADS))
-    ap.add_argument("--exchange", default="auto", choices=["auto", "allgatherv", "needed", "compact"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "allgatherv", "allgather", "needed", "compact"],
                     help="auto: compact (only the referenced entries of x travel, columns renumbered) for rmat, needed (halo ranges) otherwise")
     ap.add_argument("--small", action="store_true", help="reduced sizes for plumbing checks (not a valid benchmark)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -136,7 +136,21 @@ def main():
         del A_full
         torch.cuda.empty_cache()
         if mode == "compact":
-            exchange = gdist.CompactExchange(offs, rank, world, ci)
+            # The point-to-point set-up of the compact exchange is the one piece of this file that cannot be rehearsed over RCCL on a
+            # one-GPU box: if it raises, every rank (they agree through an all-reduce) falls back to the single padded all-gather.
+            ok = torch.ones(1, device="cuda")
+            try:
+                exchange = gdist.CompactExchange(offs, rank, world, ci)
+                probe = torch.zeros(exchange.n_ref, dtype=torch.float64, device="cuda")
+                exchange(host.synth_vector(7, r1 - r0, i0=r0), probe)
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench rank {rank}] compact exchange failed ({type(e).__name__}: {e}); falling back to --exchange allgather", file=sys.stderr, flush=True)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() < 1:
+                mode = "allgather"
+        if mode == "compact":
             A = host.CSR(rp, exchange.local_colids, va, r1 - r0, exchange.n_ref, spmv_flags=flags)
             x_cols = exchange.n_ref
         else:

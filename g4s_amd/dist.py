@@ -48,8 +48,9 @@ class VectorExchange:
     """Brings the x entries this rank's rows reference into a full-length local buffer.
 
     offsets: the row partition (rank k owns x[offsets[k]:offsets[k+1]]).
-    mode "allgatherv": receive every peer's whole slab. mode "needed": receive, from each peer, only the contiguous
-    range [lo,hi) of its slab that local columns touch (empty ranges are skipped)."""
+    mode "allgatherv": receive every peer's whole slab (grouped send/recv, exact sizes). mode "allgather": the same data through one
+    padded all_gather_into_tensor. mode "needed": receive, from each peer, only the contiguous range [lo,hi) of its slab that local
+    columns touch (empty ranges are skipped)."""
 
     def __init__(self, offsets, rank, world, colids=None, mode="allgatherv", group=None):
         self.offsets, self.rank, self.world, self.group = list(offsets), rank, world, group
@@ -85,10 +86,25 @@ class VectorExchange:
         self.recv_bytes = sum(8 * (hi - lo) for k, (lo, hi) in enumerate(self.want) if k != rank)
 
     def __call__(self, x_local, x_full):
-        """x_full[own slab] = x_local, and the wanted ranges of the peers' slabs arrive by grouped send/recv."""
+        """x_full[own slab] = x_local, and the wanted ranges of the peers' slabs arrive by grouped send/recv (mode "allgather": one
+        all_gather_into_tensor of slabs padded to the longest one, then one copy per slab — a single collective, no point-to-point)."""
         r0, r1 = self.offsets[self.rank], self.offsets[self.rank + 1]
         x_full[r0:r1].copy_(x_local)
         if self.world == 1:
+            return x_full
+        if self.mode == "allgather":
+            longest = max(self.offsets[k + 1] - self.offsets[k] for k in range(self.world))
+            if getattr(self, "_pad", None) is None or self._pad.numel() != longest or self._pad.device != x_local.device:
+                self._pad = torch.zeros(longest, dtype=x_local.dtype, device=x_local.device)
+                self._all = torch.empty(longest * self.world, dtype=x_local.dtype, device=x_local.device)
+            self._pad[:r1 - r0].copy_(x_local)
+            if _gloo_on_device(x_local, self.group):
+                torch.cuda.synchronize()
+            dist.all_gather_into_tensor(self._all, self._pad, group=self.group)
+            for k in range(self.world):
+                if k != self.rank:
+                    lo, hi = self.offsets[k], self.offsets[k + 1]
+                    x_full[lo:hi].copy_(self._all[k * longest:k * longest + hi - lo])
             return x_full
         ops = []
         for k in range(self.world):

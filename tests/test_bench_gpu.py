@@ -40,7 +40,7 @@ def test_bench_single_rank_contract():
     assert d["config"]["spmv_path"] == "blocked" and "model" not in d["config"]
 
 
-@pytest.mark.parametrize("workload,exchange", [("rmat", "allgatherv"), ("rmat", "compact"), ("lap7", "needed")])
+@pytest.mark.parametrize("workload,exchange", [("rmat", "allgatherv"), ("rmat", "compact"), ("rmat", "allgather"), ("lap7", "needed")])
 def test_bench_two_ranks_rehearsal(workload, exchange):
     env = dict(os.environ, G4S_BENCH_SAME_DEVICE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_port()),

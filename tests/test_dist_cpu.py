@@ -49,7 +49,7 @@ def _worker(rank, world, port, mode, kind, out_dir):
 
 
 @pytest.mark.parametrize("world,mode,kind", [(2, "allgatherv", "powerlaw"), (2, "needed", "lap7"), (3, "needed", "powerlaw"),
-                                             (3, "allgatherv", "lap7")])
+                                             (3, "allgatherv", "lap7"), (3, "allgather", "powerlaw")])
 def test_partitioned_spmv_matches_single(tmp_path, oracle, world, mode, kind):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, mode, kind, str(tmp_path)), nprocs=world, join=True)
