@@ -233,13 +233,13 @@ def main():
                    "partition": f"1-D rows by equal nnz+rows over {world} rank(s)",
                    "exchange": ("none (single GPU)" if world == 1 else f"{mode} over RCCL, {exchange.recv_bytes} B received per rank 0 step"),
                    "matrix_loads": "plain" if args.no_nt else "nontemporal",
-                   "spmv_path": "blocked" if info["spmv_path"] == 1 else "stream",
+                   "spmv_path": {0: "stream", 1: "blocked", 2: "blocked (tile-blocked experiment)"}[info["spmv_path"]],
                    **({"backend": "gloo (rehearsal, not a valid multi-GPU number)"} if args.backend != "nccl" else {})},
         "hbm_gbs_algorithmic_whole_job": round((12 * nnz_total + 4 * (n_rows + 1) + 8 * n_rows + 8 * n_cols) * args.steps / elapsed / 1e9, 2),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": ("pb_prepare_kernel+pb_producer_kernel+pb_consumer_kernel (propagation-blocked SpMV)" if info["spmv_path"] == 1
-                                else "spmv_csr_adaptive_kernel"), "kernel_ms": round(kernel_ms, 5),
+                     "kernel": {0: "spmv_csr_adaptive_kernel", 1: "pb_prepare_kernel+pb_producer_kernel+pb_consumer_kernel (propagation-blocked SpMV)",
+                                2: "tb_prepare_kernel+tb_cold_kernel+tb_tile_kernel (tile-blocked SpMV)"}[info["spmv_path"]], "kernel_ms": round(kernel_ms, 5),
                      "algorithmic_bytes_per_launch": info["algorithmic_bytes"],
                      "launch_rows": info["rows"], "launch_nnz": info["nnz"]},
     }
