@@ -60,6 +60,7 @@ SIGNATURES = {
     "g4s_set_device": (C.c_int, [C.c_int]),
     "g4s_device_synchronize": (C.c_int, []),
     "g4s_shutdown": (C.c_int, []),
+    "g4s_trim": (C.c_int, []),
     "g4s_malloc": (vp, [C.c_size_t]),
     "g4s_free": (None, [vp]),
     "g4s_dev_alloc": (C.c_int, [C.POINTER(vp), C.c_size_t]),

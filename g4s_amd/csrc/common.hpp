@@ -27,6 +27,8 @@ void spgemm_release_cache();   // spgemm.hip
 int big_alloc(void **p, size_t bytes);
 bool big_free(void *p);
 void big_release_all();
+void release_cached_device_memory();   // big_release_all + the SpGEMM column scratch (what g4s_trim does)
+hipError_t device_malloc(void **p, size_t bytes);   // hipMalloc that drops the library's caches and retries once on out-of-memory
 
 // 8 XCDs, each with its own L2: block b and b+8 share one (MI355X_MICROARCH.md, Workgroup dispatch).
 constexpr int kXcds = 8;

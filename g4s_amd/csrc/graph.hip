@@ -31,7 +31,7 @@ struct DevBuf {
     {
         if (p && n <= bytes) return G4S_OK;
         if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
-        hipError_t e = hipMalloc(&p, n ? n : 1);
+        hipError_t e = g4s::device_malloc(&p, n);
         if (e != hipSuccess) return g4s::set_error(e == hipErrorOutOfMemory ? G4S_ERR_NOMEM : G4S_ERR_HIP, "hipMalloc(%zu): %s", n, hipGetErrorString(e));
         bytes = n;
         return G4S_OK;

@@ -21,7 +21,7 @@ struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
     int alloc(size_t n)
     {
-        hipError_t e = hipMalloc(&p, n ? n : 1);
+        hipError_t e = g4s::device_malloc(&p, n);
         if (e != hipSuccess) return g4s::set_error(e == hipErrorOutOfMemory ? G4S_ERR_NOMEM : G4S_ERR_HIP, "hipMalloc(%zu): %s", n, hipGetErrorString(e));
         return G4S_OK;
     }

@@ -64,14 +64,30 @@ void scratch_free(void *p, hipStream_t s)
 // 4.1 s for the same 15.5 GB request one call apart), so freed blocks are kept in a small free list and handed out again when a
 // request fits one within 25 % (what a caching allocator does). big_free synchronises the device first, as hipFree would.
 namespace {
-struct BigBlock { void *p; size_t bytes; };
+struct BigBlock { void *p; size_t bytes; int device; };
 std::mutex g_big_mutex;
-std::unordered_map<void *, size_t> g_big_live;
+std::unordered_map<void *, BigBlock> g_big_live;
 std::vector<BigBlock> g_big_cache;
+size_t g_big_cached_bytes = 0;
+// Cached (freed, kept) blocks are bounded by count and by bytes: G4S_CACHE_MAX_BYTES, default 48 GiB of the 288 GB — enough for the
+// outputs of the largest SpGEMM the int32 index type allows (cval 16 GB + ccol 8 GB + column scratch 8 GB) to be recycled call after call.
+size_t big_cache_limit()
+{
+    static const size_t lim = [] { const char *e = getenv("G4S_CACHE_MAX_BYTES"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)48 << 30; }();
+    return lim;
+}
+int current_device()
+{
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d;
+}
+// hipFree needs the owning device current only for the synchronisation it implies; the pointer itself identifies the allocation
 void big_drop_cache_locked()
 {
     for (auto &b : g_big_cache) (void)hipFree(b.p);
     g_big_cache.clear();
+    g_big_cached_bytes = 0;
 }
 } // namespace
 
@@ -79,46 +95,55 @@ int big_alloc(void **p, size_t bytes)
 {
     *p = nullptr;
     if (bytes == 0) bytes = 1;
+    const int dev = current_device();
     {
         std::lock_guard<std::mutex> lock(g_big_mutex);
         int best = -1;
         for (int i = 0; i < (int)g_big_cache.size(); ++i)
-            if (g_big_cache[i].bytes >= bytes && g_big_cache[i].bytes - bytes <= bytes / 4 && (best < 0 || g_big_cache[i].bytes < g_big_cache[best].bytes)) best = i;
+            if (g_big_cache[i].device == dev && g_big_cache[i].bytes >= bytes && g_big_cache[i].bytes - bytes <= bytes / 4 &&
+                (best < 0 || g_big_cache[i].bytes < g_big_cache[best].bytes))
+                best = i;
         if (best >= 0) {
             *p = g_big_cache[best].p;
-            g_big_live[*p] = g_big_cache[best].bytes;
+            g_big_live[*p] = g_big_cache[best];
+            g_big_cached_bytes -= g_big_cache[best].bytes;
             g_big_cache.erase(g_big_cache.begin() + best);
             return G4S_OK;
         }
     }
     hipError_t e = hipMalloc(p, bytes);
-    if (e == hipErrorOutOfMemory) {                                // give the cached blocks back and try once more
+    if (e == hipErrorOutOfMemory) {                                // give the cached blocks (and the SpGEMM column scratch) back and try once more
         (void)hipGetLastError();
-        { std::lock_guard<std::mutex> lock(g_big_mutex); big_drop_cache_locked(); }
+        release_cached_device_memory();
         e = hipMalloc(p, bytes);
     }
     if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return set_error(G4S_ERR_NOMEM, "device allocation of %zu bytes: out of memory", bytes); }
     G4S_HIP_TRY(e);
     std::lock_guard<std::mutex> lock(g_big_mutex);
-    g_big_live[*p] = bytes;
+    g_big_live[*p] = BigBlock{*p, bytes, dev};
     return G4S_OK;
 }
 
 bool big_free(void *p)
 {
     if (!p) return true;
-    size_t bytes = 0;
+    BigBlock blk{};
     {
         std::lock_guard<std::mutex> lock(g_big_mutex);
         auto it = g_big_live.find(p);
         if (it == g_big_live.end()) return false;
-        bytes = it->second;
+        blk = it->second;
         g_big_live.erase(it);
     }
-    (void)hipDeviceSynchronize();                                  // nothing in flight may still touch the block when it is handed out again
+    // nothing in flight may still touch the block when it is handed out again: synchronise the device that OWNS it
+    const int cur = current_device();
+    if (cur != blk.device) (void)hipSetDevice(blk.device);
+    (void)hipDeviceSynchronize();
+    if (cur != blk.device) (void)hipSetDevice(cur);
     std::lock_guard<std::mutex> lock(g_big_mutex);
-    if (g_big_cache.size() >= 8) { (void)hipFree(p); return true; }
-    g_big_cache.push_back(BigBlock{p, bytes});
+    if (g_big_cache.size() >= 8 || g_big_cached_bytes + blk.bytes > big_cache_limit()) { (void)hipFree(p); return true; }
+    g_big_cache.push_back(blk);
+    g_big_cached_bytes += blk.bytes;
     return true;
 }
 
@@ -126,6 +151,25 @@ void big_release_all()
 {
     std::lock_guard<std::mutex> lock(g_big_mutex);
     big_drop_cache_locked();
+}
+
+void release_cached_device_memory()
+{
+    spgemm_release_cache();
+    big_release_all();
+}
+
+// hipMalloc for the library's own plans and workspaces: on out-of-memory the caches above are dropped and the request repeated, so a
+// plan build right after a large SpGEMM does not fail while tens of GB sit in the free list.
+hipError_t device_malloc(void **p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes ? bytes : 1);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        release_cached_device_memory();
+        e = hipMalloc(p, bytes ? bytes : 1);
+    }
+    return e;
 }
 
 int scratch_shutdown()
@@ -161,10 +205,15 @@ G4S_API g4s_status g4s_device_synchronize(void)
     return G4S_OK;
 }
 
+G4S_API g4s_status g4s_trim(void)
+{
+    g4s::release_cached_device_memory();
+    return G4S_OK;
+}
+
 G4S_API g4s_status g4s_shutdown(void)
 {
-    g4s::spgemm_release_cache();
-    g4s::big_release_all();
+    g4s::release_cached_device_memory();
     return g4s::scratch_shutdown();
 }
 

@@ -242,15 +242,15 @@ int build_plan(g4s_csr_s *A, const int32_t *rowptr)
     A->chunks_pad = (A->n_chunks + g4s::kXcds - 1) / g4s::kXcds * g4s::kXcds;
     A->n_long = (int)lrows.size();
     if (A->n_stream) {
-        G4S_HIP_TRY(hipMalloc((void **)&A->d_blocks, sizeof(int4) * blocks.size()));
+        G4S_HIP_TRY(g4s::device_malloc((void **)&A->d_blocks, sizeof(int4) * blocks.size()));
         G4S_HIP_TRY(hipMemcpy(A->d_blocks, blocks.data(), sizeof(int4) * blocks.size(), hipMemcpyHostToDevice));
     }
     if (A->n_chunks) {
-        G4S_HIP_TRY(hipMalloc((void **)&A->d_chunks, sizeof(LongChunk) * chunks.size()));
+        G4S_HIP_TRY(g4s::device_malloc((void **)&A->d_chunks, sizeof(LongChunk) * chunks.size()));
         G4S_HIP_TRY(hipMemcpy(A->d_chunks, chunks.data(), sizeof(LongChunk) * chunks.size(), hipMemcpyHostToDevice));
-        G4S_HIP_TRY(hipMalloc((void **)&A->d_long_rows, sizeof(LongRow) * lrows.size()));
+        G4S_HIP_TRY(g4s::device_malloc((void **)&A->d_long_rows, sizeof(LongRow) * lrows.size()));
         G4S_HIP_TRY(hipMemcpy(A->d_long_rows, lrows.data(), sizeof(LongRow) * lrows.size(), hipMemcpyHostToDevice));
-        G4S_HIP_TRY(hipMalloc((void **)&A->d_partials, sizeof(double) * chunks.size()));
+        G4S_HIP_TRY(g4s::device_malloc((void **)&A->d_partials, sizeof(double) * chunks.size()));
     }
     A->plan_bytes = (int64_t)(sizeof(int4) * blocks.size() + sizeof(LongChunk) * chunks.size() +
                               sizeof(LongRow) * lrows.size() + sizeof(double) * chunks.size());
@@ -308,11 +308,11 @@ G4S_API g4s_status g4s_csr_create(g4s_csr_t *out, int32_t rows, int32_t cols, in
     } else {
         A->owns = true;
         void *p = nullptr;
-        if (hipMalloc(&p, sizeof(int32_t) * ((size_t)rows + 1)) != hipSuccess) return fail(g4s::set_error(G4S_ERR_NOMEM, "hipMalloc rowptr"));
+        if (g4s::device_malloc(&p, sizeof(int32_t) * ((size_t)rows + 1)) != hipSuccess) return fail(g4s::set_error(G4S_ERR_NOMEM, "hipMalloc rowptr"));
         A->d_rowptr = (const int32_t *)p;
-        if (hipMalloc(&p, sizeof(int32_t) * (size_t)(nnz ? nnz : 1)) != hipSuccess) return fail(g4s::set_error(G4S_ERR_NOMEM, "hipMalloc colids"));
+        if (g4s::device_malloc(&p, sizeof(int32_t) * (size_t)(nnz ? nnz : 1)) != hipSuccess) return fail(g4s::set_error(G4S_ERR_NOMEM, "hipMalloc colids"));
         A->d_colids = (const int32_t *)p;
-        if (hipMalloc(&p, sizeof(double) * (size_t)(nnz ? nnz : 1)) != hipSuccess) return fail(g4s::set_error(G4S_ERR_NOMEM, "hipMalloc values"));
+        if (g4s::device_malloc(&p, sizeof(double) * (size_t)(nnz ? nnz : 1)) != hipSuccess) return fail(g4s::set_error(G4S_ERR_NOMEM, "hipMalloc values"));
         A->d_values = (const double *)p;
         if (hipMemcpy((void *)A->d_rowptr, rowptr, sizeof(int32_t) * ((size_t)rows + 1), hipMemcpyHostToDevice) != hipSuccess ||
             (nnz && hipMemcpy((void *)A->d_colids, colids, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice) != hipSuccess) ||
@@ -435,8 +435,8 @@ G4S_API g4s_status g4s_spmv_csr_i32_f64(int32_t rows, int32_t cols, const int32_
         if (st == G4S_OK && hipStreamSynchronize(nullptr) != hipSuccess) st = g4s::set_error(G4S_ERR_HIP, "synchronize failed");
     } else {
         double *dx = nullptr, *dy = nullptr;
-        if (hipMalloc((void **)&dx, sizeof(double) * (size_t)(cols ? cols : 1)) != hipSuccess ||
-            hipMalloc((void **)&dy, sizeof(double) * (size_t)rows) != hipSuccess) {
+        if (g4s::device_malloc((void **)&dx, sizeof(double) * (size_t)(cols ? cols : 1)) != hipSuccess ||
+            g4s::device_malloc((void **)&dy, sizeof(double) * (size_t)rows) != hipSuccess) {
             st = g4s::set_error(G4S_ERR_NOMEM, "hipMalloc of x/y failed");
         } else if ((cols && hipMemcpy(dx, x, sizeof(double) * (size_t)cols, hipMemcpyHostToDevice) != hipSuccess) ||
                    (beta != 0.0 && hipMemcpy(dy, y, sizeof(double) * (size_t)rows, hipMemcpyHostToDevice) != hipSuccess)) {

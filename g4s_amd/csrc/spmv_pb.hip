@@ -64,7 +64,7 @@ struct DevBuf {
     int alloc(size_t n)
     {
         if (p) { (void)hipFree(p); p = nullptr; }
-        hipError_t e = hipMalloc(&p, n ? n : 1);
+        hipError_t e = g4s::device_malloc(&p, n);
         if (e != hipSuccess) return set_error(e == hipErrorOutOfMemory ? G4S_ERR_NOMEM : G4S_ERR_HIP, "hipMalloc(%zu): %s", n, hipGetErrorString(e));
         bytes = n;
         return G4S_OK;
@@ -362,27 +362,27 @@ __global__ __launch_bounds__(kPbThreads) void pb_consumer_kernel(const ConsumerI
         }
 #pragma unroll
         for (int u = 0; u < kPbUnroll; ++u) {
-            if (base + u * 4 * kPbThreads < it.k1) {
-                double p[4] = {pa[u][0], pa[u][1], pb[u][0], pb[u][1]};
-                // Consecutive slots of one row (a hub row cut into many micro-runs inside a hot cell) would hit one LDS address from
-                // every lane of the wave, and ds_add_f64 serialises same-address lanes. Equal neighbours are summed in registers
-                // first; a wave whose 256 slots all belong to one row reduces across lanes and issues a single atomic.
-                const unsigned r0_ = lr[u][0], r3_ = lr[u][3];
-                const bool lane_uniform = r0_ == r3_ && lr[u][1] == r0_ && lr[u][2] == r0_;
-                const unsigned first_row = (unsigned)__builtin_amdgcn_readfirstlane((int)r0_);
-                if (__all(lane_uniform && r0_ == first_row)) {
-                    double t = (p[0] + p[1]) + (p[2] + p[3]);
+            const bool active = base + u * 4 * kPbThreads < it.k1;     // varies per lane in the tail wave of a band: the cross-lane part below runs
+                                                                        // for the whole wave, lanes past the end contribute zeros
+            double p[4] = {pa[u][0], pa[u][1], pb[u][0], pb[u][1]};
+            // Consecutive slots of one row (a hub row cut into many micro-runs inside a hot cell) would hit one LDS address from
+            // every lane of the wave, and ds_add_f64 serialises same-address lanes. Equal neighbours are summed in registers
+            // first; a wave whose 256 slots all belong to one row reduces across lanes and issues a single atomic.
+            const unsigned r0_ = lr[u][0], r3_ = lr[u][3];
+            const bool lane_uniform = r0_ == r3_ && lr[u][1] == r0_ && lr[u][2] == r0_;
+            const unsigned first_row = (unsigned)__builtin_amdgcn_readfirstlane((int)r0_);
+            if (__all(active && lane_uniform && r0_ == first_row)) {     // wave-uniform branch, every lane active: the shuffles read live registers
+                double t = (p[0] + p[1]) + (p[2] + p[3]);
 #pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-                    if ((threadIdx.x & 63) == 0) atomicAdd(&ys[first_row], t);
-                } else {
+                for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+                if ((threadIdx.x & 63) == 0) atomicAdd(&ys[first_row], t);
+            } else if (active) {
 #pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        if (lr[u][j] == lr[u][j + 1]) { p[j + 1] += p[j]; p[j] = 0.0; }
+                for (int j = 0; j < 3; ++j)
+                    if (lr[u][j] == lr[u][j + 1]) { p[j + 1] += p[j]; p[j] = 0.0; }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (p[j] != 0.0) atomicAdd(&ys[lr[u][j]], p[j]);
-                }
+                for (int j = 0; j < 4; ++j)
+                    if (p[j] != 0.0) atomicAdd(&ys[lr[u][j]], p[j]);
             }
         }
         if (more) {

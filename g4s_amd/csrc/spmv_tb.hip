@@ -63,7 +63,7 @@ struct TbBuf {
     int alloc(size_t n)
     {
         if (p) { (void)hipFree(p); p = nullptr; }
-        hipError_t e = hipMalloc(&p, n ? n : 1);
+        hipError_t e = g4s::device_malloc(&p, n);
         if (e != hipSuccess) return set_error(e == hipErrorOutOfMemory ? G4S_ERR_NOMEM : G4S_ERR_HIP, "hipMalloc(%zu): %s", n, hipGetErrorString(e));
         bytes = n;
         return G4S_OK;

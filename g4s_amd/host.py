@@ -56,6 +56,8 @@ class CSR:
         if self._handle is None:
             lib = capi.load()
             h = C.c_void_p()
+            # g4s_csr_create reads the borrowed arrays on the NULL stream: whatever torch stream filled them must be complete first
+            torch.cuda.current_stream().synchronize()
             capi.check(lib.g4s_csr_create(C.byref(h), self.rows, self.cols, self.nnz, _ptr(self.rowptr), _ptr(self.colids),
                                           _ptr(self.values), capi.DEVICE_POINTERS | self._spmv_flags))
             self._handle = h

@@ -51,6 +51,8 @@ g4s_status  g4s_device_count(int *count);
 g4s_status  g4s_set_device(int device);           /* also honours HIP_VISIBLE_DEVICES                      */
 g4s_status  g4s_device_synchronize(void);
 g4s_status  g4s_shutdown(void);                   /* releases cached workspaces                            */
+g4s_status  g4s_trim(void);                       /* returns the library's cached device blocks (freed SpGEMM outputs, column scratch) to the
+                                                    * driver; for host frameworks whose own allocator is about to need the memory            */
 
 /* Allocator that matches every callee-allocated output of this library (the reference pairs
  * my_malloc/my_free, mm/inc/utility.h:126-153; CSR::make_empty frees what mkl()/HashSpGEMM allocated,
@@ -90,8 +92,13 @@ typedef struct g4s_csr_info {
  * with G4S_DEVICE_POINTERS they are borrowed and must outlive the handle. Replaces the container role of
  * CSR<int,double> (mm/inc/CSR.h:22-113) for device residency.
  * The handle is a SNAPSHOT of the matrix: the execution plan (and, on the blocked path, a regrouped copy of the values) is
- * built here; changing the arrays afterwards requires a new handle. One g4s_spmv at a time per handle (the blocked path owns a
- * product buffer); different handles are independent. */
+ * built here; changing the arrays afterwards requires a new handle.
+ * Concurrency: a handle supports ONE product in flight at a time — g4s_spmv uses per-handle workspaces (the partial sums of split long
+ * rows on the streaming path, the product buffer and the gathered hot columns on the blocked path), so two g4s_spmv calls on the same
+ * handle must be ordered (same stream, or an event between them); different handles are independent.
+ * Stream order of create: g4s_csr_create reads the arrays and builds the plan on the NULL (legacy default) stream and returns after it
+ * has synchronised; with G4S_DEVICE_POINTERS the arrays must be complete with respect to that stream — a caller that filled them on a
+ * non-blocking stream synchronises it first. */
 g4s_status g4s_csr_create(g4s_csr_t *out, int32_t rows, int32_t cols, int64_t nnz,
                           const int32_t *rowptr, const int32_t *colids, const double *values, unsigned flags);
 g4s_status g4s_csr_destroy(g4s_csr_t A);
@@ -209,7 +216,8 @@ g4s_status g4s_elem_op_inverse_diagonal(g4s_elem_op_t op, double *BI_dev, void *
 /* Device-resident Jacobi-preconditioned conjugate gradient with the update order of conj_grad
  * (citcoms/lib/General_matrix_functions.c:307-424): d0 = 0, r = F; loop while (residual > acc && count < *cycles) || count == 0;
  * the mat-vec is g4s_elem_op_apply followed by zeroing the boundary rows (assemble_del2_u(..., strip_bcs = 1), the list of
- * citcoms/lib/BC_util.c:89-102). All vectors stay in HBM; one 8-byte D2H per iteration carries the residual to the host loop.
+ * citcoms/lib/BC_util.c:89-102). All vectors stay in HBM and the loop test runs on the device: the host enqueues iterations in batches and
+ * reads 40 bytes of state per batch.
  * *cycles: in = iteration cap (vlowstep), out = iterations done. zero_resid_dev may be NULL when n_zero == 0.
  * Exactly one of op / A selects the operator (element-by-element or assembled CSR). */
 g4s_status g4s_conj_grad(g4s_elem_op_t op, g4s_csr_t A, int32_t neq, const double *BI_dev, const int32_t *zero_resid_dev, int32_t n_zero,

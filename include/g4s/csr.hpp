@@ -35,15 +35,40 @@ struct Timings : g4s_timings {
     {
         create /= x; spmm /= x; convert /= x; order /= x; export_csr /= x; destroy /= x; total /= x;
     }
-    // Stage table in the layout of Timings::print (mm/src/Timings.cpp:36-60): ms, share of total, GFLOPS = flop/1e9/t.
-    void print(double flop) const
+    // Timings::print, byte for byte (mm/src/Timings.cpp:36-60). The reference keeps seconds and prints 1000·t; g4s_timings holds
+    // milliseconds, so t below is field/1000. Called with total_flop = 2·flop (mm/src/mkl_spgemm.cpp:82). Percentages are of `total`,
+    // the wall time around the whole call, not of the sum of the stages; perf lines divide flop/1e9 by seconds (inf for a zero stage,
+    // as in the reference).
+    bool measure_separate = true, measure_total = true;   // mm/inc/Timings.h:6-7
+    void print(double total_flop) const
     {
-        const double sum = create + spmm + convert + order + export_csr + destroy;
-        auto line = [&](const char *name, double v) { std::printf("%-12s %12.4f ms  %6.2f %%\n", name, v, sum > 0 ? 100.0 * v / sum : 0.0); };
-        line("create", create); line("spmm", spmm); line("convert", convert); line("order", order);
-        line("export_csr", export_csr); line("destroy", destroy);
-        std::printf("%-12s %12.4f ms\n", "total", total);
-        std::printf("GFLOPS(spmm) %10.4f   GFLOPS(total) %10.4f\n", spmm > 0 ? flop / 1e6 / spmm : 0.0, total > 0 ? flop / 1e6 / total : 0.0);
+        const double total_flop_G = total_flop / 1000000000;
+        std::printf("total flop %lf\n", total_flop);
+        const double c = create / 1000, s = spmm / 1000, v = convert / 1000, o = order / 1000, e = export_csr / 1000, d = destroy / 1000, t = total / 1000;
+        const double sum_total = c + s + v + o + e + d;
+        if (measure_separate) {
+            std::printf("time(ms):\n");
+            std::printf("    create             %8.3lfms %6.2lf%%\n", 1000 * c, c / t * 100);
+            std::printf("    spmm               %8.3lfms %6.2lf%%\n", 1000 * s, s / t * 100);
+            std::printf("    convert            %8.3lfms %6.2lf%%\n", 1000 * v, v / t * 100);
+            std::printf("    order              %8.3lfms %6.2lf%%\n", 1000 * o, o / t * 100);
+            std::printf("    export_csr         %8.3lfms %6.2lf%%\n", 1000 * e, e / t * 100);
+            std::printf("    destroy            %8.3lfms %6.2lf%%\n", 1000 * d, d / t * 100);
+            std::printf("    sum_total          %8.3lfms %6.2lf%%\n", 1000 * sum_total, sum_total / t * 100);
+            std::printf("perf(Gflops):\n");
+            std::printf("    create             %6.2lf\n", total_flop_G / c);
+            std::printf("    spmm               %6.2lf\n", total_flop_G / s);
+            std::printf("    convert            %6.2lf\n", total_flop_G / v);
+            std::printf("    order              %6.2lf\n", total_flop_G / o);
+            std::printf("    export_csr         %6.2lf\n", total_flop_G / e);
+            std::printf("    destroy            %6.2lf\n", total_flop_G / d);
+            std::printf("    total              %6.2lf\n", total_flop_G / t);
+        }
+    }
+    void reg_print(double total_flop) const                // mm/src/Timings.cpp:62-65
+    {
+        const double total_flop_G = total_flop / 1000000000;
+        std::printf("%le\n", total_flop_G / (total / 1000));
     }
 };
 

@@ -227,6 +227,139 @@ ORACLE_API void oracle_spgemm_numeric(int32_t M, int32_t N, const int32_t *arpt,
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * Two more SpGEMM algorithms of the reference, restated as independent CPU cross-checks of the hash oracle above (SURVEY.md §8 a11:
+ * "no GPU version needed") — never called by any main() of the reference, used here only by tests/test_oracle_cpu.py.
+ *
+ * (1) Outer-product SpGEMM — OuterSpGEMM / OuterSpGEMM_stage, mm/inc/outer_mult.h:271-542: for every inner index idx, every entry
+ *     A(i, idx) of A's COLUMN idx meets every entry B(idx, k) of B's ROW idx (:316-330) and emits the triple (i, k, a·b); the triples
+ *     are binned by blocks of rows (nrows_per_blocker :281, the two memcpy-staged passes :316-414 only regroup them), sorted by
+ *     (row, col) (doRadixSort :420-431), equal keys merged by summation (doMerge :434-449) and compacted into CSR (:470-488).
+ *     Restated single-threaded: triples generated in ascending idx, a stable counting sort by row block and a stable LSD radix sort by
+ *     (row, col) inside a block keep, for equal keys, the generation order — so every c_ik is summed in ascending idx, which is also
+ *     the order of the row-wise hash loop above (A's row entries ascend in column): values come out bit-identical to it.
+ * (2) Heap SpGEMM — HeapSpGEMM, mm/inc/heap_mult.h:47-223: written for CSC (C's column i = k-way merge of the columns of A selected by
+ *     B's column i, a heap keyed by row id: initial heap :133-143, pop / accumulate-if-same-key / refill :146-171). The reference's
+ *     CSR data run through it with the operands swapped (Cᵀ = Bᵀ·Aᵀ); restated directly in CSR: C's row i = k-way merge of the rows of
+ *     B selected by A's row i, heap keyed by column id. Rows come out sorted by column. Equal keys are added in pop order, which for
+ *     ties depends on the heap's shape: values agree with the hash oracle to rounding, index arrays exactly.
+ * Both return nnz(C); two-call protocol: crpt is always written (M+1 entries), ccol/cval only when non-NULL. */
+typedef struct { int32_t r, c; double v; } otriple;
+
+ORACLE_API int64_t oracle_spgemm_outer(int32_t M, int32_t K, int32_t N, const int32_t *arpt, const int32_t *acol, const double *aval,
+                                       const int32_t *brpt, const int32_t *bcol, const double *bval, int32_t nblockers,
+                                       int32_t *crpt, int32_t *ccol, double *cval)
+{
+    /* A as CSC (the reference takes a CSC<IT,NT> A): column pointers by counting, entries of a column in ascending row */
+    int64_t annz = arpt[M];
+    int32_t *cptr = (int32_t *)calloc((size_t)K + 2, sizeof(int32_t));
+    int32_t *crow = (int32_t *)malloc(sizeof(int32_t) * (size_t)(annz > 0 ? annz : 1));
+    double *cvalA = (double *)malloc(sizeof(double) * (size_t)(annz > 0 ? annz : 1));
+    for (int64_t k = 0; k < annz; ++k) cptr[acol[k] + 2]++;
+    for (int32_t j = 0; j < K; ++j) cptr[j + 2] += cptr[j + 1];
+    for (int32_t i = 0; i < M; ++i)
+        for (int32_t k = arpt[i]; k < arpt[i + 1]; ++k) { int32_t p = cptr[acol[k] + 1]++; crow[p] = i; cvalA[p] = aval[k]; }
+    /* now column j of A is [cptr[j], cptr[j+1]) */
+    int64_t flop = 0;
+    for (int32_t j = 0; j < K; ++j) flop += (int64_t)(cptr[j + 1] - cptr[j]) * (brpt[j + 1] - brpt[j]);
+    otriple *t = (otriple *)malloc(sizeof(otriple) * (size_t)(flop > 0 ? flop : 1)), *u = (otriple *)malloc(sizeof(otriple) * (size_t)(flop > 0 ? flop : 1));
+    int64_t n = 0;
+    for (int32_t idx = 0; idx < K; ++idx)                                   /* outer_mult.h:316-330 */
+        for (int32_t j = cptr[idx]; j < cptr[idx + 1]; ++j)
+            for (int32_t k = brpt[idx]; k < brpt[idx + 1]; ++k) { t[n].r = crow[j]; t[n].c = bcol[k]; t[n].v = cvalA[j] * bval[k]; n++; }
+    /* row blocks (:281): a stable counting sort by block, then inside the whole array a stable LSD radix sort on the fused key would do
+     * the same; the block pass is kept because it is the algorithm's structure */
+    if (nblockers < 1) nblockers = 1;
+    int32_t per = M <= nblockers * 64 ? 64 : (M + nblockers - 1) / nblockers;
+    int32_t nb = (M + per - 1) / per + 1;
+    int64_t *bstart = (int64_t *)calloc((size_t)nb + 1, sizeof(int64_t));
+    for (int64_t i = 0; i < n; ++i) bstart[t[i].r / per + 1]++;
+    for (int32_t b = 0; b < nb; ++b) bstart[b + 1] += bstart[b];
+    { int64_t *pos = (int64_t *)malloc(sizeof(int64_t) * ((size_t)nb + 1)); memcpy(pos, bstart, sizeof(int64_t) * ((size_t)nb + 1));
+      for (int64_t i = 0; i < n; ++i) u[pos[t[i].r / per]++] = t[i];
+      free(pos); }
+    /* stable LSD radix sort of every block by (row, col), 8 bits a pass: col bytes first, then row bytes */
+    for (int32_t b = 0; b < nb; ++b) {
+        otriple *src = u + bstart[b], *dst = t + bstart[b];
+        int64_t m = bstart[b + 1] - bstart[b];
+        if (m <= 1) { if (m == 1) dst[0] = src[0]; continue; }
+        for (int pass = 0; pass < 8; ++pass) {
+            int64_t cnt[257] = {0};
+            for (int64_t i = 0; i < m; ++i) { uint32_t key = pass < 4 ? (uint32_t)src[i].c : (uint32_t)src[i].r; cnt[((key >> (8 * (pass & 3))) & 255u) + 1]++; }
+            for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
+            for (int64_t i = 0; i < m; ++i) { uint32_t key = pass < 4 ? (uint32_t)src[i].c : (uint32_t)src[i].r; dst[cnt[(key >> (8 * (pass & 3))) & 255u]++] = src[i]; }
+            otriple *sw = src; src = dst; dst = sw;
+        }
+        /* 8 passes: the sorted block is back in `src` == u + bstart[b]; copy to t for the merge below */
+        memcpy(t + bstart[b], u + bstart[b], sizeof(otriple) * (size_t)m);
+    }
+    /* merge equal keys (doMerge :434-449) and compact into CSR (:470-488) */
+    for (int32_t i = 0; i <= M; ++i) crpt[i] = 0;
+    int64_t out = 0;
+    for (int64_t i = 0; i < n;) {
+        int64_t j = i;
+        double sum = t[i].v;
+        for (j = i + 1; j < n && t[j].r == t[i].r && t[j].c == t[i].c; ++j) sum = sum + t[j].v;
+        crpt[t[i].r + 1]++;
+        if (ccol) { ccol[out] = t[i].c; cval[out] = sum; }
+        out++;
+        i = j;
+    }
+    for (int32_t i = 0; i < M; ++i) crpt[i + 1] += crpt[i];
+    free(bstart); free(t); free(u); free(cptr); free(crow); free(cvalA);
+    (void)N;
+    return out;
+}
+
+typedef struct { int32_t key, runr, loc; double value; } hentry;
+static void heap_sift_down(hentry *h, int32_t n, int32_t i)
+{
+    for (;;) {
+        int32_t l = 2 * i + 1, r = l + 1, m = i;
+        if (l < n && h[l].key < h[m].key) m = l;
+        if (r < n && h[r].key < h[m].key) m = r;
+        if (m == i) return;
+        hentry x = h[i]; h[i] = h[m]; h[m] = x;
+        i = m;
+    }
+}
+
+ORACLE_API int64_t oracle_spgemm_heap(int32_t M, int32_t N, const int32_t *arpt, const int32_t *acol, const double *aval,
+                                      const int32_t *brpt, const int32_t *bcol, const double *bval,
+                                      int32_t *crpt, int32_t *ccol, double *cval)
+{
+    int32_t maxdeg = 1;
+    for (int32_t i = 0; i < M; ++i) if (arpt[i + 1] - arpt[i] > maxdeg) maxdeg = arpt[i + 1] - arpt[i];
+    hentry *h = (hentry *)malloc(sizeof(hentry) * (size_t)maxdeg);
+    int64_t out = 0;
+    crpt[0] = 0;
+    for (int32_t i = 0; i < M; ++i) {
+        int32_t hs = 0;
+        for (int32_t j = arpt[i]; j < arpt[i + 1]; ++j) {                   /* heap_mult.h:133-143: one entry per non-empty selected row of B */
+            int32_t inner = acol[j];
+            if (brpt[inner + 1] > brpt[inner]) { h[hs].loc = 1; h[hs].runr = j; h[hs].value = aval[j] * bval[brpt[inner]]; h[hs].key = bcol[brpt[inner]]; hs++; }
+        }
+        for (int32_t k = hs / 2 - 1; k >= 0; --k) heap_sift_down(h, hs, k);
+        int64_t row0 = out;
+        int32_t last = -1;
+        while (hs > 0) {
+            hentry top = h[0];
+            if (out > row0 && last == top.key) { if (cval) cval[out - 1] = top.value + cval[out - 1]; }   /* :150-153 */
+            else { if (ccol) { ccol[out] = top.key; cval[out] = top.value; } last = top.key; out++; }
+            int32_t inner = acol[top.runr];
+            if (brpt[inner + 1] - brpt[inner] > top.loc) {                  /* :160-167: refill from the same row of B */
+                int32_t idx = brpt[inner] + top.loc;
+                h[0].loc = top.loc + 1; h[0].runr = top.runr; h[0].value = aval[top.runr] * bval[idx]; h[0].key = bcol[idx];
+            } else { h[0] = h[hs - 1]; hs--; }
+            heap_sift_down(h, hs, 0);
+        }
+        crpt[i + 1] = (int32_t)out;
+    }
+    free(h);
+    (void)N;
+    return out;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * MatrixMarket coordinate reader with the semantics of CSR<IT,NT>::construct, mm/inc/CSR.h:485-669
  * (banner rules :441-478): matrix/coordinate only; real|integer|pattern|complex (real part kept :544-554,
  * pattern → 1.0 :532); 1-based → 0-based :565-568; symmetric / skew-symmetric mirror of off-diagonals

@@ -37,6 +37,10 @@ class Oracle:
         L.oracle_spgemm_symbolic.argtypes = [C.c_int32, C.c_int32, _i32, _i32, _i32, _i32, _i32]
         L.oracle_spgemm_symbolic.restype = C.c_int64
         L.oracle_spgemm_numeric.argtypes = [C.c_int32, C.c_int32, _i32, _i32, _f64, _i32, _i32, _f64, _i32, _i32, _f64, C.c_int]
+        L.oracle_spgemm_outer.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i32, _i32, _f64, _i32, _i32, _f64, C.c_int32, _i32, vp, vp]
+        L.oracle_spgemm_outer.restype = C.c_int64
+        L.oracle_spgemm_heap.argtypes = [C.c_int32, C.c_int32, _i32, _i32, _f64, _i32, _i32, _f64, _i32, vp, vp]
+        L.oracle_spgemm_heap.restype = C.c_int64
         L.oracle_mtx_read.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), vp, vp, vp]
         L.oracle_mtx_read.restype = C.c_int
         L.oracle_spmm_dense.argtypes = [C.c_uint32, C.c_uint32, vp, vp, vp, vp, FUN_GATHER, FUN_APPLY, vp, C.c_int]
@@ -88,6 +92,14 @@ class Oracle:
     def spmv_mt(self, rowptr, colids, values, x, y, threads):
         return self.lib.oracle_spmv_csr_mt(len(rowptr) - 1, rowptr, colids, values, x, y, 1.0, 0.0, threads)
 
+    def spmv_mt_y(self, rowptr, colids, values, x, threads=8):
+        """y = A·x with the rows spread over host threads; every row is still summed left to right by one thread, so the result is
+        the single-thread oracle's bit for bit (used where the matrix has 1e8 nonzeros)."""
+        y = np.zeros(len(rowptr) - 1)
+        self.spmv_mt(np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(colids, np.int32), np.ascontiguousarray(values, np.float64),
+                     np.ascontiguousarray(x, np.float64), y, threads)
+        return y
+
     # ---- SpGEMM
     def flop(self, arpt, acol, brpt, per_row=False):
         M = len(arpt) - 1
@@ -119,6 +131,24 @@ class Oracle:
         return crpt, ccol[:nnz], cval[:nnz]
 
     # ---- MatrixMarket
+    def spgemm_outer(self, A, B, K, N, nblockers=4):
+        """OuterSpGEMM restated (mm/inc/outer_mult.h:271-542) — a cross-check of spgemm(), never a GPU path."""
+        M = len(A[0]) - 1
+        crpt = np.zeros(M + 1, np.int32)
+        nnz = self.lib.oracle_spgemm_outer(M, K, N, A[0], A[1], A[2], B[0], B[1], B[2], nblockers, crpt, None, None)
+        ccol, cval = np.zeros(nnz, np.int32), np.zeros(nnz)
+        self.lib.oracle_spgemm_outer(M, K, N, A[0], A[1], A[2], B[0], B[1], B[2], nblockers, crpt, ccol.ctypes.data, cval.ctypes.data)
+        return crpt, ccol, cval
+
+    def spgemm_heap(self, A, B, N):
+        """HeapSpGEMM restated row-wise (mm/inc/heap_mult.h:47-223) — a cross-check of spgemm(), never a GPU path."""
+        M = len(A[0]) - 1
+        crpt = np.zeros(M + 1, np.int32)
+        nnz = self.lib.oracle_spgemm_heap(M, N, A[0], A[1], A[2], B[0], B[1], B[2], crpt, None, None)
+        ccol, cval = np.zeros(nnz, np.int32), np.zeros(nnz)
+        self.lib.oracle_spgemm_heap(M, N, A[0], A[1], A[2], B[0], B[1], B[2], crpt, ccol.ctypes.data, cval.ctypes.data)
+        return crpt, ccol, cval
+
     def mtx_read(self, path):
         r, c, n = C.c_int32(), C.c_int32(), C.c_int64()
         st = self.lib.oracle_mtx_read(path.encode(), C.byref(r), C.byref(c), C.byref(n), None, None, None)

@@ -1,0 +1,92 @@
+"""Every BASELINE.json config against the oracle ON the GPU box, at the size the config names (or, for the 80 M-row config 4, one
+rank's slab of it with global columns). SpMV values within 1e-10 · Σ|a_ij·x_j| (north_star); rows summed by a single lane — stencil
+rows on the streaming path — bit-identical; integer arrays bit-exact. The matrices are generated in HBM and copied to the host for the
+oracle, so the generator is checked again at size on the way."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _spmv_vs_oracle(oracle, A, x, exact=False, exact_rows=None):
+    rp, ci, va = A.to_host()
+    xh = x.cpu().numpy()
+    y = A.spmv(x).cpu().numpy()
+    want = oracle.spmv_mt_y(rp, ci, va, xh)
+    _, asum = oracle.spmv_ld(rp, ci, va, xh)
+    err = np.abs(y - want)
+    assert np.all(err <= TOL * asum + 1e-300), f"max rel err {np.max(err / np.maximum(asum, 1e-300))}"
+    if exact:
+        assert np.array_equal(y[:exact_rows], want[:exact_rows])
+    return float(np.max(err / np.maximum(asum, 1e-300)))
+
+
+def test_config0_lap5_1000x1000_bit_exact(oracle):
+    """configs[0]: 1M×1M 5-point Laplacian, nnz 4 996 000, x_i as SURVEY §8d; the generator equals the oracle's, y bit for bit."""
+    from g4s_amd import host
+    A = host.laplacian_csr(5, 1000, 1000)
+    assert A.nnz == 4_996_000 and A.info()["spmv_path"] == 0
+    for got, want in zip(A.to_host(), oracle.laplacian5(1000, 1000)):
+        assert np.array_equal(got, want)
+    x = host.synth_vector(7, A.cols)
+    _spmv_vs_oracle(oracle, A, x, exact=True)
+
+
+def test_config1_rmat_10m_full_size(oracle):
+    """configs[1] at full size (10M×10M, nnz 98 736 299): the blocked path the benchmark times, y against the oracle row by row."""
+    import bench
+    from g4s_amd import host
+    A = bench.build_matrix("rmat", host, False)
+    assert A.nnz == 98_736_299 and A.info()["spmv_path"] == 1
+    x = host.synth_vector(7, A.cols)
+    worst = _spmv_vs_oracle(oracle, A, x)
+    assert worst <= TOL
+    # and the streaming path on the same matrix: reproducible, same tolerance
+    from g4s_amd import capi
+    S = host.CSR(A.rowptr, A.colids, A.values, A.rows, A.cols, spmv_flags=capi.SPMV_STREAM)
+    ys = S.spmv(x)
+    assert torch.equal(ys, S.spmv(x))
+    yb = A.spmv(x)
+    _, asum = oracle.spmv_ld(*A.to_host(), x.cpu().numpy())
+    assert np.all(np.abs((ys - yb).cpu().numpy()) <= 2 * TOL * asum + 1e-300)
+
+
+def test_config3_lap7_slab_global_columns(oracle):
+    """configs[3]: the 431³ 7-point Laplacian (80 062 991 rows). One rank's share — a slab of 40 z-planes out of 431, rows
+    [200·431², 240·431²) — with GLOBAL column ids (cols = 80 M), as the row-partitioned run holds it; x full length. Stream path,
+    bit-identical to the oracle (one lane per row)."""
+    from g4s_amd import host
+    s = 431
+    plane = s * s
+    r0, r1 = 200 * plane, 240 * plane
+    A = host.laplacian_csr(7, s, s, s, r0=r0, r1=r1)
+    assert A.rows == 40 * plane and A.cols == s ** 3 and A.info()["spmv_path"] == 0
+    rp, ci, va = oracle.laplacian7(s, s, s, r0, r1)
+    for got, want in zip(A.to_host(), (rp, ci, va)):
+        assert np.array_equal(got, want)
+    assert A.nnz == 7 * A.rows - 2 * 40 * 2 * s                     # interior planes: only the x and y faces lose a neighbour
+    x = host.synth_vector(7, A.cols)
+    _spmv_vs_oracle(oracle, A, x, exact=True)
+    # the halo this slab needs is one plane on each side: columns outside [r0 − plane, r1 + plane) are never referenced
+    assert int(A.colids.min().item()) == r0 - plane and int(A.colids.max().item()) == r1 + plane - 1
+
+
+def test_config3_lap7_whole_cube_small(oracle):
+    """The same operator as a whole (120³ = 1.7 M rows): every boundary case of the stencil, bit-identical."""
+    from g4s_amd import host
+    A = host.laplacian_csr(7, 120, 120, 120)
+    for got, want in zip(A.to_host(), oracle.laplacian7(120, 120, 120)):
+        assert np.array_equal(got, want)
+    _spmv_vs_oracle(oracle, A, host.synth_vector(7, A.cols), exact=True)
+
+
+def test_banded_10m_full_size(oracle):
+    """north_star's banded matrix at benchmark size (10M, half-bandwidth 5)."""
+    from g4s_amd import host
+    A = host.banded_csr(10_000_000, 5, 20240521)
+    assert A.info()["spmv_path"] == 0
+    # random values: bit-identical wherever one lane sums a row in the oracle's order — every stream block of more than 128 rows, i.e. all
+    # but the matrix's last, partly filled block (its rows are reduced by several lanes + shuffles: inside the tolerance, not bit for bit)
+    _spmv_vs_oracle(oracle, A, host.synth_vector(7, A.cols), exact=True, exact_rows=A.rows - 1024)

@@ -25,7 +25,7 @@ def test_cpp_driver_runs_on_gpu(tmp_path):
     _build(exe)
     out = subprocess.run([exe, "20000"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "CHECK OK" in out.stdout and "spmm" in out.stdout and "GFLOPS" in out.stdout
+    assert "CHECK OK" in out.stdout and "spmm" in out.stdout and "perf(Gflops):" in out.stdout
 
 
 def _build_example(src, out):
@@ -66,6 +66,33 @@ def test_cpp_mtx_reader_matches_oracle(tmp_path, oracle):
         assert subprocess.run([exe, str(f)], capture_output=True).returncode == 1
 
 
+def _reference_timings_layout(ms, total_flop):
+    """The bytes Timings::print and reg_print put on stdout (mm/src/Timings.cpp:36-65) for stage times in seconds t = ms/1000."""
+    c, s, v, o, e, d, t = (x / 1000 for x in ms)
+    G = total_flop / 1000000000
+    sum_total = c + s + v + o + e + d
+    lines = ["total flop %f" % total_flop, "time(ms):"]
+    for name, x in (("create", c), ("spmm", s), ("convert", v), ("order", o), ("export_csr", e), ("destroy", d), ("sum_total", sum_total)):
+        lines.append("    %-18s %8.3fms %6.2f%%" % (name, 1000 * x, x / t * 100))
+    lines.append("perf(Gflops):")
+    for name, x in (("create", c), ("spmm", s), ("convert", v), ("order", o), ("export_csr", e), ("destroy", d), ("total", t)):
+        lines.append("    %-18s %6.2f" % (name, G / x))
+    lines.append("%e" % (G / t))
+    return "\n".join(lines) + "\n"
+
+
+def test_timings_print_has_the_reference_layout(tmp_path):
+    """a12 / f3: g4s::Timings::print writes what mm/src/Timings.cpp:36-60 writes — `total flop`, the `time(ms):` block with percentages of
+    `total` and a `sum_total` line, the `perf(Gflops):` block — and reg_print (:62-65) one %le line."""
+    exe = str(tmp_path / "timings_print")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "timings_print.cpp"), "-o", exe])
+    for ms, flop in (((1.25, 80.5, 0.0625, 3.5, 0.75, 2.0, 90.0), 2 * 2.49e9), ((0.001, 12345.678, 5.0, 0.5, 100.0, 0.25, 13000.0), 123456789012.0)):
+        out = subprocess.run([exe] + [repr(x) for x in ms] + [repr(flop)], capture_output=True, text=True, check=True).stdout
+        assert out == _reference_timings_layout(ms, flop)
+    # the fixed-width fields of the reference, literally
+    assert "    create                1.250ms   1.39%\n" in _reference_timings_layout((1.25, 80.5, 0.0625, 3.5, 0.75, 2.0, 90.0), 1e9)
+
+
 @pytest.mark.gpu
 def test_cpp_mkl_spgemm_cli(tmp_path, oracle):
     """The reference benchmark's command line (mm/src/mkl_spgemm.cpp) on the device library: C = A·B from .mtx files, stage table."""
@@ -81,9 +108,27 @@ def test_cpp_mkl_spgemm_cli(tmp_path, oracle):
             f.write(f"%%MatrixMarket matrix coordinate real general\n{M.shape[0]} {M.shape[1]} {M.nnz}\n")
             for i, j, v in zip(M.row, M.col, M.data):
                 f.write(f"{int(i) + 1} {int(j) + 1} {float(v)!r}\n")
-    out = subprocess.run([exe, str(tmp_path / "a.mtx"), str(tmp_path / "b.mtx"), "2", "--dump"], capture_output=True, text=True, timeout=300)
+    # argv as the reference's: mat1 mat2 threads (ignored, mm/src/mkl_spgemm.cpp:61), then this driver's --dump extension
+    out = subprocess.run([exe, str(tmp_path / "a.mtx"), str(tmp_path / "b.mtx"), "80", "--dump"], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, G4S_BENCH_ITERS="2"))
     assert out.returncode == 0, out.stderr
-    assert "spmm" in out.stdout and "GFLOPS" in out.stdout
+    head = out.stdout.split("\n")
+    assert head[0] == f"从文件 {tmp_path / 'a.mtx'} 读取矩阵A:"                      # mkl_spgemm.cpp:38
+    flop = oracle.flop(*[np.asarray(a) for a in (A.tocsr()[:, :45].indptr.astype(np.int32), A.tocsr()[:, :45].indices.astype(np.int32),
+                                                   B.tocsr()[:45, :].indptr.astype(np.int32))])
+    assert head[1] == "total flop %f" % (2 * flop) and head[2] == "time(ms):" and head[10] == "perf(Gflops):"
+    assert [l.split()[0] for l in head[3:10]] == ["create", "spmm", "convert", "order", "export_csr", "destroy", "sum_total"]
+    assert [l.split()[0] for l in head[11:18]] == ["create", "spmm", "convert", "order", "export_csr", "destroy", "total"]
+    # name routing of :18-37: a bare name goes to <dir>/suite_sparse/<name>/<name>.mtx, *G500* to <dir>/G500/<name>.mtx
+    os.makedirs(tmp_path / "matrix" / "suite_sparse" / "tiny", exist_ok=True)
+    os.makedirs(tmp_path / "matrix" / "G500", exist_ok=True)
+    os.replace(tmp_path / "a.mtx", tmp_path / "matrix" / "suite_sparse" / "tiny" / "tiny.mtx")
+    os.replace(tmp_path / "b.mtx", tmp_path / "matrix" / "G500" / "G500_x.mtx")
+    out2 = subprocess.run([exe, "tiny", "G500_x", "--dump"], capture_output=True, text=True, timeout=300, cwd=tmp_path,
+                          env=dict(os.environ, G4S_BENCH_ITERS="1", G4S_MATRIX_DIR=str(tmp_path / "matrix")))
+    assert out2.returncode == 0, out2.stderr
+    assert [l for l in out2.stdout.splitlines() if l.startswith("C ")] == [l for l in out.stdout.splitlines() if l.startswith("C ")]
+    assert subprocess.run([exe, "no_such_matrix"], capture_output=True, cwd=tmp_path).returncode == 1
     want = (A.tocsr()[:, :45] @ B.tocsr()[:45, :]).toarray()
     got = np.zeros_like(want)
     for line in out.stdout.splitlines():

@@ -68,6 +68,23 @@ def test_partitioned_spmv_matches_single(tmp_path, oracle, world, mode, kind):
         assert all(m[2] <= 2 * 72 * 8 for m in metas)
 
 
+def test_row_partition_equals_the_reference_rule(oracle):
+    """a5: dist.row_partition is BIN::set_rows_offset (mm/inc/BIN.h:101-122) with work = nnz + 1 per row — offsets equal, integer for
+    integer, to the oracle's restatement on the same work vector, for regular, power-law, empty-row and more-parts-than-rows inputs."""
+    from g4s_amd import dist as gdist
+    from tests.helpers import power_law_csr, random_csr
+    cases = [random_csr(1000, 800, 0.01, 0, empty_rows=[0, 1, 2, 500, 999]), power_law_csr(5000, 5000, 3, 3000), oracle.laplacian5(40, 30),
+             random_csr(5, 5, 0.5, 1), (np.zeros(8, np.int32), np.zeros(0, np.int32), np.zeros(0))]
+    for rp, _, _ in cases:
+        rows = len(rp) - 1
+        work = (np.diff(rp).astype(np.int64) + 1)
+        for parts in (1, 2, 3, 4, 7, 8, 14, 64):
+            want = oracle.rows_offset(work, parts)
+            got = gdist.row_partition(torch.from_numpy(np.ascontiguousarray(rp)), parts)
+            # BIN.h leaves the offsets as lower_bound gives them (non-decreasing by construction); row_partition also clamps to rows
+            assert got == [min(int(v), rows) for v in want], (rows, parts)
+
+
 def test_row_partition_balances_work():
     from g4s_amd import dist as gdist
     rp, ci, va = power_law_csr(5000, 5000, 3, 2000)

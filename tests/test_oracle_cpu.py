@@ -354,3 +354,34 @@ def test_node_assembled_operator_equals_element_by_element(oracle):
         v = rng.uniform(-1, 1, neq)
         assert np.allclose(oracle.n_assemble_del2_u(nno, neq, nm, idmap, k1, k2, k3, v, np.zeros(0, np.int32)), oracle.element_matvec(ien, idmap, K, v, neq),
                            rtol=0, atol=1e-12 * np.abs(want).max())
+
+
+def test_outer_and_heap_spgemm_agree_with_the_hash_oracle(oracle):
+    """a11: the reference's other two SpGEMM algorithms (OuterSpGEMM, mm/inc/outer_mult.h:271-542; HeapSpGEMM, mm/inc/heap_mult.h:47-223),
+    restated independently, against the hash restatement: crpt and ccol bit for bit from all three; the outer-product sums run in the
+    same (ascending inner index) order as the hash loop, so its values are bit-identical too; the heap's equal-key order depends on the
+    heap shape, so its values agree to rounding. And all three against oneMKL's own results (tests/golden/mkl_spgemm.npz)."""
+    import os
+    from tests.helpers import power_law_csr, random_csr
+    cases = [(random_csr(1, 1, 1.0, 0), random_csr(1, 1, 1.0, 1), 1, 1, 1),
+             (random_csr(40, 30, 0.15, 2, empty_rows=[1]), random_csr(30, 50, 0.2, 3, empty_rows=[0]), 40, 30, 50),
+             (random_csr(300, 300, 0.03, 4), random_csr(300, 300, 0.03, 5), 300, 300, 300),
+             (power_law_csr(500, 400, 6, 300), power_law_csr(400, 700, 7, 350), 500, 400, 700),
+             (random_csr(200, 8, 0.9, 8), random_csr(8, 200, 0.9, 9), 200, 8, 200)]
+    for A, B, M, K, N in cases:
+        h = oracle.spgemm(A, B, N, sort_output=True)
+        for nblockers in (1, 4, 64):
+            o = oracle.spgemm_outer(A, B, K, N, nblockers)
+            assert np.array_equal(o[0], h[0]) and np.array_equal(o[1], h[1]) and np.array_equal(o[2], h[2])
+        p = oracle.spgemm_heap(A, B, N)
+        assert np.array_equal(p[0], h[0]) and np.array_equal(p[1], h[1])
+        _, _, scale = oracle.spgemm((A[0], A[1], np.abs(A[2])), (B[0], B[1], np.abs(B[2])), N)
+        assert np.all(np.abs(p[2] - h[2]) <= 1e-14 * scale + 1e-300)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "mkl_spgemm.npz"))
+    for name in ("tri4", "rmat8", "rect", "plaw"):
+        A = tuple(g[f"{name}_a{k}"] for k in ("rpt", "col", "val"))
+        B = tuple(g[f"{name}_b{k}"] for k in ("rpt", "col", "val"))
+        M, K, N = (int(v) for v in g[f"{name}_mkn"])
+        for got in (oracle.spgemm_outer(A, B, K, N), oracle.spgemm_heap(A, B, N)):
+            assert np.array_equal(got[0], g[f"{name}_crpt"]) and np.array_equal(got[1], g[f"{name}_ccol"])
+            assert np.allclose(got[2], g[f"{name}_cval"], rtol=1e-12, atol=1e-13)

@@ -170,21 +170,44 @@ def test_spgemm_rejects_bad_ids(g4s):
     assert st == capi.ERR_INVALID
 
 
-def test_spgemm_full_size_properties():
-    """BASELINE config 3: R-MAT scale 21 (n = 2 097 152), C = A·A. Edge factor 2 here (nnz(C) ≈ 0.96e9; EF 3 gives 1.94e9, the
-    largest that still fits the reference's int32 row pointer; EF 8 gives 9.56e9 and must be refused). Size-independent checks:
-    (A·A)·x == A·(A·x), rows strictly sorted, crpt consistent, integer part reproducible."""
+def test_spgemm_rmat17_bit_exact_against_oracle_and_scipy(oracle):
+    """A 2^17-row R-MAT A·A (the structure of BASELINE config 3 at a size the oracle multiplies in seconds): crpt and ccol bit for bit
+    against the oracle AND against scipy's independent implementation; values within 1e-10 · Σ|terms|."""
+    from g4s_amd import host
+    n = 1 << 17
+    A = host.rmat_csr(n, 17, 3 * n, 20240522)
+    A.values.abs_()
+    Ah = A.to_host()
+    Cm = host.HashSpGEMM(A, A)
+    crpt, ccol, cval = Cm.to_host()
+    orpt, ocol, oval = oracle.spgemm(Ah, Ah, n, sort_output=True)
+    assert np.array_equal(crpt, orpt) and np.array_equal(ccol, ocol)
+    assert np.all(np.abs(cval - oval) <= TOL * oval + 1e-300)          # values are positive: Σ|terms| = the sum itself
+    S = to_scipy(*Ah, n, n)
+    S2 = (S @ S).tocsr()
+    S2.sort_indices()
+    assert np.array_equal(S2.indptr, crpt) and np.array_equal(S2.indices, ccol)
+    assert np.all(np.abs(S2.data - cval) <= TOL * oval + 1e-300)
+    assert host.get_flop(A, A) == oracle.flop(Ah[0], Ah[1], Ah[0])
+
+
+@pytest.mark.parametrize("ef", [2, 3])
+def test_spgemm_full_size_properties(ef):
+    """BASELINE config 3: R-MAT scale 21 (n = 2 097 152), C = A·A, at edge factor 2 (nnz(C) ≈ 0.96e9) and at edge factor 3 — the one
+    every reported number uses (nnz(C) 1.94e9, the largest that still fits the reference's int32 row pointer; EF 8 gives 9.56e9 and must
+    be refused). Size-independent checks: (A·A)·x == A·(A·x), rows strictly sorted, crpt consistent, integer part reproducible."""
     import ctypes as C
     from g4s_amd import capi, host
     n = 1 << 21
-    A8 = host.rmat_csr(n, 21, 8 * n, 20240522)
-    crpt = torch.empty(n + 1, dtype=torch.int32, device="cuda")
-    cnnz = C.c_int64()
-    st = capi.load().g4s_spgemm_symbolic(n, n, n, A8.rowptr.data_ptr(), A8.colids.data_ptr(), A8.rowptr.data_ptr(), A8.colids.data_ptr(),
-                                         crpt.data_ptr(), C.byref(cnnz), None)
-    assert st == capi.ERR_OVERFLOW and cnnz.value > 2 ** 31      # int32 crpt of the reference (define.h:14) cannot hold it
-    del A8, crpt
-    A = host.rmat_csr(n, 21, 2 * n, 20240522)
+    if ef == 2:
+        A8 = host.rmat_csr(n, 21, 8 * n, 20240522)
+        crpt = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+        cnnz = C.c_int64()
+        st = capi.load().g4s_spgemm_symbolic(n, n, n, A8.rowptr.data_ptr(), A8.colids.data_ptr(), A8.rowptr.data_ptr(), A8.colids.data_ptr(),
+                                             crpt.data_ptr(), C.byref(cnnz), None)
+        assert st == capi.ERR_OVERFLOW and cnnz.value > 2 ** 31      # int32 crpt of the reference (define.h:14) cannot hold it
+        del A8, crpt
+    A = host.rmat_csr(n, 21, ef * n, 20240522)
     A.values.abs_()                                            # values U(0,1) (SURVEY.md §8d C3): no cancellation in the check
     Cm = host.HashSpGEMM(A, A)
     assert Cm.rows == n and Cm.nnz == int(Cm.rowptr[-1].item()) and int(Cm.rowptr[0].item()) == 0
@@ -203,4 +226,6 @@ def test_spgemm_full_size_properties():
     assert flop >= Cm.nnz
     C2 = host.HashSpGEMM(A, A)
     assert torch.equal(C2.rowptr, Cm.rowptr) and torch.equal(C2.colids, Cm.colids)
-    print(f"RMAT-21 A·A: nnz(A)={A.nnz} flop={flop} nnz(C)={Cm.nnz} compression={flop / Cm.nnz:.2f}")
+    print(f"RMAT-21 A·A (EF {ef}): nnz(A)={A.nnz} flop={flop} nnz(C)={Cm.nnz} compression={flop / Cm.nnz:.2f}")
+    del Cm, C2, A
+    capi.check(capi.load().g4s_trim())                           # 25 GB of outputs go back to the driver before the next test

@@ -49,7 +49,8 @@ def test_div_grad_preconditioner_bit_exact(oracle, ex, ey, ez, seed):
 
 @pytest.mark.parametrize("ex,ey,ez,seed,check_cont,check_p,stiffness", [(3, 3, 2, 0, 0, 0, "elements"), (6, 6, 4, 1, 1, 1, "elements"),
                                                                            (16, 16, 8, 2, 0, 1, "elements"), (6, 6, 4, 1, 0, 0, "csr"),
-                                                                           (16, 16, 8, 3, 1, 0, "csr")])
+                                                                           (16, 16, 8, 3, 1, 0, "csr"),
+                                                                           (32, 32, 8, 4, 0, 0, "elements")])   # Cookbook2's mesh
 def test_uzawa_iteration_matches_oracle(oracle, ex, ey, ez, seed, check_cont, check_p, stiffness):
     """stiffness = "csr": the velocity solves and K·V run on the assembled matrix through g4s_spmv (BASELINE config 5)."""
     from g4s_amd import capi, host
