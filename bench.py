@@ -7,7 +7,7 @@ are split by equal work (the rule of mm/inc/BIN.h:101-122), every rank owns its 
 {exchange x over RCCL/xGMI, local SpMV} — total work is fixed, so scaling is "strong". Inputs are resident in HBM before
 the timed region. Prints ONE JSON line (rank 0).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload rmat|banded|lap5|lap7] [--exchange auto|allgatherv|needed|compact]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload rmat|banded|lap5|lap7] [--exchange auto|dist|allgatherv|allgather|needed|compact]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -113,8 +113,9 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="rmat", choices=sorted(WORKLOADS))
-    ap.add_argument("--exchange", default="auto", choices=["auto", "allgatherv", "allgather", "needed", "compact"],
-                    help="auto: compact (only the referenced entries of x travel, columns renumbered) for rmat, needed (halo ranges) otherwise")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "dist", "allgatherv", "allgather", "needed", "compact"],
+                    help="auto = dist: the C-ABI multi-GPU product (g4s_spmv_dist_*: RCCL send/recv of the referenced x entries, overlapped with the own-column "
+                         "product); the others are round 1's torch.distributed variants, kept for A/B runs")
     ap.add_argument("--small", action="store_true", help="reduced sizes for plumbing checks (not a valid benchmark)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nt", action="store_true", help="plain loads for the matrix stream (A/B against nontemporal)")
@@ -154,47 +155,59 @@ def main():
     offs = gdist.row_partition(A_full.rowptr, world)
     r0, r1 = offs[rank], offs[rank + 1]
     flags = (capi.SPMV_NO_NT if args.no_nt else 0) | {"auto": 0, "stream": capi.SPMV_STREAM, "blocked": capi.SPMV_BLOCKED}[args.path]
-    mode = args.exchange if args.exchange != "auto" else ("compact" if args.workload == "rmat" else "needed")
+    mode = args.exchange if args.exchange != "auto" else "dist"
+    D = None
     if world > 1:
         rp, ci, va = gdist.slice_rows(A_full.rowptr, A_full.colids, A_full.values, r0, r1)
         del A_full
         torch.cuda.empty_cache()
-        if mode == "compact":
-            # The point-to-point set-up of the compact exchange is the one piece of this file that cannot be rehearsed over RCCL on a
-            # one-GPU box: if it raises, every rank (they agree through an all-reduce) falls back to the single padded all-gather.
-            ok = torch.ones(1, device="cuda")
-            try:
-                exchange = gdist.CompactExchange(offs, rank, world, ci)
-                probe = torch.zeros(exchange.n_ref, dtype=torch.float64, device="cuda")
-                exchange(host.synth_vector(7, r1 - r0, i0=r0), probe)
-                torch.cuda.synchronize()
-            except Exception as e:  # noqa: BLE001
-                print(f"[bench rank {rank}] compact exchange failed ({type(e).__name__}: {e}); falling back to --exchange allgather", file=sys.stderr, flush=True)
-                ok.zero_()
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if ok.item() < 1:
-                mode = "allgather"
-        if mode == "compact":
-            A = host.CSR(rp, exchange.local_colids, va, r1 - r0, exchange.n_ref, spmv_flags=flags)
-            x_cols = exchange.n_ref
+        x_local = host.synth_vector(7, r1 - r0, i0=r0)
+        y_local = torch.empty(r1 - r0, dtype=torch.float64, device="cuda")
+        if mode == "dist":
+            # the library's multi-GPU product (g4s_spmv_dist_*, csrc/dist.hip): own / remote column split, packed exchange of the referenced x
+            # entries by ncclSend/ncclRecv on the library's own RCCL communicator, own-column product overlapped with it. A failure while
+            # the communicator is being wired is fatal for the run (no fallback on a possibly poisoned communicator).
+            D = gdist.DistSpMV(offs, rank, world, rp, ci, va, n_cols, spmv_flags=flags)
+            dinfo = D.info()
+            recv_bytes = dinfo["recv_bytes"]
+            info = {"spmv_path": dinfo["own_path"], "algorithmic_bytes": 12 * int(rp[-1].item()) + 4 * (r1 - r0 + 1) + 8 * (r1 - r0) + 8 * (r1 - r0 + dinfo["n_ref"]),
+                    "rows": r1 - r0, "nnz": int(rp[-1].item())}
+
+            def product():
+                D(x_local, y_local)
+            step = product
         else:
-            A = host.CSR(rp, ci, va, r1 - r0, n_cols, spmv_flags=flags)
-            exchange = gdist.VectorExchange(offs, rank, world, colids=A.colids, mode=mode)
-            x_cols = n_cols
+            # the torch.distributed variants of round 1 (g4s_amd/dist.py), kept for A/B runs: --exchange allgatherv | allgather | needed | compact
+            if mode == "compact":
+                exchange = gdist.CompactExchange(offs, rank, world, ci)
+                A = host.CSR(rp, exchange.local_colids, va, r1 - r0, exchange.n_ref, spmv_flags=flags)
+                x_cols = exchange.n_ref
+            else:
+                A = host.CSR(rp, ci, va, r1 - r0, n_cols, spmv_flags=flags)
+                exchange = gdist.VectorExchange(offs, rank, world, colids=A.colids, mode=mode)
+                x_cols = n_cols
+            x_full = torch.zeros(x_cols, dtype=torch.float64, device="cuda")
+            exchange(x_local, x_full)
+            info = A.info()
+            recv_bytes = exchange.recv_bytes
+
+            def product():
+                A.spmv(x_full, y_local)
+
+            def step():
+                exchange(x_local, x_full)
+                A.spmv(x_full, y_local)
     else:
         A = host.CSR(A_full.rowptr, A_full.colids, A_full.values, n_rows, n_cols, spmv_flags=flags)
-        exchange = gdist.VectorExchange(offs, rank, world, colids=A.colids, mode="allgatherv")
-        x_cols = n_cols
-    x_local = host.synth_vector(7, r1 - r0, i0=r0)
-    x_full = torch.zeros(x_cols, dtype=torch.float64, device="cuda")
-    y_local = torch.empty(r1 - r0, dtype=torch.float64, device="cuda")
-    exchange(x_local, x_full)
-    info = A.info()
+        x_full = host.synth_vector(7, n_cols)
+        x_local = x_full
+        y_local = torch.empty(n_rows, dtype=torch.float64, device="cuda")
+        info = A.info()
+        recv_bytes = 0
 
-    def step():
-        if world > 1:
-            exchange(x_local, x_full)
-        A.spmv(x_full, y_local)
+        def product():
+            A.spmv(x_full, y_local)
+        step = product
 
     def fence():
         torch.cuda.synchronize()
@@ -228,7 +241,7 @@ def main():
         k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         k0.record()
         for _ in range(args.steps):
-            A.spmv(x_full, y_local)
+            product()
         k1.record()
         torch.cuda.synchronize()
         kernel_ms = k0.elapsed_time(k1) / args.steps
@@ -258,7 +271,9 @@ def main():
         "config": {"workload": WORKLOADS[args.workload] + (" [--small: NOT the benchmark size]" if args.small else ""),
                    "rows": n_rows, "cols": n_cols, "nnz": nnz_total, "index": "int32",
                    "partition": f"1-D rows by equal nnz+rows over {world} rank(s)",
-                   "exchange": ("none (single GPU)" if world == 1 else f"{mode} over RCCL, {exchange.recv_bytes} B received per rank 0 step"),
+                   "exchange": ("none (single GPU)" if world == 1 else
+                                (f"dist: g4s_spmv_dist_* (own/remote column split, packed ncclSend/ncclRecv of the referenced x entries overlapped with the own-column "
+                                 f"product), {recv_bytes} B received by rank 0 per step" if mode == "dist" else f"{mode} over torch.distributed, {recv_bytes} B received by rank 0 per step")),
                    "matrix_loads": "plain" if args.no_nt else "nontemporal",
                    "spmv_path": {0: "stream", 1: "blocked", 2: "blocked (tile-blocked experiment)"}[info["spmv_path"]],
                    "reproducible": ("yes: fixed summation order, no atomics" if info["spmv_path"] == 0 else
@@ -286,6 +301,8 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
+        if D is not None:
+            D.close()
         dist.destroy_process_group()
 
 

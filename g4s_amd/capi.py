@@ -10,8 +10,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libg4s_hip.so")
 
 OK, ERR_INVALID, ERR_NOMEM, ERR_HIP, ERR_OVERFLOW, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
-HOST_POINTERS, DEVICE_POINTERS, SORT_OUTPUT, SPMV_NO_NT, SPMV_BLOCKED, SPMV_STREAM = 0, 1, 2, 4, 8, 16
+HOST_POINTERS, DEVICE_POINTERS, SORT_OUTPUT, SPMV_NO_NT, SPMV_BLOCKED, SPMV_STREAM, DIST_LOOPBACK = 0, 1, 2, 4, 8, 16, 32
 PATTERN_ELEMENT_BLOCK_MATVEC, PATTERN_DENSE_ROW_TIMES_MATRIX, PATTERN_SYM_QUADRATIC_FORM = 1, 2, 3
+DENSE_DGEMM, DENSE_DSYMM, DENSE_DTRMM, DENSE_DGEMV, DENSE_DSYMV, DENSE_DTRMV, DENSE_DSPMV = 1, 2, 3, 4, 5, 6, 7
 
 i32p = C.POINTER(C.c_int32)
 i64p = C.POINTER(C.c_int64)
@@ -27,6 +28,12 @@ class CsrInfo(C.Structure):
                 ("stream_blocks", C.c_int32), ("long_rows", C.c_int32), ("long_chunks", C.c_int32),
                 ("tile_nnz", C.c_int32), ("tile_rows", C.c_int32), ("long_chunk_nnz", C.c_int32),
                 ("algorithmic_bytes", C.c_int64), ("plan_bytes", C.c_int64), ("spmv_path", C.c_int32), ("reserved", C.c_int32)]
+
+
+class DistInfo(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("local_rows", C.c_int32), ("n_ref", C.c_int32), ("nnz_own", C.c_int64), ("nnz_rem", C.c_int64),
+                ("send_bytes", C.c_int64), ("recv_bytes", C.c_int64), ("own_path", C.c_int32), ("rem_path", C.c_int32), ("connected", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class Timings(C.Structure):
@@ -73,6 +80,20 @@ SIGNATURES = {
     "g4s_csr_device_arrays": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
     "g4s_spmv": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, vp]),
     "g4s_spmv_csr_i32_f64": (C.c_int, [C.c_int32, C.c_int32, vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_uint]),
+    "g4s_spmv_dist_create": (C.c_int, [C.POINTER(vp), C.c_int32, C.c_int32, i64p, C.c_int64, vp, vp, vp, C.c_uint]),
+    "g4s_spmv_dist_destroy": (C.c_int, [vp]),
+    "g4s_spmv_dist_get_info": (C.c_int, [vp, C.POINTER(DistInfo)]),
+    "g4s_spmv_dist_connect_rccl": (C.c_int, [vp, vp]),
+    "g4s_spmv_dist_want": (C.c_int, [vp, C.c_int32, i64p, C.POINTER(vp)]),
+    "g4s_spmv_dist_set_give": (C.c_int, [vp, C.c_int32, C.c_int64, vp, C.c_uint]),
+    "g4s_spmv_dist_apply": (C.c_int, [vp, vp, vp, vp]),
+    "g4s_spmv_dist_begin": (C.c_int, [vp, vp, vp, vp]),
+    "g4s_spmv_dist_buffers": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64p), C.POINTER(vp), C.POINTER(i64p)]),
+    "g4s_spmv_dist_finish": (C.c_int, [vp, vp, vp]),
+    "g4s_comm_unique_id": (C.c_int, [vp]),
+    "g4s_comm_create": (C.c_int, [C.POINTER(vp), C.c_int32, C.c_int32, vp]),
+    "g4s_comm_destroy": (C.c_int, [vp]),
+    "g4s_comm_allreduce_sum_f64": (C.c_int, [vp, vp, C.c_int64, vp]),
     "g4s_spgemm_flop": (C.c_int, [C.c_int32, vp, vp, vp, i64p, vp, C.c_uint]),
     "g4s_spgemm_csr_i32_f64": (C.c_int, [vp, vp, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                           C.c_int32, C.c_int32, C.c_int32, i64p, C.POINTER(Timings), C.c_uint]),
@@ -108,6 +129,8 @@ SIGNATURES = {
     "g4s_dense_rows_times_matrix": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]),
     "g4s_dense_rows_times_matrix_grad": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp]),
     "g4s_sym_quadratic_form": (C.c_int, [C.c_int32, C.c_int32, vp, vp, vp, vp]),
+    "g4s_dense_mm": (C.c_int, [C.c_int32, C.c_int32, vp, vp, vp, C.c_uint]),
+    "g4s_dense_mv": (C.c_int, [C.c_int32, C.c_int32, vp, vp, vp, C.c_uint]),
     # include/g4s_synth.h
     "g4s_synth_rmat_keys": (C.c_int, [C.c_uint64, C.c_int32, C.c_int64, C.c_int64, C.c_int64, vp, vp]),
     "g4s_synth_csr_from_keys": (C.c_int, [C.c_uint64, C.c_int64, C.c_int32, vp, C.c_int64, vp, vp, vp, vp]),

@@ -1,0 +1,419 @@
+// dist.hip — row-partitioned SpMV over several GPUs behind the C-ABI (SURVEY.md §8b B2 "g4s_spmv_dist_*", §8e): one process per GPU,
+// RCCL point-to-point over xGMI for the x entries a rank's rows reference, the own-column product overlapped with that exchange.
+//
+// The reference has no multi-device code on this path. Its distributed pattern — the one a CitcomS-shaped caller already has — is the
+// per-mat-vec neighbour exchange of citcoms/lib/Regional_parallel_related.c:744-789 (pack the shared entries, MPI_Sendrecv with each
+// neighbour, unpack) and the dot-product all-reduce of citcoms/lib/Global_operations.c:534-562; the row split over ranks is the
+// equal-work rule of mm/inc/BIN.h:101-122. Here:
+//   * rank r owns rows [off[r], off[r+1]) of A and the same slab of x and y (square operator, 1-D row partition);
+//   * at create the local rows are cut into A_own (columns inside the own slab, renumbered to the slab) and A_rem (all other columns,
+//     renumbered 0…n_ref−1 in ascending global order: only REFERENCED columns exist — the halo planes of a stencil, ≈20 % of x for
+//     an eighth of the R-MAT matrix). A peer k's referenced entries form one contiguous segment of the compact x_rem;
+//   * every owner learns once which of its entries each peer wants ("give" lists; over RCCL by g4s_spmv_dist_connect_rccl, or by
+//     any transport the caller has through g4s_spmv_dist_want / _set_give);
+//   * a product: pack (one gather kernel fills every peer's send segment) → exchange on a side stream (ncclGroupStart, one
+//     ncclSend + ncclRecv per peer with traffic, ncclGroupEnd: each pair over its own xGMI link, received straight into its
+//     segment of x_rem, no unpack) ‖ y = A_own·x_local on the caller's stream → wait → y += A_rem·x_rem.
+// RCCL is loaded with dlopen at first use (librccl.so.1: the copy the host framework already mapped, or ROCm's), so libg4s_hip.so has
+// no link-time dependency on it and single-GPU users never touch it.
+#include "common.hpp"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- RCCL entry points, resolved lazily
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mutex;
+
+int rccl_load()
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.lib) return G4S_OK;
+    void *h = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return g4s::set_error(G4S_ERR_UNSUPPORTED, "RCCL is not available: %s", dlerror());
+    Rccl r;
+    r.lib = h;
+#define G4S_RCCL_SYM(field, sym)                                                               \
+    r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, sym));                              \
+    if (!r.field) return g4s::set_error(G4S_ERR_UNSUPPORTED, "RCCL symbol %s is missing", sym);
+    G4S_RCCL_SYM(GetUniqueId, "ncclGetUniqueId") G4S_RCCL_SYM(CommInitRank, "ncclCommInitRank") G4S_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+    G4S_RCCL_SYM(Send, "ncclSend") G4S_RCCL_SYM(Recv, "ncclRecv") G4S_RCCL_SYM(AllReduce, "ncclAllReduce")
+    G4S_RCCL_SYM(GroupStart, "ncclGroupStart") G4S_RCCL_SYM(GroupEnd, "ncclGroupEnd") G4S_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef G4S_RCCL_SYM
+    g_rccl = r;
+    return G4S_OK;
+}
+
+#define G4S_RCCL_TRY(expr)                                                                                           \
+    do {                                                                                                             \
+        ncclResult_t r__ = (expr);                                                                                   \
+        if (r__ != ncclSuccess) return g4s::set_error(G4S_ERR_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(r__)); \
+    } while (0)
+
+// send[i] = x[idx[i]]: the packed entries of every peer, one launch
+__global__ void dist_pack_kernel(long long n, const int32_t *__restrict__ idx, const double *__restrict__ x, double *__restrict__ send)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) send[i] = x[idx[i]];
+}
+
+} // namespace
+
+struct g4s_spmv_dist_s {
+    int rank = 0, world = 1;
+    bool loopback = false;
+    std::vector<int64_t> off;                   // row (= x) partition, world+1
+    int32_t local_rows = 0;
+    int64_t nnz_own = 0, nnz_rem = 0;
+    g4s_csr_t A_own = nullptr, A_rem = nullptr;
+    int32_t n_ref = 0;
+    std::vector<int64_t> recv_cut;              // world+1: segment [recv_cut[k], recv_cut[k+1]) of x_rem belongs to owner k
+    std::vector<int64_t> give_cut;              // world+1: segment of the send buffer that goes to peer k
+    std::vector<char> give_set;
+    int32_t *d_want = nullptr;                  // n_ref indices, local to their owner's slab (what this rank asks for), in x_rem order
+    int32_t *d_give = nullptr;                  // indices into x_local, concatenated per peer
+    double *d_send = nullptr, *d_xrem = nullptr;
+    hipStream_t cstream = nullptr;
+    hipEvent_t ev_packed = nullptr, ev_done = nullptr;
+    ncclComm_t comm = nullptr;
+    bool exchange_posted = false;
+};
+
+namespace {
+
+void dist_release(g4s_spmv_dist_s *h)
+{
+    if (!h) return;
+    if (h->A_own) g4s_csr_destroy(h->A_own);
+    if (h->A_rem) g4s_csr_destroy(h->A_rem);
+    (void)hipFree(h->d_want); (void)hipFree(h->d_give); (void)hipFree(h->d_send); (void)hipFree(h->d_xrem);
+    if (h->ev_packed) (void)hipEventDestroy(h->ev_packed);
+    if (h->ev_done) (void)hipEventDestroy(h->ev_done);
+    if (h->cstream) (void)hipStreamDestroy(h->cstream);
+    delete h;
+}
+
+int owner_of(const std::vector<int64_t> &off, int64_t col)
+{
+    return (int)(std::upper_bound(off.begin(), off.end(), col) - off.begin()) - 1;
+}
+
+} // namespace
+
+G4S_API g4s_status g4s_spmv_dist_create(g4s_spmv_dist_t *out, int32_t rank, int32_t world, const int64_t *row_offsets, int64_t n_cols,
+                                        const int32_t *rowptr, const int32_t *colids, const double *values, unsigned flags)
+{
+    G4S_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    G4S_REQUIRE(world >= 1 && rank >= 0 && rank < world && row_offsets && rowptr, "bad partition arguments");
+    for (int k = 0; k < world; ++k) G4S_REQUIRE(row_offsets[k] <= row_offsets[k + 1], "row_offsets must not decrease");
+    G4S_REQUIRE(row_offsets[0] == 0 && row_offsets[world] == n_cols, "square operator expected: x is partitioned like the rows (row_offsets[world] == n_cols)");
+    G4S_REQUIRE(n_cols <= INT32_MAX, "n_cols exceeds the int32 index type");
+    const int64_t r0 = row_offsets[rank], r1 = row_offsets[rank + 1];
+    const int32_t m = (int32_t)(r1 - r0);
+    auto h = new (std::nothrow) g4s_spmv_dist_s();
+    if (!h) return g4s::set_error(G4S_ERR_NOMEM, "host allocation failed");
+    auto fail = [&](int code) { dist_release(h); return code; };
+    h->rank = rank; h->world = world; h->local_rows = m;
+    h->off.assign(row_offsets, row_offsets + world + 1);
+    h->loopback = (flags & G4S_DIST_LOOPBACK) != 0;
+    if (h->loopback && world != 1) return fail(g4s::set_error(G4S_ERR_INVALID, "G4S_DIST_LOOPBACK is a single-rank rehearsal mode"));
+
+    // ---- the local rows on the host (set-up runs once per matrix)
+    std::vector<int32_t> rp((size_t)m + 1);
+    const bool dp = (flags & G4S_DEVICE_POINTERS) != 0;
+    if (dp) { if (hipMemcpy(rp.data(), rowptr, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost) != hipSuccess) return fail(g4s::set_error(G4S_ERR_HIP, "D2H copy of rowptr failed")); }
+    else std::copy(rowptr, rowptr + m + 1, rp.begin());
+    if (rp[0] != 0) return fail(g4s::set_error(G4S_ERR_INVALID, "rowptr[0] != 0"));
+    const int64_t nnz = rp[m];
+    G4S_REQUIRE(nnz == 0 || (colids && values), "colids/values NULL with nnz > 0");
+    std::vector<int32_t> ci((size_t)nnz);
+    std::vector<double> va((size_t)nnz);
+    if (nnz) {
+        if (dp) {
+            if (hipMemcpy(ci.data(), colids, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(va.data(), values, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost) != hipSuccess)
+                return fail(g4s::set_error(G4S_ERR_HIP, "D2H copy of the matrix failed"));
+        } else { std::copy(colids, colids + nnz, ci.begin()); std::copy(values, values + nnz, va.begin()); }
+    }
+    // own range of columns (loopback: only the first half of the slab counts as own, the rest travels rank 0 → rank 0 through RCCL)
+    const int64_t own_lo = r0, own_hi = h->loopback ? r0 + (r1 - r0) / 2 : r1;
+    std::vector<int32_t> ref;                                       // referenced remote columns
+    for (int64_t k = 0; k < nnz; ++k) {
+        const int32_t c = ci[k];
+        if (c < 0 || c >= n_cols) return fail(g4s::set_error(G4S_ERR_INVALID, "a column index is outside [0, n_cols)"));
+        if (c < own_lo || c >= own_hi) ref.push_back(c);
+    }
+    std::sort(ref.begin(), ref.end());
+    ref.erase(std::unique(ref.begin(), ref.end()), ref.end());
+    h->n_ref = (int32_t)ref.size();
+    std::vector<int32_t> orp((size_t)m + 1, 0), rrp((size_t)m + 1, 0), oci, rci;
+    std::vector<double> ova, rva;
+    oci.reserve((size_t)nnz); ova.reserve((size_t)nnz);
+    for (int32_t i = 0; i < m; ++i) {
+        for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
+            const int32_t c = ci[k];
+            if (c >= own_lo && c < own_hi) { oci.push_back((int32_t)(c - r0)); ova.push_back(va[k]); }
+            else { rci.push_back((int32_t)(std::lower_bound(ref.begin(), ref.end(), c) - ref.begin())); rva.push_back(va[k]); }
+        }
+        orp[i + 1] = (int32_t)oci.size(); rrp[i + 1] = (int32_t)rci.size();
+    }
+    h->nnz_own = (int64_t)oci.size(); h->nnz_rem = (int64_t)rci.size();
+    const unsigned path_flags = flags & (G4S_SPMV_NO_NT | G4S_SPMV_BLOCKED | G4S_SPMV_STREAM);
+    int st = g4s_csr_create(&h->A_own, m, (int32_t)(r1 - r0), h->nnz_own, orp.data(), oci.data(), ova.data(), G4S_HOST_POINTERS | path_flags);
+    if (st != G4S_OK) return fail(st);
+    st = g4s_csr_create(&h->A_rem, m, std::max(h->n_ref, 1), h->nnz_rem, rrp.data(), rci.data(), rva.data(), G4S_HOST_POINTERS | path_flags);
+    if (st != G4S_OK) return fail(st);
+    // what this rank wants from every owner: ref is sorted, so owner k's columns are one segment
+    h->recv_cut.assign((size_t)world + 1, 0);
+    std::vector<int32_t> want((size_t)h->n_ref);
+    for (int32_t i = 0; i < h->n_ref; ++i) {
+        const int k = h->loopback ? 0 : owner_of(h->off, ref[i]);
+        h->recv_cut[(size_t)k + 1]++;
+        want[i] = (int32_t)(ref[i] - h->off[k]);
+    }
+    for (int k = 0; k < world; ++k) h->recv_cut[(size_t)k + 1] += h->recv_cut[k];
+    if (!h->loopback && h->recv_cut[(size_t)rank + 1] != h->recv_cut[rank]) return fail(g4s::set_error(G4S_ERR_INVALID, "internal: own columns among the remote ones"));
+    h->give_cut.assign((size_t)world + 1, 0);
+    h->give_set.assign((size_t)world, 0);
+    if (g4s::device_malloc((void **)&h->d_want, sizeof(int32_t) * (size_t)std::max(h->n_ref, 1)) != hipSuccess ||
+        g4s::device_malloc((void **)&h->d_xrem, sizeof(double) * (size_t)std::max(h->n_ref, 1)) != hipSuccess)
+        return fail(g4s::set_error(G4S_ERR_NOMEM, "device allocation failed"));
+    if (h->n_ref && hipMemcpy(h->d_want, want.data(), sizeof(int32_t) * (size_t)h->n_ref, hipMemcpyHostToDevice) != hipSuccess)
+        return fail(g4s::set_error(G4S_ERR_HIP, "H2D copy failed"));
+    if (hipMemset(h->d_xrem, 0, sizeof(double) * (size_t)std::max(h->n_ref, 1)) != hipSuccess) return fail(g4s::set_error(G4S_ERR_HIP, "memset failed"));
+    if (hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming) != hipSuccess)
+        return fail(g4s::set_error(G4S_ERR_HIP, "stream / event creation failed"));
+    if (world == 1 && !h->loopback) h->give_set[0] = 1;            // nothing to exchange
+    *out = h;
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_spmv_dist_destroy(g4s_spmv_dist_t h)
+{
+    if (h) (void)hipDeviceSynchronize();
+    dist_release(h);
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_spmv_dist_get_info(g4s_spmv_dist_t h, g4s_spmv_dist_info *info)
+{
+    G4S_REQUIRE(h && info, "NULL argument");
+    info->rank = h->rank; info->world = h->world; info->local_rows = h->local_rows; info->n_ref = h->n_ref;
+    info->nnz_own = h->nnz_own; info->nnz_rem = h->nnz_rem;
+    info->recv_bytes = 8 * h->recv_cut[h->world];
+    info->send_bytes = 8 * h->give_cut[h->world];
+    g4s_csr_info ci;
+    G4S_TRY(g4s_csr_get_info(h->A_own, &ci)); info->own_path = ci.spmv_path;
+    G4S_TRY(g4s_csr_get_info(h->A_rem, &ci)); info->rem_path = ci.spmv_path;
+    int ready = 1;
+    for (int k = 0; k < h->world; ++k) ready &= h->give_set[k] || (k == h->rank && !h->loopback);
+    info->connected = ready;
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_spmv_dist_want(g4s_spmv_dist_t h, int32_t peer, int64_t *count, const int32_t **idx_dev)
+{
+    G4S_REQUIRE(h && peer >= 0 && peer < h->world && count, "bad argument");
+    *count = h->recv_cut[(size_t)peer + 1] - h->recv_cut[peer];
+    if (idx_dev) *idx_dev = h->d_want + h->recv_cut[peer];
+    return G4S_OK;
+}
+
+// The give lists arrive peer by peer, in any order; the send buffer is laid out in peer order once all of them are known.
+G4S_API g4s_status g4s_spmv_dist_set_give(g4s_spmv_dist_t h, int32_t peer, int64_t count, const int32_t *idx, unsigned flags)
+{
+    G4S_REQUIRE(h && peer >= 0 && peer < h->world && count >= 0 && (idx || count == 0), "bad argument");
+    G4S_REQUIRE(!h->d_send, "the give lists are final once a product has run");
+    std::vector<int32_t> list((size_t)count);
+    if (count) {
+        if (flags & G4S_DEVICE_POINTERS) G4S_HIP_TRY(hipMemcpy(list.data(), idx, sizeof(int32_t) * (size_t)count, hipMemcpyDeviceToHost));
+        else std::copy(idx, idx + count, list.begin());
+        const int32_t slab = (int32_t)(h->off[(size_t)h->rank + 1] - h->off[h->rank]);
+        for (int32_t v : list) G4S_REQUIRE(v >= 0 && v < slab, "a requested index is outside this rank's slab");
+    }
+    // append to the device list: rebuild it in peer order from what is known so far
+    std::vector<int32_t> all((size_t)h->give_cut[h->world]);
+    if (!all.empty()) G4S_HIP_TRY(hipMemcpy(all.data(), h->d_give, sizeof(int32_t) * all.size(), hipMemcpyDeviceToHost));
+    std::vector<int32_t> next;
+    std::vector<int64_t> cut((size_t)h->world + 1, 0);
+    for (int k = 0; k < h->world; ++k) {
+        cut[k] = (int64_t)next.size();
+        if (k == peer) next.insert(next.end(), list.begin(), list.end());
+        else next.insert(next.end(), all.begin() + h->give_cut[k], all.begin() + h->give_cut[(size_t)k + 1]);
+    }
+    cut[h->world] = (int64_t)next.size();
+    (void)hipFree(h->d_give);
+    h->d_give = nullptr;
+    if (g4s::device_malloc((void **)&h->d_give, sizeof(int32_t) * std::max<size_t>(next.size(), 1)) != hipSuccess) return g4s::set_error(G4S_ERR_NOMEM, "device allocation failed");
+    if (!next.empty()) G4S_HIP_TRY(hipMemcpy(h->d_give, next.data(), sizeof(int32_t) * next.size(), hipMemcpyHostToDevice));
+    h->give_cut = cut;
+    h->give_set[peer] = 1;
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_spmv_dist_connect_rccl(g4s_spmv_dist_t h, void *comm)
+{
+    G4S_REQUIRE(h && comm, "NULL argument");
+    G4S_TRY(rccl_load());
+    h->comm = reinterpret_cast<ncclComm_t>(comm);
+    const int W = h->world;
+    // 1. how many entries does every peer want from me? one 8-byte exchange per pair
+    std::vector<long long> want_n((size_t)W), give_n((size_t)W, 0);
+    for (int k = 0; k < W; ++k) want_n[k] = h->recv_cut[(size_t)k + 1] - h->recv_cut[k];
+    long long *d_cnt = nullptr;
+    G4S_HIP_TRY(g4s::device_malloc((void **)&d_cnt, sizeof(long long) * 2 * (size_t)W));
+    G4S_HIP_TRY(hipMemcpy(d_cnt, want_n.data(), sizeof(long long) * (size_t)W, hipMemcpyHostToDevice));
+    G4S_RCCL_TRY(g_rccl.GroupStart());
+    for (int k = 0; k < W; ++k) {
+        if (k == h->rank && !h->loopback) continue;
+        G4S_RCCL_TRY(g_rccl.Send(d_cnt + k, 1, ncclInt64, k, h->comm, h->cstream));
+        G4S_RCCL_TRY(g_rccl.Recv(d_cnt + W + k, 1, ncclInt64, k, h->comm, h->cstream));
+    }
+    G4S_RCCL_TRY(g_rccl.GroupEnd());
+    G4S_HIP_TRY(hipStreamSynchronize(h->cstream));
+    G4S_HIP_TRY(hipMemcpy(give_n.data(), d_cnt + W, sizeof(long long) * (size_t)W, hipMemcpyDeviceToHost));
+    (void)hipFree(d_cnt);
+    if (!h->loopback) give_n[h->rank] = 0;
+    // 2. the index lists themselves, received straight into the give list in peer order
+    std::vector<int64_t> cut((size_t)W + 1, 0);
+    for (int k = 0; k < W; ++k) cut[(size_t)k + 1] = cut[k] + give_n[k];
+    (void)hipFree(h->d_give);
+    h->d_give = nullptr;
+    G4S_HIP_TRY(g4s::device_malloc((void **)&h->d_give, sizeof(int32_t) * (size_t)std::max<int64_t>(cut[W], 1)));
+    G4S_RCCL_TRY(g_rccl.GroupStart());
+    for (int k = 0; k < W; ++k) {
+        if (k == h->rank && !h->loopback) continue;
+        if (want_n[k]) G4S_RCCL_TRY(g_rccl.Send(h->d_want + h->recv_cut[k], (size_t)want_n[k], ncclInt32, k, h->comm, h->cstream));
+        if (give_n[k]) G4S_RCCL_TRY(g_rccl.Recv(h->d_give + cut[k], (size_t)give_n[k], ncclInt32, k, h->comm, h->cstream));
+    }
+    G4S_RCCL_TRY(g_rccl.GroupEnd());
+    G4S_HIP_TRY(hipStreamSynchronize(h->cstream));
+    h->give_cut = cut;
+    std::fill(h->give_set.begin(), h->give_set.end(), 1);
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_spmv_dist_buffers(g4s_spmv_dist_t h, double **send_dev, const int64_t **send_cut, double **recv_dev, const int64_t **recv_cut)
+{
+    G4S_REQUIRE(h, "NULL handle");
+    if (!h->d_send) G4S_HIP_TRY(g4s::device_malloc((void **)&h->d_send, sizeof(double) * (size_t)std::max<int64_t>(h->give_cut[h->world], 1)));
+    if (send_dev) *send_dev = h->d_send;
+    if (send_cut) *send_cut = h->give_cut.data();
+    if (recv_dev) *recv_dev = h->d_xrem;
+    if (recv_cut) *recv_cut = h->recv_cut.data();
+    return G4S_OK;
+}
+
+// Pack the send segments, start the exchange (RCCL mode) on the side stream, run the own-column product on the caller's stream.
+G4S_API g4s_status g4s_spmv_dist_begin(g4s_spmv_dist_t h, const double *x_local_dev, double *y_local_dev, void *stream)
+{
+    G4S_REQUIRE(h && y_local_dev && (x_local_dev || h->local_rows == 0), "NULL argument");
+    for (int k = 0; k < h->world; ++k)
+        if (!(h->give_set[k] || (k == h->rank && !h->loopback)))
+            return g4s::set_error(G4S_ERR_INVALID, "g4s_spmv_dist_begin: the give list of peer %d is not set (g4s_spmv_dist_connect_rccl or g4s_spmv_dist_set_give)", k);
+    hipStream_t s = g4s::as_stream(stream);
+    G4S_TRY(g4s_spmv_dist_buffers(h, nullptr, nullptr, nullptr, nullptr));
+    const int64_t n_send = h->give_cut[h->world];
+    if (n_send) {
+        const int grid = (int)std::min<int64_t>((n_send + 255) / 256, 4096);
+        hipLaunchKernelGGL(dist_pack_kernel, dim3(grid), dim3(256), 0, s, n_send, h->d_give, x_local_dev, h->d_send);
+        G4S_HIP_TRY(hipGetLastError());
+    }
+    h->exchange_posted = false;
+    if (h->comm && (n_send || h->n_ref)) {
+        G4S_HIP_TRY(hipEventRecord(h->ev_packed, s));
+        G4S_HIP_TRY(hipStreamWaitEvent(h->cstream, h->ev_packed, 0));
+        G4S_RCCL_TRY(g_rccl.GroupStart());
+        for (int k = 0; k < h->world; ++k) {
+            if (k == h->rank && !h->loopback) continue;
+            const int64_t ns = h->give_cut[(size_t)k + 1] - h->give_cut[k], nr = h->recv_cut[(size_t)k + 1] - h->recv_cut[k];
+            if (ns) G4S_RCCL_TRY(g_rccl.Send(h->d_send + h->give_cut[k], (size_t)ns, ncclDouble, k, h->comm, h->cstream));
+            if (nr) G4S_RCCL_TRY(g_rccl.Recv(h->d_xrem + h->recv_cut[k], (size_t)nr, ncclDouble, k, h->comm, h->cstream));
+        }
+        G4S_RCCL_TRY(g_rccl.GroupEnd());
+        G4S_HIP_TRY(hipEventRecord(h->ev_done, h->cstream));
+        h->exchange_posted = true;
+    }
+    // the part of the product that needs nothing from anybody runs while the entries travel
+    return g4s_spmv(h->A_own, x_local_dev, y_local_dev, 1.0, 0.0, stream);
+}
+
+G4S_API g4s_status g4s_spmv_dist_finish(g4s_spmv_dist_t h, double *y_local_dev, void *stream)
+{
+    G4S_REQUIRE(h && y_local_dev, "NULL argument");
+    hipStream_t s = g4s::as_stream(stream);
+    if (h->exchange_posted) G4S_HIP_TRY(hipStreamWaitEvent(s, h->ev_done, 0));
+    h->exchange_posted = false;
+    if (h->nnz_rem == 0) return G4S_OK;
+    return g4s_spmv(h->A_rem, h->d_xrem, y_local_dev, 1.0, 1.0, stream);
+}
+
+G4S_API g4s_status g4s_spmv_dist_apply(g4s_spmv_dist_t h, const double *x_local_dev, double *y_local_dev, void *stream)
+{
+    G4S_REQUIRE(h, "NULL handle");
+    if ((h->world > 1 || h->loopback) && !h->comm && (h->n_ref || h->give_cut[h->world]))
+        return g4s::set_error(G4S_ERR_INVALID, "g4s_spmv_dist_apply needs g4s_spmv_dist_connect_rccl; with another transport use _begin / _buffers / _finish");
+    G4S_TRY(g4s_spmv_dist_begin(h, x_local_dev, y_local_dev, stream));
+    return g4s_spmv_dist_finish(h, y_local_dev, stream);
+}
+
+// ---------------------------------------------------------------------------------------------- communicator helpers
+G4S_API g4s_status g4s_comm_unique_id(void *id128)
+{
+    G4S_REQUIRE(id128, "NULL argument");
+    G4S_TRY(rccl_load());
+    ncclUniqueId id;
+    G4S_RCCL_TRY(g_rccl.GetUniqueId(&id));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(id128, &id, sizeof(id));
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_comm_create(void **comm, int32_t world, int32_t rank, const void *id128)
+{
+    G4S_REQUIRE(comm && id128 && world >= 1 && rank >= 0 && rank < world, "bad argument");
+    G4S_TRY(rccl_load());
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    ncclComm_t c = nullptr;
+    G4S_RCCL_TRY(g_rccl.CommInitRank(&c, world, id, rank));
+    *comm = c;
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_comm_destroy(void *comm)
+{
+    if (!comm) return G4S_OK;
+    G4S_TRY(rccl_load());
+    G4S_RCCL_TRY(g_rccl.CommDestroy(reinterpret_cast<ncclComm_t>(comm)));
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_comm_allreduce_sum_f64(void *comm, double *buf_dev, int64_t count, void *stream)
+{
+    G4S_REQUIRE(comm && (buf_dev || count == 0) && count >= 0, "bad argument");
+    G4S_TRY(rccl_load());
+    if (count) G4S_RCCL_TRY(g_rccl.AllReduce(buf_dev, buf_dev, (size_t)count, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm), g4s::as_stream(stream)));
+    return G4S_OK;
+}

@@ -256,3 +256,138 @@ def dist_conj_grad(A_local, exchange, BI_local, F_local, zero_resid_local, acc, 
         return d0, count.value, residual.value
     finally:
         lib.g4s_cg_ws_destroy(ws)
+
+
+class DistSpMV:
+    """The row-partitioned product behind the C-ABI (g4s_spmv_dist_*, csrc/dist.hip): own-column / remote-column split, packed exchange of
+    only the referenced x entries, own-column product overlapped with the exchange. This class only wires it to a transport:
+
+      * backend "nccl": the library's own RCCL communicator (g4s_comm_create; rank 0's 128-byte id reaches the others through one
+        torch.distributed broadcast) — ncclSend/ncclRecv issued by the library itself, `apply` is one C call;
+      * any other backend (gloo on the test boxes): the packed buffers the library exposes travel through torch.distributed
+        point-to-point between g4s_spmv_dist_begin and g4s_spmv_dist_finish.
+
+    rowptr / colids / values: this rank's rows [offsets[rank], offsets[rank+1]) with GLOBAL column ids, device tensors."""
+
+    def __init__(self, offsets, rank, world, rowptr, colids, values, n_cols, spmv_flags=0, group=None, loopback=False):
+        import ctypes as C
+        from . import capi, host
+        self._C, self._capi, self._host = C, capi, host
+        self.lib = capi.load()
+        self.offsets, self.rank, self.world, self.group = [int(v) for v in offsets], rank, world, group
+        self.n_local = self.offsets[rank + 1] - self.offsets[rank]
+        self.h = C.c_void_p()
+        offs = (C.c_int64 * (world + 1))(*self.offsets)
+        torch.cuda.current_stream().synchronize()
+        flags = capi.DEVICE_POINTERS | spmv_flags | (capi.DIST_LOOPBACK if loopback else 0)
+        capi.check(self.lib.g4s_spmv_dist_create(C.byref(self.h), rank, world, offs, int(n_cols), host._ptr(rowptr), host._ptr(colids), host._ptr(values), flags))
+        self.comm = None
+        self.rccl = dist.is_initialized() and dist.get_backend(group) == "nccl" if (world > 1) else bool(loopback)
+        if self.rccl:
+            idbuf = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                raw = (C.c_char * 128)()
+                capi.check(self.lib.g4s_comm_unique_id(raw))
+                idbuf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+            if world > 1:
+                dev = torch.device("cuda", torch.cuda.current_device())
+                t = idbuf.to(dev)
+                dist.broadcast(t, 0, group=group)
+                idbuf = t.cpu()
+            raw = (C.c_char * 128).from_buffer_copy(bytes(idbuf.numpy().tobytes()))
+            self.comm = C.c_void_p()
+            capi.check(self.lib.g4s_comm_create(C.byref(self.comm), world, rank, raw))
+            capi.check(self.lib.g4s_spmv_dist_connect_rccl(self.h, self.comm))
+        elif world > 1:
+            self._wire_by_torch()
+        self._views = None
+
+    # -- set-up over torch.distributed point-to-point: every rank tells every owner which entries it wants
+    def _wire_by_torch(self):
+        C, capi = self._C, self._capi
+        dev = torch.device("cuda", torch.cuda.current_device())
+        cdev = torch.device("cpu") if dist.get_backend(self.group) != "nccl" else dev
+        want = []
+        for k in range(self.world):
+            n, p = C.c_int64(), C.c_void_p()
+            capi.check(self.lib.g4s_spmv_dist_want(self.h, k, C.byref(n), C.byref(p)))
+            want.append(self._host.view_i32(p, n.value, dev).to(cdev) if n.value else torch.empty(0, dtype=torch.int32, device=cdev))
+        counts = torch.tensor([w.numel() for w in want], dtype=torch.int64, device=cdev)
+        allc = [torch.zeros_like(counts) for _ in range(self.world)]
+        dist.all_gather(allc, counts, group=self.group)
+        give_n = [int(allc[k][self.rank].item()) for k in range(self.world)]
+        ops, recv = [], [None] * self.world
+        for k in range(self.world):
+            if k == self.rank:
+                continue
+            if want[k].numel():
+                ops.append(dist.P2POp(dist.isend, want[k], k, group=self.group))
+            if give_n[k]:
+                recv[k] = torch.empty(give_n[k], dtype=torch.int32, device=cdev)
+                ops.append(dist.P2POp(dist.irecv, recv[k], k, group=self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for k in range(self.world):
+            if k == self.rank:
+                continue
+            g = recv[k].cpu().contiguous() if recv[k] is not None else torch.empty(0, dtype=torch.int32)
+            capi.check(self.lib.g4s_spmv_dist_set_give(self.h, k, g.numel(), C.c_void_p(g.data_ptr()) if g.numel() else None, capi.HOST_POINTERS))
+
+    def info(self):
+        i = self._capi.DistInfo()
+        self._capi.check(self.lib.g4s_spmv_dist_get_info(self.h, self._C.byref(i)))
+        return {n: getattr(i, n) for n, _ in i._fields_}
+
+    def _buffers(self):
+        if self._views is None:
+            C = self._C
+            sp, rp = C.c_void_p(), C.c_void_p()
+            sc, rc = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)()
+            self._capi.check(self.lib.g4s_spmv_dist_buffers(self.h, C.byref(sp), C.byref(sc), C.byref(rp), C.byref(rc)))
+            scut, rcut = [sc[k] for k in range(self.world + 1)], [rc[k] for k in range(self.world + 1)]
+            dev = torch.device("cuda", torch.cuda.current_device())
+            self._views = (self._host.view_f64(sp, max(scut[-1], 1), dev), scut, self._host.view_f64(rp, max(rcut[-1], 1), dev), rcut)
+        return self._views
+
+    def __call__(self, x_local, y_local=None):
+        """y_local = (A·x)[own rows]."""
+        host, capi = self._host, self._capi
+        if y_local is None:
+            y_local = torch.empty(self.n_local, dtype=torch.float64, device=x_local.device)
+        st = host._stream()
+        if self.rccl or self.world == 1:
+            capi.check(self.lib.g4s_spmv_dist_apply(self.h, host._ptr(x_local), host._ptr(y_local), st))
+            return y_local
+        capi.check(self.lib.g4s_spmv_dist_begin(self.h, host._ptr(x_local), host._ptr(y_local), st))
+        send, scut, recv, rcut = self._buffers()
+        ops = []
+        for k in range(self.world):
+            if k == self.rank:
+                continue
+            if scut[k + 1] > scut[k]:
+                ops.append(dist.P2POp(dist.isend, send[scut[k]:scut[k + 1]], k, group=self.group))
+            if rcut[k + 1] > rcut[k]:
+                ops.append(dist.P2POp(dist.irecv, recv[rcut[k]:rcut[k + 1]], k, group=self.group))
+        if ops:
+            if _gloo_on_device(x_local, self.group):
+                torch.cuda.synchronize()
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        capi.check(self.lib.g4s_spmv_dist_finish(self.h, host._ptr(y_local), st))
+        return y_local
+
+    def allreduce_sum(self, t):
+        """Sum over the ranks, in place: the library's RCCL communicator when there is one, torch.distributed otherwise."""
+        if self.comm is not None and self.world > 1:
+            self._capi.check(self.lib.g4s_comm_allreduce_sum_f64(self.comm, self._host._ptr(t), t.numel(), self._host._stream()))
+        else:
+            _all_reduce_sum(t, self.group)
+
+    def close(self):
+        if self.h:
+            self.lib.g4s_spmv_dist_destroy(self.h)
+            self.h = None
+        if self.comm is not None:
+            self.lib.g4s_comm_destroy(self.comm)
+            self.comm = None

@@ -134,6 +134,11 @@ def view_f64(ptr, count, device="cuda"):
     return torch.as_tensor(_BorrowedBuffer(ptr.value if hasattr(ptr, "value") else ptr, count, "<f8"), device=device)
 
 
+def view_i32(ptr, count, device="cuda"):
+    """torch view of `count` int32 at a device pointer the caller keeps alive."""
+    return torch.as_tensor(_BorrowedBuffer(ptr.value if hasattr(ptr, "value") else ptr, count, "<i4"), device=device)
+
+
 def _view(ptr, count, typestr, dtype, device):
     if count == 0:
         if ptr:

@@ -116,6 +116,50 @@ g4s_status g4s_spmv_csr_i32_f64(int32_t rows, int32_t cols, const int32_t *rowpt
                                 const double *values, const double *x, double *y,
                                 double alpha, double beta, unsigned flags);
 
+/* ---- B2 on several GPUs: the 1-D row-partitioned product (SURVEY.md §8b "g4s_spmv_dist_*", §8e). One process per GPU. Rank r owns rows
+ * [row_offsets[r], row_offsets[r+1]) of a square operator and the same slab of x and y; the local rows are given as CSR with GLOBAL column
+ * ids. The reference has no multi-device code on this path; the pattern replaced is CitcomS's per-mat-vec neighbour exchange
+ * (citcoms/lib/Regional_parallel_related.c:744-789) with the equal-work row split of mm/inc/BIN.h:101-122. Per product only the x entries
+ * a rank's rows actually reference travel (halo planes for stencils), each peer pair over its own xGMI link (ncclSend/ncclRecv in one
+ * group), while the own-column part of the product runs. */
+#define G4S_DIST_LOOPBACK 32u   /* single-rank rehearsal: half of the own slab is treated as remote and travels rank 0 → rank 0 through RCCL */
+typedef struct g4s_spmv_dist_s *g4s_spmv_dist_t;
+typedef struct g4s_spmv_dist_info {
+    int32_t rank, world, local_rows, n_ref;     /* n_ref: distinct remote columns this rank's rows reference (length of the compact remote x) */
+    int64_t nnz_own, nnz_rem;                   /* nonzeros in own / remote columns */
+    int64_t send_bytes, recv_bytes;             /* per product */
+    int32_t own_path, rem_path;                 /* g4s_csr_info.spmv_path of the two parts */
+    int32_t connected, reserved;                /* every peer's give list is known */
+} g4s_spmv_dist_info;
+/* flags: G4S_HOST_POINTERS / G4S_DEVICE_POINTERS for the three matrix arrays, the G4S_SPMV_* path flags, G4S_DIST_LOOPBACK.
+ * row_offsets: world+1 entries, host memory; row_offsets[world] == n_cols. Collective only in the sense that every rank creates its own. */
+g4s_status g4s_spmv_dist_create(g4s_spmv_dist_t *out, int32_t rank, int32_t world, const int64_t *row_offsets, int64_t n_cols,
+                                const int32_t *rowptr, const int32_t *colids, const double *values, unsigned flags);
+g4s_status g4s_spmv_dist_destroy(g4s_spmv_dist_t h);
+g4s_status g4s_spmv_dist_get_info(g4s_spmv_dist_t h, g4s_spmv_dist_info *info);
+/* Wiring, RCCL: comm is an ncclComm_t over the same ranks (the caller's own, or g4s_comm_create below); the want / give index lists
+ * are exchanged once with ncclSend / ncclRecv. Collective over the communicator. */
+g4s_status g4s_spmv_dist_connect_rccl(g4s_spmv_dist_t h, void *comm);
+/* Wiring, any other transport (MPI, gloo): idx_dev[0..count) are the entries this rank wants from `peer` (indices local to the peer's
+ * slab, device memory); the caller carries every list to its owner and hands it over with _set_give (flags: host or device pointer). */
+g4s_status g4s_spmv_dist_want(g4s_spmv_dist_t h, int32_t peer, int64_t *count, const int32_t **idx_dev);
+g4s_status g4s_spmv_dist_set_give(g4s_spmv_dist_t h, int32_t peer, int64_t count, const int32_t *idx, unsigned flags);
+/* y_local = (A·x)[own rows]. x_local_dev / y_local_dev: this rank's slabs, device memory. Asynchronous on `stream`; RCCL traffic runs on
+ * a stream of the handle. Needs g4s_spmv_dist_connect_rccl when world > 1. */
+g4s_status g4s_spmv_dist_apply(g4s_spmv_dist_t h, const double *x_local_dev, double *y_local_dev, void *stream);
+/* The same in two halves for callers with their own transport: _begin packs the send buffer and starts y = A_own·x_local; the caller moves
+ * send_dev[send_cut[k]..send_cut[k+1]) to peer k and receives peer k's entries into recv_dev[recv_cut[k]..recv_cut[k+1]) (both ordered after
+ * _begin on `stream`); _finish adds the remote-column part. */
+g4s_status g4s_spmv_dist_begin(g4s_spmv_dist_t h, const double *x_local_dev, double *y_local_dev, void *stream);
+g4s_status g4s_spmv_dist_buffers(g4s_spmv_dist_t h, double **send_dev, const int64_t **send_cut, double **recv_dev, const int64_t **recv_cut);
+g4s_status g4s_spmv_dist_finish(g4s_spmv_dist_t h, double *y_local_dev, void *stream);
+/* RCCL communicator for hosts that have none (rank 0 makes the 128-byte id, every rank gets it by its own means and calls _create), and
+ * the sum all-reduce the dot products of a Krylov solver need (citcoms/lib/Global_operations.c:534-562). RCCL is dlopen'ed at first use. */
+g4s_status g4s_comm_unique_id(void *id128);
+g4s_status g4s_comm_create(void **comm, int32_t world, int32_t rank, const void *id128);
+g4s_status g4s_comm_destroy(void *comm);
+g4s_status g4s_comm_allreduce_sum_f64(void *comm, double *buf_dev, int64_t count, void *stream);
+
 /* ------------------------------------------------------------------ B1: CSR SpGEMM  C = A·B */
 
 /* Stage timer with the reference's seven fields, milliseconds (mm/inc/Timings.h:4-23). */
@@ -312,6 +356,26 @@ g4s_status g4s_dense_rows_times_matrix(int32_t M, int32_t N, int32_t K, const do
  * slab order (no atomics): the same inputs give the same bits. */
 g4s_status g4s_dense_rows_times_matrix_grad(int32_t M, int32_t N, int32_t K, const double *xx_dev, const double *w_dev,
                                             const double *grad_dev, double *dxx_dev, double *dw_dev, void *stream);
+
+/* ---- The reference's dense comparison drivers: what it times next to the sparse kernels, not the hot path.
+ * Column-major dim×dim fp64, alpha = 1, beta = 0, as the reference calls MKL. Host pointers, or device pointers with
+ * G4S_DEVICE_POINTERS; synchronous.
+ *   g4s_dense_mm — mm/src/cblas_dxxmm.c:57-111:  DGEMM  C = A·B          (cblas_dgemm ColMajor NoTrans NoTrans, :96-111)
+ *                                                DSYMM  C = sym(A)·B     (cblas_dsymm Left Upper: only A's upper triangle is read, :57-76)
+ *                                                DTRMM  B := B·triu(A)   (cblas_dtrmm Right Upper NoTrans NonUnit, in place; C unused, :78-95)
+ *   g4s_dense_mv — mv/mv.c:6-27:                 DGEMV  y = A·x (:23-27)   DSYMV  y = sym(A)·x (Upper, :6-10)
+ *                                                DTRMV  x := triu(A)ᵀ·x (Upper Trans NonUnit, in place; y unused, :12-15)
+ *                                                DSPMV  y = sym(AP)·x, AP the packed upper triangle, dim(dim+1)/2 doubles (:17-21)
+ * Level 3 runs on the fp64 MFMA GEMM of g4s_dense_rows_times_matrix; level 2 is one HBM pass over the matrix. */
+#define G4S_DENSE_DGEMM 1
+#define G4S_DENSE_DSYMM 2
+#define G4S_DENSE_DTRMM 3
+#define G4S_DENSE_DGEMV 4
+#define G4S_DENSE_DSYMV 5
+#define G4S_DENSE_DTRMV 6
+#define G4S_DENSE_DSPMV 7
+g4s_status g4s_dense_mm(int32_t kind, int32_t dim, const double *A, double *B, double *C, unsigned flags);
+g4s_status g4s_dense_mv(int32_t kind, int32_t dim, const double *A, double *x, double *y, unsigned flags);
 
 /* result[0] += Σ_i Σ_{j<i} x_i x_j (a[num·(i+m·j)] + a[num·(j+m·i)]) + Σ_i x_i² a[num·(i+m·i)];
  * numbers == 1: result[1] += Σ_i x_i·b_i (apply1); numbers > 1: result[1] likewise on a[…+1] (gather2/apply2).

@@ -38,9 +38,22 @@ def test_bench_single_rank_contract():
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1.5 and d["roofline"]["unit"] == "GB/s"
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
     assert d["config"]["spmv_path"] == "blocked" and "model" not in d["config"]
+    assert d["max_rel_err"] <= 1e-10 and d["parity"]["ok"] is True                 # the bench checks its own y against the oracle's
+    assert set(d["cpu_baseline"]["by_threads"]) >= {"1"} and "reproducible" in d["config"] and "traffic_source" in d["roofline"]
 
 
-@pytest.mark.parametrize("workload,exchange", [("rmat", "allgatherv"), ("rmat", "compact"), ("rmat", "allgather"), ("lap7", "needed")])
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver calls --gpus 1) starts its own ranks before touching the GPU."""
+    env = dict(os.environ, G4S_BENCH_SAME_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--small", "--backend", "gloo", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "dist" in d["config"]["exchange"]
+
+
+@pytest.mark.parametrize("workload,exchange", [("rmat", "dist"), ("lap7", "dist"), ("rmat", "allgatherv"), ("rmat", "compact"), ("rmat", "allgather"), ("lap7", "needed")])
 def test_bench_two_ranks_rehearsal(workload, exchange):
     env = dict(os.environ, G4S_BENCH_SAME_DEVICE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_port()),

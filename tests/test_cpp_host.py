@@ -138,6 +138,21 @@ def test_cpp_mkl_spgemm_cli(tmp_path, oracle):
     assert np.allclose(got, want, rtol=1e-12, atol=1e-14)
 
 
+def test_dense_compare_driver_compiles(tmp_path):
+    _build_example("dense_compare_g4s.cpp", str(tmp_path / "dense_compare_g4s"))
+
+
+@pytest.mark.gpu
+def test_dense_compare_driver_runs_on_gpu(tmp_path):
+    """a14: the reference's dense comparison programs (mm/src/cblas_dxxmm.c, mv/mv.c) against the device library, one line per routine."""
+    exe = str(tmp_path / "dense_compare_g4s")
+    _build_example("dense_compare_g4s.cpp", exe)
+    out = subprocess.run([exe, "700"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "CHECK OK" in out.stdout, out.stdout + out.stderr
+    for name in ("cblas_dsymm", "cblas_dtrmm", "cblas_dgemm", "matrix_multiply_dsymv", "matrix_multiply_dtrmv", "matrix_multiply_sspmv", "matrix_multiply_dgemv"):
+        assert name + " 运行时间：" in out.stdout
+
+
 def _build_c_example(out):
     lib = os.path.join(ROOT, "g4s_amd", "lib")
     subprocess.check_call(["gcc", "-std=c99", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "citcoms_like.c"),

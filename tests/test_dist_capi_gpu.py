@@ -1,0 +1,113 @@
+"""The multi-GPU SpMV of the C-ABI (g4s_spmv_dist_*, csrc/dist.hip): own-column / remote-column split, packed exchange of the referenced x
+entries, own-column product overlapped with the exchange.
+
+A one-GPU test box cannot run RCCL between ranks, so two things are rehearsed separately:
+  * the partition logic, the want/give wiring, begin / buffers / finish — with 1, 2 and 3 ranks that share the GPU and carry the packed
+    buffers through gloo (the "any other transport" half of the API);
+  * the RCCL half (g4s_comm_create, g4s_spmv_dist_connect_rccl, ncclSend/ncclRecv inside g4s_spmv_dist_apply on a side stream with the
+    event hand-over) — with ONE rank in loopback mode: half of its own slab is treated as remote and travels rank 0 → rank 0.
+Every y must equal the single-rank oracle within 1e-10 · Σ|terms|."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests.helpers import power_law_csr
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _matrix(kind, oracle):
+    if kind == "powerlaw":
+        n = 60000
+        return (*power_law_csr(n, n, 31, 20000), n)
+    if kind == "lap7":
+        rp, ci, va = oracle.laplacian7(40, 30, 25)
+        return rp, ci, va, 40 * 30 * 25
+    n = 5000
+    rp, ci, va = oracle.banded(n, 3, 5)
+    return rp, ci, va, n
+
+
+def _worker(rank, world, port, kind, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from g4s_amd import dist as gdist
+    from tests import oracle_lib
+    rp, ci, va, n = _matrix(kind, oracle_lib.load())
+    rpt = torch.from_numpy(rp).cuda()
+    offs = gdist.row_partition(rpt, world)
+    r0, r1 = offs[rank], offs[rank + 1]
+    lrp, lci, lva = gdist.slice_rows(rpt, torch.from_numpy(ci).cuda(), torch.from_numpy(va).cuda(), r0, r1)
+    D = gdist.DistSpMV(offs, rank, world, lrp, lci, lva, n)
+    x = np.random.default_rng(3).uniform(-1, 1, n)
+    xl = torch.from_numpy(x[r0:r1]).cuda()
+    y1 = D(xl).clone()
+    y2 = D(xl)                                                      # a second product on the same handle
+    info = D.info()
+    np.save(os.path.join(out_dir, f"y{rank}.npy"), y1.cpu().numpy())
+    np.save(os.path.join(out_dir, f"z{rank}.npy"), y2.cpu().numpy())
+    np.save(os.path.join(out_dir, f"i{rank}.npy"), np.array([r0, r1, info["n_ref"], info["nnz_own"], info["nnz_rem"], info["recv_bytes"], info["send_bytes"]]))
+    dist.barrier()
+    D.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kind", [(1, "powerlaw"), (2, "powerlaw"), (3, "powerlaw"), (2, "lap7"), (3, "banded")])
+def test_dist_spmv_capi_matches_oracle(tmp_path, oracle, world, kind):
+    mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
+    rp, ci, va, n = _matrix(kind, oracle)
+    x = np.random.default_rng(3).uniform(-1, 1, n)
+    want = oracle.spmv(rp, ci, va, x)
+    _, asum = oracle.spmv_ld(rp, ci, va, x)
+    got = np.concatenate([np.load(tmp_path / f"y{r}.npy") for r in range(world)])
+    again = np.concatenate([np.load(tmp_path / f"z{r}.npy") for r in range(world)])
+    assert np.all(np.abs(got - want) <= TOL * asum + 1e-300) and np.all(np.abs(again - want) <= TOL * asum + 1e-300)
+    metas = [np.load(tmp_path / f"i{r}.npy") for r in range(world)]
+    assert sum(int(m[3] + m[4]) for m in metas) == len(ci)          # every nonzero is in exactly one of the two parts
+    assert sum(int(m[5]) for m in metas) == sum(int(m[6]) for m in metas)   # what is received was sent
+    if world == 1:
+        assert int(metas[0][2]) == 0 and int(metas[0][5]) == 0
+    if kind == "lap7" and world == 2:
+        # the halo of a slab cut along z is one plane of 40·30 columns per neighbour
+        assert [int(m[2]) for m in metas] == [1200, 1200]
+
+
+def test_dist_spmv_rccl_loopback_single_rank(oracle):
+    """RCCL itself, on one GPU: the library makes its own communicator of one rank; with G4S_DIST_LOOPBACK the upper half of the slab is
+    'remote', so every product packs, ncclSend/ncclRecv's (to itself) on the side stream, and finishes with the remote-column part."""
+    from g4s_amd import dist as gdist
+    n = 50000
+    rp, ci, va = power_law_csr(n, n, 41, 9000)
+    x = np.random.default_rng(8).uniform(-1, 1, n)
+    D = gdist.DistSpMV([0, n], 0, 1, torch.from_numpy(rp).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(va).cuda(), n, loopback=True)
+    info = D.info()
+    assert info["connected"] == 1 and info["n_ref"] > 0 and info["recv_bytes"] == info["send_bytes"] == 8 * info["n_ref"]
+    assert info["nnz_own"] + info["nnz_rem"] == len(ci) and info["nnz_rem"] > 0
+    xl = torch.from_numpy(x).cuda()
+    want = oracle.spmv(rp, ci, va, x)
+    _, asum = oracle.spmv_ld(rp, ci, va, x)
+    for _ in range(3):
+        y = D(xl).cpu().numpy()
+        assert np.all(np.abs(y - want) <= TOL * asum + 1e-300)
+    # the all-reduce the Krylov dots use
+    t = torch.arange(8, dtype=torch.float64, device="cuda")
+    D.allreduce_sum(t)
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.arange(8, dtype=torch.float64))
+    D.close()

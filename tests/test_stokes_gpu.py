@@ -88,7 +88,7 @@ def test_uzawa_iteration_matches_oracle(oracle, ex, ey, ez, seed, check_cont, ch
     # the printed convergence line of every outer iteration: v, p, dv/v, dp/p, div/v
     assert np.allclose(hist[:cnt_o + 1, :2], hist_o[:, :2], rtol=1e-8)
     assert np.allclose(hist[:cnt_o + 1, 2:], hist_o[:, 2:], rtol=1e-4, atol=1e-12)
-    assert res.incompressibility <= imp or check_cont
+    assert np.isclose(res.incompressibility, inc_o, rtol=1e-4, atol=1e-14)   # the loop's own exit rule decides how small it gets (keep_iterating)
     # the solution satisfies the discrete Stokes system: momentum residual small, divergence small
     mom = pr["F"] - oracle.assemble_grad_p(ien, idmap, pr["g"], neq, pr["bc"], Pg)
     Kv = oracle.element_matvec(ien, idmap, pr["K"], Vg, neq)
