@@ -42,7 +42,8 @@ typedef int g4s_status;
 #define G4S_SORT_OUTPUT      2u /* SpGEMM: rows of C sorted by column (HashSpGEMM sortOutput, hash_mult.h:526-553) */
 #define G4S_SPMV_NO_NT       4u /* SpMV: plain (cache-allocating) loads for the matrix stream instead of nontemporal */
 #define G4S_SPMV_BLOCKED     8u /* SpMV: force the propagation-blocked path (x band / y band in LDS; for matrices without gather locality) */
-#define G4S_SPMV_STREAM     16u /* SpMV: force the row-streaming CSR path (default: chosen per matrix by a locality probe)  */
+#define G4S_SPMV_STREAM     16u /* SpMV: force the row-streaming CSR kernel (default: chosen per matrix — blocked for matrices without gather locality,
+                                 * the index-free diagonal form for stencil / banded matrices, the CSR kernel otherwise) */
 
 /* ------------------------------------------------------------------ runtime */
 const char *g4s_version(void);
@@ -83,7 +84,8 @@ typedef struct g4s_csr_info {
     int32_t tile_nnz, tile_rows, long_chunk_nnz;
     int64_t algorithmic_bytes;/* 12·nnz + 4·(rows+1) + 8·rows + 8·cols                      */
     int64_t plan_bytes;       /* extra device bytes the plan itself occupies                               */
-    int32_t spmv_path;        /* 0 = row-streaming CSR kernel, 1 = propagation-blocked (regrouped copy of the matrix), 2 = tile-blocked experiment (G4S_SPMV_IMPL=tb) */
+    int32_t spmv_path;        /* 0 = row-streaming CSR kernel, 1 = propagation-blocked (regrouped copy of the matrix), 2 = tile-blocked experiment (G4S_SPMV_IMPL=tb),
+                               * 3 = diagonal-structured, index-free (stencil / banded matrices: values by diagonal + a presence mask per row) */
     int32_t reserved;
 } g4s_csr_info;
 

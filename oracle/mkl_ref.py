@@ -62,7 +62,7 @@ def load(threading="sequential"):
     lib.mkl_sparse_d_export_csr.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(vp), C.POINTER(vp),
                                             C.POINTER(vp), C.POINTER(vp)]
     lib.mkl_sparse_destroy.argtypes = [vp]
-    lib.mkl_set_num_threads.argtypes = [C.c_int]
+    lib.MKL_Set_Num_Threads.argtypes = [C.c_int]   # the lower-case symbol is the Fortran binding (argument by reference)
     lib.mkl_get_version_string.argtypes = [C.c_char_p, C.c_int]
     d_ = C.c_double
     lib.cblas_dgemv.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, d_, _f64, C.c_int, _f64, C.c_int, d_, _f64, C.c_int]
@@ -94,7 +94,7 @@ def mkl_spgemm(A, B, M, K, N, timings=None, threads=None):
     import time
     lib = load()
     if threads is not None:
-        lib.mkl_set_num_threads(int(threads))
+        lib.MKL_Set_Num_Threads(int(threads))
     arpt, acol, aval = (np.ascontiguousarray(A[0], np.int32), np.ascontiguousarray(A[1], np.int32), np.ascontiguousarray(A[2], np.float64))
     brpt, bcol, bval = (np.ascontiguousarray(B[0], np.int32), np.ascontiguousarray(B[1], np.int32), np.ascontiguousarray(B[2], np.float64))
     hA, hB, hC = vp(), vp(), vp()

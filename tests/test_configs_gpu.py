@@ -27,7 +27,7 @@ def test_config0_lap5_1000x1000_bit_exact(oracle):
     """configs[0]: 1M×1M 5-point Laplacian, nnz 4 996 000, x_i as SURVEY §8d; the generator equals the oracle's, y bit for bit."""
     from g4s_amd import host
     A = host.laplacian_csr(5, 1000, 1000)
-    assert A.nnz == 4_996_000 and A.info()["spmv_path"] == 0
+    assert A.nnz == 4_996_000 and A.info()["spmv_path"] == 3          # diagonal-structured: the index-free path
     for got, want in zip(A.to_host(), oracle.laplacian5(1000, 1000)):
         assert np.array_equal(got, want)
     x = host.synth_vector(7, A.cols)
@@ -62,7 +62,7 @@ def test_config3_lap7_slab_global_columns(oracle):
     plane = s * s
     r0, r1 = 200 * plane, 240 * plane
     A = host.laplacian_csr(7, s, s, s, r0=r0, r1=r1)
-    assert A.rows == 40 * plane and A.cols == s ** 3 and A.info()["spmv_path"] == 0
+    assert A.rows == 40 * plane and A.cols == s ** 3 and A.info()["spmv_path"] == 3
     rp, ci, va = oracle.laplacian7(s, s, s, r0, r1)
     for got, want in zip(A.to_host(), (rp, ci, va)):
         assert np.array_equal(got, want)
@@ -85,8 +85,14 @@ def test_config3_lap7_whole_cube_small(oracle):
 def test_banded_10m_full_size(oracle):
     """north_star's banded matrix at benchmark size (10M, half-bandwidth 5)."""
     from g4s_amd import host
+    from g4s_amd import capi
     A = host.banded_csr(10_000_000, 5, 20240521)
-    assert A.info()["spmv_path"] == 0
-    # random values: bit-identical wherever one lane sums a row in the oracle's order — every stream block of more than 128 rows, i.e. all
-    # but the matrix's last, partly filled block (its rows are reduced by several lanes + shuffles: inside the tolerance, not bit for bit)
-    _spmv_vs_oracle(oracle, A, host.synth_vector(7, A.cols), exact=True, exact_rows=A.rows - 1024)
+    assert A.info()["spmv_path"] == 3
+    # random values, index-free diagonal path: one lane per row adds the present products in ascending column order — the oracle's order —
+    # so EVERY row is bit-identical
+    _spmv_vs_oracle(oracle, A, host.synth_vector(7, A.cols), exact=True)
+    # the CSR kernel on the same matrix (G4S_SPMV_STREAM): bit-identical wherever one lane sums a row — every stream block of more than 128
+    # rows, i.e. all but the matrix's last, partly filled block (its rows are reduced by several lanes + shuffles: inside the tolerance)
+    S = host.CSR(A.rowptr, A.colids, A.values, A.rows, A.cols, spmv_flags=capi.SPMV_STREAM)
+    assert S.info()["spmv_path"] == 0
+    _spmv_vs_oracle(oracle, S, host.synth_vector(7, A.cols), exact=True, exact_rows=A.rows - 1024)

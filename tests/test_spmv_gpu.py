@@ -196,7 +196,8 @@ def test_spmv_blocked_path(oracle, kind, impl, monkeypatch):
 def test_spmv_path_selection():
     from g4s_amd import host
     # banded 10M: gathers are local → streaming path; R-MAT 10M: no locality → blocked path
-    assert host.banded_csr(6_000_000, 5, 1).info()["spmv_path"] == 0
+    assert host.banded_csr(6_000_000, 5, 1).info()["spmv_path"] == 3      # diagonal-structured → index-free path
+    assert host.banded_csr(6_000_000, 5, 1, spmv_flags=16).info()["spmv_path"] == 0   # G4S_SPMV_STREAM forces the CSR kernel
     A = host.rmat_csr(6_000_000, 23, 30_000_000, 5)
     assert A.info()["spmv_path"] in (1, 2)
 
@@ -278,3 +279,44 @@ def test_spmv_blocked_hot_column_bands(oracle, monkeypatch, hot):
     x = rng.uniform(-1, 1, cols)
     _check(oracle, A, rp, ci, va, x)
     _check(oracle, A, rp, ci, va, x, alpha=0.75, beta=-2.0, y0=rng.uniform(-1, 1, rows))
+
+
+def test_spmv_diagonal_path(oracle):
+    """The index-free path for diagonal-structured matrices: chosen for stencils and bands, refused for anything else, bit-identical to the
+    oracle on every row (one lane per row, products added in ascending column order), alpha/beta, rectangular shapes, boundary rows."""
+    from g4s_amd import capi, host
+    import scipy.sparse as sp
+    rng = np.random.default_rng(12)
+    cases = []
+    for (nx, ny, nz) in [(50, 40, 30), (300, 7, 5)]:
+        rp, ci, va = oracle.laplacian7(nx, ny, nz)
+        cases.append((rp, ci, rng.uniform(-1, 1, len(ci)), nx * ny * nz, nx * ny * nz, 7))
+    rp, ci, va = oracle.banded(40000, 9, 4)
+    cases.append((rp, ci, va, 40000, 40000, 19))
+    # rectangular: rows × (rows + 50), offsets {0, 3, 50}, the last rows lose entries
+    rows, cols = 30000, 30020
+    M = sp.diags([rng.uniform(-1, 1, rows), rng.uniform(-1, 1, rows), rng.uniform(-1, 1, rows)], [0, 3, 50], shape=(rows, cols), format="csr")
+    M.sort_indices()
+    cases.append((M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data.astype(np.float64), rows, cols, 3))
+    for rp, ci, va, rows, cols, nd in cases:
+        A = host.CSR.from_host(rp, ci, va, rows, cols)
+        assert A.info()["spmv_path"] == 3
+        x = rng.uniform(-1, 1, cols)
+        _check(oracle, A, rp, ci, va, x, exact=True)
+        _check(oracle, A, rp, ci, va, x, alpha=-0.5, beta=2.0, y0=rng.uniform(-1, 1, rows), exact=True)
+    # not diagonal-structured: a random matrix, and a band with one stray entry → the CSR kernel
+    rp, ci, va = random_csr(20000, 20000, 0.0005, 3)
+    assert host.CSR.from_host(rp, ci, va, 20000, 20000).info()["spmv_path"] == 0
+    rp, ci, va = oracle.banded(40000, 2, 4)
+    B = sp.csr_matrix((va, ci, rp), shape=(40000, 40000)).tolil()
+    for stray_row, want_path in ((5000, 0), (20000, 3)):
+        # a stray entry in a row the candidate scan does not sample (first / middle / last 2048 rows) is found by the fill pass → CSR kernel;
+        # in a sampled row its offset simply becomes one more (nearly empty) diagonal
+        Bs = B.copy()
+        Bs[stray_row, 7] = 1.5
+        Bs = Bs.tocsr()
+        Bs.sort_indices()
+        arrs = (Bs.indptr.astype(np.int32), Bs.indices.astype(np.int32), Bs.data)
+        S = host.CSR.from_host(*arrs, 40000, 40000)
+        assert S.info()["spmv_path"] == want_path
+        _check(oracle, S, *arrs, rng.uniform(-1, 1, 40000), exact=(want_path == 3))

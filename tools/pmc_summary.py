@@ -18,9 +18,10 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
                 if key in k:
                     short = key
             if short is None:
-                for key in ("spgemm", "elem_", "dense_rows"):
-                    if key in k:
-                        short = k.split("(")[0][-60:]
+                import re
+                m = re.search(r"(\w+_kernel)(<[^>]*>)?", k)
+                if m and any(key in m.group(1) for key in ("spgemm", "hub_", "row_flop", "elem_", "dense_", "tb_", "spmv_dia")):
+                    short = m.group(1) + (m.group(2) or "")
             if short is None:
                 continue
             acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
