@@ -92,6 +92,59 @@ def cpu_baseline(A, x, budget_s=18.0):
     return base, y, asum
 
 
+def config3_lap7(world, rank, steps, warmup, small, host, gdist, dist, torch):
+    """BASELINE configs[3] beside the headline number: the 431^3 7-point Laplacian (80M rows), rows split evenly over the ranks, every rank
+    generating only its slab; N = 1: one g4s_spmv handle; N > 1: the library's distributed product (halo planes travel, overlapped with the
+    own-column part). Same timing protocol as the main measurement. Reported as `also`, never as `value`."""
+    s = 431 if not small else 48
+    n = s ** 3
+    offs = [(n * k) // world for k in range(world + 1)]
+    r0, r1 = offs[rank], offs[rank + 1]
+    A = host.laplacian_csr(7, s, s, s, r0=r0, r1=r1)
+    x_local = host.synth_vector(7, r1 - r0, i0=r0)
+    y_local = torch.empty(r1 - r0, dtype=torch.float64, device="cuda")
+    nnz_local = A.nnz
+    if world > 1:
+        D = gdist.DistSpMV(offs, rank, world, A.rowptr, A.colids, A.values, n)
+        path = D.info()["own_path"]
+        A = None
+        torch.cuda.empty_cache()
+
+        def step():
+            D(x_local, y_local)
+    else:
+        D = None
+        path = A.info()["spmv_path"]
+
+        def step():
+            A.spmv(x_local, y_local)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    nz = torch.tensor([float(nnz_local)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(nz)
+    el, nnz = float(el.item()), int(nz.item())
+    if D is not None:
+        D.close()
+    alg = 12 * nnz + 4 * (n + 1) + 16 * n
+    return {"workload": WORKLOADS["lap7"] + (" [--small size]" if small else ""), "n_gpus": world, "rows": n, "nnz": nnz, "steps": steps, "ms_per_step": round(el / steps * 1e3, 5),
+            "value": round(nnz * steps / el / 1e9, 3), "unit": "GEdges/s", "spmv_path": {0: "stream", 1: "blocked", 3: "diagonal (index-free)"}.get(path, str(path)),
+            "hbm_gbs_algorithmic_whole_job": round(alg * steps / el / 1e9, 1), "frac_of_n_gpus_x_8TBs": round(alg * steps / el / 1e9 / (8000.0 * world), 4)}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as fresh child processes (this process has not
     touched the GPU yet and never will), relay rank 0's JSON line, return the children's exit code."""
@@ -118,6 +171,7 @@ def main():
                          "product); the others are round 1's torch.distributed variants, kept for A/B runs")
     ap.add_argument("--small", action="store_true", help="reduced sizes for plumbing checks (not a valid benchmark)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary configs[3] (7-point Laplacian 431^3) measurement reported under `also`")
     ap.add_argument("--no-nt", action="store_true", help="plain loads for the matrix stream (A/B against nontemporal)")
     ap.add_argument("--path", default="auto", choices=["auto", "stream", "blocked"],
                     help="SpMV path: auto = the library picks per matrix (propagation-blocked without gather locality, index-free diagonal form for "
@@ -171,7 +225,8 @@ def main():
             D = gdist.DistSpMV(offs, rank, world, rp, ci, va, n_cols, spmv_flags=flags)
             dinfo = D.info()
             recv_bytes = dinfo["recv_bytes"]
-            info = {"spmv_path": dinfo["own_path"], "algorithmic_bytes": 12 * int(rp[-1].item()) + 4 * (r1 - r0 + 1) + 8 * (r1 - r0) + 8 * (r1 - r0 + dinfo["n_ref"]),
+            info = {"spmv_path": dinfo["rem_path"] if dinfo["reserved"] else dinfo["own_path"], "dist_form": "merged (one product on a compact x)" if dinfo["reserved"] else "own + remote columns",
+                    "algorithmic_bytes": 12 * int(rp[-1].item()) + 4 * (r1 - r0 + 1) + 8 * (r1 - r0) + 8 * (r1 - r0 + dinfo["n_ref"]),
                     "rows": r1 - r0, "nnz": int(rp[-1].item())}
 
             def product():
@@ -273,8 +328,8 @@ def main():
                    "rows": n_rows, "cols": n_cols, "nnz": nnz_total, "index": "int32",
                    "partition": f"1-D rows by equal nnz+rows over {world} rank(s)",
                    "exchange": ("none (single GPU)" if world == 1 else
-                                (f"dist: g4s_spmv_dist_* (own/remote column split, packed ncclSend/ncclRecv of the referenced x entries overlapped with the own-column "
-                                 f"product), {recv_bytes} B received by rank 0 per step" if mode == "dist" else f"{mode} over torch.distributed, {recv_bytes} B received by rank 0 per step")),
+                                (f"dist: g4s_spmv_dist_* ({info.get('dist_form')}; packed ncclSend/ncclRecv of the referenced x entries"
+                                 f"{'' if dinfo['reserved'] else ', overlapped with the own-column product'}), {recv_bytes} B received by rank 0 per step" if mode == "dist" else f"{mode} over torch.distributed, {recv_bytes} B received by rank 0 per step")),
                    "matrix_loads": "plain" if args.no_nt else "nontemporal",
                    "spmv_path": {0: "stream", 1: "blocked", 2: "blocked (tile-blocked experiment)", 3: "diagonal (index-free)"}[info["spmv_path"]],
                    "reproducible": ("yes: fixed summation order, no atomics" if info["spmv_path"] in (0, 3) else
@@ -298,6 +353,12 @@ def main():
         result["parity"] = {"against": "oracle/g4s_oracle.c CSR SpMV on the same matrix and x", "tolerance": 1e-10, "ok": bool(err.max() <= 1e-10)}
     elif rank == 0:
         result["cpu_baseline"] = None
+    if not args.no_also and args.workload == "rmat":
+        # the multi-GPU config of BASELINE.json (configs[3]) in the same run, same ranks — R-MAT has no column locality and its strong
+        # scaling is exchange-bound by construction; the stencil shows what the row partition does when only halos travel
+        torch.cuda.empty_cache()
+        also = config3_lap7(world, rank, max(10, args.steps // 2), min(args.warmup, 5), args.small, host, gdist, dist, torch)
+        result["also"] = also
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -81,6 +81,7 @@ __global__ void dist_pack_kernel(long long n, const int32_t *__restrict__ idx, c
 struct g4s_spmv_dist_s {
     int rank = 0, world = 1;
     bool loopback = false;
+    bool merged = false;                        // the own columns are few: one product on a compact x that holds own and remote entries alike
     std::vector<int64_t> off;                   // row (= x) partition, world+1
     int32_t local_rows = 0;
     int64_t nnz_own = 0, nnz_rem = 0;
@@ -155,8 +156,16 @@ G4S_API g4s_status g4s_spmv_dist_create(g4s_spmv_dist_t *out, int32_t rank, int3
                 return fail(g4s::set_error(G4S_ERR_HIP, "D2H copy of the matrix failed"));
         } else { std::copy(colids, colids + nnz, ci.begin()); std::copy(values, values + nnz, va.begin()); }
     }
-    // own range of columns (loopback: only the first half of the slab counts as own, the rest travels rank 0 → rank 0 through RCCL)
-    const int64_t own_lo = r0, own_hi = h->loopback ? r0 + (r1 - r0) / 2 : r1;
+    // own range of columns (loopback: only the first half of the slab counts as own, the rest travels rank 0 → rank 0 through RCCL).
+    // Merged form: when fewer than a quarter of the entries sit in own columns (a power-law graph cut into row slabs: ≈10 %), two products
+    // cost more than the overlap buys (tools/dist_probe.py: 0.12–0.16 ms against 0.07–0.09 ms for one product on an eighth of configs[1]),
+    // so the own columns are renumbered into the compact x like everybody else's and filled by a local gather instead of a message.
+    int64_t own_lo = r0, own_hi = h->loopback ? r0 + (r1 - r0) / 2 : r1;
+    if (!h->loopback && world > 1 && !getenv("G4S_DIST_NO_MERGE")) {
+        int64_t in_own = 0;
+        for (int64_t k = 0; k < nnz; ++k) in_own += ci[k] >= own_lo && ci[k] < own_hi;
+        if (getenv("G4S_DIST_MERGE") || 4 * in_own < nnz) { h->merged = true; own_hi = own_lo; }
+    }
     std::vector<int32_t> ref;                                       // referenced remote columns
     for (int64_t k = 0; k < nnz; ++k) {
         const int32_t c = ci[k];
@@ -192,7 +201,7 @@ G4S_API g4s_status g4s_spmv_dist_create(g4s_spmv_dist_t *out, int32_t rank, int3
         want[i] = (int32_t)(ref[i] - h->off[k]);
     }
     for (int k = 0; k < world; ++k) h->recv_cut[(size_t)k + 1] += h->recv_cut[k];
-    if (!h->loopback && h->recv_cut[(size_t)rank + 1] != h->recv_cut[rank]) return fail(g4s::set_error(G4S_ERR_INVALID, "internal: own columns among the remote ones"));
+    if (!h->loopback && !h->merged && h->recv_cut[(size_t)rank + 1] != h->recv_cut[rank]) return fail(g4s::set_error(G4S_ERR_INVALID, "internal: own columns among the remote ones"));
     h->give_cut.assign((size_t)world + 1, 0);
     h->give_set.assign((size_t)world, 0);
     if (g4s::device_malloc((void **)&h->d_want, sizeof(int32_t) * (size_t)std::max(h->n_ref, 1)) != hipSuccess ||
@@ -221,7 +230,8 @@ G4S_API g4s_status g4s_spmv_dist_get_info(g4s_spmv_dist_t h, g4s_spmv_dist_info 
     G4S_REQUIRE(h && info, "NULL argument");
     info->rank = h->rank; info->world = h->world; info->local_rows = h->local_rows; info->n_ref = h->n_ref;
     info->nnz_own = h->nnz_own; info->nnz_rem = h->nnz_rem;
-    info->recv_bytes = 8 * h->recv_cut[h->world];
+    info->recv_bytes = 8 * (h->recv_cut[h->world] - (h->merged ? h->recv_cut[(size_t)h->rank + 1] - h->recv_cut[h->rank] : 0));
+    info->reserved = h->merged ? 1 : 0;
     info->send_bytes = 8 * h->give_cut[h->world];
     g4s_csr_info ci;
     G4S_TRY(g4s_csr_get_info(h->A_own, &ci)); info->own_path = ci.spmv_path;
@@ -355,6 +365,15 @@ G4S_API g4s_status g4s_spmv_dist_begin(g4s_spmv_dist_t h, const double *x_local_
         G4S_HIP_TRY(hipEventRecord(h->ev_done, h->cstream));
         h->exchange_posted = true;
     }
+    if (h->merged) {                                               // own entries of the compact x: a local gather, no message
+        const int64_t n_self = h->recv_cut[(size_t)h->rank + 1] - h->recv_cut[h->rank];
+        if (n_self) {
+            const int grid = (int)std::min<int64_t>((n_self + 255) / 256, 4096);
+            hipLaunchKernelGGL(dist_pack_kernel, dim3(grid), dim3(256), 0, s, n_self, h->d_want + h->recv_cut[h->rank], x_local_dev, h->d_xrem + h->recv_cut[h->rank]);
+            G4S_HIP_TRY(hipGetLastError());
+        }
+        return G4S_OK;
+    }
     // the part of the product that needs nothing from anybody runs while the entries travel
     return g4s_spmv(h->A_own, x_local_dev, y_local_dev, 1.0, 0.0, stream);
 }
@@ -365,6 +384,7 @@ G4S_API g4s_status g4s_spmv_dist_finish(g4s_spmv_dist_t h, double *y_local_dev, 
     hipStream_t s = g4s::as_stream(stream);
     if (h->exchange_posted) G4S_HIP_TRY(hipStreamWaitEvent(s, h->ev_done, 0));
     h->exchange_posted = false;
+    if (h->merged) return g4s_spmv(h->A_rem, h->d_xrem, y_local_dev, 1.0, 0.0, stream);
     if (h->nnz_rem == 0) return G4S_OK;
     return g4s_spmv(h->A_rem, h->d_xrem, y_local_dev, 1.0, 1.0, stream);
 }

@@ -131,7 +131,8 @@ typedef struct g4s_spmv_dist_info {
     int64_t nnz_own, nnz_rem;                   /* nonzeros in own / remote columns */
     int64_t send_bytes, recv_bytes;             /* per product */
     int32_t own_path, rem_path;                 /* g4s_csr_info.spmv_path of the two parts */
-    int32_t connected, reserved;                /* every peer's give list is known */
+    int32_t connected, reserved;                /* connected: every peer's give list is known; reserved: 1 = merged form (own columns are few and live in
+                                                 * the compact x with the remote ones: one product per step instead of two) */
 } g4s_spmv_dist_info;
 /* flags: G4S_HOST_POINTERS / G4S_DEVICE_POINTERS for the three matrix arrays, the G4S_SPMV_* path flags, G4S_DIST_LOOPBACK.
  * row_offsets: world+1 entries, host memory; row_offsets[world] == n_cols. Collective only in the sense that every rank creates its own. */

@@ -43,6 +43,9 @@ def _matrix(kind, oracle):
 
 def _worker(rank, world, port, kind, out_dir):
     import torch.distributed as dist
+    if kind.endswith("+merged"):
+        os.environ["G4S_DIST_MERGE"] = "1"                          # force the one-product form (own columns inside the compact x)
+        kind = kind[:-7]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -62,15 +65,17 @@ def _worker(rank, world, port, kind, out_dir):
     info = D.info()
     np.save(os.path.join(out_dir, f"y{rank}.npy"), y1.cpu().numpy())
     np.save(os.path.join(out_dir, f"z{rank}.npy"), y2.cpu().numpy())
-    np.save(os.path.join(out_dir, f"i{rank}.npy"), np.array([r0, r1, info["n_ref"], info["nnz_own"], info["nnz_rem"], info["recv_bytes"], info["send_bytes"]]))
+    np.save(os.path.join(out_dir, f"i{rank}.npy"), np.array([r0, r1, info["n_ref"], info["nnz_own"], info["nnz_rem"], info["recv_bytes"], info["send_bytes"], info["reserved"]]))
     dist.barrier()
     D.close()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,kind", [(1, "powerlaw"), (2, "powerlaw"), (3, "powerlaw"), (2, "lap7"), (3, "banded")])
+@pytest.mark.parametrize("world,kind", [(1, "powerlaw"), (2, "powerlaw"), (3, "powerlaw"), (2, "lap7"), (3, "banded"), (3, "powerlaw+merged"), (2, "lap7+merged")])
 def test_dist_spmv_capi_matches_oracle(tmp_path, oracle, world, kind):
     mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
+    merged = kind.endswith("+merged")
+    kind = kind[:-7] if merged else kind
     rp, ci, va, n = _matrix(kind, oracle)
     x = np.random.default_rng(3).uniform(-1, 1, n)
     want = oracle.spmv(rp, ci, va, x)
@@ -81,9 +86,12 @@ def test_dist_spmv_capi_matches_oracle(tmp_path, oracle, world, kind):
     metas = [np.load(tmp_path / f"i{r}.npy") for r in range(world)]
     assert sum(int(m[3] + m[4]) for m in metas) == len(ci)          # every nonzero is in exactly one of the two parts
     assert sum(int(m[5]) for m in metas) == sum(int(m[6]) for m in metas)   # what is received was sent
+    assert all(int(m[7]) == (1 if merged else 0) for m in metas)
+    if merged:
+        assert all(int(m[3]) == 0 for m in metas)                   # everything is in the one compact product
     if world == 1:
         assert int(metas[0][2]) == 0 and int(metas[0][5]) == 0
-    if kind == "lap7" and world == 2:
+    if kind == "lap7" and world == 2 and not merged:
         # the halo of a slab cut along z is one plane of 40·30 columns per neighbour
         assert [int(m[2]) for m in metas] == [1200, 1200]
 
