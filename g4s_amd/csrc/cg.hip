@@ -25,6 +25,9 @@ namespace {
 constexpr int kDotBlocks = 256;   // partial sums per dot product
 constexpr int kThreads = 256;
 
+// Workgroups of the vector kernels: one per 256 unknowns, at most kDotBlocks (= partial sums per dot product; unused slots stay zero).
+inline int dot_blocks(int n) { const int b = (n + 255) / 256; return b < 1 ? 1 : (b > 256 ? 256 : b); }
+
 struct CgState { double r1z1, r0z0, residual, residual0; int count, done; };   // residual0 = |F|, kept for the host's batch-size fit
 
 __device__ __forceinline__ double block_sum(double v, double *sh)
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(kThreads) void cg_init_kernel(int n, const double *
 {
     __shared__ double sh[4];
     double rr = 0.0, rz = 0.0;
-    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += kDotBlocks * kThreads) {
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
         const double f = F[i], zi = BI[i] * f;
         r1[i] = f; d0[i] = 0.0; z[i] = zi;
         rr += f * f;
@@ -62,6 +65,8 @@ __global__ __launch_bounds__(kThreads) void cg_init_kernel(int n, const double *
     rr = block_sum(rr, sh);
     rz = block_sum(rz, sh);
     if (threadIdx.x == 0) { part_rr[blockIdx.x] = rr; part_rz[blockIdx.x] = rz; }
+    // slots of workgroups that do not exist stay zero (a multi-rank caller all-reduces all kDotBlocks slots in place between the steps)
+    if (blockIdx.x == 0 && threadIdx.x >= gridDim.x) { part_rr[threadIdx.x] = 0.0; part_rz[threadIdx.x] = 0.0; }
 }
 
 // The loop head of :364 and the direction update of :369-379, on the device:
@@ -113,13 +118,14 @@ __global__ __launch_bounds__(kThreads) void cg_pAp_kernel(int n, const CgState *
     __shared__ double sh[4];
     if (st->done) return;
     double acc = 0.0;
-    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += kDotBlocks * kThreads) {
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
         double a = Ap[i];
         if (bc_mask && bc_mask[i]) { a = 0.0; Ap[i] = 0.0; }
         acc += p2[i] * a;
     }
     acc = block_sum(acc, sh);
     if (threadIdx.x == 0) part[blockIdx.x] = acc;
+    if (blockIdx.x == 0 && threadIdx.x >= gridDim.x) part[threadIdx.x] = 0.0;
 }
 
 __global__ void cg_mask_kernel(int n_zero, const int *__restrict__ zero_resid, unsigned char *__restrict__ mask)
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void cg_update_kernel(int n, const double
     const double r1z1 = st->r1z1;
     const double alpha = (pAp == 0.0) ? 1.0e-3 : r1z1 / pAp;
     double rr = 0.0, rz = 0.0;
-    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += kDotBlocks * kThreads) {
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
         d0[i] += alpha * p2[i];
         const double r = r1[i] - alpha * Ap[i];
         const double zi = BI[i] * r;
@@ -154,6 +160,7 @@ __global__ __launch_bounds__(kThreads) void cg_update_kernel(int n, const double
     rr = block_sum(rr, sh);
     rz = block_sum(rz, sh);
     if (threadIdx.x == 0) { part_rr[blockIdx.x] = rr; part_rz[blockIdx.x] = rz; }
+    if (blockIdx.x == 0 && threadIdx.x >= gridDim.x) { part_rr[threadIdx.x] = 0.0; part_rz[threadIdx.x] = 0.0; }
     __syncthreads();
     // count and r0z0 are read by every block of this kernel only through `st->done` / `st->r1z1` above: safe to write here
     if (blockIdx.x == 0 && threadIdx.x == 0) { st->r0z0 = r1z1; st->count = st->count + 1; }
@@ -223,7 +230,7 @@ int conj_grad_impl(const MatVec &matvec, int32_t neq, const double *BI, const in
     double *part_rz = reinterpret_cast<double *>(base + 6 * nbp), *part_pAp = part_rz + kDotBlocks, *part_rr = part_pAp + kDotBlocks;
     CgState *st = reinterpret_cast<CgState *>(part_rr + kDotBlocks);
     static_assert(sizeof(CgState) <= 256, "state slot");
-    G4S_HIP_TRY(hipMemsetAsync(st, 0, sizeof(CgState), s));
+    G4S_HIP_TRY(hipMemsetAsync(part_rz, 0, sizeof(double) * 3 * kDotBlocks + sizeof(CgState), s));   // partial sums of unused workgroup slots stay zero; state
     unsigned char *bc_mask = nullptr;
     if (n_zero) {
         bc_mask = reinterpret_cast<unsigned char *>(st) + 256;
@@ -231,7 +238,7 @@ int conj_grad_impl(const MatVec &matvec, int32_t neq, const double *BI, const in
         hipLaunchKernelGGL(cg_mask_kernel, dim3((n_zero + kThreads - 1) / kThreads), dim3(kThreads), 0, s, n_zero, zero_resid, bc_mask);
     }
     const int steps = *cycles;
-    hipLaunchKernelGGL(cg_init_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, neq, F, BI, r1, d0, z, part_rr, part_rz);
+    hipLaunchKernelGGL(cg_init_kernel, dim3(dot_blocks(neq)), dim3(kThreads), 0, s, neq, F, BI, r1, d0, z, part_rr, part_rz);
     CgState h{};
     // first batch: one more than the previous solve of this thread needed — consecutive velocity solves of an Uzawa iteration take
     // nearly the same number of iterations, so the whole solve is usually one batch, one read-back and no wasted launches
@@ -242,10 +249,10 @@ int conj_grad_impl(const MatVec &matvec, int32_t neq, const double *BI, const in
         // irrelevant: nothing reads r1/r2/p1/p2 again)
         const int todo = std::max(1, std::min(batch, steps - enqueued + 1));
         for (int it = 0; it < todo; ++it) {
-            hipLaunchKernelGGL(cg_direction_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, neq, steps, acc, part_rr, part_rz, st, z, p1, p2);
+            hipLaunchKernelGGL(cg_direction_kernel, dim3(dot_blocks(neq)), dim3(kThreads), 0, s, neq, steps, acc, part_rr, part_rz, st, z, p1, p2);
             G4S_TRY(matvec(p2, Ap, &st->done, s));
-            hipLaunchKernelGGL(cg_pAp_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, neq, st, bc_mask, p2, Ap, part_pAp);
-            hipLaunchKernelGGL(cg_update_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, neq, part_pAp, st, BI, p2, Ap, r1, r2, d0, z, part_rr, part_rz);
+            hipLaunchKernelGGL(cg_pAp_kernel, dim3(dot_blocks(neq)), dim3(kThreads), 0, s, neq, st, bc_mask, p2, Ap, part_pAp);
+            hipLaunchKernelGGL(cg_update_kernel, dim3(dot_blocks(neq)), dim3(kThreads), 0, s, neq, part_pAp, st, BI, p2, Ap, r1, r2, d0, z, part_rr, part_rz);
             std::swap(r1, r2);
             std::swap(p1, p2);
         }
@@ -342,13 +349,13 @@ G4S_API g4s_status g4s_cg_begin(g4s_cg_ws_t ws, const double *F_dev, const doubl
     G4S_REQUIRE(ws && F_dev && BI_dev && d0_dev, "NULL argument");
     G4S_REQUIRE(n_zero >= 0 && (n_zero == 0 || zero_resid_dev), "zero_resid is NULL");
     hipStream_t s = g4s::as_stream(stream);
-    G4S_HIP_TRY(hipMemsetAsync(ws->st, 0, sizeof(CgState), s));
+    G4S_HIP_TRY(hipMemsetAsync(ws->part, 0, sizeof(double) * 3 * kDotBlocks + sizeof(CgState), s));
     ws->use_mask = n_zero > 0;
     if (n_zero) {
         G4S_HIP_TRY(hipMemsetAsync(ws->mask, 0, (size_t)ws->n, s));
         hipLaunchKernelGGL(cg_mask_kernel, dim3((n_zero + kThreads - 1) / kThreads), dim3(kThreads), 0, s, n_zero, zero_resid_dev, ws->mask);
     }
-    hipLaunchKernelGGL(cg_init_kernel, dim3(kDotBlocks), dim3(kThreads), 0, s, ws->n, F_dev, BI_dev, ws->r1, d0_dev, ws->z, ws->part + 2 * kDotBlocks, ws->part);
+    hipLaunchKernelGGL(cg_init_kernel, dim3(dot_blocks(ws->n)), dim3(kThreads), 0, s, ws->n, F_dev, BI_dev, ws->r1, d0_dev, ws->z, ws->part + 2 * kDotBlocks, ws->part);
     G4S_HIP_TRY(hipGetLastError());
     return G4S_OK;
 }
@@ -356,7 +363,7 @@ G4S_API g4s_status g4s_cg_begin(g4s_cg_ws_t ws, const double *F_dev, const doubl
 G4S_API g4s_status g4s_cg_direction(g4s_cg_ws_t ws, int32_t steps, double acc, void *stream)
 {
     G4S_REQUIRE(ws, "ws is NULL");
-    hipLaunchKernelGGL(cg_direction_kernel, dim3(kDotBlocks), dim3(kThreads), 0, g4s::as_stream(stream), ws->n, steps, acc, ws->part + 2 * kDotBlocks, ws->part, ws->st,
+    hipLaunchKernelGGL(cg_direction_kernel, dim3(dot_blocks(ws->n)), dim3(kThreads), 0, g4s::as_stream(stream), ws->n, steps, acc, ws->part + 2 * kDotBlocks, ws->part, ws->st,
                        ws->z, ws->p1, ws->p2);
     G4S_HIP_TRY(hipGetLastError());
     return G4S_OK;
@@ -387,7 +394,7 @@ G4S_API g4s_status g4s_cg_buffers(g4s_cg_ws_t ws, double **p_dev, double **Ap_de
 G4S_API g4s_status g4s_cg_reduce_pAp(g4s_cg_ws_t ws, void *stream)
 {
     G4S_REQUIRE(ws, "ws is NULL");
-    hipLaunchKernelGGL(cg_pAp_kernel, dim3(kDotBlocks), dim3(kThreads), 0, g4s::as_stream(stream), ws->n, ws->st, ws->use_mask ? ws->mask : nullptr, ws->p2, ws->Ap,
+    hipLaunchKernelGGL(cg_pAp_kernel, dim3(dot_blocks(ws->n)), dim3(kThreads), 0, g4s::as_stream(stream), ws->n, ws->st, ws->use_mask ? ws->mask : nullptr, ws->p2, ws->Ap,
                        ws->part + kDotBlocks);
     G4S_HIP_TRY(hipGetLastError());
     return G4S_OK;
@@ -396,7 +403,7 @@ G4S_API g4s_status g4s_cg_reduce_pAp(g4s_cg_ws_t ws, void *stream)
 G4S_API g4s_status g4s_cg_update(g4s_cg_ws_t ws, const double *BI_dev, double *d0_dev, void *stream)
 {
     G4S_REQUIRE(ws && BI_dev && d0_dev, "NULL argument");
-    hipLaunchKernelGGL(cg_update_kernel, dim3(kDotBlocks), dim3(kThreads), 0, g4s::as_stream(stream), ws->n, ws->part + kDotBlocks, ws->st, BI_dev, ws->p2, ws->Ap,
+    hipLaunchKernelGGL(cg_update_kernel, dim3(dot_blocks(ws->n)), dim3(kThreads), 0, g4s::as_stream(stream), ws->n, ws->part + kDotBlocks, ws->st, BI_dev, ws->p2, ws->Ap,
                        ws->r1, ws->r2, d0_dev, ws->z, ws->part + 2 * kDotBlocks, ws->part);
     G4S_HIP_TRY(hipGetLastError());
     std::swap(ws->r1, ws->r2);      // the pointer rotation of General_matrix_functions.c:398-402

@@ -476,6 +476,14 @@ __device__ __forceinline__ int bm_slot(int w) { return w ^ ((w >> 6) & 31); }
 constexpr int kWindowMaxN = 4 << kBigWindowBits;      // widest B for which the window kernels take the mid-size rows too
 inline int window_max_n() { const char *e = getenv("G4S_SPGEMM_WINDOW_MAX_N"); return e ? atoi(e) : kWindowMaxN; }   // tests force the table kernels with 0
 constexpr size_t kBigLdsBytes = sizeof(unsigned) * kBigWindowWords + sizeof(int) * (kBigThreads + 4) + kLongListBytes + sizeof(int) * kBigStage;
+// grid of the persistent big-row kernels: one workgroup per CU (their LDS allows no more), fewer when the class is small
+inline int big_grid(int nrows)
+{
+    static const int cus = [] { int d = 0; hipDeviceProp_t p; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }();
+    const char *e = getenv("G4S_SPGEMM_BIG_GRID");
+    const int g = e ? atoi(e) : cus;
+    return nrows < g ? nrows : g;
+}
 
 // Inclusive prefix sum over the 64 lanes of a wave on the DPP datapath (row shifts inside each 16-lane row, then the row totals
 // broadcast down): six full-rate VALU adds, no LDS crossbar traffic as with ds_bpermute-based shuffles.
@@ -598,8 +606,10 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_symbolic_window_kernel(
     int4 *longs = reinterpret_cast<int4 *>(s_scan + kBigThreads + 4);
     int *stage = reinterpret_cast<int *>(longs + kLongCap + 1);
     const int t = threadIdx.x;
-    const int row = rows[blockIdx.x];
-    (void)nrows;
+    // Persistent: the grid is one workgroup per CU (136 KiB of LDS each) and every workgroup walks its share of the class's rows — starting a
+    // 1024-thread workgroup with this much LDS costs several µs, and a class holds 10^5 rows of a few thousand products each.
+    for (int ridx = blockIdx.x; ridx < nrows; ridx += gridDim.x) {
+    const int row = rows[ridx];
     const int a0 = arpt[row], a1 = arpt[row + 1];
     const int gs = group_shift(row_flop[row], a1 - a0, kBigThreads), gmask = (1 << gs) - 1;
     const int long_thr = long_b_threshold(kBigThreads);
@@ -634,6 +644,8 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_symbolic_window_kernel(
         __syncthreads();
     }
     if (t == 0) row_nz[row] = s_total;
+    __syncthreads();
+    }
 }
 
 #ifdef G4S_PROFILE_BIG
@@ -660,8 +672,8 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
     int *stage = reinterpret_cast<int *>(longs + kLongCap + 1);          // kBigStage ints
     const int long_thr = long_b_threshold(kBigThreads);
     const int t = threadIdx.x;
-    const int row = rows[blockIdx.x];
-    (void)nrows;
+    for (int ridx = blockIdx.x; ridx < nrows; ridx += gridDim.x) {   // persistent: see spgemm_symbolic_window_kernel
+    const int row = rows[ridx];
     const int a0 = arpt[row], a1 = arpt[row + 1];
     const int off = crpt[row], nz = crpt[row + 1] - off;
     const int gs = group_shift(row_flop[row], a1 - a0, kBigThreads), gmask = (1 << gs) - 1;
@@ -754,6 +766,8 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
         for (int i = t; i < qn; i += kBigThreads) cval[off + q0 + i] = V[i];
         __syncthreads();
         BIG_PROF(10);
+    }
+    __syncthreads();
     }
 }
 
@@ -1250,7 +1264,7 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
         auto k = spgemm_symbolic_window_kernel;
         const size_t lds = kBigLdsBytes;
         G4S_TRY(allow_lds(k, lds));
-        if (n) hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rows, n, N, K, wsplit, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, pre_off, pre_cols);
+        if (n) hipLaunchKernelGGL(k, dim3(big_grid(n)), dim3(kBigThreads), lds, s, rows, n, N, K, wsplit, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, pre_off, pre_cols);
         return G4S_OK;
     };
     if (x_med) { G4S_TRY(window(rc.list(CLS_MEDIUM), rc.count[CLS_MEDIUM])); }
@@ -1277,10 +1291,10 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
         auto k = spgemm_symbolic_window_kernel;
         const size_t lds = kBigLdsBytes;
         G4S_TRY(allow_lds(k, lds));
-        if (n_ovf) hipLaunchKernelGGL(k, dim3(n_ovf), dim3(kBigThreads), lds, s, ovf_rows.as<int>(), n_ovf, N, K, wsplit, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz,
+        if (n_ovf) hipLaunchKernelGGL(k, dim3(big_grid(n_ovf)), dim3(kBigThreads), lds, s, ovf_rows.as<int>(), n_ovf, N, K, wsplit, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz,
                                       (const long long *)nullptr, (int *)nullptr);   // rows of the optimistic table class are not in the scratch
         if (int n = rc.count[CLS_M2])
-            hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rc.list(CLS_M2), n, N, K, wsplit, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, pre_off, pre_cols);
+            hipLaunchKernelGGL(k, dim3(big_grid(n)), dim3(kBigThreads), lds, s, rc.list(CLS_M2), n, N, K, wsplit, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, pre_off, pre_cols);
         G4S_HIP_TRY(hipGetLastError());
     }
     // hub rows (flop > 2 M): many workgroups per row on a bitmap in HBM
@@ -1358,7 +1372,7 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         auto k = spgemm_numeric_big_kernel;
         const size_t lds = kBigLdsBytes;
         G4S_TRY(allow_lds(k, lds));
-        if (n) hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rows, n, N, K, wsplit, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols);
+        if (n) hipLaunchKernelGGL(k, dim3(big_grid(n)), dim3(kBigThreads), lds, s, rows, n, N, K, wsplit, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols);
         return G4S_OK;
     };
     if (int n = rc.count[CLS_MEDIUM]) {
@@ -1381,7 +1395,7 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         auto k = spgemm_numeric_big_kernel;
         const size_t lds = kBigLdsBytes;   // 128 KiB bitmap (phase 2 reuses it) + scan scratch + long-B list
         G4S_TRY(allow_lds(k, lds));
-        hipLaunchKernelGGL(k, dim3(n), dim3(kBigThreads), lds, s, rc.list(CLS_M3), n, N, K, wsplit, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols);
+        hipLaunchKernelGGL(k, dim3(big_grid(n)), dim3(kBigThreads), lds, s, rc.list(CLS_M3), n, N, K, wsplit, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols);
     }
     G4S_HIP_TRY(hipGetLastError());
     std::vector<int> hub, ranges;
