@@ -22,6 +22,9 @@
 // Integer results (crpt, ccol) are exact; fp64 sums are accumulated with LDS/HBM atomics, i.e. in a different order than
 // the reference's (j outer, k inner): equal within the 1e-10 relative tolerance of the north star, not bit for bit.
 #include "common.hpp"
+#ifndef G4S_SPGEMM_UPR
+#define G4S_SPGEMM_UPR 4
+#endif
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <chrono>
@@ -465,23 +468,39 @@ __global__ __launch_bounds__(WGSIZE) void spgemm_numeric_lds_kernel(
 //   phase 2 — per chunk of 8192 consecutive output entries: their (sorted) columns in LDS as keys, fp64 accumulators beside them,
 //             every product whose column falls in the chunk finds its slot by binary search and is added with ds_add_f64.
 // The products are traversed (#windows + #chunks) times; B rows come from L2. No global atomics, sorted output for free.
-constexpr int kBigThreads = 1024;
-constexpr int kBigWindowBits = 20;                    // columns per bitmap window
-constexpr int kBigWindowWords = 1 << (kBigWindowBits - 5);
-constexpr int kBigChunk = 8192;                       // output entries per value pass
-constexpr int kBigStage = 4096;                        // sorted column ids staged in LDS per coalesced store burst
+// Two shapes of the one-row-per-workgroup bitmap kernels, everything derived from the thread count T (a thread owns 32 consecutive bitmap words):
+//   T = 1024: windows of 2^20 columns (128 KiB bitmap), value chunks of 8 192 outputs — 136 KiB of LDS, one workgroup per CU (the long rows);
+//   T =  256: windows of 2^18 columns (32 KiB), chunks of 2 048 — 41 KiB, three workgroups per CU. The PMC passes of round 2 showed the big shape
+//             waiting on dependent loads 60–75 % of its wave-cycles with the fabric at a quarter of its rate: the rows of a few thousand
+//             products (most rows) gain nothing from 1 024 threads, and three of them in flight per CU hide each other's latency.
+template <int T>
+struct BigCfg {
+    static_assert(T == 1024 || T == 512 || T == 256, "three shapes");
+    static constexpr int kThreads = T;
+    static constexpr int kWindowBits = T == 1024 ? 20 : T == 512 ? 19 : 18;   // columns per bitmap window = 1024·T
+    static constexpr int kWindowWords = 1 << (kWindowBits - 5);      // = 32·T
+    static constexpr int kChunk = 8 * T;                             // output entries per value pass
+    static constexpr int kChunkBits = kWindowBits - 7;
+    static constexpr int kStage = T == 256 ? 2 * T : 4 * T;          // sorted column ids staged in LDS per coalesced store burst
+    static constexpr int kPerCu = 1024 / T;                          // workgroups per CU that fit in LDS (136 / 72 / 40 KiB each)
+};
+constexpr int kFlatUnitsPerRound = G4S_SPGEMM_UPR;   // 64-entry units of B rows a wave loads per round (independent loads in flight per lane)
+// which shape takes which row class (G4S_SPGEMM_T_* override them for sweeps)
+constexpr int kShapeNumMedium = 256, kShapeSymMedium = 256, kShapeSymLarge = 1024, kShapeNumLarge = 256, kShapeNumM2 = 256, kShapeNumM3 = 1024, kNumM3Cut = 8192;
+inline int shape_of(const char *env, int dflt) { const char *e = getenv(env); const int v = e ? atoi(e) : dflt; return v == 256 || v == 512 ? v : 1024; }
+// granularity of the window splits: the smallest shape's window while that keeps the table at <= 16 pieces per B row, else the largest's
+__host__ __device__ __forceinline__ int split_bits(int N) { return N <= (16 << 18) ? 18 : 20; }
 // Word w of a window lives at LDS slot w ^ ((w >> 6) & 31): the emit step gives each thread 32 consecutive words, and unswizzled
 // the 64 lanes of a wave would read 2 banks (a 32-way conflict); swizzled they read 64.
 __device__ __forceinline__ int bm_slot(int w) { return w ^ ((w >> 6) & 31); }
-constexpr int kWindowMaxN = 4 << kBigWindowBits;      // widest B for which the window kernels take the mid-size rows too
+constexpr int kWindowMaxN = 4 << 20;                  // widest B for which the window kernels take the mid-size rows too
 inline int window_max_n() { const char *e = getenv("G4S_SPGEMM_WINDOW_MAX_N"); return e ? atoi(e) : kWindowMaxN; }   // tests force the table kernels with 0
-constexpr size_t kBigLdsBytes = sizeof(unsigned) * kBigWindowWords + sizeof(int) * (kBigThreads + 4) + kLongListBytes + sizeof(int) * kBigStage;
 // grid of the persistent big-row kernels: one workgroup per CU (their LDS allows no more), fewer when the class is small
-inline int big_grid(int nrows)
+inline int big_grid(int nrows, int wgs_per_cu = 1)
 {
     static const int cus = [] { int d = 0; hipDeviceProp_t p; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }();
     const char *e = getenv("G4S_SPGEMM_BIG_GRID");
-    const int g = e ? atoi(e) : cus;
+    const int g = (e ? atoi(e) : cus) * wgs_per_cu;
     return nrows < g ? nrows : g;
 }
 
@@ -499,15 +518,15 @@ __device__ __forceinline__ unsigned wave_inclusive_sum(unsigned x)
 }
 
 // Window splits. B's rows are sorted by column, so the entries of row c that fall into bitmap window w are one contiguous piece:
-// wsplit[(j − 1)·K + c] = first position of row c whose column is >= j·2^20 (j = 1 … W − 1), computed once per product by
+// wsplit[(j − 1)·K + c] = first position of row c whose column is >= j·2^sb (sb = split_bits(N), j = 1 … W − 1; a coarser window is a union of pieces, a finer one a subset of one), computed once per product by
 // window_splits_kernel. A window pass (and a value chunk, which spans one or a few windows) then walks only that piece of every B
 // row instead of reading the whole row and discarding what is outside — with two windows that halves the products visited.
-__global__ void window_splits_kernel(int K, int W, const int *__restrict__ brpt, const int *__restrict__ bcol, int *__restrict__ wsplit)
+__global__ void window_splits_kernel(int K, int W, int sbits, const int *__restrict__ brpt, const int *__restrict__ bcol, int *__restrict__ wsplit)
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)K * (W - 1)) return;
     const int j = (int)(idx / K) + 1, c = (int)(idx - (long long)(j - 1) * K);
-    const int bound = j << kBigWindowBits;
+    const int bound = j << sbits;
     int lo = brpt[c], hi = brpt[c + 1];
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
@@ -521,9 +540,133 @@ __device__ __forceinline__ void window_bounds(const int *brpt, const int *wsplit
 {
     lo = brpt; hi = brpt + 1;
     if (!wsplit) return;
-    const int wf = cfirst >> kBigWindowBits, wl = clast >> kBigWindowBits, W = (N + (1 << kBigWindowBits) - 1) >> kBigWindowBits;
+    const int sb = split_bits(N), wf = cfirst >> sb, wl = clast >> sb, W = (N + (1 << sb) - 1) >> sb;
     if (wf > 0) lo = wsplit + (size_t)(wf - 1) * K;
     if (wl < W - 1) hi = wsplit + (size_t)wl * K;
+}
+
+#ifdef G4S_PROFILE_BIG
+// Section timers of the big-row kernels (tools/big_prof.py): s_memtime deltas summed in registers, flushed with one atomic per slot by
+// thread 0 at BIG_PROF_FLUSH (a global atomic per stamp would itself be the longest thing in an inner loop).
+__device__ unsigned long long g_big_prof[16];
+#define BIG_PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[16] = {}
+#define BIG_PROF(slot) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof_acc[slot] += n_ - prof_t; prof_t = n_; } while (0)
+#define BIG_PROF_FLUSH do { if (threadIdx.x == 0) { _Pragma("unroll") for (int s_ = 0; s_ < 16; ++s_) if (prof_acc[s_]) atomicAdd(&g_big_prof[s_], prof_acc[s_]); } _Pragma("unroll") for (int s_ = 0; s_ < 16; ++s_) prof_acc[s_] = 0; } while (0)
+#else
+#define BIG_PROF_DECL
+#define BIG_PROF(slot)
+#define BIG_PROF_FLUSH
+#endif
+
+// LDS beside the bitmap in the one-row-per-workgroup kernels: [ctrl: 32 ints][scan: 64 ints][union of the emit stage and the flat lists]
+// (T = 1024: 128 KiB + 24.4 KiB of the CU's 160).
+template <int T>
+struct BigSide {
+    static constexpr int kCtrlInts = 32, kScanInts = 64, kTotalSlot = 24;   // ctrl[0 … 16): wave totals of the unit scan; ctrl[24]: the row's running count
+    static constexpr int kUnitBatch = 2 * T;                                 // units mapped per batch (u16 entry index each)
+    static constexpr size_t kFlatBytes = sizeof(int4) * T + sizeof(int) * (T + 4) + sizeof(unsigned short) * kUnitBatch;
+    static constexpr size_t kStageBytes = sizeof(int) * BigCfg<T>::kStage;
+    static constexpr size_t kBytes = sizeof(int) * (kCtrlInts + kScanInts) + (kFlatBytes > kStageBytes ? kFlatBytes : kStageBytes);
+    int *ctrl, *scan, *stage, *P;
+    int4 *E;            // per A-entry: its B row [x, y) and the bits of its value
+    unsigned short *M;  // per unit of the batch: its A-entry
+    __device__ __forceinline__ explicit BigSide(int *base)
+    {
+        ctrl = base; scan = base + kCtrlInts; stage = scan + kScanInts;
+        E = reinterpret_cast<int4 *>(stage); P = reinterpret_cast<int *>(E + T); M = reinterpret_cast<unsigned short *>(P + T + 4);
+    }
+};
+template <int T>
+constexpr size_t big_lds_bytes() { return sizeof(unsigned) * BigCfg<T>::kWindowWords + BigSide<T>::kBytes; }
+
+// The products of one row, flat. The rows of these classes are a few A-entries pointing at long B rows (R-MAT scale 21: a mean of 6 … 90
+// entries per row, 90 % of the products in B rows of more than 256 entries), so lanes-per-A-entry groups leave most of the workgroup idle
+// behind a handful of serial load → insert round trips. Instead:
+//   1. entry pass — thread j takes A-entry j: (b0, b1) of its B row clipped to [lo, hi), its value, and its number of UNITS (64 consecutive
+//      entries of the B row) go to LDS; a block scan of the unit counts gives every entry its first unit;
+//   2. map — the units are numbered across the row; thread u finds unit u's entry by binary search over the scan (u16 per unit);
+//   3. rounds — wave w takes UPR consecutive units at a time (UPR·64 products: UPR independent coalesced loads per lane in flight), the
+//      waves striding the unit range, so every wave does the same work whatever the B-row lengths are.
+// body(col[UPR], b_value[UPR], a_value[UPR], valid[UPR]) gets a lane's products of one round together, so that it can interleave their
+// dependent LDS chains. Contains barriers: call from uniform control flow; on return every product has been handed to body.
+template <int T, bool WITH_VAL, int UPR, typename Body>
+__device__ __forceinline__ void flat_products(int a0, int a1, const int *__restrict__ acol, const double *__restrict__ aval,
+                                              const int *__restrict__ lo, const int *__restrict__ hi, const int *__restrict__ bcol,
+                                              const double *__restrict__ bval, const BigSide<T> &sd, int t, Body body)
+{
+    constexpr int kWaves = T / 64, kUB = BigSide<T>::kUnitBatch;
+    const int lane = t & 63, wave = t >> 6;
+    BIG_PROF_DECL;
+    for (int e0 = a0; e0 < a1; e0 += T) {                           // tiles of T A-entries (one tile for all but hub-like rows of A)
+        const int ne = min(T, a1 - e0);
+        int units = 0;
+        if (t < ne) {
+            const int c = acol[e0 + t];
+            const int b0 = lo[c], b1 = hi[c];
+            const long long bits = WITH_VAL ? __double_as_longlong(aval[e0 + t]) : 0ll;
+            sd.E[t] = make_int4(b0, b1, (int)(bits & 0xFFFFFFFFll), (int)(bits >> 32));
+            units = b1 > b0 ? (b1 - b0 + 63) >> 6 : 0;
+        }
+        const int incl = (int)wave_inclusive_sum((unsigned)units);
+        if (lane == 63) sd.ctrl[wave] = incl;
+        __syncthreads();
+        if (WITH_VAL) BIG_PROF(11);
+        int first = incl - units, nu = 0;
+#pragma unroll
+        for (int u = 0; u < kWaves; ++u) {
+            const int v = sd.ctrl[u];
+            if (u < wave) first += v;
+            nu += v;
+        }
+        if (t < ne) sd.P[t] = first;
+        if (t == 0) sd.P[ne] = nu;
+        __syncthreads();
+        if (WITH_VAL) BIG_PROF(12);
+        for (int ub0 = 0; ub0 < nu; ub0 += kUB) {
+            const int nb = min(kUB, nu - ub0);
+            for (int u = t; u < nb; u += T) {                       // the last entry j with P[j] <= unit (entries without units share their successor's P)
+                const int unit = ub0 + u;
+                int l = 0, h = ne;
+                while (h - l > 1) {
+                    const int mid = (l + h) >> 1;
+                    if (sd.P[mid] <= unit) l = mid; else h = mid;
+                }
+                sd.M[u] = (unsigned short)l;
+            }
+            __syncthreads();
+            if (WITH_VAL) BIG_PROF(13);
+            for (int g = wave * UPR; g < nb; g += kWaves * UPR) {
+                int kk[UPR], c[UPR];
+                bool ok[UPR];
+                double av[UPR], v[UPR];
+#pragma unroll
+                for (int q = 0; q < UPR; ++q) {
+                    const int uu = min(g + q, nb - 1);
+                    const int j = sd.M[uu];
+                    const int4 e = sd.E[j];
+                    const int k = e.x + ((ub0 + uu - sd.P[j]) << 6) + lane;
+                    ok[q] = g + q < nb && k < e.y;
+                    kk[q] = min(k, e.y - 1);                        // a unit exists only in a non-empty piece: e.y - 1 >= e.x
+                    av[q] = WITH_VAL ? long_b_value(e) : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < UPR; ++q) {
+                    c[q] = bcol[kk[q]];
+                    v[q] = WITH_VAL ? bval[kk[q]] : 0.0;
+                }
+#ifdef G4S_PROFILE_BIG
+                if (WITH_VAL) { BIG_PROF(2); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); BIG_PROF(4); }
+#endif
+                body(c, v, av, ok);
+#ifdef G4S_PROFILE_BIG
+                if (WITH_VAL) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); BIG_PROF(5); }
+#endif
+            }
+            __syncthreads();                                        // M — and after the last batch E and P — are rewritten next
+            if (WITH_VAL) BIG_PROF(14);
+        }
+    }
+    BIG_PROF_FLUSH;
 }
 
 // Emits the set bits of one LDS bitmap window (words swizzled by bm_slot) in ascending column order to out[0 … total) and returns
@@ -532,9 +675,11 @@ __device__ __forceinline__ void window_bounds(const int *brpt, const int *wsplit
 // the non-empty words, one word per thread: in a power-law row the first few hundred columns are all present, and a thread emitting
 // its own 32 words would write a thousand ids while the rest write a handful (measured: 38 % of the numeric kernel).
 // s_scan: 34 ints of LDS scratch, stage: kBigStage ints. Contains barriers: call from uniform control flow.
+template <int T>
 __device__ __forceinline__ int emit_window_columns(const unsigned *bm, int w0, int *__restrict__ out, int *s_scan, int *stage, int t)
 {
-    static_assert(kBigWindowWords / kBigThreads == 32 && kBigThreads == 1024, "emit layout");
+    constexpr int kBigThreads = T, kBigStage = BigCfg<T>::kStage;
+    static_assert(BigCfg<T>::kWindowWords / T == 32, "emit layout");
     static_assert(G4S_SPGEMM_BIG_LIMIT <= (1 << 17), "a list item packs the output position in 17 bits");
     const int lane = t & 63, wave = t >> 6;
     unsigned nonempty = 0;
@@ -594,45 +739,39 @@ __device__ __forceinline__ int emit_window_columns(const unsigned *bm, int w0, i
 // same LDS bitmap windows (no hash table that can overflow, no HBM bitmap, no global atomics). One workgroup per row.
 // pre_off / pre_cols (one-shot call only): rows with pre_off[row] >= 0 also write their sorted distinct columns to
 // pre_cols[pre_off[row] …], so that the numeric phase does not have to mark and emit them a second time.
-__global__ __launch_bounds__(kBigThreads) void spgemm_symbolic_window_kernel(
+template <int T>
+__global__ __launch_bounds__(T) void spgemm_symbolic_window_kernel(
     const int *__restrict__ rows, int nrows, int N, int K, const int *__restrict__ wsplit, const int *__restrict__ arpt, const int *__restrict__ acol,
     const int *__restrict__ brpt, const int *__restrict__ bcol, const long long *__restrict__ row_flop, int *__restrict__ row_nz,
     const long long *__restrict__ pre_off, int *__restrict__ pre_cols)
 {
+    constexpr int kBigThreads = T, kBigWindowBits = BigCfg<T>::kWindowBits, kBigWindowWords = BigCfg<T>::kWindowWords;
     extern __shared__ int lds_i[];                                 // dynamic only (Guideline 17): the layout of the numeric big-row kernel
     unsigned *bm = reinterpret_cast<unsigned *>(lds_i);
-    int *s_scan = lds_i + kBigWindowWords;                         // kBigThreads ints
-    int &s_total = s_scan[kBigThreads];
-    int4 *longs = reinterpret_cast<int4 *>(s_scan + kBigThreads + 4);
-    int *stage = reinterpret_cast<int *>(longs + kLongCap + 1);
+    const BigSide<T> sd(lds_i + kBigWindowWords);
+    int &s_total = sd.ctrl[BigSide<T>::kTotalSlot];
     const int t = threadIdx.x;
-    // Persistent: the grid is one workgroup per CU (136 KiB of LDS each) and every workgroup walks its share of the class's rows — starting a
-    // 1024-thread workgroup with this much LDS costs several µs, and a class holds 10^5 rows of a few thousand products each.
+    // Persistent: the grid is a few workgroups per CU (as many as their LDS allows) and every workgroup walks its share of the class's rows —
+    // starting a 1024-thread workgroup with this much LDS costs several µs, and a class holds 10^5 rows of a few thousand products each.
     for (int ridx = blockIdx.x; ridx < nrows; ridx += gridDim.x) {
     const int row = rows[ridx];
     const int a0 = arpt[row], a1 = arpt[row + 1];
-    const int gs = group_shift(row_flop[row], a1 - a0, kBigThreads), gmask = (1 << gs) - 1;
-    const int long_thr = long_b_threshold(kBigThreads);
     const long long po = pre_off ? pre_off[row] : -1;              // uniform
     if (t == 0) s_total = 0;
     for (int w0 = 0; w0 < N; w0 += (1 << kBigWindowBits)) {
         for (int i = t; i < kBigWindowWords / 4; i += kBigThreads) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (t == 0) longs[0].x = 0;
         __syncthreads();
         const int w1 = min(N, w0 + (1 << kBigWindowBits));
         const int *wlo, *whi;
         window_bounds(brpt, wsplit, K, N, w0, w1 - 1, wlo, whi);
-        auto mark = [&](int col) { if (col >= w0 && col < w1) atomicOr(&bm[bm_slot((col - w0) >> 5)], 1u << ((col - w0) & 31)); };
-        walk_a_entries<false>(a0, a1, t >> gs, kBigThreads >> gs, acol, nullptr, wlo, whi, [&](int b0, int b1, double) {
-            if (defer_long_b(longs, b0, b1, 0.0, t & gmask, gmask, long_thr)) return true;
-            for (int k = b0 + (t & gmask); k < b1; k += gmask + 1) mark(bcol[k]);
-            return true;
-        });
-        __syncthreads();
-        for_deferred_rows<false>(longs, t, kBigThreads, bcol, nullptr, [&](int col, double, double) { mark(col); });
-        __syncthreads();
+        flat_products<T, false, kFlatUnitsPerRound>(a0, a1, acol, nullptr, wlo, whi, bcol, nullptr, sd, t,
+            [&](const int (&col)[kFlatUnitsPerRound], const double (&)[kFlatUnitsPerRound], const double (&)[kFlatUnitsPerRound], const bool (&ok)[kFlatUnitsPerRound]) {
+#pragma unroll
+                for (int q = 0; q < kFlatUnitsPerRound; ++q)
+                    if (ok[q] && col[q] >= w0 && col[q] < w1) atomicOr(&bm[bm_slot((col[q] - w0) >> 5)], 1u << ((col[q] - w0) & 31));
+            });
         if (po >= 0) {
-            const int total = emit_window_columns(bm, w0, pre_cols + po + s_total, s_scan, stage, t);
+            const int total = emit_window_columns<T>(bm, w0, pre_cols + po + s_total, sd.scan, sd.stage, t);
             if (t == 0) s_total += total;
         } else {
             int cnt = 0;
@@ -648,35 +787,26 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_symbolic_window_kernel(
     }
 }
 
-#ifdef G4S_PROFILE_BIG
-__device__ unsigned long long g_big_prof[16];
-#define BIG_PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime()
-#define BIG_PROF(slot) do { if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_big_prof[slot], n_ - prof_t); prof_t = n_; } } while (0)
-#else
-#define BIG_PROF_DECL
-#define BIG_PROF(slot)
-#endif
 
-__global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
-    const int *__restrict__ rows, int nrows, int N, int K, const int *__restrict__ wsplit, const int *__restrict__ arpt, const int *__restrict__ acol, const double *__restrict__ aval,
+template <int T>
+__global__ __launch_bounds__(T) void spgemm_numeric_big_kernel(
+    const int *__restrict__ rows, int nrows, int nz_lo, int nz_hi /* rows with nz outside (nz_lo, nz_hi] are left to the other shape */, int N, int K, const int *__restrict__ wsplit, const int *__restrict__ arpt, const int *__restrict__ acol, const double *__restrict__ aval,
     const int *__restrict__ brpt, const int *__restrict__ bcol, const double *__restrict__ bval, const long long *__restrict__ row_flop,
     const int *__restrict__ crpt, int *__restrict__ ccol, double *__restrict__ cval,
     const long long *__restrict__ pre_off, const int *__restrict__ pre_cols)
 {
     // No static __shared__ in this kernel: it would sit in front of the dynamic region and push the fp64 table of phase 2 off its
     // 8-byte alignment (cdna_hip_programming.md Guideline 17). Everything is carved from the dynamic region instead.
+    constexpr int kBigThreads = T, kBigWindowBits = BigCfg<T>::kWindowBits, kBigWindowWords = BigCfg<T>::kWindowWords, kBigChunk = BigCfg<T>::kChunk;
     extern __shared__ int lds_i[];
-    int *s_scan = lds_i + kBigWindowWords;                         // kBigThreads ints
-    int &s_base = s_scan[kBigThreads];
-    int4 *longs = reinterpret_cast<int4 *>(s_scan + kBigThreads + 4);   // 16-byte aligned: (32768 + 1024 + 4) ints
-    int *stage = reinterpret_cast<int *>(longs + kLongCap + 1);          // kBigStage ints
-    const int long_thr = long_b_threshold(kBigThreads);
+    const BigSide<T> sd(lds_i + kBigWindowWords);
+    int &s_base = sd.ctrl[BigSide<T>::kTotalSlot];
     const int t = threadIdx.x;
     for (int ridx = blockIdx.x; ridx < nrows; ridx += gridDim.x) {   // persistent: see spgemm_symbolic_window_kernel
     const int row = rows[ridx];
     const int a0 = arpt[row], a1 = arpt[row + 1];
     const int off = crpt[row], nz = crpt[row + 1] - off;
-    const int gs = group_shift(row_flop[row], a1 - a0, kBigThreads), gmask = (1 << gs) - 1;
+    if (nz <= nz_lo || nz > nz_hi) continue;                       // uniform: the whole workgroup skips the row
 
     BIG_PROF_DECL;
     // ---- phase 1: sorted distinct columns — unless the symbolic phase of the one-shot call already left them in pre_cols
@@ -685,24 +815,19 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
     if (t == 0) s_base = 0;
     for (int w0 = 0; w0 < N && po < 0; w0 += (1 << kBigWindowBits)) {
         for (int i = t; i < kBigWindowWords / 4; i += kBigThreads) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (t == 0) longs[0].x = 0;
         __syncthreads();
         BIG_PROF(0);
         const int w1 = min(N, w0 + (1 << kBigWindowBits));
         const int *wlo, *whi;
         window_bounds(brpt, wsplit, K, N, w0, w1 - 1, wlo, whi);
-        auto mark = [&](int col) { if (col >= w0 && col < w1) atomicOr(&bm[bm_slot((col - w0) >> 5)], 1u << ((col - w0) & 31)); };
-        walk_a_entries<false>(a0, a1, t >> gs, kBigThreads >> gs, acol, nullptr, wlo, whi, [&](int b0, int b1, double) {
-            if (defer_long_b(longs, b0, b1, 0.0, t & gmask, gmask, long_thr)) return true;
-            for (int k = b0 + (t & gmask); k < b1; k += gmask + 1) mark(bcol[k]);
-            return true;
-        });
-        __syncthreads();
+        flat_products<T, false, kFlatUnitsPerRound>(a0, a1, acol, nullptr, wlo, whi, bcol, nullptr, sd, t,
+            [&](const int (&col)[kFlatUnitsPerRound], const double (&)[kFlatUnitsPerRound], const double (&)[kFlatUnitsPerRound], const bool (&ok)[kFlatUnitsPerRound]) {
+#pragma unroll
+                for (int q = 0; q < kFlatUnitsPerRound; ++q)
+                    if (ok[q] && col[q] >= w0 && col[q] < w1) atomicOr(&bm[bm_slot((col[q] - w0) >> 5)], 1u << ((col[q] - w0) & 31));
+            });
         BIG_PROF(1);
-        for_deferred_rows<false>(longs, t, kBigThreads, bcol, nullptr, [&](int col, double, double) { mark(col); });
-        __syncthreads();
-        BIG_PROF(2);
-        const int total = emit_window_columns(bm, w0, ccol + off + s_base, s_scan, stage, t);
+        const int total = emit_window_columns<T>(bm, w0, ccol + off + s_base, sd.scan, sd.stage, t);
         BIG_PROF(3);
         __syncthreads();
         if (t == 0) s_base += total;
@@ -719,54 +844,99 @@ __global__ __launch_bounds__(kBigThreads) void spgemm_numeric_big_kernel(
     int *KC = lds_i + 2 * kBigChunk;                                // kBigChunk ints
     unsigned *IDX = reinterpret_cast<unsigned *>(lds_i + 3 * kBigChunk);   // kBigChunk buckets: 4·kBigChunk ints = the bitmap's 128 KiB
     static_assert(4 * kBigChunk <= kBigWindowWords && kBigChunk <= 65536, "phase 2 reuses the bitmap region; slots are packed in 16 bits");
+    constexpr int kPerThread = kBigChunk / kBigThreads;             // 8 slots per thread
+    constexpr int kU = kFlatUnitsPerRound;
+    int kfirst = 0, klast = 0, shift = 0;
+    // One round of a lane's products: their slots are found in lock-step (the dependent LDS reads of the kU searches interleave) for as many
+    // halvings as the wave's deepest bucket needs — a unit is 64 consecutive entries of a sorted B row, so a wave's lanes sit in neighbouring
+    // buckets — and the atomics come last. A round whose units all lie outside the chunk's column range is skipped by the whole wave.
+    auto accumulate = [&](const int (&col)[kU], const double (&bv)[kU], const double (&av)[kU], const bool (&ok)[kU]) {
+        int lo[kU], hi[kU], key[kU];
+        bool in[kU], any_in = false;
+#pragma unroll
+        for (int q = 0; q < kU; ++q) {
+            in[q] = ok[q] && col[q] >= kfirst && col[q] <= klast;
+            any_in |= in[q];
+        }
+        if (!__any(any_in)) return;
+#pragma unroll
+        for (int q = 0; q < kU; ++q) {
+            key[q] = in[q] ? col[q] : kfirst;
+            const unsigned w = IDX[(key[q] - kfirst) >> shift];    // the column is present, so its bucket is not empty
+            lo[q] = (int)(w >> 16); hi[q] = (int)(w & 0xffffu);
+        }
+        for (;;) {
+            bool more = false;
+#pragma unroll
+            for (int q = 0; q < kU; ++q) more |= lo[q] < hi[q];
+            if (!__any(more)) break;
+#pragma unroll
+            for (int q = 0; q < kU; ++q) {
+                const int mid = (lo[q] + hi[q]) >> 1;
+                const bool less = KC[mid] < key[q];
+                lo[q] = less ? mid + 1 : lo[q];
+                hi[q] = less ? hi[q] : mid;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kU; ++q)
+            if (in[q]) atomicAdd(&V[lo[q]], av[q] * bv[q]);
+    };
+    // The chunk's sorted columns: all of a thread's loads in flight together, and issued a chunk ahead (they are consumed at the top of the
+    // next chunk, a whole accumulation pass later).
+    int cc[kPerThread], kf_next = 0, kl_next = 0;
+    auto fetch_chunk = [&](int q0) {
+        const int qn = min(kBigChunk, nz - q0);
+        const int *src = po >= 0 ? pre_cols + po + q0 : ccol + off + q0;
+#pragma unroll
+        for (int u = 0; u < kPerThread; ++u) cc[u] = src[min(t + u * kBigThreads, qn - 1)];
+        kf_next = src[0]; kl_next = src[qn - 1];
+    };
+    auto open_chunk = [&](int q0, int qn) {                        // cc → LDS (and to ccol where they came from the scratch), empty buckets
+#pragma unroll
+        for (int u = 0; u < kPerThread; ++u) {
+            const int i = t + u * kBigThreads;
+            IDX[i] = 0u;
+            if (i < qn) {
+                if (po >= 0) ccol[off + q0 + i] = cc[u];
+                KC[i] = cc[u]; V[i] = 0.0;
+            }
+        }
+        kfirst = kf_next; klast = kl_next;
+        const int span = klast - kfirst;                           // < 2^31
+        shift = span < kBigChunk ? 0 : 32 - __clz(span) - BigCfg<T>::kChunkBits;   // (span >> shift) < kBigChunk
+        static_assert(kBigChunk == (1 << BigCfg<T>::kChunkBits), "bucket shift");
+    };
+    auto build_index = [&](int qn) {                               // bucket b = (col − first) >> shift → (first slot << 16 | last slot)
+#pragma unroll
+        for (int u = 0; u < kPerThread; ++u) {
+            const int i = t + u * kBigThreads;
+            if (i < qn) {
+                const int b = (KC[i] - kfirst) >> shift;
+                if (i == 0 || ((KC[i - 1] - kfirst) >> shift) != b) atomicOr(&IDX[b], (unsigned)i << 16);
+                if (i == qn - 1 || ((KC[i + 1] - kfirst) >> shift) != b) atomicOr(&IDX[b], (unsigned)i);
+            }
+        }
+    };
+    fetch_chunk(0);
     for (int q0 = 0; q0 < nz; q0 += kBigChunk) {
         const int qn = min(kBigChunk, nz - q0);
-        for (int i = t; i < qn; i += kBigThreads) {
-            int c;
-            if (po >= 0) { c = pre_cols[po + q0 + i]; ccol[off + q0 + i] = c; } else c = ccol[off + q0 + i];
-            KC[i] = c; V[i] = 0.0;
-        }
-        for (int i = t; i < kBigChunk; i += kBigThreads) IDX[i] = 0u;
-        if (t == 0) longs[0].x = 0;
+        open_chunk(q0, qn);
+        if (q0 + kBigChunk < nz) fetch_chunk(q0 + kBigChunk);
         __syncthreads();
         BIG_PROF(6);
-        const int kfirst = KC[0], klast = KC[qn - 1];
-        const int *clo, *chi;
-        window_bounds(brpt, wsplit, K, N, kfirst, klast, clo, chi);   // the part of each B row inside the windows this chunk spans
-        const int span = klast - kfirst;                           // < 2^31
-        const int shift = span < kBigChunk ? 0 : 32 - __clz(span) - 13;   // (span >> shift) < kBigChunk = 2^13
-        static_assert(kBigChunk == 8192, "bucket shift assumes 2^13 buckets");
-        for (int i = t; i < qn; i += kBigThreads) {
-            const int b = (KC[i] - kfirst) >> shift;
-            if (i == 0 || ((KC[i - 1] - kfirst) >> shift) != b) atomicOr(&IDX[b], (unsigned)i << 16);
-            if (i == qn - 1 || ((KC[i + 1] - kfirst) >> shift) != b) atomicOr(&IDX[b], (unsigned)i);
-        }
+        build_index(qn);
         __syncthreads();
         BIG_PROF(7);
-        auto add = [&](int col, double prod) {
-            if (col < kfirst || col > klast) return;
-            const unsigned w = IDX[(col - kfirst) >> shift];       // col is present, so its bucket is not empty
-            int lo = (int)(w >> 16), hi = (int)(w & 0xffffu);
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (KC[mid] < col) lo = mid + 1; else hi = mid;
-            }
-            atomicAdd(&V[lo], prod);
-        };
-        walk_a_entries<true>(a0, a1, t >> gs, kBigThreads >> gs, acol, aval, clo, chi, [&](int b0, int b1, double av) {
-            if (defer_long_b(longs, b0, b1, av, t & gmask, gmask, long_thr)) return true;
-            for (int k = b0 + (t & gmask); k < b1; k += gmask + 1) add(bcol[k], av * bval[k]);
-            return true;
-        });
-        __syncthreads();
+        const int *clo, *chi;
+        window_bounds(brpt, wsplit, K, N, kfirst, klast, clo, chi);   // the part of each B row inside the windows this chunk spans
+        flat_products<T, true, kU>(a0, a1, acol, aval, clo, chi, bcol, bval, sd, t, accumulate);
         BIG_PROF(8);
-        for_deferred_rows<true>(longs, t, kBigThreads, bcol, bval, [&](int col, double bv, double av) { add(col, av * bv); });
-        __syncthreads();
-        BIG_PROF(9);
         for (int i = t; i < qn; i += kBigThreads) cval[off + q0 + i] = V[i];
         __syncthreads();
         BIG_PROF(10);
     }
+    BIG_PROF_FLUSH;
     __syncthreads();
     }
 }
@@ -1167,11 +1337,11 @@ namespace {
 int build_window_splits(int K, int N, const int *brpt, const int *bcol, DevBuf &buf, const int **out, hipStream_t s)
 {
     *out = nullptr;
-    const int W = (N + (1 << kBigWindowBits) - 1) >> kBigWindowBits;
+    const int sb = split_bits(N), W = (N + (1 << sb) - 1) >> sb;
     if (W < 2 || W > 16 || K <= 0 || getenv("G4S_SPGEMM_NO_SPLITS")) return G4S_OK;
     const long long total = (long long)K * (W - 1);
     G4S_TRY(buf.alloc(sizeof(int) * (size_t)total));
-    hipLaunchKernelGGL(window_splits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, K, W, brpt, bcol, buf.as<int>());
+    hipLaunchKernelGGL(window_splits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, K, W, sb, brpt, bcol, buf.as<int>());
     G4S_HIP_TRY(hipGetLastError());
     *out = buf.as<int>();
     return G4S_OK;
@@ -1260,20 +1430,28 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
             G4S_HIP_TRY(hipStreamSynchronize(s));
         }
     }
-    auto window = [&](const int *rows, int n) -> int {
-        auto k = spgemm_symbolic_window_kernel;
-        const size_t lds = kBigLdsBytes;
+    auto window_t = [&](auto shape, const int *rows, int n, const long long *poff, int *pcols) -> int {
+        constexpr int T = decltype(shape)::value;
+        auto k = spgemm_symbolic_window_kernel<T>;
+        const size_t lds = big_lds_bytes<T>();
         G4S_TRY(allow_lds(k, lds));
-        if (n) hipLaunchKernelGGL(k, dim3(big_grid(n)), dim3(kBigThreads), lds, s, rows, n, N, K, wsplit, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, pre_off, pre_cols);
+        if (n) hipLaunchKernelGGL(k, dim3(big_grid(n, BigCfg<T>::kPerCu)), dim3(T), lds, s, rows, n, N, K, wsplit, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, poff, pcols);
         return G4S_OK;
     };
-    if (x_med) { G4S_TRY(window(rc.list(CLS_MEDIUM), rc.count[CLS_MEDIUM])); }
+    auto window = [&](int threads, const int *rows, int n, const long long *poff, int *pcols) -> int {
+        if (threads == 256) return window_t(std::integral_constant<int, 256>{}, rows, n, poff, pcols);
+        if (threads == 512) return window_t(std::integral_constant<int, 512>{}, rows, n, poff, pcols);
+        return window_t(std::integral_constant<int, 1024>{}, rows, n, poff, pcols);
+    };
+    const int t_med = shape_of("G4S_SPGEMM_T_SYM_MED", kShapeSymMedium), t_large = shape_of("G4S_SPGEMM_T_SYM_LARGE", kShapeSymLarge),
+              t_win = shape_of("G4S_SPGEMM_T_SYM_WINDOW", 1024);
+    if (x_med) { G4S_TRY(window(t_med, rc.list(CLS_MEDIUM), rc.count[CLS_MEDIUM], pre_off, pre_cols)); }
     else if (int n = rc.count[CLS_MEDIUM]) {
         auto k = spgemm_symbolic_lds_kernel<256, 256, 16384, false>;
         G4S_TRY(allow_lds(k, sym_lds_bytes(1, 16384)));
         hipLaunchKernelGGL(k, dim3(n), dim3(256), sym_lds_bytes(1, 16384), s, rc.list(CLS_MEDIUM), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr);
     }
-    if (x_large) { G4S_TRY(window(rc.list(CLS_LARGE), rc.count[CLS_LARGE])); }
+    if (x_large) { G4S_TRY(window(t_large, rc.list(CLS_LARGE), rc.count[CLS_LARGE], pre_off, pre_cols)); }
     else if (int n = rc.count[CLS_LARGE]) {
         auto k = spgemm_symbolic_lds_kernel<1024, 1024, 32768, true>;
         G4S_TRY(allow_lds(k, sym_lds_bytes(1, 32768)));
@@ -1287,16 +1465,9 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     G4S_HIP_TRY(hipMemcpyAsync(&n_ovf, ovf_count.p, sizeof(int), hipMemcpyDeviceToHost, s));
     G4S_HIP_TRY(hipStreamSynchronize(s));
     if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s symbolic: %d optimistic tables overflowed, %d window-class rows\n", n_ovf, rc.count[CLS_M2]);
-    {
-        auto k = spgemm_symbolic_window_kernel;
-        const size_t lds = kBigLdsBytes;
-        G4S_TRY(allow_lds(k, lds));
-        if (n_ovf) hipLaunchKernelGGL(k, dim3(big_grid(n_ovf)), dim3(kBigThreads), lds, s, ovf_rows.as<int>(), n_ovf, N, K, wsplit, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz,
-                                      (const long long *)nullptr, (int *)nullptr);   // rows of the optimistic table class are not in the scratch
-        if (int n = rc.count[CLS_M2])
-            hipLaunchKernelGGL(k, dim3(big_grid(n)), dim3(kBigThreads), lds, s, rc.list(CLS_M2), n, N, K, wsplit, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, pre_off, pre_cols);
-        G4S_HIP_TRY(hipGetLastError());
-    }
+    G4S_TRY(window(1024, ovf_rows.as<int>(), n_ovf, nullptr, nullptr));   // rows of the optimistic table class are not in the scratch
+    G4S_TRY(window(t_win, rc.list(CLS_M2), rc.count[CLS_M2], pre_off, pre_cols));
+    G4S_HIP_TRY(hipGetLastError());
     // hub rows (flop > 2 M): many workgroups per row on a bitmap in HBM
     std::vector<int> hub, ranges;
     G4S_TRY(fetch_rows_and_ranges(rc.list(CLS_HUB), rc.count[CLS_HUB], arpt, hub, ranges, s));
@@ -1368,34 +1539,45 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
     G4S_TRY(build_window_splits(K, N, brpt, bcol, wsplit_buf, &wsplit, s));
     // Rows past 1 K entries: bitmap windows + bucketed slots beat table + in-LDS bitonic sort while the column range is <= 4 windows.
     const bool xn_large = N <= window_max_n(), xn_m2 = xn_large;
-    auto big = [&](const int *rows, int n) -> int {
-        auto k = spgemm_numeric_big_kernel;
-        const size_t lds = kBigLdsBytes;
+    auto big_t = [&](auto shape, const int *rows, int n, int nz_lo, int nz_hi) -> int {
+        constexpr int T = decltype(shape)::value;
+        auto k = spgemm_numeric_big_kernel<T>;
+        const size_t lds = big_lds_bytes<T>();   // the bitmap (phase 2 reuses it) + scan scratch + long-B list + store staging
         G4S_TRY(allow_lds(k, lds));
-        if (n) hipLaunchKernelGGL(k, dim3(big_grid(n)), dim3(kBigThreads), lds, s, rows, n, N, K, wsplit, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols);
+        if (n) hipLaunchKernelGGL(k, dim3(big_grid(n, BigCfg<T>::kPerCu)), dim3(T), lds, s, rows, n, nz_lo, nz_hi, N, K, wsplit, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols);
         return G4S_OK;
     };
-    if (int n = rc.count[CLS_MEDIUM]) {
+    auto big = [&](int threads, const int *rows, int n, int nz_lo = 0, int nz_hi = INT_MAX) -> int {
+        if (threads == 256) return big_t(std::integral_constant<int, 256>{}, rows, n, nz_lo, nz_hi);
+        if (threads == 512) return big_t(std::integral_constant<int, 512>{}, rows, n, nz_lo, nz_hi);
+        return big_t(std::integral_constant<int, 1024>{}, rows, n, nz_lo, nz_hi);
+    };
+    const int t_large = shape_of("G4S_SPGEMM_T_NUM_LARGE", kShapeNumLarge), t_m2 = shape_of("G4S_SPGEMM_T_NUM_M2", kShapeNumM2),
+              t_m3 = shape_of("G4S_SPGEMM_T_NUM_M3", kShapeNumM3);
+    const int m3_cut = getenv("G4S_SPGEMM_M3_CUT") ? atoi(getenv("G4S_SPGEMM_M3_CUT")) : kNumM3Cut;
+    const char *e_med = getenv("G4S_SPGEMM_T_NUM_MED");
+    const int t_med = e_med ? (atoi(e_med) ? shape_of("G4S_SPGEMM_T_NUM_MED", 1024) : 0) : kShapeNumMedium;   // 0: the table kernel
+    if (t_med && xn_large) { G4S_TRY(big(t_med, rc.list(CLS_MEDIUM), rc.count[CLS_MEDIUM])); }
+    else if (int n = rc.count[CLS_MEDIUM]) {
         auto k = spgemm_numeric_lds_kernel<256, 256, 2048>;
         hipLaunchKernelGGL(k, dim3(n), dim3(256), num_lds_bytes(2048), s, rc.list(CLS_MEDIUM), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
-    if (xn_large) { G4S_TRY(big(rc.list(CLS_LARGE), rc.count[CLS_LARGE])); }
+    if (xn_large) { G4S_TRY(big(t_large, rc.list(CLS_LARGE), rc.count[CLS_LARGE])); }
     else if (int n = rc.count[CLS_LARGE]) {
         auto k = spgemm_numeric_lds_kernel<512, 512, 4096>;
         G4S_TRY(allow_lds(k, num_lds_bytes(4096)));
         hipLaunchKernelGGL(k, dim3(n), dim3(512), num_lds_bytes(4096), s, rc.list(CLS_LARGE), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
-    if (xn_m2) { G4S_TRY(big(rc.list(CLS_M2), rc.count[CLS_M2])); }
+    if (xn_m2) { G4S_TRY(big(t_m2, rc.list(CLS_M2), rc.count[CLS_M2])); }
     else if (int n = rc.count[CLS_M2]) {
         auto k = spgemm_numeric_lds_kernel<1024, 1024, 8192>;
         G4S_TRY(allow_lds(k, num_lds_bytes(8192)));
         hipLaunchKernelGGL(k, dim3(n), dim3(1024), num_lds_bytes(8192), s, rc.list(CLS_M2), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
     if (int n = rc.count[CLS_M3]) {
-        auto k = spgemm_numeric_big_kernel;
-        const size_t lds = kBigLdsBytes;   // 128 KiB bitmap (phase 2 reuses it) + scan scratch + long-B list
-        G4S_TRY(allow_lds(k, lds));
-        hipLaunchKernelGGL(k, dim3(big_grid(n)), dim3(kBigThreads), lds, s, rc.list(CLS_M3), n, N, K, wsplit, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols);
+        // the class spans 4 K … 128 K entries: its short rows go to the many-workgroups shape, the long ones keep 1 024 threads
+        if (t_m3 != 1024 && m3_cut > 0) { G4S_TRY(big(t_m3, rc.list(CLS_M3), n, 0, m3_cut)); G4S_TRY(big(1024, rc.list(CLS_M3), n, m3_cut, INT_MAX)); }
+        else G4S_TRY(big(1024, rc.list(CLS_M3), n));
     }
     G4S_HIP_TRY(hipGetLastError());
     std::vector<int> hub, ranges;

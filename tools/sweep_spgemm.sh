@@ -1,9 +1,9 @@
 #!/bin/bash
+# A/B runs of the SpGEMM bench (one tools/bench_spgemm.py call per setting, same box). Usage: tools/sweep_spgemm.sh "VAR=val VAR=val" "" ...
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-cd $ROOT
-for v in "" "-DG4S_SPGEMM_BIG_LIMIT=65536" "-DG4S_SPGEMM_BIG_LIMIT=131072"; do
-  touch g4s_amd/csrc/spgemm.hip
-  make -C g4s_amd/csrc -j4 EXTRA="$v" > /dev/null 2>&1 || { echo "build failed for $v"; continue; }
-  echo "variant [$v]: $(python tools/bench_spgemm.py --ef 3 --runs 2 2>/dev/null | tail -1 | cut -c1-60) $(python tools/bench_spgemm.py --ef 3 --runs 2 2>/dev/null | tail -1 | grep -o '"symbolic_ms.*runs')"
+mkdir -p $ROOT/gpurun_out
+for setting in "$@"; do
+  out=$(env $setting timeout -k 10 200 python3 $ROOT/tools/bench_spgemm.py --ef ${EF:-3} --runs ${RUNS:-5} 2>&1 | tail -1)
+  ms=$(echo "$out" | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['call_ms'], d['value'])" 2>/dev/null || echo "FAILED: $out")
+  echo "[$setting] call_ms GFLOPS = $ms" | tee -a $ROOT/gpurun_out/sweep_spgemm.log
 done
-touch g4s_amd/csrc/spgemm.hip; make -C g4s_amd/csrc -j4 > /dev/null 2>&1
