@@ -488,8 +488,13 @@ constexpr int kFlatUnitsPerRound = G4S_SPGEMM_UPR;   // 64-entry units of B rows
 // which shape takes which row class (G4S_SPGEMM_T_* override them for sweeps)
 constexpr int kShapeNumMedium = 256, kShapeSymMedium = 256, kShapeSymLarge = 1024, kShapeNumLarge = 256, kShapeNumM2 = 256, kShapeNumM3 = 1024, kNumM3Cut = 8192;
 inline int shape_of(const char *env, int dflt) { const char *e = getenv(env); const int v = e ? atoi(e) : dflt; return v == 256 || v == 512 ? v : 1024; }
-// granularity of the window splits: the smallest shape's window while that keeps the table at <= 16 pieces per B row, else the largest's
-__host__ __device__ __forceinline__ int split_bits(int N) { return N <= (16 << 18) ? 18 : 20; }
+// granularity of the window splits: the column range in 16 pieces (at most — the table holds a position per piece and B row), never finer
+// than 2^16 columns; every window size is a multiple, and a value chunk's columns are bracketed by whole pieces
+__host__ __device__ __forceinline__ int split_bits(int N)
+{
+    const int lg = N > 1 ? 32 - __builtin_clz((unsigned)(N - 1)) : 0;   // ceil(log2 N)
+    return lg - 4 < 16 ? 16 : (lg - 4 > 20 ? 20 : lg - 4);
+}
 // Word w of a window lives at LDS slot w ^ ((w >> 6) & 31): the emit step gives each thread 32 consecutive words, and unswizzled
 // the 64 lanes of a wave would read 2 banks (a 32-way conflict); swizzled they read 64.
 __device__ __forceinline__ int bm_slot(int w) { return w ^ ((w >> 6) & 31); }
@@ -791,7 +796,8 @@ __global__ __launch_bounds__(T) void spgemm_symbolic_window_kernel(
 template <int T>
 __global__ __launch_bounds__(T) void spgemm_numeric_big_kernel(
     const int *__restrict__ rows, int nrows, int nz_lo, int nz_hi /* rows with nz outside (nz_lo, nz_hi] are left to the other shape */, int N, int K, const int *__restrict__ wsplit, const int *__restrict__ arpt, const int *__restrict__ acol, const double *__restrict__ aval,
-    const int *__restrict__ brpt, const int *__restrict__ bcol, const double *__restrict__ bval, const long long *__restrict__ row_flop,
+    const int *__restrict__ brpt, const int *__restrict__ bcol /* window ids: compact when col_of is given */, const int *__restrict__ col_of,
+    const double *__restrict__ bval, const long long *__restrict__ row_flop,
     const int *__restrict__ crpt, int *__restrict__ ccol, double *__restrict__ cval,
     const long long *__restrict__ pre_off, const int *__restrict__ pre_cols)
 {
@@ -892,15 +898,12 @@ __global__ __launch_bounds__(T) void spgemm_numeric_big_kernel(
         for (int u = 0; u < kPerThread; ++u) cc[u] = src[min(t + u * kBigThreads, qn - 1)];
         kf_next = src[0]; kl_next = src[qn - 1];
     };
-    auto open_chunk = [&](int q0, int qn) {                        // cc → LDS (and to ccol where they came from the scratch), empty buckets
+    auto open_chunk = [&](int qn) {                                // cc → LDS, empty buckets
 #pragma unroll
         for (int u = 0; u < kPerThread; ++u) {
             const int i = t + u * kBigThreads;
             IDX[i] = 0u;
-            if (i < qn) {
-                if (po >= 0) ccol[off + q0 + i] = cc[u];
-                KC[i] = cc[u]; V[i] = 0.0;
-            }
+            if (i < qn) { KC[i] = cc[u]; V[i] = 0.0; }
         }
         kfirst = kf_next; klast = kl_next;
         const int span = klast - kfirst;                           // < 2^31
@@ -921,7 +924,7 @@ __global__ __launch_bounds__(T) void spgemm_numeric_big_kernel(
     fetch_chunk(0);
     for (int q0 = 0; q0 < nz; q0 += kBigChunk) {
         const int qn = min(kBigChunk, nz - q0);
-        open_chunk(q0, qn);
+        open_chunk(qn);
         if (q0 + kBigChunk < nz) fetch_chunk(q0 + kBigChunk);
         __syncthreads();
         BIG_PROF(6);
@@ -932,7 +935,28 @@ __global__ __launch_bounds__(T) void spgemm_numeric_big_kernel(
         window_bounds(brpt, wsplit, K, N, kfirst, klast, clo, chi);   // the part of each B row inside the windows this chunk spans
         flat_products<T, true, kU>(a0, a1, acol, aval, clo, chi, bcol, bval, sd, t, accumulate);
         BIG_PROF(8);
-        for (int i = t; i < qn; i += kBigThreads) cval[off + q0 + i] = V[i];
+        {   // the chunk's values, and its columns as B's column ids (window ids → ids: a gather whose latency the value stores cover)
+            int orig[kPerThread];
+            if (col_of) {
+#pragma unroll
+                for (int u = 0; u < kPerThread; ++u) orig[u] = col_of[KC[min(t + u * kBigThreads, qn - 1)]];
+            } else {
+#pragma unroll
+                for (int u = 0; u < kPerThread; ++u) orig[u] = KC[min(t + u * kBigThreads, qn - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < kPerThread; ++u) {
+                const int i = t + u * kBigThreads;
+                if (i < qn) cval[off + q0 + i] = V[i];
+            }
+            if (col_of || po >= 0) {                               // (a numeric-only call without a column map has them in place already)
+#pragma unroll
+                for (int u = 0; u < kPerThread; ++u) {
+                    const int i = t + u * kBigThreads;
+                    if (i < qn) ccol[off + q0 + i] = orig[u];
+                }
+            }
+        }
         __syncthreads();
         BIG_PROF(10);
     }
@@ -1276,8 +1300,86 @@ namespace {
 // window kernel whose product bound lies in (1 K, 128 K] — the rows the numeric big-row kernel will take — also write their distinct
 // columns, in order, to cols[off[row] …] (off[row] = −1 for every other row); the big-row kernel then skips its own mark-and-emit
 // phase for them. The scratch is sized by the bound Σ min(flop_i, N), so it is only used while that fits comfortably in free HBM.
-constexpr long long kPresortMinFlop = 1024;   // rows with fewer products cannot reach the numeric big-row class (nz > 1 K)
+constexpr long long kPresortMinFlop = 512;    // every row that reaches a window kernel in the numeric phase (nz > 512) carries its sorted columns over
+// Column compaction for the bitmap-window kernels. The windows span B's COLUMN RANGE, and a power-law B leaves much of it unused
+// (R-MAT scale 21: 59 % of the columns hold no entry): renumbering the non-empty columns 0 … N2 − 1 in order shrinks every bitmap pass
+// by that share (two 2^20 windows become one) and keeps sorted rows sorted. The window kernels then work on bcol2 (compact ids) and
+// translate back through inv when they write ccol; the table and hub kernels keep the original ids. Left out when fewer than an
+// eighth of the columns are empty.
+struct ColumnMap {
+    DevBuf bcol2, inv;           // int[nnz(B)] compact id per entry; int[N2] original id per compact id
+    int n2 = 0;                  // 0: not in use
+    const int *cols(const int *bcol) const { return n2 ? bcol2.as<int>() : bcol; }
+    int width(int N) const { return n2 ? n2 : N; }
+    const int *inverse() const { return n2 ? inv.as<int>() : nullptr; }
+};
+__global__ void colmap_mark_kernel(long long nnz, const int *__restrict__ bcol, unsigned *__restrict__ bm)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    const int c = bcol[k];
+    const unsigned bit = 1u << (c & 31);
+    if (!(bm[c >> 5] & bit)) atomicOr(&bm[c >> 5], bit);
+}
+__global__ void colmap_popc_kernel(int W, const unsigned *__restrict__ bm, int *__restrict__ cnt)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w <= W) cnt[w] = w < W ? __popc(bm[w]) : 0;                // W + 1 items: the scan's last element is the total
+}
+__global__ void colmap_inverse_kernel(int W, const unsigned *__restrict__ bm, const int *__restrict__ prefix, int *__restrict__ inv)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    unsigned bits = bm[w];
+    int pos = prefix[w];
+    while (bits) {
+        const int bit = __ffs(bits) - 1;
+        bits &= bits - 1;
+        inv[pos++] = (w << 5) + bit;
+    }
+}
+__global__ void colmap_apply_kernel(long long nnz, const int *__restrict__ bcol, const unsigned *__restrict__ bm, const int *__restrict__ prefix,
+                                    int *__restrict__ bcol2)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    const int c = bcol[k];
+    bcol2[k] = prefix[c >> 5] + __popc(bm[c >> 5] & ((1u << (c & 31)) - 1u));
+}
+int build_column_map(int N, long long bnnz, const int *bcol, ColumnMap &cm, hipStream_t s)
+{
+    cm.n2 = 0;
+    if (N < (1 << 16) || bnnz <= 0 || getenv("G4S_SPGEMM_NO_COLMAP")) return G4S_OK;   // a single small window either way
+    const int W = (N + 31) >> 5;
+    DevBuf bm, cnt, prefix, tmp;
+    G4S_TRY(bm.alloc(sizeof(unsigned) * (size_t)W));
+    G4S_TRY(cnt.alloc(sizeof(int) * ((size_t)W + 1)));
+    G4S_TRY(prefix.alloc(sizeof(int) * ((size_t)W + 1)));
+    G4S_HIP_TRY(hipMemsetAsync(bm.p, 0, sizeof(unsigned) * (size_t)W, s));
+    hipLaunchKernelGGL(colmap_mark_kernel, dim3((unsigned)((bnnz + 255) / 256)), dim3(256), 0, s, bnnz, bcol, bm.as<unsigned>());
+    hipLaunchKernelGGL(colmap_popc_kernel, dim3((W + 256) / 256), dim3(256), 0, s, W, bm.as<unsigned>(), cnt.as<int>());
+    size_t tb = 0;
+    G4S_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt.as<int>(), prefix.as<int>(), W + 1, s));
+    G4S_TRY(tmp.alloc(tb));
+    G4S_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, cnt.as<int>(), prefix.as<int>(), W + 1, s));
+    int n2 = 0;
+    G4S_HIP_TRY(hipMemcpyAsync(&n2, prefix.as<int>() + W, sizeof(int), hipMemcpyDeviceToHost, s));
+    G4S_HIP_TRY(hipStreamSynchronize(s));
+    if (n2 <= 0 || (long long)n2 * 8 > (long long)N * 7) return G4S_OK;
+    G4S_TRY(cm.bcol2.alloc(sizeof(int) * (size_t)bnnz));
+    G4S_TRY(cm.inv.alloc(sizeof(int) * (size_t)n2));
+    hipLaunchKernelGGL(colmap_inverse_kernel, dim3((W + 255) / 256), dim3(256), 0, s, W, bm.as<unsigned>(), prefix.as<int>(), cm.inv.as<int>());
+    hipLaunchKernelGGL(colmap_apply_kernel, dim3((unsigned)((bnnz + 255) / 256)), dim3(256), 0, s, bnnz, bcol, bm.as<unsigned>(), prefix.as<int>(),
+                       cm.bcol2.as<int>());
+    G4S_HIP_TRY(hipGetLastError());
+    G4S_HIP_TRY(hipStreamSynchronize(s));                         // bm / prefix die here
+    cm.n2 = n2;
+    if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s column map: %d of %d columns of B hold entries\n", n2, N);
+    return G4S_OK;
+}
+
 struct PreSorted {
+    ColumnMap cmap;              // built by the symbolic phase of the one-shot call, reused by its numeric phase
     DevBuf off;                  // long long off[M]
     const long long *d_off = nullptr;
     int *d_cols = nullptr;       // int cols[total], borrowed from the cache below
@@ -1376,9 +1478,15 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     if (getenv("G4S_DEBUG"))
         fprintf(stderr, "g4s symbolic classes: empty %d tiny %d small %d medium %d large %d hub %d (flop %lld)\n", rc.count[CLS_EMPTY], rc.count[CLS_TINY],
                 rc.count[CLS_SMALL], rc.count[CLS_MEDIUM], rc.count[CLS_LARGE], rc.count[CLS_HUB], (long long)flop);
+    // the bitmap-window kernels work on B's non-empty columns, renumbered (N2 of them; the original ids when that would not pay)
+    ColumnMap local_map;
+    ColumnMap &cmap = pre ? pre->cmap : local_map;
+    G4S_TRY(build_column_map(N, bnnz, bcol, cmap, s));
+    const int *wcol = cmap.cols(bcol);
+    const int N2 = cmap.width(N);
     DevBuf wsplit_buf;
     const int *wsplit = nullptr;
-    G4S_TRY(build_window_splits(K, N, brpt, bcol, wsplit_buf, &wsplit, s));
+    G4S_TRY(build_window_splits(K, N2, brpt, wcol, wsplit_buf, &wsplit, s));
     G4S_TRY(ovf_rows.alloc(sizeof(int) * (size_t)std::max(1, rc.count[CLS_LARGE])));
     G4S_TRY(ovf_count.alloc(sizeof(int)));
     G4S_HIP_TRY(hipMemsetAsync(ovf_count.p, 0, sizeof(int), s));
@@ -1394,7 +1502,7 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     }
     // Up to kWindowMaxN columns (4 bitmap windows) the window kernel beats the key tables for every row past 512 products (it has no
     // probe chains and cannot overflow); with more windows each row would re-walk its products once per window, so tables take over.
-    const bool x_med = N <= window_max_n(), x_large = x_med;
+    const bool x_med = N2 <= window_max_n(), x_large = x_med;
     const long long *pre_off = nullptr;
     int *pre_cols = nullptr;
     if (pre && !getenv("G4S_SPGEMM_NO_PRESORT")) {
@@ -1405,7 +1513,7 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
         G4S_TRY(pre->off.alloc(sizeof(long long) * ((size_t)M + 1)));
         G4S_HIP_TRY(hipMemsetAsync(need.p, 0, sizeof(long long) * ((size_t)M + 1), s));
         const long long min_flop = getenv("G4S_SPGEMM_PRESORT_MIN") ? atoll(getenv("G4S_SPGEMM_PRESORT_MIN")) : kPresortMinFlop;
-        hipLaunchKernelGGL(presorted_need_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, rc.cls.as<int>(), class_mask, row_flop.as<long long>(), N, min_flop, need.as<long long>());
+        hipLaunchKernelGGL(presorted_need_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, rc.cls.as<int>(), class_mask, row_flop.as<long long>(), N2, min_flop, need.as<long long>());
         size_t tb = 0;
         G4S_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, need.as<long long>(), pre->off.as<long long>(), M + 1, s));
         G4S_TRY(tmp.alloc(tb));
@@ -1435,7 +1543,7 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
         auto k = spgemm_symbolic_window_kernel<T>;
         const size_t lds = big_lds_bytes<T>();
         G4S_TRY(allow_lds(k, lds));
-        if (n) hipLaunchKernelGGL(k, dim3(big_grid(n, BigCfg<T>::kPerCu)), dim3(T), lds, s, rows, n, N, K, wsplit, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, poff, pcols);
+        if (n) hipLaunchKernelGGL(k, dim3(big_grid(n, BigCfg<T>::kPerCu)), dim3(T), lds, s, rows, n, N2, K, wsplit, arpt, acol, brpt, wcol, row_flop.as<long long>(), nz, poff, pcols);
         return G4S_OK;
     };
     auto window = [&](int threads, const int *rows, int n, const long long *poff, int *pcols) -> int {
@@ -1534,17 +1642,26 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         auto k = spgemm_numeric_lds_kernel<256, 256, 1024>;
         hipLaunchKernelGGL(k, dim3(n), dim3(256), num_lds_bytes(1024), s, rc.list(CLS_SMALL), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
+    ColumnMap local_map;                                           // see spgemm_symbolic_impl; the one-shot call hands its map over
+    if (!pre) {
+        int bnnz = 0;
+        G4S_TRY(read_last(brpt, K, &bnnz, s));
+        G4S_TRY(build_column_map(N, bnnz, bcol, local_map, s));
+    }
+    const ColumnMap &cmap = pre ? pre->cmap : local_map;
+    const int *wcol = cmap.cols(bcol), *winv = cmap.inverse();
+    const int N2 = cmap.width(N);
     DevBuf wsplit_buf;
     const int *wsplit = nullptr;
-    G4S_TRY(build_window_splits(K, N, brpt, bcol, wsplit_buf, &wsplit, s));
+    G4S_TRY(build_window_splits(K, N2, brpt, wcol, wsplit_buf, &wsplit, s));
     // Rows past 1 K entries: bitmap windows + bucketed slots beat table + in-LDS bitonic sort while the column range is <= 4 windows.
-    const bool xn_large = N <= window_max_n(), xn_m2 = xn_large;
+    const bool xn_large = N2 <= window_max_n(), xn_m2 = xn_large;
     auto big_t = [&](auto shape, const int *rows, int n, int nz_lo, int nz_hi) -> int {
         constexpr int T = decltype(shape)::value;
         auto k = spgemm_numeric_big_kernel<T>;
         const size_t lds = big_lds_bytes<T>();   // the bitmap (phase 2 reuses it) + scan scratch + long-B list + store staging
         G4S_TRY(allow_lds(k, lds));
-        if (n) hipLaunchKernelGGL(k, dim3(big_grid(n, BigCfg<T>::kPerCu)), dim3(T), lds, s, rows, n, nz_lo, nz_hi, N, K, wsplit, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols);
+        if (n) hipLaunchKernelGGL(k, dim3(big_grid(n, BigCfg<T>::kPerCu)), dim3(T), lds, s, rows, n, nz_lo, nz_hi, N2, K, wsplit, arpt, acol, aval, brpt, wcol, winv, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols);
         return G4S_OK;
     };
     auto big = [&](int threads, const int *rows, int n, int nz_lo = 0, int nz_hi = INT_MAX) -> int {
