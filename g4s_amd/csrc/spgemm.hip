@@ -119,7 +119,7 @@ struct ClassLimits { long long lim[6]; int raw[6]; };
 constexpr ClassLimits kSymLimits{{32, 512, 8192, 32768, 2097152, -1}, {0, 0, 0, 1, 1, 0}};
 // numeric: by the exact nz of the output row; tables hold keys + fp64 at <= 50 % fill: TINY 64, SMALL 1 K, MEDIUM 2 K, LARGE 4 K, M2 8 K slots.
 #ifndef G4S_SPGEMM_BIG_LIMIT
-#define G4S_SPGEMM_BIG_LIMIT 131072
+#define G4S_SPGEMM_BIG_LIMIT 1048576
 #endif
 constexpr ClassLimits kNumLimits{{32, 512, 1024, 2048, 4096, G4S_SPGEMM_BIG_LIMIT}, {0, 0, 0, 0, 0, 0}};   // M3: the all-LDS big-row kernel
 
@@ -571,13 +571,14 @@ struct BigSide {
     static constexpr int kUnitBatch = 2 * T;                                 // units mapped per batch (u16 entry index each)
     static constexpr size_t kFlatBytes = sizeof(int4) * T + sizeof(int) * (T + 4) + sizeof(unsigned short) * kUnitBatch;
     static constexpr size_t kStageBytes = sizeof(int) * BigCfg<T>::kStage;
-    static constexpr size_t kBytes = sizeof(int) * (kCtrlInts + kScanInts) + (kFlatBytes > kStageBytes ? kFlatBytes : kStageBytes);
-    int *ctrl, *scan, *stage, *P;
+    static constexpr size_t kStageBytes2 = kStageBytes + sizeof(int) * T;   // + the emit step's per-thread first positions
+    static constexpr size_t kBytes = sizeof(int) * (kCtrlInts + kScanInts) + (kFlatBytes > kStageBytes2 ? kFlatBytes : kStageBytes2);
+    int *ctrl, *scan, *stage, *base, *P;
     int4 *E;            // per A-entry: its B row [x, y) and the bits of its value
     unsigned short *M;  // per unit of the batch: its A-entry
-    __device__ __forceinline__ explicit BigSide(int *base)
+    __device__ __forceinline__ explicit BigSide(int *base_)
     {
-        ctrl = base; scan = base + kCtrlInts; stage = scan + kScanInts;
+        ctrl = base_; scan = base_ + kCtrlInts; stage = scan + kScanInts; base = stage + BigCfg<T>::kStage;
         E = reinterpret_cast<int4 *>(stage); P = reinterpret_cast<int *>(E + T); M = reinterpret_cast<unsigned short *>(P + T + 4);
     }
 };
@@ -679,13 +680,12 @@ __device__ __forceinline__ void flat_products(int a0, int a1, const int *__restr
 // (set bits, non-empty words) places its columns and its words. The bits themselves are then written word by word from a list of
 // the non-empty words, one word per thread: in a power-law row the first few hundred columns are all present, and a thread emitting
 // its own 32 words would write a thousand ids while the rest write a handful (measured: 38 % of the numeric kernel).
-// s_scan: 34 ints of LDS scratch, stage: kBigStage ints. Contains barriers: call from uniform control flow.
+// s_scan: 34 ints of LDS scratch, stage: kBigStage ints, first_pos: T ints. Contains barriers: call from uniform control flow.
 template <int T>
-__device__ __forceinline__ int emit_window_columns(const unsigned *bm, int w0, int *__restrict__ out, int *s_scan, int *stage, int t)
+__device__ __forceinline__ int emit_window_columns(const unsigned *bm, int w0, int *__restrict__ out, int *s_scan, int *stage, int *first_pos, int t)
 {
     constexpr int kBigThreads = T, kBigStage = BigCfg<T>::kStage;
     static_assert(BigCfg<T>::kWindowWords / T == 32, "emit layout");
-    static_assert(G4S_SPGEMM_BIG_LIMIT <= (1 << 17), "a list item packs the output position in 17 bits");
     const int lane = t & 63, wave = t >> 6;
     unsigned nonempty = 0;
     int cnt = 0;
@@ -707,16 +707,17 @@ __device__ __forceinline__ int emit_window_columns(const unsigned *bm, int w0, i
         total += vc;
         total_w += vw;
     }
+    first_pos[t] = p;                                              // a list item is (word << 10 | offset from its owner's first column)
     for (int tile0 = 0; tile0 < total_w; tile0 += kBigStage) {
         const int tile1 = tile0 + kBigStage;
         if (wq < tile1 && wq + nw > tile0) {
-            int q = p, j = wq;
+            int q = 0, j = wq;
             unsigned m = nonempty;
             while (m) {
                 const int i = __ffs(m) - 1;
                 m &= m - 1;
-                if (j >= tile0 && j < tile1) stage[j - tile0] = ((t * 32 + i) << 17) | q;
-                q += __popc(bm[bm_slot(t * 32 + i)]);
+                if (j >= tile0 && j < tile1) stage[j - tile0] = ((t * 32 + i) << 10) | q;
+                q += __popc(bm[bm_slot(t * 32 + i)]);              // < 1024 before the thread's last word
                 ++j;
             }
         }
@@ -724,9 +725,9 @@ __device__ __forceinline__ int emit_window_columns(const unsigned *bm, int w0, i
         const int n = min(kBigStage, total_w - tile0);
         for (int e = t; e < n; e += kBigThreads) {
             const unsigned item = (unsigned)stage[e];
-            const int w = (int)(item >> 17);
+            const int w = (int)(item >> 10);
             unsigned bits = bm[bm_slot(w)];
-            int pos = (int)(item & 0x1ffffu);
+            int pos = first_pos[w >> 5] + (int)(item & 0x3ffu);
             const int col0 = w0 + (w << 5);
             while (bits) {
                 const int bit = __ffs(bits) - 1;
@@ -776,7 +777,7 @@ __global__ __launch_bounds__(T) void spgemm_symbolic_window_kernel(
                     if (ok[q] && col[q] >= w0 && col[q] < w1) atomicOr(&bm[bm_slot((col[q] - w0) >> 5)], 1u << ((col[q] - w0) & 31));
             });
         if (po >= 0) {
-            const int total = emit_window_columns<T>(bm, w0, pre_cols + po + s_total, sd.scan, sd.stage, t);
+            const int total = emit_window_columns<T>(bm, w0, pre_cols + po + s_total, sd.scan, sd.stage, sd.base, t);
             if (t == 0) s_total += total;
         } else {
             int cnt = 0;
@@ -795,7 +796,8 @@ __global__ __launch_bounds__(T) void spgemm_symbolic_window_kernel(
 
 template <int T>
 __global__ __launch_bounds__(T) void spgemm_numeric_big_kernel(
-    const int *__restrict__ rows, int nrows, int nz_lo, int nz_hi /* rows with nz outside (nz_lo, nz_hi] are left to the other shape */, int N, int K, const int *__restrict__ wsplit, const int *__restrict__ arpt, const int *__restrict__ acol, const double *__restrict__ aval,
+    const int *__restrict__ rows, int nrows, int nz_lo, int nz_hi /* rows with nz outside (nz_lo, nz_hi] are left to the other shape */,
+    int *__restrict__ next_row /* not NULL: rows are handed out one at a time through this counter (a list sorted longest first) */, int N, int K, const int *__restrict__ wsplit, const int *__restrict__ arpt, const int *__restrict__ acol, const double *__restrict__ aval,
     const int *__restrict__ brpt, const int *__restrict__ bcol /* window ids: compact when col_of is given */, const int *__restrict__ col_of,
     const double *__restrict__ bval, const long long *__restrict__ row_flop,
     const int *__restrict__ crpt, int *__restrict__ ccol, double *__restrict__ cval,
@@ -808,7 +810,14 @@ __global__ __launch_bounds__(T) void spgemm_numeric_big_kernel(
     const BigSide<T> sd(lds_i + kBigWindowWords);
     int &s_base = sd.ctrl[BigSide<T>::kTotalSlot];
     const int t = threadIdx.x;
-    for (int ridx = blockIdx.x; ridx < nrows; ridx += gridDim.x) {   // persistent: see spgemm_symbolic_window_kernel
+    for (int ridx = blockIdx.x;; ridx += gridDim.x) {               // persistent: see spgemm_symbolic_window_kernel
+    if (next_row) {                                                // uniform
+        if (t == 0) sd.ctrl[28] = atomicAdd(next_row, 1);
+        __syncthreads();
+        ridx = sd.ctrl[28];
+        __syncthreads();
+    }
+    if (ridx >= nrows) break;
     const int row = rows[ridx];
     const int a0 = arpt[row], a1 = arpt[row + 1];
     const int off = crpt[row], nz = crpt[row + 1] - off;
@@ -833,7 +842,7 @@ __global__ __launch_bounds__(T) void spgemm_numeric_big_kernel(
                     if (ok[q] && col[q] >= w0 && col[q] < w1) atomicOr(&bm[bm_slot((col[q] - w0) >> 5)], 1u << ((col[q] - w0) & 31));
             });
         BIG_PROF(1);
-        const int total = emit_window_columns<T>(bm, w0, ccol + off + s_base, sd.scan, sd.stage, t);
+        const int total = emit_window_columns<T>(bm, w0, ccol + off + s_base, sd.scan, sd.stage, sd.base, t);
         BIG_PROF(3);
         __syncthreads();
         if (t == 0) s_base += total;
@@ -1417,13 +1426,18 @@ void release_column_scratch()
 }
 PreSorted::~PreSorted() { if (holds_cache) release_column_scratch(); }
 
+__global__ void row_nz_keys_kernel(int n, const int *__restrict__ rows, const int *__restrict__ crpt, int *__restrict__ keys)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = crpt[rows[i] + 1] - crpt[rows[i]];
+}
 __global__ void presorted_need_kernel(int M, const int *__restrict__ cls, unsigned class_mask, const long long *__restrict__ row_flop, int N,
                                       long long min_flop, long long *__restrict__ need)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const long long f = row_flop[i];
-    const bool take = ((class_mask >> cls[i]) & 1u) && f > min_flop && f <= G4S_SPGEMM_BIG_LIMIT;
+    const bool take = ((class_mask >> cls[i]) & 1u) && f > min_flop;
     need[i] = take ? (f < N ? f : (long long)N) : 0;
 }
 __global__ void presorted_mark_kernel(int M, const long long *__restrict__ need, long long *__restrict__ off)
@@ -1656,18 +1670,18 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
     G4S_TRY(build_window_splits(K, N2, brpt, wcol, wsplit_buf, &wsplit, s));
     // Rows past 1 K entries: bitmap windows + bucketed slots beat table + in-LDS bitonic sort while the column range is <= 4 windows.
     const bool xn_large = N2 <= window_max_n(), xn_m2 = xn_large;
-    auto big_t = [&](auto shape, const int *rows, int n, int nz_lo, int nz_hi) -> int {
+    auto big_t = [&](auto shape, const int *rows, int n, int nz_lo, int nz_hi, int *next_row) -> int {
         constexpr int T = decltype(shape)::value;
         auto k = spgemm_numeric_big_kernel<T>;
         const size_t lds = big_lds_bytes<T>();   // the bitmap (phase 2 reuses it) + scan scratch + long-B list + store staging
         G4S_TRY(allow_lds(k, lds));
-        if (n) hipLaunchKernelGGL(k, dim3(big_grid(n, BigCfg<T>::kPerCu)), dim3(T), lds, s, rows, n, nz_lo, nz_hi, N2, K, wsplit, arpt, acol, aval, brpt, wcol, winv, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols);
+        if (n) hipLaunchKernelGGL(k, dim3(big_grid(n, BigCfg<T>::kPerCu)), dim3(T), lds, s, rows, n, nz_lo, nz_hi, next_row, N2, K, wsplit, arpt, acol, aval, brpt, wcol, winv, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols);
         return G4S_OK;
     };
-    auto big = [&](int threads, const int *rows, int n, int nz_lo = 0, int nz_hi = INT_MAX) -> int {
-        if (threads == 256) return big_t(std::integral_constant<int, 256>{}, rows, n, nz_lo, nz_hi);
-        if (threads == 512) return big_t(std::integral_constant<int, 512>{}, rows, n, nz_lo, nz_hi);
-        return big_t(std::integral_constant<int, 1024>{}, rows, n, nz_lo, nz_hi);
+    auto big = [&](int threads, const int *rows, int n, int nz_lo = 0, int nz_hi = INT_MAX, int *next_row = nullptr) -> int {
+        if (threads == 256) return big_t(std::integral_constant<int, 256>{}, rows, n, nz_lo, nz_hi, next_row);
+        if (threads == 512) return big_t(std::integral_constant<int, 512>{}, rows, n, nz_lo, nz_hi, next_row);
+        return big_t(std::integral_constant<int, 1024>{}, rows, n, nz_lo, nz_hi, next_row);
     };
     const int t_large = shape_of("G4S_SPGEMM_T_NUM_LARGE", kShapeNumLarge), t_m2 = shape_of("G4S_SPGEMM_T_NUM_M2", kShapeNumM2),
               t_m3 = shape_of("G4S_SPGEMM_T_NUM_M3", kShapeNumM3);
@@ -1694,7 +1708,23 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
     if (int n = rc.count[CLS_M3]) {
         // the class spans 4 K … 128 K entries: its short rows go to the many-workgroups shape, the long ones keep 1 024 threads
         if (t_m3 != 1024 && m3_cut > 0) { G4S_TRY(big(t_m3, rc.list(CLS_M3), n, 0, m3_cut)); G4S_TRY(big(1024, rc.list(CLS_M3), n, m3_cut, INT_MAX)); }
-        else G4S_TRY(big(1024, rc.list(CLS_M3), n));
+        else if (getenv("G4S_SPGEMM_STATIC_ROWS")) G4S_TRY(big(1024, rc.list(CLS_M3), n));
+        else {
+            // The class spans 4 K … 1 M outputs per row (a 250-fold range of work): longest rows first, handed out one at a time.
+            DevBuf keys, keys_sorted, rows_sorted, tmp, counter;
+            G4S_TRY(keys.alloc(sizeof(int) * (size_t)n));
+            G4S_TRY(keys_sorted.alloc(sizeof(int) * (size_t)n));
+            G4S_TRY(rows_sorted.alloc(sizeof(int) * (size_t)n));
+            G4S_TRY(counter.alloc(sizeof(int)));
+            G4S_HIP_TRY(hipMemsetAsync(counter.p, 0, sizeof(int), s));
+            hipLaunchKernelGGL(row_nz_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, rc.list(CLS_M3), crpt, keys.as<int>());
+            size_t tb = 0;
+            G4S_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, keys.as<int>(), keys_sorted.as<int>(), rc.list(CLS_M3), rows_sorted.as<int>(), n, 0, 32, s));
+            G4S_TRY(tmp.alloc(tb));
+            G4S_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp.p, tb, keys.as<int>(), keys_sorted.as<int>(), rc.list(CLS_M3), rows_sorted.as<int>(), n, 0, 32, s));
+            G4S_TRY(big(1024, rows_sorted.as<int>(), n, 0, INT_MAX, counter.as<int>()));
+            G4S_HIP_TRY(hipStreamSynchronize(s));                 // the sorted list and the counter die with this block
+        }
     }
     G4S_HIP_TRY(hipGetLastError());
     std::vector<int> hub, ranges;
