@@ -73,26 +73,51 @@ __device__ __forceinline__ long long wave_sum_ll(long long v)
 }
 
 // ------------------------------------------------------------------------------------------------ flop per row (a4)
-// Eight lanes per row (most rows of a power-law graph hold a handful of entries; hubs just loop longer): lanes stride the row's
-// A-entries. BIN::set_intprod_num (BIN.h:78-95) / compute_flop (mkl_mult.h:8-38).
+// Eight lanes per row (most rows of a power-law graph hold a handful of entries); a row past 64 entries is left to the whole
+// workgroup afterwards — eight lanes looping over a hub's 16 K entries were a 2 ms tail on their own — and the grand total takes
+// one atomic per workgroup, not one per row. BIN::set_intprod_num (BIN.h:78-95) / compute_flop (mkl_mult.h:8-38).
 __global__ __launch_bounds__(256) void row_flop_kernel(int M, const int *__restrict__ arpt, const int *__restrict__ acol,
                                                         const int *__restrict__ brpt, long long *__restrict__ row_flop,
                                                         unsigned long long *__restrict__ total)
 {
-    const int sub = threadIdx.x & 7;
-    const int row = blockIdx.x * 32 + (threadIdx.x >> 3);
+    __shared__ long long s_f[32];
+    __shared__ long long s_part[4];
+    const int t = threadIdx.x, sub = t & 7, r = t >> 3;
+    const int row = blockIdx.x * 32 + r;
+    const int a0 = row < M ? arpt[row] : 0, a1 = row < M ? arpt[row + 1] : 0;
+    const bool is_long = a1 - a0 > 64;
     long long f = 0;
-    if (row < M)
-        for (int j = arpt[row] + sub; j < arpt[row + 1]; j += 8) {
+    if (!is_long)
+        for (int j = a0 + sub; j < a1; j += 8) {
             const int c = acol[j];
             f += brpt[c + 1] - brpt[c];
         }
     f += __shfl_down(f, 4, 8);
     f += __shfl_down(f, 2, 8);
     f += __shfl_down(f, 1, 8);
-    if (row < M && sub == 0) {
-        row_flop[row] = f;
-        if (f) atomicAdd(total, (unsigned long long)f);
+    if (sub == 0) s_f[r] = is_long ? -1 : f;
+    __syncthreads();
+    for (int q = 0; q < 32; ++q) {
+        if (s_f[q] >= 0) continue;                                 // uniform
+        const int qrow = blockIdx.x * 32 + q;
+        long long g = 0;
+        for (int j = arpt[qrow] + t; j < arpt[qrow + 1]; j += 256) {
+            const int c = acol[j];
+            g += brpt[c + 1] - brpt[c];
+        }
+        g = wave_sum_ll(g);
+        if ((t & 63) == 0) s_part[t >> 6] = g;
+        __syncthreads();
+        if (t == 0) s_f[q] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        __syncthreads();
+    }
+    if (t < 32) {
+        const long long v = s_f[t];
+        if (blockIdx.x * 32 + t < M) row_flop[blockIdx.x * 32 + t] = v;
+        long long sum = blockIdx.x * 32 + t < M ? v : 0;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) sum += __shfl_down(sum, off, 32);
+        if (t == 0 && sum) atomicAdd(total, (unsigned long long)sum);
     }
 }
 
@@ -747,7 +772,8 @@ __device__ __forceinline__ int emit_window_columns(const unsigned *bm, int w0, i
 // pre_cols[pre_off[row] …], so that the numeric phase does not have to mark and emit them a second time.
 template <int T>
 __global__ __launch_bounds__(T) void spgemm_symbolic_window_kernel(
-    const int *__restrict__ rows, int nrows, int N, int K, const int *__restrict__ wsplit, const int *__restrict__ arpt, const int *__restrict__ acol,
+    const int *__restrict__ rows, int nrows, int *__restrict__ next_row /* not NULL: rows handed out one at a time (list sorted longest first) */,
+    int N, int K, const int *__restrict__ wsplit, const int *__restrict__ arpt, const int *__restrict__ acol,
     const int *__restrict__ brpt, const int *__restrict__ bcol, const long long *__restrict__ row_flop, int *__restrict__ row_nz,
     const long long *__restrict__ pre_off, int *__restrict__ pre_cols)
 {
@@ -759,7 +785,14 @@ __global__ __launch_bounds__(T) void spgemm_symbolic_window_kernel(
     const int t = threadIdx.x;
     // Persistent: the grid is a few workgroups per CU (as many as their LDS allows) and every workgroup walks its share of the class's rows —
     // starting a 1024-thread workgroup with this much LDS costs several µs, and a class holds 10^5 rows of a few thousand products each.
-    for (int ridx = blockIdx.x; ridx < nrows; ridx += gridDim.x) {
+    for (int ridx = blockIdx.x;; ridx += gridDim.x) {
+    if (next_row) {                                                // uniform
+        if (t == 0) sd.ctrl[28] = atomicAdd(next_row, 1);
+        __syncthreads();
+        ridx = sd.ctrl[28];
+        __syncthreads();
+    }
+    if (ridx >= nrows) break;
     const int row = rows[ridx];
     const int a0 = arpt[row], a1 = arpt[row + 1];
     const long long po = pre_off ? pre_off[row] : -1;              // uniform
@@ -1426,11 +1459,33 @@ void release_column_scratch()
 }
 PreSorted::~PreSorted() { if (holds_cache) release_column_scratch(); }
 
-__global__ void row_nz_keys_kernel(int n, const int *__restrict__ rows, const int *__restrict__ crpt, int *__restrict__ keys)
+// A class's rows, longest first, with the counter the persistent kernels hand them out through. The key of a row is size[row]
+// (64-bit, clipped to int) or, without size, its output length crpt[row + 1] − crpt[row].
+__global__ void row_size_keys_kernel(int n, const int *__restrict__ rows, const long long *__restrict__ size, const int *__restrict__ crpt, int *__restrict__ keys)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) keys[i] = crpt[rows[i] + 1] - crpt[rows[i]];
+    if (i >= n) return;
+    const int r = rows[i];
+    const long long v = size ? size[r] : (long long)crpt[r + 1] - crpt[r];
+    keys[i] = v > INT_MAX ? INT_MAX : (int)v;
 }
+struct SortedRows {
+    DevBuf keys, keys_sorted, rows, tmp, counter;
+    int build(int n, const int *list, const long long *size, const int *crpt, hipStream_t s)
+    {
+        G4S_TRY(keys.alloc(sizeof(int) * (size_t)n));
+        G4S_TRY(keys_sorted.alloc(sizeof(int) * (size_t)n));
+        G4S_TRY(rows.alloc(sizeof(int) * (size_t)n));
+        G4S_TRY(counter.alloc(sizeof(int)));
+        G4S_HIP_TRY(hipMemsetAsync(counter.p, 0, sizeof(int), s));
+        hipLaunchKernelGGL(row_size_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, list, size, crpt, keys.as<int>());
+        size_t tb = 0;
+        G4S_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, keys.as<int>(), keys_sorted.as<int>(), list, rows.as<int>(), n, 0, 32, s));
+        G4S_TRY(tmp.alloc(tb));
+        G4S_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp.p, tb, keys.as<int>(), keys_sorted.as<int>(), list, rows.as<int>(), n, 0, 32, s));
+        return G4S_OK;
+    }
+};
 __global__ void presorted_need_kernel(int M, const int *__restrict__ cls, unsigned class_mask, const long long *__restrict__ row_flop, int N,
                                       long long min_flop, long long *__restrict__ need)
 {
@@ -1552,28 +1607,36 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
             G4S_HIP_TRY(hipStreamSynchronize(s));
         }
     }
-    auto window_t = [&](auto shape, const int *rows, int n, const long long *poff, int *pcols) -> int {
+    auto window_t = [&](auto shape, const int *rows, int n, const long long *poff, int *pcols, int *next_row) -> int {
         constexpr int T = decltype(shape)::value;
         auto k = spgemm_symbolic_window_kernel<T>;
         const size_t lds = big_lds_bytes<T>();
         G4S_TRY(allow_lds(k, lds));
-        if (n) hipLaunchKernelGGL(k, dim3(big_grid(n, BigCfg<T>::kPerCu)), dim3(T), lds, s, rows, n, N2, K, wsplit, arpt, acol, brpt, wcol, row_flop.as<long long>(), nz, poff, pcols);
+        if (n) hipLaunchKernelGGL(k, dim3(big_grid(n, BigCfg<T>::kPerCu)), dim3(T), lds, s, rows, n, next_row, N2, K, wsplit, arpt, acol, brpt, wcol, row_flop.as<long long>(), nz, poff, pcols);
         return G4S_OK;
     };
-    auto window = [&](int threads, const int *rows, int n, const long long *poff, int *pcols) -> int {
-        if (threads == 256) return window_t(std::integral_constant<int, 256>{}, rows, n, poff, pcols);
-        if (threads == 512) return window_t(std::integral_constant<int, 512>{}, rows, n, poff, pcols);
-        return window_t(std::integral_constant<int, 1024>{}, rows, n, poff, pcols);
+    SortedRows sorted[3];                                          // live until the stream is synchronised below
+    int n_sorted = 0;
+    auto window = [&](int threads, const int *rows, int n, const long long *poff, int *pcols, bool longest_first = false) -> int {
+        int *next_row = nullptr;
+        if (longest_first && n > 1 && !getenv("G4S_SPGEMM_STATIC_ROWS")) {
+            SortedRows &sr = sorted[n_sorted++];
+            G4S_TRY(sr.build(n, rows, row_flop.as<long long>(), nullptr, s));
+            rows = sr.rows.as<int>(); next_row = sr.counter.as<int>();
+        }
+        if (threads == 256) return window_t(std::integral_constant<int, 256>{}, rows, n, poff, pcols, next_row);
+        if (threads == 512) return window_t(std::integral_constant<int, 512>{}, rows, n, poff, pcols, next_row);
+        return window_t(std::integral_constant<int, 1024>{}, rows, n, poff, pcols, next_row);
     };
     const int t_med = shape_of("G4S_SPGEMM_T_SYM_MED", kShapeSymMedium), t_large = shape_of("G4S_SPGEMM_T_SYM_LARGE", kShapeSymLarge),
               t_win = shape_of("G4S_SPGEMM_T_SYM_WINDOW", 1024);
-    if (x_med) { G4S_TRY(window(t_med, rc.list(CLS_MEDIUM), rc.count[CLS_MEDIUM], pre_off, pre_cols)); }
+    if (x_med) { G4S_TRY(window(t_med, rc.list(CLS_MEDIUM), rc.count[CLS_MEDIUM], pre_off, pre_cols, true)); }
     else if (int n = rc.count[CLS_MEDIUM]) {
         auto k = spgemm_symbolic_lds_kernel<256, 256, 16384, false>;
         G4S_TRY(allow_lds(k, sym_lds_bytes(1, 16384)));
         hipLaunchKernelGGL(k, dim3(n), dim3(256), sym_lds_bytes(1, 16384), s, rc.list(CLS_MEDIUM), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr);
     }
-    if (x_large) { G4S_TRY(window(t_large, rc.list(CLS_LARGE), rc.count[CLS_LARGE], pre_off, pre_cols)); }
+    if (x_large) { G4S_TRY(window(t_large, rc.list(CLS_LARGE), rc.count[CLS_LARGE], pre_off, pre_cols, true)); }
     else if (int n = rc.count[CLS_LARGE]) {
         auto k = spgemm_symbolic_lds_kernel<1024, 1024, 32768, true>;
         G4S_TRY(allow_lds(k, sym_lds_bytes(1, 32768)));
@@ -1588,7 +1651,7 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     G4S_HIP_TRY(hipStreamSynchronize(s));
     if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s symbolic: %d optimistic tables overflowed, %d window-class rows\n", n_ovf, rc.count[CLS_M2]);
     G4S_TRY(window(1024, ovf_rows.as<int>(), n_ovf, nullptr, nullptr));   // rows of the optimistic table class are not in the scratch
-    G4S_TRY(window(t_win, rc.list(CLS_M2), rc.count[CLS_M2], pre_off, pre_cols));
+    G4S_TRY(window(t_win, rc.list(CLS_M2), rc.count[CLS_M2], pre_off, pre_cols, true));
     G4S_HIP_TRY(hipGetLastError());
     // hub rows (flop > 2 M): many workgroups per row on a bitmap in HBM
     std::vector<int> hub, ranges;
@@ -1711,18 +1774,9 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         else if (getenv("G4S_SPGEMM_STATIC_ROWS")) G4S_TRY(big(1024, rc.list(CLS_M3), n));
         else {
             // The class spans 4 K … 1 M outputs per row (a 250-fold range of work): longest rows first, handed out one at a time.
-            DevBuf keys, keys_sorted, rows_sorted, tmp, counter;
-            G4S_TRY(keys.alloc(sizeof(int) * (size_t)n));
-            G4S_TRY(keys_sorted.alloc(sizeof(int) * (size_t)n));
-            G4S_TRY(rows_sorted.alloc(sizeof(int) * (size_t)n));
-            G4S_TRY(counter.alloc(sizeof(int)));
-            G4S_HIP_TRY(hipMemsetAsync(counter.p, 0, sizeof(int), s));
-            hipLaunchKernelGGL(row_nz_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, rc.list(CLS_M3), crpt, keys.as<int>());
-            size_t tb = 0;
-            G4S_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, keys.as<int>(), keys_sorted.as<int>(), rc.list(CLS_M3), rows_sorted.as<int>(), n, 0, 32, s));
-            G4S_TRY(tmp.alloc(tb));
-            G4S_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp.p, tb, keys.as<int>(), keys_sorted.as<int>(), rc.list(CLS_M3), rows_sorted.as<int>(), n, 0, 32, s));
-            G4S_TRY(big(1024, rows_sorted.as<int>(), n, 0, INT_MAX, counter.as<int>()));
+            SortedRows sr;
+            G4S_TRY(sr.build(n, rc.list(CLS_M3), nullptr, crpt, s));
+            G4S_TRY(big(1024, sr.rows.as<int>(), n, 0, INT_MAX, sr.counter.as<int>()));
             G4S_HIP_TRY(hipStreamSynchronize(s));                 // the sorted list and the counter die with this block
         }
     }
