@@ -670,15 +670,19 @@ __device__ __forceinline__ void flat_products(int a0, int a1, const int *__restr
                 int kk[UPR], c[UPR];
                 bool ok[UPR];
                 double av[UPR], v[UPR];
+                // (each stage for all UPR units before the next: written unit by unit, every LDS read was followed by its own wait)
+                int uu[UPR], j[UPR], p0[UPR];
+                int4 e[UPR];
+#pragma unroll
+                for (int q = 0; q < UPR; ++q) { uu[q] = min(g + q, nb - 1); j[q] = sd.M[uu[q]]; }
+#pragma unroll
+                for (int q = 0; q < UPR; ++q) { e[q] = sd.E[j[q]]; p0[q] = sd.P[j[q]]; }
 #pragma unroll
                 for (int q = 0; q < UPR; ++q) {
-                    const int uu = min(g + q, nb - 1);
-                    const int j = sd.M[uu];
-                    const int4 e = sd.E[j];
-                    const int k = e.x + ((ub0 + uu - sd.P[j]) << 6) + lane;
-                    ok[q] = g + q < nb && k < e.y;
-                    kk[q] = min(k, e.y - 1);                        // a unit exists only in a non-empty piece: e.y - 1 >= e.x
-                    av[q] = WITH_VAL ? long_b_value(e) : 0.0;
+                    const int k = e[q].x + ((ub0 + uu[q] - p0[q]) << 6) + lane;
+                    ok[q] = g + q < nb && k < e[q].y;
+                    kk[q] = min(k, e[q].y - 1);                     // a unit exists only in a non-empty piece: e.y - 1 >= e.x
+                    av[q] = WITH_VAL ? long_b_value(e[q]) : 0.0;
                 }
 #pragma unroll
                 for (int q = 0; q < UPR; ++q) {
@@ -706,19 +710,30 @@ __device__ __forceinline__ void flat_products(int a0, int a1, const int *__restr
 // the non-empty words, one word per thread: in a power-law row the first few hundred columns are all present, and a thread emitting
 // its own 32 words would write a thousand ids while the rest write a handful (measured: 38 % of the numeric kernel).
 // s_scan: 34 ints of LDS scratch, stage: kBigStage ints, first_pos: T ints. Contains barriers: call from uniform control flow.
-template <int T>
+template <int T, bool KEEP_WORDS>
 __device__ __forceinline__ int emit_window_columns(const unsigned *bm, int w0, int *__restrict__ out, int *s_scan, int *stage, int *first_pos, int t)
 {
+    // KEEP_WORDS: the thread's 32 words stay in registers between the count and the list step (32 VGPRs the numeric kernel cannot spare)
     constexpr int kBigThreads = T, kBigStage = BigCfg<T>::kStage;
     static_assert(BigCfg<T>::kWindowWords / T == 32, "emit layout");
     const int lane = t & 63, wave = t >> 6;
-    unsigned nonempty = 0;
+    unsigned nonempty = 0, words[KEEP_WORDS ? 32 : 1];
     int cnt = 0;
+    if constexpr (KEEP_WORDS) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) words[i] = bm[bm_slot(t * 32 + i)];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            cnt += __popc(words[i]);
+            nonempty |= (words[i] != 0u ? 1u : 0u) << i;
+        }
+    } else {
 #pragma unroll 8
-    for (int i = 0; i < 32; ++i) {
-        const unsigned w = bm[bm_slot(t * 32 + i)];
-        cnt += __popc(w);
-        nonempty |= (w != 0u ? 1u : 0u) << i;
+        for (int i = 0; i < 32; ++i) {
+            const unsigned w = bm[bm_slot(t * 32 + i)];
+            cnt += __popc(w);
+            nonempty |= (w != 0u ? 1u : 0u) << i;
+        }
     }
     const int nw = __popc(nonempty);
     const int incl_c = (int)wave_inclusive_sum((unsigned)cnt), incl_w = (int)wave_inclusive_sum((unsigned)nw);
@@ -737,13 +752,24 @@ __device__ __forceinline__ int emit_window_columns(const unsigned *bm, int w0, i
         const int tile1 = tile0 + kBigStage;
         if (wq < tile1 && wq + nw > tile0) {
             int q = 0, j = wq;
-            unsigned m = nonempty;
-            while (m) {
-                const int i = __ffs(m) - 1;
-                m &= m - 1;
-                if (j >= tile0 && j < tile1) stage[j - tile0] = ((t * 32 + i) << 10) | q;
-                q += __popc(bm[bm_slot(t * 32 + i)]);              // < 1024 before the thread's last word
-                ++j;
+            if constexpr (KEEP_WORDS) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    if (words[i]) {
+                        if (j >= tile0 && j < tile1) stage[j - tile0] = ((t * 32 + i) << 10) | q;
+                        q += __popc(words[i]);                     // < 1024 before the thread's last word
+                        ++j;
+                    }
+                }
+            } else {
+                unsigned m = nonempty;
+                while (m) {
+                    const int i = __ffs(m) - 1;
+                    m &= m - 1;
+                    if (j >= tile0 && j < tile1) stage[j - tile0] = ((t * 32 + i) << 10) | q;
+                    q += __popc(bm[bm_slot(t * 32 + i)]);
+                    ++j;
+                }
             }
         }
         __syncthreads();
@@ -771,7 +797,7 @@ __device__ __forceinline__ int emit_window_columns(const unsigned *bm, int w0, i
 // pre_off / pre_cols (one-shot call only): rows with pre_off[row] >= 0 also write their sorted distinct columns to
 // pre_cols[pre_off[row] …], so that the numeric phase does not have to mark and emit them a second time.
 template <int T>
-__global__ __launch_bounds__(T) void spgemm_symbolic_window_kernel(
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void spgemm_symbolic_window_kernel(
     const int *__restrict__ rows, int nrows, int *__restrict__ next_row /* not NULL: rows handed out one at a time (list sorted longest first) */,
     int N, int K, const int *__restrict__ wsplit, const int *__restrict__ arpt, const int *__restrict__ acol,
     const int *__restrict__ brpt, const int *__restrict__ bcol, const long long *__restrict__ row_flop, int *__restrict__ row_nz,
@@ -810,7 +836,7 @@ __global__ __launch_bounds__(T) void spgemm_symbolic_window_kernel(
                     if (ok[q] && col[q] >= w0 && col[q] < w1) atomicOr(&bm[bm_slot((col[q] - w0) >> 5)], 1u << ((col[q] - w0) & 31));
             });
         if (po >= 0) {
-            const int total = emit_window_columns<T>(bm, w0, pre_cols + po + s_total, sd.scan, sd.stage, sd.base, t);
+            const int total = emit_window_columns<T, true>(bm, w0, pre_cols + po + s_total, sd.scan, sd.stage, sd.base, t);
             if (t == 0) s_total += total;
         } else {
             int cnt = 0;
@@ -828,7 +854,7 @@ __global__ __launch_bounds__(T) void spgemm_symbolic_window_kernel(
 
 
 template <int T>
-__global__ __launch_bounds__(T) void spgemm_numeric_big_kernel(
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void spgemm_numeric_big_kernel(
     const int *__restrict__ rows, int nrows, int nz_lo, int nz_hi /* rows with nz outside (nz_lo, nz_hi] are left to the other shape */,
     int *__restrict__ next_row /* not NULL: rows are handed out one at a time through this counter (a list sorted longest first) */, int N, int K, const int *__restrict__ wsplit, const int *__restrict__ arpt, const int *__restrict__ acol, const double *__restrict__ aval,
     const int *__restrict__ brpt, const int *__restrict__ bcol /* window ids: compact when col_of is given */, const int *__restrict__ col_of,
@@ -875,7 +901,7 @@ __global__ __launch_bounds__(T) void spgemm_numeric_big_kernel(
                     if (ok[q] && col[q] >= w0 && col[q] < w1) atomicOr(&bm[bm_slot((col[q] - w0) >> 5)], 1u << ((col[q] - w0) & 31));
             });
         BIG_PROF(1);
-        const int total = emit_window_columns<T>(bm, w0, ccol + off + s_base, sd.scan, sd.stage, sd.base, t);
+        const int total = emit_window_columns<T, false>(bm, w0, ccol + off + s_base, sd.scan, sd.stage, sd.base, t);
         BIG_PROF(3);
         __syncthreads();
         if (t == 0) s_base += total;
@@ -918,12 +944,14 @@ __global__ __launch_bounds__(T) void spgemm_numeric_big_kernel(
 #pragma unroll
             for (int q = 0; q < kU; ++q) more |= lo[q] < hi[q];
             if (!__any(more)) break;
+            int mid[kU], km[kU];
+#pragma unroll
+            for (int q = 0; q < kU; ++q) { mid[q] = (lo[q] + hi[q]) >> 1; km[q] = KC[mid[q]]; }   // the kU reads in flight together
 #pragma unroll
             for (int q = 0; q < kU; ++q) {
-                const int mid = (lo[q] + hi[q]) >> 1;
-                const bool less = KC[mid] < key[q];
-                lo[q] = less ? mid + 1 : lo[q];
-                hi[q] = less ? hi[q] : mid;
+                const bool less = km[q] < key[q];
+                lo[q] = less ? mid[q] + 1 : lo[q];
+                hi[q] = less ? hi[q] : mid[q];
             }
         }
 #pragma unroll
@@ -953,13 +981,19 @@ __global__ __launch_bounds__(T) void spgemm_numeric_big_kernel(
         static_assert(kBigChunk == (1 << BigCfg<T>::kChunkBits), "bucket shift");
     };
     auto build_index = [&](int qn) {                               // bucket b = (col − first) >> shift → (first slot << 16 | last slot)
+        int b[kPerThread], bp[kPerThread], bn[kPerThread];         // (all LDS reads first: read by read, each waits on its own)
+#pragma unroll
+        for (int u = 0; u < kPerThread; ++u) {
+            const int i = min(t + u * kBigThreads, qn - 1);
+            b[u] = KC[i]; bp[u] = KC[max(i - 1, 0)]; bn[u] = KC[min(i + 1, qn - 1)];
+        }
 #pragma unroll
         for (int u = 0; u < kPerThread; ++u) {
             const int i = t + u * kBigThreads;
             if (i < qn) {
-                const int b = (KC[i] - kfirst) >> shift;
-                if (i == 0 || ((KC[i - 1] - kfirst) >> shift) != b) atomicOr(&IDX[b], (unsigned)i << 16);
-                if (i == qn - 1 || ((KC[i + 1] - kfirst) >> shift) != b) atomicOr(&IDX[b], (unsigned)i);
+                const int bb = (b[u] - kfirst) >> shift;
+                if (i == 0 || ((bp[u] - kfirst) >> shift) != bb) atomicOr(&IDX[bb], (unsigned)i << 16);
+                if (i == qn - 1 || ((bn[u] - kfirst) >> shift) != bb) atomicOr(&IDX[bb], (unsigned)i);
             }
         }
     };
@@ -986,10 +1020,13 @@ __global__ __launch_bounds__(T) void spgemm_numeric_big_kernel(
 #pragma unroll
                 for (int u = 0; u < kPerThread; ++u) orig[u] = KC[min(t + u * kBigThreads, qn - 1)];
             }
+            double val[kPerThread];
+#pragma unroll
+            for (int u = 0; u < kPerThread; ++u) val[u] = V[min(t + u * kBigThreads, qn - 1)];
 #pragma unroll
             for (int u = 0; u < kPerThread; ++u) {
                 const int i = t + u * kBigThreads;
-                if (i < qn) cval[off + q0 + i] = V[i];
+                if (i < qn) cval[off + q0 + i] = val[u];
             }
             if (col_of || po >= 0) {                               // (a numeric-only call without a column map has them in place already)
 #pragma unroll
