@@ -18,11 +18,11 @@ def _abs(A):
     return (A[0], A[1], np.abs(A[2]))
 
 
-def _check(oracle, A, B, M, K, N):
+def _check(oracle, A, B, M, K, N, two_phase=False):
     from g4s_amd import host
     a = host.CSR.from_host(*A, M, K)
     b = host.CSR.from_host(*B, K, N)
-    c = host.HashSpGEMM(a, b)
+    c = host.HashSpGEMM(a, b, two_phase=two_phase)
     crpt, ccol, cval = c.to_host()
     orpt, ocol, oval = oracle.spgemm(A, B, N, sort_output=True)
     assert np.array_equal(crpt, orpt), "row pointer differs"
@@ -108,9 +108,17 @@ def test_spgemm_power_law_square(oracle, mid_row_kernels):
     _check(oracle, (rp, ci, va), (rp, ci, va), 6000, 6000, 6000)
 
 
-def test_spgemm_three_windows(oracle):
-    """B with 2.6 M columns: the window kernels make three passes per row; rows of 600–9000 products, columns bunched at the
-    window seams (2^20, 2^21) and at both ends."""
+@pytest.fixture(params=["colmap", "plain"])
+def column_map(request, monkeypatch):
+    """The window kernels renumber B's non-empty columns when at least an eighth of them are empty; "plain" keeps B's ids."""
+    if request.param == "plain":
+        monkeypatch.setenv("G4S_SPGEMM_NO_COLMAP", "1")
+    return request.param
+
+
+def _three_window_case(oracle, two_phase):
+    """B with 2.6 M columns: without the column map the window kernels make three passes per row; rows of 600–9000 products, columns
+    bunched at the window seams (2^20, 2^21) and at both ends."""
     rng = np.random.default_rng(29)
     K, N = 400, 2_600_000
     seams = np.array([0, 1 << 20, 1 << 21, N - 64])
@@ -127,9 +135,50 @@ def test_spgemm_three_windows(oracle):
     arp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     aci = np.concatenate(rows).astype(np.int32)
     ava = rng.uniform(-1, 1, arp[-1])
-    c = _check(oracle, (arp, aci, ava), (brp, bci, bva), len(lens), K, N)
+    c = _check(oracle, (arp, aci, ava), (brp, bci, bva), len(lens), K, N, two_phase=two_phase)
     nz = np.diff(c.to_host()[0])
     assert nz[5] > 8192 and 1024 < nz[2] <= 4096                  # one row needs two value chunks; mid rows use the window kernel
+
+
+@pytest.mark.parametrize("two_phase", [False, True])
+def test_spgemm_three_windows(oracle, column_map, two_phase):
+    """Both column numberings, and both call forms: the one-call form carries the sorted columns (window ids) from the symbolic phase to the
+    numeric one; g4s_spgemm_symbolic + g4s_spgemm_numeric makes the numeric kernel mark and emit them itself and translate in place."""
+    _three_window_case(oracle, two_phase)
+
+
+@pytest.mark.parametrize("shape", ["256", "512", "1024"])
+@pytest.mark.parametrize("static_rows", [False, True])
+def test_spgemm_workgroup_shapes(oracle, monkeypatch, shape, static_rows):
+    """Every row class through every workgroup shape of the window kernels (the defaults pick one per class), with the rows handed out
+    through the counter and strided."""
+    for v in ("SYM_MED", "SYM_LARGE", "SYM_WINDOW", "NUM_MED", "NUM_LARGE", "NUM_M2", "NUM_M3"):
+        monkeypatch.setenv("G4S_SPGEMM_T_" + v, shape)
+    monkeypatch.setenv("G4S_SPGEMM_M3_CUT", "20000")
+    if static_rows:
+        monkeypatch.setenv("G4S_SPGEMM_STATIC_ROWS", "1")
+    rp, ci, va = power_law_csr(6000, 6000, 23, 1500)
+    _check(oracle, (rp, ci, va), (rp, ci, va), 6000, 6000, 6000)
+    _three_window_case(oracle, False)
+
+
+@pytest.mark.parametrize("two_phase", [False, True])
+def test_spgemm_row_of_300k_outputs(oracle, column_map, two_phase):
+    """Output rows of ≈ 150 K and ≈ 142 K entries (19 value chunks; past the 131 072 a list item of the emit step once packed) next to
+    ordinary rows: the numeric big-row kernel takes them, the symbolic window kernel counts them (flop 1.65 M < the 2 M of the hub class)."""
+    rng = np.random.default_rng(41)
+    K, N = 2000, 300_000
+    brp = (np.arange(K + 1) * 1100).astype(np.int32)
+    bci = np.concatenate([2 * np.sort(rng.choice(N // 2, 1100, replace=False)) for _ in range(K)]).astype(np.int32)   # odd columns stay empty
+    bva = rng.uniform(0.5, 1, brp[-1])
+    lens = [1500, 3, 40, 0, 400]
+    rows = [np.sort(rng.choice(K, l, replace=False)) for l in lens]
+    arp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    aci = np.concatenate(rows).astype(np.int32)
+    ava = rng.uniform(0.5, 1, arp[-1])
+    c = _check(oracle, (arp, aci, ava), (brp, bci, bva), len(lens), K, N, two_phase=two_phase)
+    nz = np.diff(c.to_host()[0])
+    assert nz[0] > 131_072 and nz[4] > 131_072
 
 
 def test_spgemm_raw_pointer_host_call(oracle, g4s):
