@@ -220,9 +220,21 @@ def main():
         y_local = torch.empty(r1 - r0, dtype=torch.float64, device="cuda")
         if mode == "dist":
             # the library's multi-GPU product (g4s_spmv_dist_*, csrc/dist.hip): own / remote column split, packed exchange of the referenced x
-            # entries by ncclSend/ncclRecv on the library's own RCCL communicator, own-column product overlapped with it. A failure while
-            # the communicator is being wired is fatal for the run (no fallback on a possibly poisoned communicator).
-            D = gdist.DistSpMV(offs, rank, world, rp, ci, va, n_cols, spmv_flags=flags)
+            # entries by ncclSend/ncclRecv on the library's own RCCL communicator, own-column product overlapped with it. DistSpMV agrees
+            # after every set-up phase whether it succeeded on ALL ranks and raises everywhere at the same point if not; the ranks then fall
+            # back — together — to round 1's padded all-gather on torch.distributed.
+            err = ""
+            try:
+                D = gdist.DistSpMV(offs, rank, world, rp, ci, va, n_cols, spmv_flags=flags)
+            except Exception as e:                                  # noqa: BLE001 — reported below, decided collectively
+                D, err = None, f"{type(e).__name__}: {e}"
+            okf = torch.tensor([1 if D is not None else 0], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if int(okf.item()) == 0:
+                if err:
+                    print(f"[bench rank {rank}] g4s_spmv_dist set-up failed ({err}); every rank falls back to --exchange allgather", file=sys.stderr, flush=True)
+                D, mode = None, "allgather"
+        if mode == "dist":
             dinfo = D.info()
             recv_bytes = dinfo["recv_bytes"]
             info = {"spmv_path": dinfo["rem_path"] if dinfo["reserved"] else dinfo["own_path"], "dist_form": "merged (one product on a compact x)" if dinfo["reserved"] else "own + remote columns",
@@ -357,7 +369,10 @@ def main():
         # the multi-GPU config of BASELINE.json (configs[3]) in the same run, same ranks — R-MAT has no column locality and its strong
         # scaling is exchange-bound by construction; the stencil shows what the row partition does when only halos travel
         torch.cuda.empty_cache()
-        also = config3_lap7(world, rank, max(10, args.steps // 2), min(args.warmup, 5), args.small, host, gdist, dist, torch)
+        try:                                                       # a failure here (raised on every rank alike, see DistSpMV) must not cost the headline line
+            also = config3_lap7(world, rank, max(10, args.steps // 2), min(args.warmup, 5), args.small, host, gdist, dist, torch)
+        except Exception as e:                                     # noqa: BLE001
+            also = {"error": f"{type(e).__name__}: {e}"}
         result["also"] = also
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -10,6 +10,8 @@ the x entries it references from their owners:
     this is the halo, a few planes, instead of the whole vector — SURVEY.md §8e).
 This module is device-agnostic torch code (the tests drive it with gloo on CPU tensors); the SpMV itself is g4s_amd.host.CSR.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -280,9 +282,12 @@ class DistSpMV:
         offs = (C.c_int64 * (world + 1))(*self.offsets)
         torch.cuda.current_stream().synchronize()
         flags = capi.DEVICE_POINTERS | spmv_flags | (capi.DIST_LOOPBACK if loopback else 0)
-        capi.check(self.lib.g4s_spmv_dist_create(C.byref(self.h), rank, world, offs, int(n_cols), host._ptr(rowptr), host._ptr(colids), host._ptr(values), flags))
         self.comm = None
         self.rccl = dist.is_initialized() and dist.get_backend(group) == "nccl" if (world > 1) else bool(loopback)
+        # Set-up is a sequence of phases, the later ones collective. After each one the ranks agree (one all-reduce of a flag) whether it
+        # succeeded EVERYWHERE; if not, every rank raises at the same point — none is left waiting inside a collective the others never enter.
+        self._phase("create", lambda: capi.check(self.lib.g4s_spmv_dist_create(
+            C.byref(self.h), rank, world, offs, int(n_cols), host._ptr(rowptr), host._ptr(colids), host._ptr(values), flags)))
         if self.rccl:
             idbuf = torch.zeros(128, dtype=torch.uint8)
             if rank == 0:
@@ -296,11 +301,28 @@ class DistSpMV:
                 idbuf = t.cpu()
             raw = (C.c_char * 128).from_buffer_copy(bytes(idbuf.numpy().tobytes()))
             self.comm = C.c_void_p()
-            capi.check(self.lib.g4s_comm_create(C.byref(self.comm), world, rank, raw))
-            capi.check(self.lib.g4s_spmv_dist_connect_rccl(self.h, self.comm))
+            self._phase("communicator", lambda: capi.check(self.lib.g4s_comm_create(C.byref(self.comm), world, rank, raw)))
+            self._phase("connect", lambda: capi.check(self.lib.g4s_spmv_dist_connect_rccl(self.h, self.comm)))
         elif world > 1:
             self._wire_by_torch()
         self._views = None
+
+    def _phase(self, name, fn):
+        err = None
+        try:
+            if os.environ.get("G4S_DIST_FAIL") == f"{name}:{self.rank}":      # test hook: this phase "fails" on this rank
+                raise RuntimeError("G4S_DIST_FAIL")
+            fn()
+        except Exception as e:                                               # noqa: BLE001 — re-raised below, on every rank
+            err = e
+        if self.world > 1 and dist.is_initialized():
+            on_gpu = dist.get_backend(self.group) == "nccl"
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if int(ok.item()) == 0 and err is None:
+                err = RuntimeError(f"g4s_spmv_dist set-up: phase '{name}' failed on another rank")
+        if err is not None:
+            raise err
 
     # -- set-up over torch.distributed point-to-point: every rank tells every owner which entries it wants
     def _wire_by_torch(self):
