@@ -869,24 +869,40 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     const BigSide<T> sd(lds_i + kBigWindowWords);
     int &s_base = sd.ctrl[BigSide<T>::kTotalSlot];
     const int t = threadIdx.x;
-    for (int ridx = blockIdx.x;; ridx += gridDim.x) {               // persistent: see spgemm_symbolic_window_kernel
+    constexpr int kPerThread = kBigChunk / kBigThreads;             // 8 slots per thread
+    int cc[kPerThread], nridx = 0;
+    auto fetch_from = [&](const int *src, int qn) {                 // a chunk's sorted columns: all of a thread's loads in flight together
+#pragma unroll
+        for (int u = 0; u < kPerThread; ++u) cc[u] = src[min(t + u * kBigThreads, qn - 1)];
+    };                                                             // (no uniform loads here: hipcc reads those into SGPRs and waits on the spot)
+    int ridx = blockIdx.x;
     if (next_row) {                                                // uniform
         if (t == 0) sd.ctrl[28] = atomicAdd(next_row, 1);
         __syncthreads();
         ridx = sd.ctrl[28];
         __syncthreads();
     }
-    if (ridx >= nrows) break;
+    for (; ridx < nrows; ridx = nridx) {                           // persistent: see spgemm_symbolic_window_kernel
+    if (next_row) { if (t == 0) sd.ctrl[29] = atomicAdd(next_row, 1); }   // read below, behind a barrier
+    else nridx = ridx + gridDim.x;
     const int row = rows[ridx];
     const int a0 = arpt[row], a1 = arpt[row + 1];
     const int off = crpt[row], nz = crpt[row + 1] - off;
-    if (nz <= nz_lo || nz > nz_hi) continue;                       // uniform: the whole workgroup skips the row
+    if (nz <= nz_lo || nz > nz_hi) {                               // uniform: the whole workgroup skips the row
+        if (next_row) { __syncthreads(); nridx = sd.ctrl[29]; __syncthreads(); }
+        continue;
+    }
 
     BIG_PROF_DECL;
     // ---- phase 1: sorted distinct columns — unless the symbolic phase of the one-shot call already left them in pre_cols
     const long long po = pre_off ? pre_off[row] : -1;              // uniform
     unsigned *bm = reinterpret_cast<unsigned *>(lds_i);
     if (t == 0) s_base = 0;
+#ifdef G4S_PROFILE_BIG
+    if (po + a0 + a1 + off + nz == -12345) s_base = 1;             // (forces the row's metadata to have arrived)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    BIG_PROF(3);
+#endif
     for (int w0 = 0; w0 < N && po < 0; w0 += (1 << kBigWindowBits)) {
         for (int i = t; i < kBigWindowWords / 4; i += kBigThreads) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
@@ -909,6 +925,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     }
     __threadfence_block();
     __syncthreads();
+    BIG_PROF(0);
+    if (next_row) nridx = sd.ctrl[29];                              // (nobody writes it again before this row's last barrier)
 
     // ---- phase 2: values, one chunk of the sorted columns at a time
     // A product finds its slot through a bucket index over the chunk's column span: bucket b = (col - first) >> shift holds
@@ -918,7 +936,6 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     int *KC = lds_i + 2 * kBigChunk;                                // kBigChunk ints
     unsigned *IDX = reinterpret_cast<unsigned *>(lds_i + 3 * kBigChunk);   // kBigChunk buckets: 4·kBigChunk ints = the bitmap's 128 KiB
     static_assert(4 * kBigChunk <= kBigWindowWords && kBigChunk <= 65536, "phase 2 reuses the bitmap region; slots are packed in 16 bits");
-    constexpr int kPerThread = kBigChunk / kBigThreads;             // 8 slots per thread
     constexpr int kU = kFlatUnitsPerRound;
     int kfirst = 0, klast = 0, shift = 0;
     // One round of a lane's products: their slots are found in lock-step (the dependent LDS reads of the kU searches interleave) for as many
@@ -939,11 +956,17 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
             const unsigned w = IDX[(key[q] - kfirst) >> shift];    // the column is present, so its bucket is not empty
             lo[q] = (int)(w >> 16); hi[q] = (int)(w & 0xffffu);
         }
+#ifdef G4S_PROFILE_BIG
+        prof_acc[9] += 1;                                          // rounds that search
+#endif
         for (;;) {
             bool more = false;
 #pragma unroll
             for (int q = 0; q < kU; ++q) more |= lo[q] < hi[q];
             if (!__any(more)) break;
+#ifdef G4S_PROFILE_BIG
+            prof_acc[15] += 1;                                     // halvings
+#endif
             int mid[kU], km[kU];
 #pragma unroll
             for (int q = 0; q < kU; ++q) { mid[q] = (lo[q] + hi[q]) >> 1; km[q] = KC[mid[q]]; }   // the kU reads in flight together
@@ -958,16 +981,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         for (int q = 0; q < kU; ++q)
             if (in[q]) atomicAdd(&V[lo[q]], av[q] * bv[q]);
     };
-    // The chunk's sorted columns: all of a thread's loads in flight together, and issued a chunk ahead (they are consumed at the top of the
-    // next chunk, a whole accumulation pass later).
-    int cc[kPerThread], kf_next = 0, kl_next = 0;
-    auto fetch_chunk = [&](int q0) {
-        const int qn = min(kBigChunk, nz - q0);
-        const int *src = po >= 0 ? pre_cols + po + q0 : ccol + off + q0;
-#pragma unroll
-        for (int u = 0; u < kPerThread; ++u) cc[u] = src[min(t + u * kBigThreads, qn - 1)];
-        kf_next = src[0]; kl_next = src[qn - 1];
-    };
+    // The chunk's sorted columns are issued a chunk ahead (they are consumed at the top of the next chunk, a whole accumulation pass later).
+    auto fetch_chunk = [&](int q0) { fetch_from(po >= 0 ? pre_cols + po + q0 : ccol + off + q0, min(kBigChunk, nz - q0)); };
     auto open_chunk = [&](int qn) {                                // cc → LDS, empty buckets
 #pragma unroll
         for (int u = 0; u < kPerThread; ++u) {
@@ -975,7 +990,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
             IDX[i] = 0u;
             if (i < qn) { KC[i] = cc[u]; V[i] = 0.0; }
         }
-        kfirst = kf_next; klast = kl_next;
+    };
+    auto chunk_span = [&](int qn) {                                // after the barrier behind open_chunk
+        kfirst = KC[0]; klast = KC[qn - 1];
         const int span = klast - kfirst;                           // < 2^31
         shift = span < kBigChunk ? 0 : 32 - __clz(span) - BigCfg<T>::kChunkBits;   // (span >> shift) < kBigChunk
         static_assert(kBigChunk == (1 << BigCfg<T>::kChunkBits), "bucket shift");
@@ -1001,8 +1018,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     for (int q0 = 0; q0 < nz; q0 += kBigChunk) {
         const int qn = min(kBigChunk, nz - q0);
         open_chunk(qn);
-        if (q0 + kBigChunk < nz) fetch_chunk(q0 + kBigChunk);
+        fetch_chunk(q0 + kBigChunk < nz ? q0 + kBigChunk : q0);    // unconditional (the last chunk re-reads itself): a load under a branch makes
+                                                                   // hipcc wait at the join for every load that might be in flight
         __syncthreads();
+        chunk_span(qn);
         BIG_PROF(6);
         build_index(qn);
         __syncthreads();
