@@ -181,6 +181,24 @@ def test_spgemm_row_of_300k_outputs(oracle, column_map, two_phase):
     assert nz[0] > 131_072 and nz[4] > 131_072
 
 
+def test_spgemm_row_past_a_million_outputs(oracle):
+    """An output row of 1.1 M entries (B rows with disjoint column blocks): past the big-row kernel's class (1 M), so the numeric phase takes
+    the HBM-bitmap hub path for it, next to rows of the window and table classes."""
+    rng = np.random.default_rng(43)
+    K, per, N = 1200, 1000, 1_200_000
+    brp = (np.arange(K + 1) * per).astype(np.int32)
+    bci = np.arange(K * per, dtype=np.int32)                      # row k holds columns [1000 k, 1000 (k + 1))
+    bva = rng.uniform(0.5, 1, K * per)
+    lens = [1100, 3, 0, 40]
+    rows = [np.sort(rng.choice(K, l, replace=False)) for l in lens]
+    arp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    aci = np.concatenate(rows).astype(np.int32)
+    ava = rng.uniform(0.5, 1, arp[-1])
+    c = _check(oracle, (arp, aci, ava), (brp, bci, bva), len(lens), K, N)
+    nz = np.diff(c.to_host()[0])
+    assert nz[0] == 1_100_000 and nz[3] == 40_000
+
+
 def test_spgemm_raw_pointer_host_call(oracle, g4s):
     """The mkl(...)-shaped entry point (mm/inc/mkl_mult.h:40-43): host arrays in, callee-allocated host arrays out, 7 stage timings."""
     from g4s_amd import capi
