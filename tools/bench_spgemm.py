@@ -88,11 +88,22 @@ if args.mkl > 0:
             if i:
                 tot.append(dict(tm))
             nnzc = len(cci)
-            del crp, cci, cva
+            if i < 2:
+                del crp, cci, cva
         mean = {k: sum(t[k] for t in tot) / len(tot) for k in tot[0]}
+        # the GPU result against the reference library's, whole arrays: index arrays bit for bit, values relative (all terms positive)
+        import numpy as np
+        c = host.HashSpGEMM(A, A)
+        grp, gci, gva = c.to_host()
+        del c
+        cmp = {"crpt_equal": bool(np.array_equal(grp, crp)), "ccol_equal": bool(len(gci) == len(cci) and np.array_equal(gci, cci))}
+        if cmp["ccol_equal"]:
+            cmp["values_max_rel_err"] = float(np.max(np.abs(gva - cva) / cva))
+        del grp, gci, gva, crp, cci, cva
         ref = {"value": round(2 * flop / (mean["total"] * 1e-3) / 1e9, 3), "unit": "GFLOPS", "cores": args.mkl, "kind": "reference call sequence on oneMKL " + mkl_ref.version()[35:52].strip(),
                "sample": f"the same matrix (flop {flop}, nnz(C) {nnzc}), mean of 2 runs after 1 warm-up, stage times ms: " + ", ".join(f"{k} {v:.1f}" for k, v in mean.items()),
-               "spmm_only_GFLOPS": round(2 * flop / (mean["spmm"] * 1e-3) / 1e9, 3), "nnz_C_equal_to_gpu": nnzc == cnnz.value}
+               "spmm_only_GFLOPS": round(2 * flop / (mean["spmm"] * 1e-3) / 1e9, 3), "nnz_C_equal_to_gpu": nnzc == cnnz.value,
+               "gpu_result_against_it": cmp}
     else:
         ref = {"skipped": "libmkl_rt.so not found on this box"}
 # SURVEY.md §8d byte model: A once, every B row once per use (12 B per product), C once, the row pointers
