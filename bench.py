@@ -89,7 +89,38 @@ def cpu_baseline(A, x, budget_s=18.0):
                       + "; ".join(f"{t} thread(s): {out[t][0]:.4f} GEdges/s ({out[t][1]} passes)" for t in counts),
             "by_threads": {str(t): round(out[t][0], 4) for t in counts},
             "single_thread_value": round(out[1][0], 4)}
+    base["reference_library"] = reference_library_baseline(rp, ci, va, xh, A.rows, A.cols, A.nnz, y, asum)
     return base, y, asum
+
+
+def reference_library_baseline(rp, ci, va, xh, rows, cols, nnz, y_oracle, asum, threads=14):
+    """The reference's own sparse CPU path — its mm/ call sequence on oneMKL (mm/inc/mkl_mult.h:40-111: create ×2, mkl_sparse_spmm, convert,
+    order, export; 14 threads as mm/src/mkl_spgemm.cpp:61) — computing the same product: x as a cols×1 CSR matrix, so C = A·X holds y on the
+    rows of A that hold entries. (Its mv/ benchmark is dense BLAS-2 on dim² doubles and cannot hold this matrix) Run where
+    the oneMKL runtime exists (it ships in this image; no headers, no reference source compiled — oracle/mkl_ref.py); reported, not a target."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle"))
+    try:
+        import mkl_ref
+        if not mkl_ref.available():
+            return {"skipped": "libmkl_rt.so not found on this box"}
+        mkl_ref.load(threading="gnu")
+        B = (np.arange(cols + 1, dtype=np.int32), np.zeros(cols, dtype=np.int32), xh)
+        tm, runs = {}, []
+        for i in range(3):                                        # 1 warm-up + mean of 2, the protocol of tools/bench_spgemm.py --mkl
+            crp, cci, cva = mkl_ref.mkl_spgemm((rp, ci, va), B, rows, cols, 1, timings=tm, threads=threads)
+            if i:
+                runs.append(dict(tm))
+        mean = {k: sum(r[k] for r in runs) / len(runs) for k in runs[0]}
+        y = np.zeros(rows)
+        y[np.diff(crp) > 0] = cva
+        return {"value": round(nnz / (mean["total"] * 1e-3) / 1e9, 4), "unit": "GEdges/s", "cores": threads, "kind": "reference",
+                "what": "mm/inc/mkl_mult.h:40-111 call sequence on oneMKL " + mkl_ref.version()[35:52].strip() + ", A·x as a cols×1 product",
+                "stage_ms": {k: round(v, 1) for k, v in mean.items()},
+                "spmm_stage_only": round(nnz / (mean["spmm"] * 1e-3) / 1e9, 4),
+                "agrees_with_oracle": bool(np.all(np.abs(y - y_oracle) <= 1e-10 * asum + 1e-300))}
+    except Exception as e:                                         # noqa: BLE001 — a baseline, never fatal for the bench line
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def config3_lap7(world, rank, steps, warmup, small, host, gdist, dist, torch):

@@ -40,6 +40,8 @@ def test_bench_single_rank_contract():
     assert d["config"]["spmv_path"] == "blocked" and "model" not in d["config"]
     assert d["max_rel_err"] <= 1e-10 and d["parity"]["ok"] is True                 # the bench checks its own y against the oracle's
     assert set(d["cpu_baseline"]["by_threads"]) >= {"1"} and "reproducible" in d["config"] and "traffic_source" in d["roofline"]
+    ref = d["cpu_baseline"]["reference_library"]                                   # the reference's mm/ call sequence on oneMKL, where its runtime exists
+    assert "skipped" in ref or (ref["kind"] == "reference" and ref["value"] > 0 and ref["agrees_with_oracle"] is True), ref
 
 
 def test_bench_self_launch_two_ranks():
