@@ -10,14 +10,18 @@
 // MI355X mapping (one accumulator per ROW in LDS instead of one table per THREAD in cache); DESIGN.md §4.2 has the class table:
 //   * tiny rows  (bound ≤ 32)     one wavefront per row, 64-slot table, 8 lanes per A-entry
 //   * small rows (bound ≤ 512)    one 256-thread workgroup per row, 1024-slot table (numeric: + in-LDS bitonic sort)
-//   * mid-size rows, B ≤ 4 M cols LDS bitmap windows of 2^20 columns instead of a table: symbolic marks and popcounts
-//                                 (spgemm_symbolic_window_kernel); numeric emits the sorted columns from the bitmap and adds the
-//                                 values per 8 K-entry chunk through a bucketed slot index (spgemm_numeric_big_kernel)
+//   * larger rows, B ≤ 4 M       LDS bitmap windows instead of a table, one row per workgroup of a persistent grid, three shapes
+//     non-empty columns           (1024 / 512 / 256 threads: windows of 2^20 / 2^19 / 2^18 columns, 1 / 2 / 4 workgroups per CU) on B's
+//                                 non-empty columns renumbered (build_column_map): symbolic marks, popcounts and emits the sorted
+//                                 columns (spgemm_symbolic_window_kernel); numeric adds the values per chunk of sorted columns through
+//                                 a bucketed slot index (spgemm_numeric_big_kernel, rows up to 1 M outputs). A row's products are
+//                                 dealt to the waves flat, in 64-entry units of the B rows (flat_products); the long classes take
+//                                 their rows longest first through a counter.
 //   * mid-size rows, wider B      key tables up to 32 K slots (the largest one optimistic: it hands the row to the window kernel
 //                                 when a probe sequence gets long)
-//   * hub rows                    bitmap-rank path in HBM: mark columns in a per-row bitmap, popcount-prefix it; a column's
-//                                 rank is its position in the sorted output row, so products are atomically added straight
-//                                 into C (no table, no sort).
+//   * hub rows (flop > 2 M in     bitmap-rank path in HBM: mark columns in a per-row bitmap, popcount-prefix it; a column's
+//     symbolic, > 1 M outputs     rank is its position in the sorted output row, so products are atomically added straight
+//     in numeric)                 into C (no table, no sort).
 // Numeric classes use the EXACT row sizes known from symbolic, so the tables are at most half full.
 // Integer results (crpt, ccol) are exact; fp64 sums are accumulated with LDS/HBM atomics, i.e. in a different order than
 // the reference's (j outer, k inner): equal within the 1e-10 relative tolerance of the north star, not bit for bit.
