@@ -510,7 +510,7 @@ struct BigCfg {
     static constexpr int kWindowWords = 1 << (kWindowBits - 5);      // = 32·T
     static constexpr int kChunk = 8 * T;                             // output entries per value pass
     static constexpr int kChunkBits = kWindowBits - 7;
-    static constexpr int kStage = T == 256 ? 2 * T : 4 * T;          // sorted column ids staged in LDS per coalesced store burst
+    static constexpr int kStage = 4 * T;                             // list items (non-empty words) staged in LDS per emit tile; fits the union with the flat lists
     static constexpr int kPerCu = 1024 / T;                          // workgroups per CU that fit in LDS (136 / 72 / 40 KiB each)
 };
 constexpr int kFlatUnitsPerRound = G4S_SPGEMM_UPR;   // 64-entry units of B rows a wave loads per round (independent loads in flight per lane)
@@ -580,14 +580,16 @@ __device__ __forceinline__ void window_bounds(const int *brpt, const int *wsplit
 }
 
 #ifdef G4S_PROFILE_BIG
-// Section timers of the big-row kernels (tools/big_prof.py): s_memtime deltas summed in registers, flushed with one atomic per slot by
-// thread 0 at BIG_PROF_FLUSH (a global atomic per stamp would itself be the longest thing in an inner loop).
-__device__ unsigned long long g_big_prof[16];
-#define BIG_PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[16] = {}
+// Section timers of the big-row kernels (tools/big_prof.py, tools/sym_prof.py): s_memtime deltas summed in registers, flushed with one atomic
+// per slot by thread 0 of every 16th workgroup at BIG_PROF_FLUSH (a global atomic per stamp would itself be the longest thing in an inner loop).
+__device__ unsigned long long g_big_prof[32];                     // [0, 16): numeric big-row kernel; [16, 32): symbolic window kernel and its emit step
+#define BIG_PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[16] = {}; constexpr int prof_base = 0
+#define BIG_PROF_DECL_SYM unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[16] = {}; constexpr int prof_base = 16
 #define BIG_PROF(slot) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof_acc[slot] += n_ - prof_t; prof_t = n_; } while (0)
-#define BIG_PROF_FLUSH do { if (threadIdx.x == 0) { _Pragma("unroll") for (int s_ = 0; s_ < 16; ++s_) if (prof_acc[s_]) atomicAdd(&g_big_prof[s_], prof_acc[s_]); } _Pragma("unroll") for (int s_ = 0; s_ < 16; ++s_) prof_acc[s_] = 0; } while (0)
+#define BIG_PROF_FLUSH do { if (threadIdx.x == 0 && (blockIdx.x & 15) == 0) {   /* one workgroup in 16 reports: the flush atomics of all of them would sit in front of the next loads */ _Pragma("unroll") for (int s_ = 0; s_ < 16; ++s_) if (prof_acc[s_]) atomicAdd(&g_big_prof[prof_base + s_], prof_acc[s_]); } _Pragma("unroll") for (int s_ = 0; s_ < 16; ++s_) prof_acc[s_] = 0; } while (0)
 #else
 #define BIG_PROF_DECL
+#define BIG_PROF_DECL_SYM
 #define BIG_PROF(slot)
 #define BIG_PROF_FLUSH
 #endif
@@ -721,6 +723,7 @@ __device__ __forceinline__ int emit_window_columns(const unsigned *bm, int w0, i
     constexpr int kBigThreads = T, kBigStage = BigCfg<T>::kStage;
     static_assert(BigCfg<T>::kWindowWords / T == 32, "emit layout");
     const int lane = t & 63, wave = t >> 6;
+    BIG_PROF_DECL_SYM;
     unsigned nonempty = 0, words[KEEP_WORDS ? 32 : 1];
     int cnt = 0;
     if constexpr (KEEP_WORDS) {
@@ -740,9 +743,12 @@ __device__ __forceinline__ int emit_window_columns(const unsigned *bm, int w0, i
         }
     }
     const int nw = __popc(nonempty);
+    const bool dense = __any(nw > 6);                              // wave-uniform: most windows of most rows leave a thread 0–2 words
+    if (KEEP_WORDS) BIG_PROF(8);
     const int incl_c = (int)wave_inclusive_sum((unsigned)cnt), incl_w = (int)wave_inclusive_sum((unsigned)nw);
     if (lane == 63) { s_scan[wave] = incl_c; s_scan[16 + wave] = incl_w; }
     __syncthreads();
+    if (KEEP_WORDS) BIG_PROF(9);
     int p = incl_c - cnt, wq = incl_w - nw, total = 0, total_w = 0;   // first column / first word of this thread within the window
 #pragma unroll
     for (int u = 0; u < kBigThreads / 64; ++u) {
@@ -756,7 +762,7 @@ __device__ __forceinline__ int emit_window_columns(const unsigned *bm, int w0, i
         const int tile1 = tile0 + kBigStage;
         if (wq < tile1 && wq + nw > tile0) {
             int q = 0, j = wq;
-            if constexpr (KEEP_WORDS) {
+            if (KEEP_WORDS && dense) {                              // 32 predicated steps out of registers …
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
                     if (words[i]) {
@@ -765,7 +771,7 @@ __device__ __forceinline__ int emit_window_columns(const unsigned *bm, int w0, i
                         ++j;
                     }
                 }
-            } else {
+            } else {                                                // … or one step per non-empty word (re-read from LDS)
                 unsigned m = nonempty;
                 while (m) {
                     const int i = __ffs(m) - 1;
@@ -777,6 +783,7 @@ __device__ __forceinline__ int emit_window_columns(const unsigned *bm, int w0, i
             }
         }
         __syncthreads();
+        if (KEEP_WORDS) BIG_PROF(10);
         const int n = min(kBigStage, total_w - tile0);
         for (int e = t; e < n; e += kBigThreads) {
             const unsigned item = (unsigned)stage[e];
@@ -791,8 +798,10 @@ __device__ __forceinline__ int emit_window_columns(const unsigned *bm, int w0, i
             }
         }
         __syncthreads();
+        if (KEEP_WORDS) BIG_PROF(11);
     }
     __syncthreads();
+    if (KEEP_WORDS) { BIG_PROF(12); BIG_PROF_FLUSH; }
     return total;
 }
 
@@ -827,9 +836,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     const int a0 = arpt[row], a1 = arpt[row + 1];
     const long long po = pre_off ? pre_off[row] : -1;              // uniform
     if (t == 0) s_total = 0;
+    BIG_PROF_DECL_SYM;
     for (int w0 = 0; w0 < N; w0 += (1 << kBigWindowBits)) {
         for (int i = t; i < kBigWindowWords / 4; i += kBigThreads) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
+        BIG_PROF(0);
         const int w1 = min(N, w0 + (1 << kBigWindowBits));
         const int *wlo, *whi;
         window_bounds(brpt, wsplit, K, N, w0, w1 - 1, wlo, whi);
@@ -839,9 +850,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
                 for (int q = 0; q < kFlatUnitsPerRound; ++q)
                     if (ok[q] && col[q] >= w0 && col[q] < w1) atomicOr(&bm[bm_slot((col[q] - w0) >> 5)], 1u << ((col[q] - w0) & 31));
             });
+        BIG_PROF(1);
         if (po >= 0) {
             const int total = emit_window_columns<T, true>(bm, w0, pre_cols + po + s_total, sd.scan, sd.stage, sd.base, t);
             if (t == 0) s_total += total;
+            BIG_PROF(3);
         } else {
             int cnt = 0;
             for (int i = t; i < kBigWindowWords; i += kBigThreads) cnt += __popc(bm[i]);
@@ -853,6 +866,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     }
     if (t == 0) row_nz[row] = s_total;
     __syncthreads();
+    BIG_PROF(6);
+    BIG_PROF_FLUSH;
     }
 }
 
@@ -1982,8 +1997,8 @@ G4S_API g4s_status g4s_spgemm_csr_i32_f64(const int32_t *arpt, const int32_t *ac
 #ifdef G4S_PROFILE_BIG
 extern "C" __attribute__((visibility("default"))) int g4s_debug_big_prof(unsigned long long *out, int reset)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_big_prof), z, sizeof(z)) != hipSuccess) return 1; }
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_prof), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_big_prof), z, sizeof(z)) != hipSuccess) return 1; }
     return 0;
 }
 #endif
