@@ -296,3 +296,14 @@ def test_spgemm_full_size_properties(ef):
     print(f"RMAT-21 A·A (EF {ef}): nnz(A)={A.nnz} flop={flop} nnz(C)={Cm.nnz} compression={flop / Cm.nnz:.2f}")
     del Cm, C2, A
     capi.check(capi.load().g4s_trim())                           # 25 GB of outputs go back to the driver before the next test
+
+
+def test_spgemm_randomised_seams():
+    """tools/stress_spgemm.py, 25 cases: A rows of exactly T / T + 1 / 2T entries, B rows of 63 … 129 entries, empty B rows, column counts around the
+    column map's threshold, every workgroup shape, both call forms — against scipy (index arrays bit for bit, values to 1e-10)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_spgemm.py"), "--cases", "25", "--seed", "5"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "all ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
