@@ -109,7 +109,9 @@ g4s_status g4s_csr_get_info(g4s_csr_t A, g4s_csr_info *info);
 g4s_status g4s_csr_device_arrays(g4s_csr_t A, const int32_t **rowptr, const int32_t **colids, const double **values);
 
 /* Asynchronous SpMV on `stream` (a hipStream_t; NULL = the default stream). x_dev (cols doubles) and
- * y_dev (rows doubles) are device pointers and must not alias. beta == 0 never reads y (BLAS convention). */
+ * y_dev (rows doubles) are device pointers and must not alias. beta == 0 never reads y (BLAS convention).
+ * The call only enqueues kernels on `stream` — no allocation, no synchronisation, no host read — so a sequence of products may be recorded
+ * in a hipGraph (stream capture) and replayed (tests/test_graph_capture_gpu.py, all three paths). */
 g4s_status g4s_spmv(g4s_csr_t A, const double *x_dev, double *y_dev, double alpha, double beta, void *stream);
 
 /* One-shot form with the call shape of mv/mv.c:6-27 (caller-owned in/out arrays, synchronous).
