@@ -51,7 +51,6 @@ constexpr int kTbThreads = 1024;
 constexpr int kBatch = 2 * kTbThreads;       // hot entries per batch: one pair per thread
 constexpr int kPad = 8;                      // cells are padded to a multiple of 8 entries (16-byte aligned pairs, whole 64-byte product groups)
 constexpr int kMaxXTiles = 256;              // at most 786 K ranked columns
-constexpr int kPiece = 128;                  // cold entries per wave piece: a pair per lane
 constexpr int kColdDepth = 4;                // cold pieces in flight per wave
 constexpr int kColdItem = 1 << 16;           // cold entries per producer work item
 constexpr unsigned kPadCol = 0x8000u;        // local-column flag of a pad slot: its product is forced to 0
