@@ -16,6 +16,7 @@
 // Stream blocks are dealt to the 8 XCDs in contiguous runs (blockIdx%8 selects the run) so that neighbouring row
 // blocks, which touch neighbouring parts of x on banded/stencil matrices, share one L2.
 #include "common.hpp"
+#include <hipcub/hipcub.hpp>
 #include "spmv_pb.hpp"
 #include <algorithm>
 #include <vector>
@@ -125,8 +126,9 @@ __global__ __launch_bounds__(WG) void spmv_csr_adaptive_kernel(
     }
     __syncthreads();
 
-    if (nrows * 2 > WG) {
-        // one lane per row, left-to-right (the oracle's summation order)
+    if (nrows * 2 > WG || nnzb <= 16 * nrows) {
+        // one lane per row, left-to-right (the oracle's summation order): blocks of many rows, and blocks of short rows however few
+        // (a stencil's last block, the forced cuts of the device-side plan builder) — rows of a stencil or band are exact everywhere
         for (int r = tid; r < nrows; r += WG) {
             const int a = rp[r] - k0, b = rp[r + 1] - k0;
             double s = 0.0;
@@ -257,6 +259,8 @@ struct g4s_csr_s {
 
 namespace {
 
+int finish_plan(g4s_csr_s *A, size_t n_blocks, std::vector<LongChunk> &chunks, std::vector<LongRow> &lrows);
+
 // Row classification + equal-share blocking on the host (one pass over rowptr).
 int build_plan(g4s_csr_s *A, const int32_t *rowptr)
 {
@@ -295,7 +299,57 @@ int build_plan(g4s_csr_s *A, const int32_t *rowptr)
         }
         blocks.push_back(make_int4(rb, r - rb, rowptr[rb], (int)nz));
     }
-    A->n_stream = (int)blocks.size();
+    if (!blocks.empty()) {
+        G4S_HIP_TRY(g4s::device_malloc((void **)&A->d_blocks, sizeof(int4) * blocks.size()));
+        G4S_HIP_TRY(hipMemcpy(A->d_blocks, blocks.data(), sizeof(int4) * blocks.size(), hipMemcpyHostToDevice));
+    }
+    return finish_plan(A, blocks.size(), chunks, lrows);
+}
+
+// The same plan built on the device, for matrices whose row pointer is already there: reading 80 M row pointers back and walking them
+// on the host cost 100 ms of a 140 ms create (431³ stencil). Rows are cut into runs of kPlanRun; one thread walks each run with the
+// greedy rule of build_plan (a binary search per block instead of a row-by-row loop), first counting, then — after a scan — writing. The
+// forced cut at the end of a run leaves one short block per run (the kernel reduces short-row blocks with one lane per row, see above).
+// Long rows are collected through a counter (few: the hubs) and laid out on the host as before.
+constexpr int kPlanRun = 4096;
+struct PlanLong { int32_t row, k0, k1; };
+template <bool WRITE>
+__global__ void plan_walk_kernel(int rows, int nruns, const int32_t *__restrict__ rowptr, const int *__restrict__ blk_off, int *__restrict__ blk_count,
+                                 int4 *__restrict__ blocks, PlanLong *__restrict__ longs, int long_cap, int *__restrict__ n_long, int *__restrict__ fail)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nruns) return;
+    int r = c * kPlanRun, cnt = 0;
+    const int end = min(rows, r + kPlanRun);
+    int4 *out = WRITE ? blocks + blk_off[c] : nullptr;
+    while (r < end) {
+        const int k0 = rowptr[r], len = rowptr[r + 1] - k0;
+        if (len < 0) { if (!WRITE) atomicExch(fail, r + 1); return; }
+        if (len > TILE_NNZ) {
+            if (!WRITE) { const int slot = atomicAdd(n_long, 1); if (slot < long_cap) longs[slot] = PlanLong{r, k0, k0 + len}; }
+            ++r;
+            continue;
+        }
+        int lo = r + 1, hi = min(end, r + TILE_ROWS);               // the last row boundary e in [lo, hi] with rowptr[e] − k0 <= TILE_NNZ
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (rowptr[mid] - k0 <= TILE_NNZ && rowptr[mid] >= k0) lo = mid; else hi = mid - 1;
+        }
+        if (WRITE) out[cnt] = make_int4(r, lo - r, k0, rowptr[lo] - k0);
+        ++cnt;
+        r = lo;
+    }
+    if (!WRITE) blk_count[c] = cnt;
+}
+__global__ void plan_monotone_kernel(int rows, const int32_t *__restrict__ rowptr, int *__restrict__ fail)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows && rowptr[r + 1] < rowptr[r]) atomicExch(fail, r + 1);
+}
+
+int finish_plan(g4s_csr_s *A, size_t n_blocks, std::vector<LongChunk> &chunks, std::vector<LongRow> &lrows)
+{
+    A->n_stream = (int)n_blocks;
     // Contiguous runs of blocks per XCD pay off while the matrix stays cache-resident across launches (+12 % on the 80 MB 5-point
     // Laplacian); on matrices far beyond the 256 MiB Infinity Cache plain launch order measured 2 % faster (banded 10M, 7-point 431³).
     A->xcd_runs = 12 * A->nnz <= (256ll << 20);
@@ -303,10 +357,6 @@ int build_plan(g4s_csr_s *A, const int32_t *rowptr)
     A->n_chunks = (int)chunks.size();
     A->chunks_pad = (A->n_chunks + g4s::kXcds - 1) / g4s::kXcds * g4s::kXcds;
     A->n_long = (int)lrows.size();
-    if (A->n_stream) {
-        G4S_HIP_TRY(g4s::device_malloc((void **)&A->d_blocks, sizeof(int4) * blocks.size()));
-        G4S_HIP_TRY(hipMemcpy(A->d_blocks, blocks.data(), sizeof(int4) * blocks.size(), hipMemcpyHostToDevice));
-    }
     if (A->n_chunks) {
         G4S_HIP_TRY(g4s::device_malloc((void **)&A->d_chunks, sizeof(LongChunk) * chunks.size()));
         G4S_HIP_TRY(hipMemcpy(A->d_chunks, chunks.data(), sizeof(LongChunk) * chunks.size(), hipMemcpyHostToDevice));
@@ -314,9 +364,67 @@ int build_plan(g4s_csr_s *A, const int32_t *rowptr)
         G4S_HIP_TRY(hipMemcpy(A->d_long_rows, lrows.data(), sizeof(LongRow) * lrows.size(), hipMemcpyHostToDevice));
         G4S_HIP_TRY(g4s::device_malloc((void **)&A->d_partials, sizeof(double) * chunks.size()));
     }
-    A->plan_bytes = (int64_t)(sizeof(int4) * blocks.size() + sizeof(LongChunk) * chunks.size() +
-                              sizeof(LongRow) * lrows.size() + sizeof(double) * chunks.size());
+    A->plan_bytes = (int64_t)(sizeof(int4) * n_blocks + sizeof(LongChunk) * chunks.size() + sizeof(LongRow) * lrows.size() + sizeof(double) * chunks.size());
     return G4S_OK;
+}
+
+int build_plan_device(g4s_csr_s *A)
+{
+    const int32_t rows = A->rows;
+    int32_t ends[2] = {0, 0};
+    G4S_HIP_TRY(hipMemcpy(&ends[0], A->d_rowptr, sizeof(int32_t), hipMemcpyDeviceToHost));
+    G4S_HIP_TRY(hipMemcpy(&ends[1], A->d_rowptr + rows, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (ends[0] != 0) return g4s::set_error(G4S_ERR_INVALID, "g4s_csr_create: rowptr[0] != 0 (zero-based CSR expected)");
+    if ((int64_t)ends[1] != A->nnz) return g4s::set_error(G4S_ERR_INVALID, "g4s_csr_create: rowptr[rows] != nnz");
+    const int nruns = (rows + kPlanRun - 1) / kPlanRun;
+    const int long_cap = (int)std::min<int64_t>(A->nnz / TILE_NNZ + 1, rows);
+    int *d_cnt = nullptr, *d_off = nullptr, *d_scalars = nullptr;   // scalars: [0] n_long, [1] fail (row + 1)
+    PlanLong *d_longs = nullptr;
+    void *d_tmp = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_scalars); (void)hipFree(d_longs); (void)hipFree(d_tmp); };
+#define PLAN_TRY(expr) do { if ((expr) != hipSuccess) { const hipError_t e_ = hipGetLastError(); cleanup(); return g4s::set_error(G4S_ERR_HIP, "g4s_csr_create (device plan): %s", hipGetErrorString(e_)); } } while (0)
+    PLAN_TRY(g4s::device_malloc((void **)&d_cnt, sizeof(int) * ((size_t)nruns + 1)));
+    PLAN_TRY(g4s::device_malloc((void **)&d_off, sizeof(int) * ((size_t)nruns + 1)));
+    PLAN_TRY(g4s::device_malloc((void **)&d_scalars, sizeof(int) * 2));
+    PLAN_TRY(g4s::device_malloc((void **)&d_longs, sizeof(PlanLong) * (size_t)long_cap));
+    PLAN_TRY(hipMemset(d_scalars, 0, sizeof(int) * 2));
+    PLAN_TRY(hipMemset(d_cnt, 0, sizeof(int) * ((size_t)nruns + 1)));
+    hipLaunchKernelGGL(plan_monotone_kernel, dim3((rows + 255) / 256), dim3(256), 0, nullptr, rows, A->d_rowptr, d_scalars + 1);
+    int h_scalars[2] = {0, 0};
+    PLAN_TRY(hipMemcpy(h_scalars, d_scalars, sizeof(int) * 2, hipMemcpyDeviceToHost));
+    if (h_scalars[1]) { cleanup(); return g4s::set_error(G4S_ERR_INVALID, "g4s_csr_create: rowptr decreases at row %d", h_scalars[1] - 1); }
+    hipLaunchKernelGGL(plan_walk_kernel<false>, dim3((nruns + 63) / 64), dim3(64), 0, nullptr, rows, nruns, A->d_rowptr, (const int *)nullptr, d_cnt, (int4 *)nullptr, d_longs,
+                       long_cap, d_scalars, d_scalars + 1);
+    size_t tb = 0;
+    PLAN_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_cnt, d_off, nruns + 1));
+    PLAN_TRY(g4s::device_malloc(&d_tmp, tb ? tb : 1));
+    PLAN_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_cnt, d_off, nruns + 1));
+    int n_blocks = 0;
+    PLAN_TRY(hipMemcpy(&n_blocks, d_off + nruns, sizeof(int), hipMemcpyDeviceToHost));
+    PLAN_TRY(hipMemcpy(h_scalars, d_scalars, sizeof(int) * 2, hipMemcpyDeviceToHost));
+    if (n_blocks) {
+        PLAN_TRY(g4s::device_malloc((void **)&A->d_blocks, sizeof(int4) * (size_t)n_blocks));
+        hipLaunchKernelGGL(plan_walk_kernel<true>, dim3((nruns + 63) / 64), dim3(64), 0, nullptr, rows, nruns, A->d_rowptr, d_off, d_cnt, A->d_blocks, d_longs, long_cap,
+                           d_scalars, d_scalars + 1);
+        PLAN_TRY(hipGetLastError());
+    }
+    std::vector<PlanLong> longs((size_t)std::min(h_scalars[0], long_cap));
+    if (!longs.empty()) PLAN_TRY(hipMemcpy(longs.data(), d_longs, sizeof(PlanLong) * longs.size(), hipMemcpyDeviceToHost));
+    PLAN_TRY(hipDeviceSynchronize());
+    cleanup();
+#undef PLAN_TRY
+    std::sort(longs.begin(), longs.end(), [](const PlanLong &a, const PlanLong &b) { return a.row < b.row; });
+    std::vector<LongChunk> chunks;
+    std::vector<LongRow> lrows;
+    for (const PlanLong &l : longs) {
+        LongRow lr{l.row, (int32_t)chunks.size(), 0, 0};
+        for (int64_t k = l.k0; k < l.k1; k += LONG_CHUNK) {
+            chunks.push_back(LongChunk{l.row, (int32_t)k, (int32_t)std::min<int64_t>(k + LONG_CHUNK, l.k1), (int32_t)chunks.size()});
+            lr.nslots++;
+        }
+        lrows.push_back(lr);
+    }
+    return finish_plan(A, (size_t)n_blocks, chunks, lrows);
 }
 
 void release(g4s_csr_s *A)
@@ -340,7 +448,7 @@ void release(g4s_csr_s *A)
 
 // Try the diagonal-structured form: candidate offsets from a sample of rows (first, middle, last 2048), then one pass over the matrix that
 // either fills the diagonals or reports an entry outside the candidate set. Kept when the diagonals are at least 60 % full.
-int try_build_dia(g4s_csr_s *A, const int32_t *h_rowptr)
+int try_build_dia(g4s_csr_s *A)
 {
     const int32_t rows = A->rows;
     if (rows < 1024 || A->nnz < 4096 || getenv("G4S_SPMV_NO_DIA")) return G4S_OK;
@@ -349,6 +457,9 @@ int try_build_dia(g4s_csr_s *A, const int32_t *h_rowptr)
     std::vector<int32_t> cbuf;
     for (int part = 0; part < 3; ++part) {
         const int32_t ra = part == 0 ? 0 : (part == 1 ? std::max(0, rows / 2 - S / 2) : std::max(0, rows - S)), rb = std::min(rows, ra + S);
+        std::vector<int32_t> rp_slice((size_t)(rb - ra) + 1);     // the sampled rows' pointers, from the device copy
+        G4S_HIP_TRY(hipMemcpy(rp_slice.data(), A->d_rowptr + ra, sizeof(int32_t) * rp_slice.size(), hipMemcpyDeviceToHost));
+        const int32_t *h_rowptr = rp_slice.data() - ra;
         const int64_t k0 = h_rowptr[ra], k1 = h_rowptr[rb];
         if (k1 - k0 > 64ll * S) return G4S_OK;                     // rows this long are not a stencil
         cbuf.resize((size_t)(k1 - k0));
@@ -405,12 +516,17 @@ G4S_API g4s_status g4s_csr_create(g4s_csr_t *out, int32_t rows, int32_t cols, in
     int st = G4S_OK;
     auto fail = [&](int code) { release(A); return code; };
 
+    // Row pointers that live on the device are planned there once the matrix is large (G4S_PLAN_HOST forces the host builder, G4S_PLAN_DEVICE
+    // the device one at any size: the tests compare the two).
+    const bool plan_on_device = (flags & G4S_DEVICE_POINTERS) && !getenv("G4S_PLAN_HOST") && (rows >= (1 << 18) || getenv("G4S_PLAN_DEVICE")) && rows > 0;
     if (flags & G4S_DEVICE_POINTERS) {
         A->d_rowptr = rowptr; A->d_colids = colids; A->d_values = values; A->owns = false;
-        h_rowptr_copy.resize((size_t)rows + 1);
-        if (hipMemcpy(h_rowptr_copy.data(), rowptr, sizeof(int32_t) * ((size_t)rows + 1), hipMemcpyDeviceToHost) != hipSuccess)
-            return fail(g4s::set_error(G4S_ERR_HIP, "g4s_csr_create: D2H copy of rowptr failed"));
-        h_rowptr = h_rowptr_copy.data();
+        if (!plan_on_device) {
+            h_rowptr_copy.resize((size_t)rows + 1);
+            if (hipMemcpy(h_rowptr_copy.data(), rowptr, sizeof(int32_t) * ((size_t)rows + 1), hipMemcpyDeviceToHost) != hipSuccess)
+                return fail(g4s::set_error(G4S_ERR_HIP, "g4s_csr_create: D2H copy of rowptr failed"));
+            h_rowptr = h_rowptr_copy.data();
+        }
     } else {
         A->owns = true;
         void *p = nullptr;
@@ -427,7 +543,7 @@ G4S_API g4s_status g4s_csr_create(g4s_csr_t *out, int32_t rows, int32_t cols, in
         h_rowptr = rowptr;
     }
 
-    st = build_plan(A, h_rowptr);
+    st = plan_on_device ? build_plan_device(A) : build_plan(A, h_rowptr);
     if (st != G4S_OK) return fail(st);
 
     // Column range check on the device copy (an out-of-range gather is a GPU fault, not an error code).
@@ -459,7 +575,7 @@ G4S_API g4s_status g4s_csr_create(g4s_csr_t *out, int32_t rows, int32_t cols, in
     }
     // stencil / banded matrices: the index-free diagonal form (not when the caller forces the CSR kernels)
     if (!A->pb && !A->tb && !(flags & G4S_SPMV_STREAM) && nnz > 0) {
-        st = try_build_dia(A, h_rowptr);
+        st = try_build_dia(A);
         if (st != G4S_OK) return fail(st);
     }
     *out = A;
