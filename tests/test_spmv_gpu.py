@@ -320,3 +320,14 @@ def test_spmv_diagonal_path(oracle):
         S = host.CSR.from_host(*arrs, 40000, 40000)
         assert S.info()["spmv_path"] == want_path
         _check(oracle, S, *arrs, rng.uniform(-1, 1, 40000), exact=(want_path == 3))
+
+
+def test_spmv_randomised_structures():
+    """tools/stress_spmv.py, 24 cases: power-law rows with hubs past the long-row limit, bands with stray entries, stencils with holes, rectangular
+    shapes, alpha / beta, every path and both plan builders — against scipy in extended precision (1e-10·Σ|terms| per row)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_spmv.py"), "--cases", "24", "--seed", "7"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "all ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
