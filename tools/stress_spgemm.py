@@ -12,6 +12,7 @@ import scipy.sparse as sp
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=40)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--wide", action="store_true", help="B with 5 M … 40 M columns: past the window kernels' mid-row limit (key tables), more than 16 window pieces (no splits)")
 args = ap.parse_args()
 from g4s_amd import host  # noqa: E402
 
@@ -21,8 +22,8 @@ SHAPE_VARS = ("SYM_MED", "SYM_LARGE", "SYM_WINDOW", "NUM_MED", "NUM_LARGE", "NUM
 
 def random_case():
     K = int(rng.choice([300, 1500, 5000]))
-    N = int(rng.choice([70_000, 131_073, 400_000, 1_100_000]))
-    used = N if rng.random() < 0.4 else int(N * rng.uniform(0.3, 0.8))          # share of B's columns that hold entries (column map on / off)
+    N = int(rng.choice([70_000, 131_073, 400_000, 1_100_000])) if not args.wide else int(rng.choice([5_000_000, 17_000_000, 40_000_000]))
+    used = N if rng.random() < 0.4 else int(N * rng.uniform(0.3, 0.8)) if not args.wide else int(N * rng.choice([0.05, 0.5, 1.0]))          # share of B's columns that hold entries (column map on / off)
     cols_pool = np.sort(rng.choice(N, used, replace=False))
     blens = rng.choice([0, 1, 63, 64, 65, 127, 128, 129, 300, 1000, 4000], K, p=[.05, .1, .1, .1, .1, .1, .1, .1, .15, .07, .03])
     blens = np.minimum(blens, used)
