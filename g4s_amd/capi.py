@@ -94,6 +94,7 @@ SIGNATURES = {
     "g4s_comm_create": (C.c_int, [C.POINTER(vp), C.c_int32, C.c_int32, vp]),
     "g4s_comm_destroy": (C.c_int, [vp]),
     "g4s_comm_allreduce_sum_f64": (C.c_int, [vp, vp, C.c_int64, vp]),
+    "g4s_conj_grad_dist": (C.c_int, [vp, vp, C.c_int32, vp, vp, C.c_int32, vp, vp, C.c_double, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double), vp]),
     "g4s_spgemm_flop": (C.c_int, [C.c_int32, vp, vp, vp, i64p, vp, C.c_uint]),
     "g4s_spgemm_csr_i32_f64": (C.c_int, [vp, vp, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                           C.c_int32, C.c_int32, C.c_int32, i64p, C.POINTER(Timings), C.c_uint]),

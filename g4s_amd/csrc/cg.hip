@@ -420,3 +420,44 @@ G4S_API g4s_status g4s_cg_end(g4s_cg_ws_t ws, double *d0_dev, const int32_t *zer
     G4S_HIP_TRY(hipStreamSynchronize(s));
     return G4S_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ the whole distributed solve in C
+// conj_grad on a row-partitioned operator with nothing but this library underneath: the product is g4s_spmv_dist_apply (packed exchange
+// of the direction vector over RCCL, overlapped with the own-column part), the dot products' 256 partial sums are all-reduced
+// element-wise by g4s_comm_allreduce_sum_f64 on the same communicator (every rank then adds the same 256 numbers in the same order
+// and reaches the same α, β and verdict) — the two collectives of the CitcomS loop it replaces (Regional_parallel_related.c:744-789
+// neighbour exchange, Global_operations.c:534-562 MPI_Allreduce). One host read of (count, done, residual) per iteration.
+G4S_API g4s_status g4s_conj_grad_dist(g4s_spmv_dist_t A, void *comm, int32_t n_local, const double *BI_dev, const int32_t *zero_resid_dev, int32_t n_zero,
+                                      const double *F_dev, double *d0_dev, double acc, int32_t steps, int32_t *cycles, double *residual, void *stream)
+{
+    G4S_REQUIRE(A && comm && BI_dev && F_dev && d0_dev, "NULL argument");
+    G4S_REQUIRE(n_local >= 0 && n_zero >= 0 && (n_zero == 0 || zero_resid_dev), "bad size");
+    g4s_cg_ws_t ws = nullptr;
+    G4S_TRY(g4s_cg_ws_create(&ws, n_local));
+    auto run = [&]() -> int {
+        G4S_TRY(g4s_cg_begin(ws, F_dev, BI_dev, d0_dev, zero_resid_dev, n_zero, stream));
+        double *p = nullptr, *Ap = nullptr, *part = nullptr;
+        G4S_TRY(g4s_cg_buffers(ws, &p, &Ap, &part));
+        G4S_TRY(g4s_comm_allreduce_sum_f64(comm, part, 3 * kDotBlocks, stream));            // r·z and r·r of the start vector
+        int32_t count = 0, done = 0;
+        double res = 0.0;
+        for (;;) {
+            G4S_TRY(g4s_cg_direction(ws, steps, acc, stream));
+            G4S_TRY(g4s_cg_state(ws, &count, &done, &res, stream));
+            if (done) break;
+            G4S_TRY(g4s_cg_buffers(ws, &p, &Ap, nullptr));
+            G4S_TRY(g4s_spmv_dist_apply(A, p, Ap, stream));
+            G4S_TRY(g4s_cg_reduce_pAp(ws, stream));
+            G4S_TRY(g4s_comm_allreduce_sum_f64(comm, part + kDotBlocks, kDotBlocks, stream));
+            G4S_TRY(g4s_cg_update(ws, BI_dev, d0_dev, stream));
+            G4S_TRY(g4s_comm_allreduce_sum_f64(comm, part, 3 * kDotBlocks, stream));        // [0, 256) r·z and [512, 768) r·r; the middle third is rewritten before its next use
+        }
+        G4S_TRY(g4s_cg_end(ws, d0_dev, zero_resid_dev, n_zero, stream));
+        if (cycles) *cycles = count;
+        if (residual) *residual = res;
+        return G4S_OK;
+    };
+    const int st = run();
+    (void)g4s_cg_ws_destroy(ws);
+    return st;
+}

@@ -350,6 +350,14 @@ g4s_status g4s_cg_reduce_pAp(g4s_cg_ws_t ws, void *stream);                     
 g4s_status g4s_cg_update(g4s_cg_ws_t ws, const double *BI_dev, double *d0_dev, void *stream);   /* α, d0, r, z (:383-402) */
 g4s_status g4s_cg_end(g4s_cg_ws_t ws, double *d0_dev, const int32_t *zero_resid_dev, int32_t n_zero, void *stream);   /* d0 boundary rows := 0 (:409) */
 
+/* The same loop closed in C for a row-partitioned operator: conj_grad (General_matrix_functions.c:307-424) with the product
+ * g4s_spmv_dist_apply(A) and the dot products' partial sums all-reduced by g4s_comm_allreduce_sum_f64(comm) — the neighbour exchange of
+ * Regional_parallel_related.c:744-789 and the MPI_Allreduce of Global_operations.c:534-562 on RCCL. Every rank calls it with its slab
+ * (n_local rows; BI, F, d0 device arrays of that length; zero_resid: LOCAL indices of the boundary equations) and gets the same cycles
+ * and residual. A must be connected to comm (g4s_spmv_dist_connect_rccl). */
+g4s_status g4s_conj_grad_dist(g4s_spmv_dist_t A, void *comm, int32_t n_local, const double *BI_dev, const int32_t *zero_resid_dev, int32_t n_zero,
+                              const double *F_dev, double *d0_dev, double acc, int32_t steps, int32_t *cycles, double *residual, void *stream);
+
 /* result[M×K] = xx[M×N] · w[N×K], row-major fp64, device pointers (opt_matmul.cc:24-62). */
 g4s_status g4s_dense_rows_times_matrix(int32_t M, int32_t N, int32_t K, const double *xx_dev, const double *w_dev,
                                        double *result_dev, void *stream);

@@ -82,3 +82,32 @@ def test_dist_conj_grad_matches_oracle(tmp_path, oracle, world, mode):
     assert all(m[3] <= m[4] for m in metas)
     assert np.all(got[bc] == 0.0)
     assert np.allclose(got, d_or, rtol=1e-6, atol=1e-7 * np.abs(d_or).max())
+
+
+def test_conj_grad_dist_c_entry_point_over_rccl_loopback(oracle):
+    """g4s_conj_grad_dist — the whole distributed solve behind one C call (product: g4s_spmv_dist_apply, dots: g4s_comm_allreduce_sum_f64) —
+    with the library's own RCCL communicator of one rank in loopback mode (half of the slab travels rank 0 → rank 0 by ncclSend/ncclRecv on
+    every product, every dot product goes through ncclAllReduce): same iteration count and solution as the oracle's CG."""
+    import ctypes as C
+    from g4s_amd import capi, dist as gdist
+    ien, idmap, nno, neq, K, bc, F = _problem()
+    rp, ci, va = assemble_csr(ien, idmap, K, neq)
+    diag = np.array([va[rp[r] + np.searchsorted(ci[rp[r]:rp[r + 1]], r)] for r in range(neq)])
+    D = gdist.DistSpMV([0, neq], 0, 1, torch.from_numpy(rp).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(va).cuda(), neq, loopback=True)
+    assert D.info()["nnz_rem"] > 0
+    BI = torch.from_numpy(1.0 / diag).cuda()
+    Fd = torch.from_numpy(F).cuda()
+    bcd = torch.from_numpy(bc).cuda()
+    d0 = torch.empty(neq, dtype=torch.float64, device="cuda")
+    acc = 1e-8 * float(np.linalg.norm(F))
+    cycles, res = C.c_int32(0), C.c_double(0.0)
+    torch.cuda.synchronize()
+    capi.check(capi.load().g4s_conj_grad_dist(D.h, D.comm, neq, BI.data_ptr(), bcd.data_ptr(), len(bc), Fd.data_ptr(), d0.data_ptr(), acc, 250,
+                                              C.byref(cycles), C.byref(res), None))
+    BIo = oracle.element_inverse_diagonal(ien, idmap, K, neq)
+    d_or, cyc_or, res_or, _ = oracle.conj_grad_elem(ien, idmap, K, neq, BIo, bc, F, acc, 250)
+    got = d0.cpu().numpy()
+    assert abs(cycles.value - cyc_or) <= 1 and res.value <= acc
+    assert np.all(got[bc] == 0.0)
+    assert np.allclose(got, d_or, rtol=1e-6, atol=1e-7 * np.abs(d_or).max())
+    D.close()
