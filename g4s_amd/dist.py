@@ -406,6 +406,20 @@ class DistSpMV:
         else:
             _all_reduce_sum(t, self.group)
 
+    def conj_grad(self, BI_local, F_local, zero_resid_local, acc, steps):
+        """Jacobi-CG on the partitioned operator in one C call (g4s_conj_grad_dist: product and dot products on the library's RCCL
+        communicator). Needs the RCCL wiring (backend nccl, or loopback). Returns (d0_local, iterations, residual)."""
+        C, capi, host = self._C, self._capi, self._host
+        if self.comm is None:
+            raise RuntimeError("DistSpMV.conj_grad needs the library's RCCL communicator (backend nccl); over gloo use dist_conj_grad")
+        d0 = torch.empty(self.n_local, dtype=torch.float64, device=F_local.device)
+        zr = zero_resid_local if zero_resid_local is not None and zero_resid_local.numel() else None
+        cycles, res = C.c_int32(0), C.c_double(0.0)
+        capi.check(self.lib.g4s_conj_grad_dist(self.h, self.comm, self.n_local, host._ptr(BI_local), host._ptr(zr) if zr is not None else None,
+                                               int(zr.numel()) if zr is not None else 0, host._ptr(F_local), host._ptr(d0), float(acc), int(steps),
+                                               C.byref(cycles), C.byref(res), host._stream()))
+        return d0, cycles.value, res.value
+
     def close(self):
         if self.h:
             self.lib.g4s_spmv_dist_destroy(self.h)

@@ -104,6 +104,8 @@ def test_conj_grad_dist_c_entry_point_over_rccl_loopback(oracle):
     torch.cuda.synchronize()
     capi.check(capi.load().g4s_conj_grad_dist(D.h, D.comm, neq, BI.data_ptr(), bcd.data_ptr(), len(bc), Fd.data_ptr(), d0.data_ptr(), acc, 250,
                                               C.byref(cycles), C.byref(res), None))
+    d1, cyc1, res1 = D.conj_grad(BI, Fd, bcd, acc, 250)             # the ctypes wrapper of the same call
+    assert cyc1 == cycles.value and torch.equal(d1, d0)
     BIo = oracle.element_inverse_diagonal(ien, idmap, K, neq)
     d_or, cyc_or, res_or, _ = oracle.conj_grad_elem(ien, idmap, K, neq, BIo, bc, F, acc, 250)
     got = d0.cpu().numpy()
