@@ -95,6 +95,7 @@ struct TileDesc { int b0, b1, k0, k1, r0, r1, c0, xt0, split, xt1, pad1, pad2; }
 // buffer of this cell (cell index mod 3), bits 4-7 min(batches of the previous two cells, kDepth + 1) = how many younger stream batches may stay in
 // flight at the transition. xt_next: x tile of the item's cell after next (−1: none), valid on a first batch.
 struct BatchDesc { int e0, n, flags, xt_next; };
+constexpr int kMaxItemBatches = 1024;                                // batch descriptors of one work item staged in LDS (16 KiB): see tb_tile_kernel
 struct ColdPiece { int e0, n; };                                    // cold entries [e0, e0+n), n <= kPiece (0 = padding), of one (column band, tile) chunk
 struct ColdChunk { int e0, n; };                                    // cold entries [e0, e0+n) of one (column band, tile) cell, n a multiple of kPad
 struct ColdItem { int cband, e0, e1, pad; };                        // cold entries [e0, e1) of one column band
@@ -341,6 +342,11 @@ __global__ __launch_bounds__(kTbThreads) void tb_tile_kernel(const TileDesc *__r
     double *ys = tb_lds;                                           // kYTile doubles
     double *xbuf = tb_lds + kYTile;                                // three x tiles: cell i of the item reads buffer i % 3
     int *slot = reinterpret_cast<int *>(tb_lds + kYTile + kXBufs * kXTile);
+    // The item's batch descriptors, copied to LDS once per item. Read from global memory they were scalar loads (the index is uniform), and
+    // hipcc waits for a scalar load where it is first used: two exposed L2 round trips per batch step (lgkmcnt is shared with LDS, so a
+    // scalar load issued ahead would stall the next LDS wait instead). Measured: no change in the step time — see DESIGN.md §7.
+    int4 *bd = reinterpret_cast<int4 *>(tb_lds + kYTile + kXBufs * kXTile + 2);
+    auto desc = [&](int i) { const int4 v = bd[i]; return BatchDesc{v.x, v.y, v.z, v.w}; };
     const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // diagnostic build only (G4S_TB_DBG & 64): shader-clock stamps at the section boundaries, written to a buffer nothing else reads
 #define G4S_TB_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(size_t)item * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -352,6 +358,9 @@ __global__ __launch_bounds__(kTbThreads) void tb_tile_kernel(const TileDesc *__r
         const TileDesc T = tiles[item];
         G4S_TB_STAMP(0);
         for (int i = tid; i < kYTile; i += kTbThreads) ys[i] = 0.0;
+        const int nbd = T.b1 - T.b0 + 2 * kDepth;                  // <= kMaxItemBatches (tb_build); the list is padded past its end
+        for (int i = tid; i < nbd; i += kTbThreads) bd[i] = reinterpret_cast<const int4 *>(batches)[T.b0 + i];
+        __syncthreads();
 
         // ---- prologue: the first kDepth batches of the entry stream (the lists are padded, so there is always a descriptor) and the x tile of
         // the first cell. Every stream load is unconditional and clamped: the compiler counts them exactly and leaves the younger ones in flight.
@@ -360,7 +369,7 @@ __global__ __launch_bounds__(kTbThreads) void tb_tile_kernel(const TileDesc *__r
         double2_t val[D];
 #pragma unroll
         for (int u = 0; u < D; ++u) {
-            const BatchDesc d = batches[T.b0 + u];
+            const BatchDesc d = desc(u);
             const long long p = ((long long)d.e0 + min(2 * tid, max(d.n - 2, 0))) >> 1;
             meta[u] = tb_stream_load(h_meta + p);
             val[u] = tb_stream_load(reinterpret_cast<const double2_t *>(h_val) + p);
@@ -411,7 +420,7 @@ __global__ __launch_bounds__(kTbThreads) void tb_tile_kernel(const TileDesc *__r
         for (int b = T.b0; b < ((dbg & 32) ? T.b0 : T.b1); b += D) {
 #pragma unroll
             for (int u = 0; u < D; ++u) {
-                const BatchDesc d = batches[b + u];
+                const BatchDesc d = desc(b - T.b0 + u);
                 const int buf = (d.flags >> 1) & 3;
                 if (d.flags & 1) {
                     // the tile of THIS cell was requested two cells ago; the request for the next cell's tile (one cell ago, >= 1 hidden DMA
@@ -433,7 +442,7 @@ __global__ __launch_bounds__(kTbThreads) void tb_tile_kernel(const TileDesc *__r
                     if (d.xt_next >= 0 && !(dbg & 4)) tb_dma_x_tile(hot_x + (size_t)d.xt_next * kXTile, xbuf + ((buf + 2) % kXBufs) * kXTile, wave, lane);
                 }
                 if (!(dbg & 2)) tb_accumulate_pair(2 * tid < d.n, meta[u][0], meta[u][1], val[u], xbuf + buf * kXTile, ys);
-                const BatchDesc dn = batches[b + u + D];
+                const BatchDesc dn = desc(b - T.b0 + u + D);
                 const long long p = ((long long)dn.e0 + min(2 * tid, max(dn.n - 2, 0))) >> 1;
                 meta[u] = tb_stream_load(h_meta + p);
                 val[u] = tb_stream_load(reinterpret_cast<const double2_t *>(h_val) + p);
@@ -724,7 +733,15 @@ int tb_build(TbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     int n_chunks_total = 0;
     for (int t = 0; t < NT; ++t) {
         n_chunks_total += (int)per_tile[t].size();
-        const int k = (int)((tile_work[t] + cap - 1) / cap);
+        // an item's batch descriptors live in LDS (kMaxItemBatches, less the two groups the stream runs ahead): heavy tiles are cut by that too
+        constexpr int kBatchLimit = kMaxItemBatches - 2 * kDepth - kDepth;
+        long long tile_batches = 0;
+        for (const HotCell &hc : tcells[t]) {
+            const long long nb = (hc.n + kBatch - 1) / kBatch;
+            if (nb > kBatchLimit) return set_error(G4S_ERR_UNSUPPORTED, "tb_build: a cell of %d entries exceeds the per-item batch list", hc.n);
+            tile_batches += nb;
+        }
+        const int k = (int)std::max<long long>((tile_work[t] + cap - 1) / cap, (tile_batches + kBatchLimit - 1) / kBatchLimit);
         if (k <= 1) { emit_item(t, 0, tcells[t].size(), 0, per_tile[t].size(), 0, tile_work[t]); continue; }
         const int r0 = tile_chunk0[t] * kRowChunk, r1 = std::min(rows, tile_chunk0[t + 1] * kRowChunk);
         for (int r = r0; r < r1; r += 256) split_blocks.push_back(make_int2(r, std::min(r1, r + 256)));
@@ -732,13 +749,16 @@ int tb_build(TbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
         size_t c = 0, q = 0;
         while (c < tcells[t].size() || q < per_tile[t].size()) {
             const size_t c_begin = c, q_begin = q;
-            long long w = 0;
-            while (c < tcells[t].size() && w < share) w += tcells[t][c++].n;
+            long long w = 0, nbat = 0;
+            while (c < tcells[t].size() && w < share && nbat + (tcells[t][c].n + kBatch - 1) / kBatch <= kBatchLimit) {
+                nbat += (tcells[t][c].n + kBatch - 1) / kBatch;
+                w += tcells[t][c++].n;
+            }
             while (c == tcells[t].size() && q < per_tile[t].size() && w < share) w += 2ll * per_tile[t][q++].n;
             emit_item(t, c_begin, c, q_begin, q, 1, w);
         }
     }
-    for (int i = 0; i < kDepth; ++i) batches.push_back(BatchDesc{0, 0, 0, -1});                 // the stream runs kDepth batches past an item's end
+    for (int i = 0; i < 2 * kDepth; ++i) batches.push_back(BatchDesc{0, 0, 0, -1});             // the stream runs kDepth batches past an item's end; its LDS copy 2·kDepth
     const int NI = (int)work_items.size();
     std::vector<int> tord((size_t)NI);
     for (int t = 0; t < NI; ++t) tord[t] = t;
@@ -777,7 +797,7 @@ int tb_build(TbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     P->dbg = (int)env_int("G4S_TB_DBG", 0);
     { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) P->n_cus = prop.multiProcessorCount; }
     if (P->dbg & 64) G4S_TRY(P->stamps.alloc(sizeof(unsigned long long) * 8 * (size_t)P->n_work_items));
-    P->lds_tile = sizeof(double) * (kYTile + kXBufs * kXTile) + 16;        // + the work-queue slot
+    P->lds_tile = sizeof(double) * (kYTile + kXBufs * kXTile) + 16 + sizeof(int4) * kMaxItemBatches;   // + the work-queue slot + the item's batch descriptors
     P->lds_cold = sizeof(double) * kCBand;
     G4S_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(tb_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_tile));
     G4S_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(tb_cold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_cold));
