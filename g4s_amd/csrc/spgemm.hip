@@ -1497,6 +1497,9 @@ int build_column_map(int N, long long bnnz, const int *bcol, ColumnMap &cm, hipS
 
 struct PreSorted {
     ColumnMap cmap;              // built by the symbolic phase of the one-shot call, reused by its numeric phase
+    DevBuf wsplit_buf;           // likewise the window splits of B
+    const int *wsplit = nullptr;
+    bool has_wsplit = false;
     DevBuf off;                  // long long off[M]
     const long long *d_off = nullptr;
     int *d_cols = nullptr;       // int cols[total], borrowed from the cache below
@@ -1628,9 +1631,10 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     G4S_TRY(build_column_map(N, bnnz, bcol, cmap, s));
     const int *wcol = cmap.cols(bcol);
     const int N2 = cmap.width(N);
-    DevBuf wsplit_buf;
+    DevBuf wsplit_local;
     const int *wsplit = nullptr;
-    G4S_TRY(build_window_splits(K, N2, brpt, wcol, wsplit_buf, &wsplit, s));
+    G4S_TRY(build_window_splits(K, N2, brpt, wcol, pre ? pre->wsplit_buf : wsplit_local, &wsplit, s));
+    if (pre) { pre->wsplit = wsplit; pre->has_wsplit = true; }
     G4S_TRY(ovf_rows.alloc(sizeof(int) * (size_t)std::max(1, rc.count[CLS_LARGE])));
     G4S_TRY(ovf_count.alloc(sizeof(int)));
     G4S_HIP_TRY(hipMemsetAsync(ovf_count.p, 0, sizeof(int), s));
@@ -1804,8 +1808,8 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
     const int *wcol = cmap.cols(bcol), *winv = cmap.inverse();
     const int N2 = cmap.width(N);
     DevBuf wsplit_buf;
-    const int *wsplit = nullptr;
-    G4S_TRY(build_window_splits(K, N2, brpt, wcol, wsplit_buf, &wsplit, s));
+    const int *wsplit = pre && pre->has_wsplit ? pre->wsplit : nullptr;
+    if (!(pre && pre->has_wsplit)) G4S_TRY(build_window_splits(K, N2, brpt, wcol, wsplit_buf, &wsplit, s));
     // Rows past 1 K entries: bitmap windows + bucketed slots beat table + in-LDS bitonic sort while the column range is <= 4 windows.
     const bool xn_large = N2 <= window_max_n(), xn_m2 = xn_large;
     auto big_t = [&](auto shape, const int *rows, int n, int nz_lo, int nz_hi, int *next_row) -> int {
