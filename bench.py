@@ -381,7 +381,7 @@ def main():
         "hbm_gbs_algorithmic_whole_job": round((12 * nnz_total + 4 * (n_rows + 1) + 8 * n_rows + 8 * n_cols) * args.steps / elapsed / 1e9, 2),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": {0: "spmv_csr_adaptive_kernel", 1: "pb_prepare_kernel+pb_producer_kernel+pb_consumer_kernel (propagation-blocked SpMV)",
+                     "kernel": {0: "spmv_csr_adaptive_kernel", 1: "pb_fused_kernel (propagation-blocked SpMV, one persistent launch: hot-x gather, producer and consumer items)",
                                 2: "tb_prepare_kernel+tb_cold_kernel+tb_tile_kernel (tile-blocked SpMV)", 3: "spmv_dia_kernel"}[info["spmv_path"]], "kernel_ms": round(kernel_ms, 5),
                      "algorithmic_bytes_per_launch": info["algorithmic_bytes"],
                      "launch_rows": info["rows"], "launch_nnz": info["nnz"]},

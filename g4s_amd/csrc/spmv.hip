@@ -591,6 +591,7 @@ G4S_API g4s_status g4s_csr_destroy(g4s_csr_t A)
 G4S_API g4s_status g4s_csr_get_info(g4s_csr_t A, g4s_csr_info *info)
 {
     G4S_REQUIRE(A && info, "NULL argument");
+    G4S_TRY(g4s::pb_spmv_status(A->pb));
     info->rows = A->rows; info->cols = A->cols; info->nnz = A->nnz;
     info->stream_blocks = A->n_stream; info->long_rows = A->n_long; info->long_chunks = A->n_chunks;
     info->tile_nnz = TILE_NNZ; info->tile_rows = TILE_ROWS; info->long_chunk_nnz = LONG_CHUNK;

@@ -331,3 +331,37 @@ def test_spmv_randomised_structures():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_spmv.py"), "--cases", "24", "--seed", "7"], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "all ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("groups,lag", [("1", None), ("6", "1"), ("16", None), ("16", "16"), ("0", None)])
+def test_spmv_blocked_one_launch_fresh_vectors(oracle, monkeypatch, groups, lag):
+    """The one-launch form of the blocked path (pb_fused_kernel: producer and consumer items of one product in one persistent launch, handed over
+    through agent-scope counters). A stale hand-off — a consumer reading last launch's partial sums, or a producer staging last launch's hot x —
+    is invisible while x stays the same, so every launch gets a NEW x and is compared with the oracle. lag 1 makes consumers wait for their
+    producers (the dependency is exercised, not just ordered away); groups 0 = the three-launch form (G4S_PB_FUSED=0)."""
+    from g4s_amd import capi, host
+    if groups == "0":
+        monkeypatch.setenv("G4S_PB_FUSED", "0")
+    else:
+        monkeypatch.setenv("G4S_PB_GROUPS", groups)
+    if lag:
+        monkeypatch.setenv("G4S_PB_LAG", lag)
+    n = 1_500_000
+    G = host.rmat_csr(n, 21, 24_000_000, 77)
+    A = host.CSR(G.rowptr, G.colids, G.values, n, n, spmv_flags=capi.SPMV_BLOCKED)
+    assert A.info()["spmv_path"] == 1
+    rp, ci, va = A.to_host()
+    y = torch.empty(n, dtype=torch.float64, device="cuda")
+    y0 = host.synth_vector(99, n)
+    for it in range(6):
+        x = host.synth_vector(100 + it, n)
+        xh = x.cpu().numpy()
+        alpha, beta = (1.0, 0.0) if it % 2 == 0 else (-0.5, 1.25)
+        y.copy_(y0)
+        A.spmv(x, y, alpha, beta)
+        want = oracle.spmv_mt_y(rp, ci, va, xh)
+        _, asum = oracle.spmv_ld(rp, ci, va, xh)
+        want = alpha * want + (beta * y0.cpu().numpy() if beta != 0.0 else 0.0)
+        scale = abs(alpha) * asum + abs(beta) * np.abs(y0.cpu().numpy())
+        err = np.abs(y.cpu().numpy() - want)
+        assert np.all(err <= TOL * scale + 1e-300), f"launch {it}: max rel err {np.max(err / (scale + 1e-300))}"
