@@ -374,15 +374,15 @@ def main():
                                 (f"dist: g4s_spmv_dist_* ({info.get('dist_form')}; packed ncclSend/ncclRecv of the referenced x entries"
                                  f"{'' if dinfo['reserved'] else ', overlapped with the own-column product'}), {recv_bytes} B received by rank 0 per step" if mode == "dist" else f"{mode} over torch.distributed, {recv_bytes} B received by rank 0 per step")),
                    "matrix_loads": "plain" if args.no_nt else "nontemporal",
-                   "spmv_path": {0: "stream", 1: "blocked", 2: "blocked (tile-blocked experiment)", 3: "diagonal (index-free)"}[info["spmv_path"]],
+                   "spmv_path": {0: "stream", 1: "blocked", 3: "diagonal (index-free)"}[info["spmv_path"]],
                    "reproducible": ("yes: fixed summation order, no atomics" if info["spmv_path"] in (0, 3) else
                                     "no: fp64 sums meet in LDS / global atomics, last bits may differ run to run (inside the 1e-10 tolerance)"),
                    **({"backend": "gloo (rehearsal, not a valid multi-GPU number)"} if args.backend != "nccl" else {})},
         "hbm_gbs_algorithmic_whole_job": round((12 * nnz_total + 4 * (n_rows + 1) + 8 * n_rows + 8 * n_cols) * args.steps / elapsed / 1e9, 2),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": {0: "spmv_csr_adaptive_kernel", 1: "pb_fused_kernel (propagation-blocked SpMV, one persistent launch: hot-x gather, producer and consumer items)",
-                                2: "tb_prepare_kernel+tb_cold_kernel+tb_tile_kernel (tile-blocked SpMV)", 3: "spmv_dia_kernel"}[info["spmv_path"]], "kernel_ms": round(kernel_ms, 5),
+                     "kernel": {0: "spmv_csr_adaptive_kernel", 1: "pb_prepare_kernel+pb_producer_kernel+pb_consumer_kernel (propagation-blocked SpMV)",
+                                3: "spmv_dia_kernel"}[info["spmv_path"]], "kernel_ms": round(kernel_ms, 5),
                      "algorithmic_bytes_per_launch": info["algorithmic_bytes"],
                      "launch_rows": info["rows"], "launch_nnz": info["nnz"]},
     }

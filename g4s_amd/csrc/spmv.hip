@@ -254,7 +254,6 @@ struct g4s_csr_s {
     long long dia_ld = 0;
     DiaOffsets dia_offs{};
     g4s::PbPlan *pb = nullptr;      // propagation-blocked path (spmv_pb.hip) for matrices without gather locality
-    g4s::TbPlan *tb = nullptr;      // tile-blocked experiment (spmv_tb.hip, G4S_SPMV_IMPL=tb)
 };
 
 namespace {
@@ -442,7 +441,6 @@ void release(g4s_csr_s *A)
     (void)hipFree(A->d_dia);
     (void)hipFree(A->d_dia_mask);
     g4s::pb_destroy(A->pb);
-    g4s::tb_destroy(A->tb);
     delete A;
 }
 
@@ -561,20 +559,12 @@ G4S_API g4s_status g4s_csr_create(g4s_csr_t *out, int32_t rows, int32_t cols, in
     // Path choice: the row-streaming kernel unless the x gathers have no locality (or the caller forces one).
     const bool want_pb = (flags & G4S_SPMV_BLOCKED) || (!(flags & G4S_SPMV_STREAM) && g4s::pb_should_use(rows, cols, nnz, A->d_colids));
     if (want_pb && nnz > 0) {
-        // Two blocked implementations: propagation blocking (spmv_pb.hip, the default) and the round-2 tile-blocked experiment
-        // (spmv_tb.hip, G4S_SPMV_IMPL=tb: parity-green, measured slower on configs[1] — DESIGN.md §4.1).
-        const char *impl = getenv("G4S_SPMV_IMPL");
-        if (impl && !strcmp(impl, "tb")) {
-            st = g4s::tb_build(&A->tb, rows, cols, nnz, A->d_rowptr, A->d_colids, A->d_values);
-            A->plan_bytes += g4s::tb_bytes(A->tb);
-        } else {
-            st = g4s::pb_build(&A->pb, rows, cols, nnz, A->d_rowptr, A->d_colids, A->d_values);
-            A->plan_bytes += g4s::pb_bytes(A->pb);
-        }
+        st = g4s::pb_build(&A->pb, rows, cols, nnz, A->d_rowptr, A->d_colids, A->d_values);
+        A->plan_bytes += g4s::pb_bytes(A->pb);
         if (st != G4S_OK && (flags & G4S_SPMV_BLOCKED)) return fail(st);   // auto mode falls back to the streaming path
     }
     // stencil / banded matrices: the index-free diagonal form (not when the caller forces the CSR kernels)
-    if (!A->pb && !A->tb && !(flags & G4S_SPMV_STREAM) && nnz > 0) {
+    if (!A->pb && !(flags & G4S_SPMV_STREAM) && nnz > 0) {
         st = try_build_dia(A);
         if (st != G4S_OK) return fail(st);
     }
@@ -591,13 +581,12 @@ G4S_API g4s_status g4s_csr_destroy(g4s_csr_t A)
 G4S_API g4s_status g4s_csr_get_info(g4s_csr_t A, g4s_csr_info *info)
 {
     G4S_REQUIRE(A && info, "NULL argument");
-    G4S_TRY(g4s::pb_spmv_status(A->pb));
     info->rows = A->rows; info->cols = A->cols; info->nnz = A->nnz;
     info->stream_blocks = A->n_stream; info->long_rows = A->n_long; info->long_chunks = A->n_chunks;
     info->tile_nnz = TILE_NNZ; info->tile_rows = TILE_ROWS; info->long_chunk_nnz = LONG_CHUNK;
     info->algorithmic_bytes = 12 * A->nnz + 4 * ((int64_t)A->rows + 1) + 8 * (int64_t)A->rows + 8 * (int64_t)A->cols;
     info->plan_bytes = A->plan_bytes;
-    info->spmv_path = A->tb ? 2 : (A->pb ? 1 : (A->d_dia ? 3 : 0));
+    info->spmv_path = A->pb ? 1 : (A->d_dia ? 3 : 0);
     return G4S_OK;
 }
 
@@ -618,7 +607,6 @@ G4S_API g4s_status g4s_spmv(g4s_csr_t A, const double *x_dev, double *y_dev, dou
     G4S_REQUIRE(x_dev || A->nnz == 0, "x is NULL");
     G4S_REQUIRE((const void *)x_dev != (const void *)y_dev, "x and y must not alias");
     hipStream_t s = g4s::as_stream(stream);
-    if (A->tb) return g4s::tb_spmv(A->tb, x_dev, y_dev, alpha, beta, s);
     if (A->pb) return g4s::pb_spmv(A->pb, x_dev, y_dev, alpha, beta, s);
     if (A->d_dia) {
         const int nblocks = (A->rows + WG - 1) / WG, per_xcd = (nblocks + g4s::kXcds - 1) / g4s::kXcds;

@@ -228,11 +228,15 @@ __device__ __forceinline__ double row_down_d(double v)
 #endif
 constexpr int kPairUnroll = G4S_PB_PAIR_UNROLL;
 
-__device__ __forceinline__ void pb_produce(const ProducerItem it, int cols, int H, const double *__restrict__ hot_x,
-                                           const unsigned short *__restrict__ p_lcol, const double *__restrict__ p_val,
-                                           const unsigned char *__restrict__ masks, const int *__restrict__ mbase /* consumer slot of each span's first micro-run */,
-                                           const double *__restrict__ x, double *__restrict__ prod, double *__restrict__ xs /* LDS, kBand doubles */)
+__global__ __launch_bounds__(kPbThreads) void pb_producer_kernel(const ProducerItem *__restrict__ items, int cols, int RB, int H, const double *__restrict__ hot_x,
+                                                                  const unsigned short *__restrict__ p_lcol, const double *__restrict__ p_val,
+                                                                  const unsigned char *__restrict__ masks, const int *__restrict__ mbase /* consumer slot of each span's first micro-run */,
+                                                                  const double *__restrict__ x, double *__restrict__ prod)
 {
+    extern __shared__ double pb_lds[];
+    double *xs = pb_lds;                                           // kBand doubles
+    (void)RB;
+    const ProducerItem it = items[blockIdx.x];
     const bool hot = it.cband < H;                                 // hot bands read the gathered copy; the others a natural 16 K slice of x
     const int c0 = hot ? it.cband << kBandBits : (it.cband - H) << kBandBits;
     const double *xsrc = hot ? hot_x : x;
@@ -300,15 +304,6 @@ __device__ __forceinline__ void pb_produce(const ProducerItem it, int cols, int 
     }
 }
 
-__global__ __launch_bounds__(kPbThreads) void pb_producer_kernel(const ProducerItem *__restrict__ items, int cols, int H, const double *__restrict__ hot_x,
-                                                                  const unsigned short *__restrict__ p_lcol, const double *__restrict__ p_val,
-                                                                  const unsigned char *__restrict__ masks, const int *__restrict__ mbase,
-                                                                  const double *__restrict__ x, double *__restrict__ prod)
-{
-    extern __shared__ double pb_lds[];
-    pb_produce(items[blockIdx.x], cols, H, hot_x, p_lcol, p_val, masks, mbase, x, prod, pb_lds);
-}
-
 // One launch ahead of the producer: blocks [0, n_split·64) pre-scale y for the row bands whose sums arrive from several consumer
 // workgroups (those add into y with atomics), the remaining blocks gather the x values of the hot columns into hot_x.
 __global__ void pb_prepare_kernel(int n_split, const int *__restrict__ split_bands, int rows, double *__restrict__ y, double beta,
@@ -331,9 +326,13 @@ __global__ void pb_prepare_kernel(int n_split, const int *__restrict__ split_ban
 #endif
 constexpr int kPbUnroll = G4S_PB_CONS_UNROLL;   // consumer: groups of 4 consecutive slots per thread per iteration
 
-__device__ __forceinline__ void pb_consume(const ConsumerItem it, int rows, const unsigned short *__restrict__ c_lrow, const double *__restrict__ prod,
-                                           double *__restrict__ y, double alpha, double beta, double *__restrict__ ys /* LDS, kBand doubles */)
+__global__ __launch_bounds__(kPbThreads) void pb_consumer_kernel(const ConsumerItem *__restrict__ items, int rows,
+                                                                  const unsigned short *__restrict__ c_lrow, const double *__restrict__ prod,
+                                                                  double *__restrict__ y, double alpha, double beta)
 {
+    extern __shared__ double pb_lds[];
+    double *ys = pb_lds;
+    const ConsumerItem it = items[blockIdx.x];                     // [k0, k1): multiples of 4; pad slots carry 0 for local row 0
     const int last_group = it.k1 - 4;
     constexpr int STEP = 4 * kPbThreads * kPbUnroll;
     int base = it.k0 + 4 * (int)threadIdx.x;
@@ -404,130 +403,6 @@ __device__ __forceinline__ void pb_consume(const ConsumerItem it, int rows, cons
     }
 }
 
-__global__ __launch_bounds__(kPbThreads) void pb_consumer_kernel(const ConsumerItem *__restrict__ items, int rows,
-                                                                  const unsigned short *__restrict__ c_lrow, const double *__restrict__ prod,
-                                                                  double *__restrict__ y, double alpha, double beta)
-{
-    extern __shared__ double pb_lds[];
-    pb_consume(items[blockIdx.x], rows, c_lrow, prod, y, alpha, beta, pb_lds);
-}
-
-// ================================================================================================ one launch for the whole product
-// pb_fused_kernel: one persistent workgroup per CU pulls work items from ONE ordered queue (a ticket counter) — the hot-column
-// gather and the y pre-scale, the producer items, the consumer items. Why one launch: (1) a 1024-thread / 128 KiB workgroup costs
-// ≈ 10 µs to start and the three launches started ≈ 1 500 of them; (2) prepare → producer → consumer ran strictly one after another,
-// each with its own tail; (3) the consumer of a row-band GROUP can start as soon as the producer items of that group are done — its
-// partial sums are then still in the Infinity Cache — while the producer streams the next groups from HBM.
-// Order of the queue (host, pb_build): prepare items, producer items of the light column bands (not cut by row group), then for
-// g = 0 … G−1 the producer items of row group g in the heavy bands, the consumer items of group g−L right behind them (L = lag, so
-// that ≈ one chip-full of tickets separates a group's last producer ticket from its first consumer ticket), the last L groups'
-// consumer items at the end. A consumer item waits (one lane polling a counter, s_sleep between polls) until the counters of the
-// items it reads from are complete. No deadlock: every item an item waits for has a SMALLER ticket, tickets are claimed only by
-// running workgroups, and an item that waits for nothing (or whose dependencies are complete) always finishes — by induction on the
-// ticket number every claimed item finishes, whatever the number of resident workgroups.
-// Visibility across CUs / XCDs (MI355X_MICROARCH.md, inter-workgroup visibility): every storing wave drains its stores
-// (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane: agent-scope release → drained → relaxed agent-scope add on the counter;
-// reader: ONE lane polls (relaxed), agent-scope acquire, drained, workgroup barrier, then plain loads.
-// The counters are reset by the last workgroup to leave, so a captured launch can be replayed (no host-side epoch argument).
-struct FusedItem { int kind, a, b, c; };   // kind = role | split << 3 | group << 8
-constexpr int kRolePrepHot = 0, kRolePrepY = 1, kRoleProd = 2, kRoleCons = 3;
-constexpr int kCtrStride = 32;             // one counter per 128-byte line
-constexpr int kCtrError = 0, kCtrTicket = 1, kCtrExited = 2, kCtrPrep = 3, kCtrGroup = 4;   // kCtrGroup + 0: light bands; + 1 + g: row group g of the heavy bands; kCtrError is never reset
-
-struct FusedArgs {
-    const FusedItem *items;
-    int n_items, n_prep, n_groups, xflags;   // xflags: timing experiments only (1: no release fence, 2: no acquire fence)
-    int *ctr;
-    const int *need;                       // items behind each group counter
-    int rows, cols, H;
-    const int *hot_cols;
-    double *hot_x;
-    const unsigned short *p_lcol;
-    const double *p_val;
-    const unsigned char *masks;
-    const int *mbase;
-    const unsigned short *c_lrow;
-    double *prod;
-    const double *x;
-    double *y;
-    double alpha, beta;
-};
-
-// Bounded: a wait that outlasts any product by orders of magnitude (seconds) is a broken queue, not a slow producer. The waiter then gives
-// up, raises the plan's error counter (pb_spmv_status reads it) and carries on with whatever is there: every wave of a persistent kernel
-// must reach its exit, a wrong product that is reported beats a hung device.
-__device__ __forceinline__ bool pb_wait_counter(const int *c, int need)
-{
-    int spins = 0;
-    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && spins < (1 << 21)) {
-        __builtin_amdgcn_s_sleep(32);
-        ++spins;
-    }
-    return spins < (1 << 21);
-}
-
-__global__ __launch_bounds__(kPbThreads) void pb_fused_kernel(const FusedArgs a)
-{
-    extern __shared__ double pb_lds[];
-    int *ctl = reinterpret_cast<int *>(pb_lds + kBand);            // behind the band: no static LDS in front of fp64 atomics' region
-    // The completion signal of an item is sent at the TOP of the next iteration, in the same one-lane block as the ticket pull: a one-lane
-    // block at the loop's tail made hipcc route lane 0 out of the loop and the other 63 lanes of its wave straight to the next iteration's
-    // barrier — wave 0 arrived there without lane 0's new ticket, every wave re-read the old one, and the kernel never ended.
-    int signal = -1;
-    for (;;) {
-        if (signal >= 0) {                                         // uniform over the workgroup
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its stores
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            if (signal >= 0) {
-                if (!(a.xflags & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the compiler may drop the wait behind buffer_wbl2 (guide: compiler hazard)
-                __hip_atomic_fetch_add(a.ctr + signal * kCtrStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            ctl[0] = __hip_atomic_fetch_add(a.ctr + kCtrTicket * kCtrStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();                                           // also: every wave has left the previous item's LDS band
-        const int t = __builtin_amdgcn_readfirstlane(ctl[0]);
-        if (t >= a.n_items) break;
-        const FusedItem it = a.items[t];
-        const int role = it.kind & 7, grp = it.kind >> 8;
-        if (role == kRoleCons || (role == kRoleProd && it.a < a.H)) {
-            if (threadIdx.x == 0) {
-                bool ok = pb_wait_counter(a.ctr + kCtrPrep * kCtrStride, a.n_prep);
-                if (role == kRoleCons) {
-                    ok &= pb_wait_counter(a.ctr + kCtrGroup * kCtrStride, a.need[0]);
-                    ok &= pb_wait_counter(a.ctr + (kCtrGroup + 1 + grp) * kCtrStride, a.need[1 + grp]);
-                }
-                if (!ok) __hip_atomic_fetch_add(a.ctr + kCtrError * kCtrStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (!(a.xflags & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __syncthreads();
-        }
-        if (role == kRoleProd) {
-            pb_produce(ProducerItem{it.a, it.b, it.c, 0}, a.cols, a.H, a.hot_x, a.p_lcol, a.p_val, a.masks, a.mbase, a.x, a.prod, pb_lds);
-            signal = kCtrGroup + grp;
-        } else if (role == kRoleCons) {
-            pb_consume(ConsumerItem{it.a, it.b, it.c, (it.kind >> 3) & 1}, a.rows, a.c_lrow, a.prod, a.y, a.alpha, a.beta, pb_lds);
-            signal = -1;
-        } else if (role == kRolePrepHot) {
-            for (int r = it.a + (int)threadIdx.x; r < it.b; r += kPbThreads) a.hot_x[r] = a.x[a.hot_cols[r]];
-            signal = kCtrPrep;
-        } else {                                                   // kRolePrepY: y of a split row band, scaled before its consumers add into it
-            const int r0 = it.a << kBandBits;
-            for (int i = threadIdx.x; i < kBand && r0 + i < a.rows; i += kPbThreads) a.y[r0 + i] = a.beta == 0.0 ? 0.0 : a.beta * a.y[r0 + i];
-            signal = kCtrPrep;
-        }
-    }
-    if (threadIdx.x == 0) {
-        // every workgroup has made its last ticket pull before it adds here: the last one to leave resets the counters for the next launch
-        const int left = __hip_atomic_fetch_add(a.ctr + kCtrExited * kCtrStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (left == (int)gridDim.x - 1)
-            for (int i = kCtrTicket; i < kCtrGroup + 1 + a.n_groups; ++i) __hip_atomic_store(a.ctr + i * kCtrStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 } // namespace
 
 struct PbPlan {
@@ -535,10 +410,6 @@ struct PbPlan {
     long long nnz = 0, micro_runs = 0;
     DevBuf p_lcol, p_val, masks, mbase, c_lrow, prod, delta, pitems, citems, split_bands, hot_cols, hot_x;
     int n_pitems = 0, n_citems = 0, n_split = 0, H = 0;
-    // one-launch form (pb_fused_kernel)
-    DevBuf fitems, fctr, fneed;
-    int n_fitems = 0, n_prep = 0, n_groups = 0, lag = 0, grid = 0;
-    bool fused = false;
     size_t lds_producer = 0, lds_consumer = 0;
     long long bytes = 0;
 };
@@ -629,47 +500,10 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     // 2. padded producer layout (host): every cell starts at a multiple of kSpan
     std::vector<int> hP((size_t)ncells + 1);
     G4S_HIP_TRY(hipMemcpy(hP.data(), startP.p, sizeof(int) * hP.size(), hipMemcpyDeviceToHost));
-    // Row-band groups of the one-launch form: the heavy column bands (the hot ones on a power-law matrix) are cut into G groups of
-    // consecutive row bands holding about the same number of their entries; a group's producer items are then complete long before
-    // the whole producer is, and its consumer items can start. A light band (fewer than 32 K entries per group) is not cut.
-    const bool want_fused = !(getenv("G4S_PB_FUSED") && atoi(getenv("G4S_PB_FUSED")) == 0);
-    int G = 1;
-    std::vector<char> heavy((size_t)CB, 0);
-    std::vector<int> gb;                                            // group g = row bands [gb[g], gb[g+1])
-    if (want_fused) {
-        const int Gwant = std::max(1, std::min(64, getenv("G4S_PB_GROUPS") ? atoi(getenv("G4S_PB_GROUPS")) : 16));
-        std::vector<long long> w((size_t)RB, 0);
-        long long tot_heavy = 0;
-        for (int c = 0; c < CB; ++c) {
-            const long long in_band = (long long)hP[(size_t)(c + 1) * RB] - hP[(size_t)c * RB];
-            if (Gwant > 1 && in_band >= 32768ll * Gwant) {
-                heavy[c] = 1;
-                tot_heavy += in_band;
-                for (int r = 0; r < RB; ++r) w[r] += hP[(size_t)c * RB + r + 1] - hP[(size_t)c * RB + r];
-            }
-        }
-        gb.push_back(0);
-        if (tot_heavy > 0) {
-            long long cum = 0, share = 1;                           // close a group behind row band r once the running total reaches the next share
-            for (int r = 0; r < RB; ++r) {
-                cum += w[r];
-                if (r + 1 < RB && cum * Gwant >= tot_heavy * share) { gb.push_back(r + 1); share = cum * Gwant / tot_heavy + 1; }
-            }
-        }
-        gb.push_back(RB);
-        G = (int)gb.size() - 1;
-    } else {
-        gb = {0, RB};
-    }
-    std::vector<int> group_of((size_t)RB, 0);
-    for (int g = 0; g < G; ++g)
-        for (int r = gb[g]; r < gb[g + 1]; ++r) group_of[r] = g;
     std::vector<int> padP((size_t)ncells + 1), shP((size_t)ncells);
     long long totP = 0;
     for (long long q = 0; q < ncells; ++q) {
-        const int qc = (int)(q / RB), qr = (int)(q % RB);
-        // a column band starts on a window boundary; so does every row group inside a heavy band (its items start there)
-        if (qr == 0 || (heavy[qc] && qr == gb[group_of[qr]])) totP = (totP + kWindow - 1) & ~(long long)(kWindow - 1);
+        if (q % RB == 0) totP = (totP + kWindow - 1) & ~(long long)(kWindow - 1);   // a column band starts on a window boundary
         padP[q] = (int)totP;
         shP[q] = (int)(totP - hP[q]);
         totP += hP[q + 1] - hP[q];
@@ -763,60 +597,6 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
             for (int k = b0; k < b1; k += kCC) cit.push_back(ConsumerItem{r, k, std::min(b1, k + kCC), 1});
         }
     }
-    // 5b. the one-launch queue (pb_fused_kernel): prepare items, light-band producer items, then per row group the heavy-band producer
-    // items with the consumer items of the group `lag` groups back behind them; heaviest first inside every run
-    if (want_fused) {
-        std::vector<FusedItem> fq;
-        auto by_weight = [](const FusedItem &a, const FusedItem &b) { return (a.c - a.b) > (b.c - b.b); };
-        for (int h = 0; h < H; ++h) fq.push_back(FusedItem{kRolePrepHot, h * kBand, (h + 1) * kBand, 0});
-        for (int r : split) fq.push_back(FusedItem{kRolePrepY, r, 0, 0});
-        P->n_prep = (int)fq.size();
-        std::vector<int> need((size_t)G + 1, 0);
-        size_t run0 = fq.size();
-        for (int c = 0; c < CB; ++c) {
-            if (heavy[c]) continue;
-            const int s0 = padP[(size_t)c * RB] / kSpan, s1 = padP[(size_t)(c + 1) * RB] / kSpan;
-            for (int s = s0; s < s1; s += kPC) { fq.push_back(FusedItem{kRoleProd, c, s, std::min(s1, s + kPC)}); ++need[0]; }
-        }
-        std::stable_sort(fq.begin() + run0, fq.end(), by_weight);
-        std::vector<std::vector<FusedItem>> pg((size_t)G), cg((size_t)G);
-        for (int g = 0; g < G; ++g) {
-            for (int c = 0; c < CB; ++c) {
-                if (!heavy[c]) continue;
-                const int s0 = padP[(size_t)c * RB + gb[g]] / kSpan;
-                const int s1 = (gb[g + 1] == RB ? padP[(size_t)(c + 1) * RB] : padP[(size_t)c * RB + gb[g + 1]]) / kSpan;   // a group's end = the next group's aligned start
-                for (int s = s0; s < s1; s += kPC) { pg[g].push_back(FusedItem{kRoleProd | (1 + g) << 8, c, s, std::min(s1, s + kPC)}); ++need[1 + g]; }
-            }
-            std::stable_sort(pg[g].begin(), pg[g].end(), by_weight);
-        }
-        for (const ConsumerItem &ci : cit) cg[group_of[ci.rband]].push_back(FusedItem{kRoleCons | (ci.split ? 8 : 0) | group_of[ci.rband] << 8, ci.rband, ci.k0, ci.k1});
-        for (int g = 0; g < G; ++g) std::stable_sort(cg[g].begin(), cg[g].end(), by_weight);
-        size_t n_grouped = 0;
-        for (int g = 0; g < G; ++g) n_grouped += pg[g].size() + cg[g].size();
-        hipDeviceProp_t prop;
-        int dev = 0;
-        G4S_HIP_TRY(hipGetDevice(&dev));
-        G4S_HIP_TRY(hipGetDeviceProperties(&prop, dev));
-        const int n_cu = std::max(1, prop.multiProcessorCount);
-        // lag: about one chip-full of tickets (plus a margin) between a group's last producer ticket and its first consumer ticket
-        int L = getenv("G4S_PB_LAG") ? atoi(getenv("G4S_PB_LAG")) : (int)((n_cu + n_cu / 4) * (size_t)G / std::max<size_t>(1, n_grouped)) + 1;
-        L = std::max(1, std::min(L, G));
-        for (int g = 0; g < G; ++g) {
-            fq.insert(fq.end(), pg[g].begin(), pg[g].end());
-            if (g - L >= 0) fq.insert(fq.end(), cg[g - L].begin(), cg[g - L].end());
-        }
-        for (int g = std::max(0, G - L); g < G; ++g) fq.insert(fq.end(), cg[g].begin(), cg[g].end());
-        P->n_fitems = (int)fq.size(); P->n_groups = G; P->lag = L;
-        P->grid = std::min(P->n_fitems, n_cu);
-        G4S_TRY(P->fitems.alloc(sizeof(FusedItem) * fq.size()));
-        G4S_TRY(P->fneed.alloc(sizeof(int) * need.size()));
-        G4S_TRY(P->fctr.alloc(sizeof(int) * kCtrStride * (size_t)(kCtrGroup + 1 + G)));
-        G4S_HIP_TRY(hipMemcpy(P->fitems.p, fq.data(), sizeof(FusedItem) * fq.size(), hipMemcpyHostToDevice));
-        G4S_HIP_TRY(hipMemcpy(P->fneed.p, need.data(), sizeof(int) * need.size(), hipMemcpyHostToDevice));
-        G4S_HIP_TRY(hipMemset(P->fctr.p, 0, P->fctr.bytes));
-        G4S_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pb_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kBand + 64)));
-        P->fused = P->grid > 0;
-    }
     std::stable_sort(cit.begin(), cit.end(), [](const ConsumerItem &a, const ConsumerItem &b) { return (a.k1 - a.k0) > (b.k1 - b.k0); });
     std::stable_sort(pit.begin(), pit.end(), [](const ProducerItem &a, const ProducerItem &b) { return (a.s1 - a.s0) > (b.s1 - b.s0); });
     P->n_pitems = (int)pit.size(); P->n_citems = (int)cit.size(); P->n_split = (int)split.size();
@@ -830,50 +610,25 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     G4S_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pb_consumer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_consumer));
     G4S_HIP_TRY(hipDeviceSynchronize());
     P->bytes = (long long)(P->p_lcol.bytes + P->p_val.bytes + P->masks.bytes + P->mbase.bytes + P->c_lrow.bytes + P->prod.bytes + P->delta.bytes +
-                           P->pitems.bytes + P->citems.bytes + P->split_bands.bytes + P->hot_cols.bytes + P->hot_x.bytes + P->fitems.bytes + P->fctr.bytes + P->fneed.bytes);
+                           P->pitems.bytes + P->citems.bytes + P->split_bands.bytes + P->hot_cols.bytes + P->hot_x.bytes);
     if (getenv("G4S_DEBUG"))
-        fprintf(stderr, "g4s blocked SpMV plan: %d x %d bands (%d hot), nnz %lld, padded %lld, micro-runs %lld (%.3f per nonzero), %d producer / %d consumer items, %d split bands, %.2f GB; one launch: %s, %d queue items, %d row groups, lag %d, grid %d\n",
-                CB, RB, H, nnz, totP, P->micro_runs, (double)P->micro_runs / (double)nnz, P->n_pitems, P->n_citems, P->n_split, P->bytes / 1e9,
-                P->fused ? "yes" : "no", P->n_fitems, P->n_groups, P->lag, P->grid);
+        fprintf(stderr, "g4s blocked SpMV plan: %d x %d bands (%d hot), nnz %lld, padded %lld, micro-runs %lld (%.3f per nonzero), %d producer / %d consumer items, %d split bands, %.2f GB\n",
+                CB, RB, H, nnz, totP, P->micro_runs, (double)P->micro_runs / (double)nnz, P->n_pitems, P->n_citems, P->n_split, P->bytes / 1e9);
     *out = guard.release();
     return G4S_OK;
 }
 
 void pb_destroy(PbPlan *P) { delete P; }
 
-// Synchronises the device: has any launch of the one-launch form given up waiting for a counter (a product that must not be trusted)?
-int pb_spmv_status(const PbPlan *P)
-{
-    if (!P || !P->fused) return G4S_OK;
-    int timeouts = 0;
-    G4S_HIP_TRY(hipDeviceSynchronize());
-    G4S_HIP_TRY(hipMemcpy(&timeouts, P->fctr.as<int>() + kCtrError * kCtrStride, sizeof(int), hipMemcpyDeviceToHost));
-    if (timeouts) return set_error(G4S_ERR_HIP, "blocked SpMV: %d work item(s) gave up waiting for their producers (pb_fused_kernel); the products since are not valid", timeouts);
-    return G4S_OK;
-}
-
 long long pb_bytes(const PbPlan *P) { return P ? P->bytes : 0; }
 
 int pb_spmv(PbPlan *P, const double *x, double *y, double alpha, double beta, hipStream_t s)
 {
-    if (P->fused) {
-        FusedArgs a;
-        a.items = P->fitems.as<FusedItem>(); a.n_items = P->n_fitems; a.n_prep = P->n_prep; a.n_groups = P->n_groups; a.xflags = getenv("G4S_PB_XFLAGS") ? atoi(getenv("G4S_PB_XFLAGS")) : 0;
-        a.ctr = P->fctr.as<int>(); a.need = P->fneed.as<int>();
-        a.rows = P->rows; a.cols = P->cols; a.H = P->H;
-        a.hot_cols = P->hot_cols.as<int>(); a.hot_x = P->hot_x.as<double>();
-        a.p_lcol = P->p_lcol.as<unsigned short>(); a.p_val = P->p_val.as<double>(); a.masks = P->masks.as<unsigned char>(); a.mbase = P->mbase.as<int>();
-        a.c_lrow = P->c_lrow.as<unsigned short>(); a.prod = P->prod.as<double>();
-        a.x = x; a.y = y; a.alpha = alpha; a.beta = beta;
-        hipLaunchKernelGGL(pb_fused_kernel, dim3(P->grid), dim3(kPbThreads), sizeof(double) * kBand + 64, s, a);
-        G4S_HIP_TRY(hipGetLastError());
-        return G4S_OK;
-    }
     if (P->n_split || P->H)
         hipLaunchKernelGGL(pb_prepare_kernel, dim3((P->n_split + P->H) * (kBand / 256)), dim3(256), 0, s, P->n_split, P->split_bands.as<int>(), P->rows, y, beta,
                            P->H * kBand, P->hot_cols.as<int>(), x, P->hot_x.as<double>());
     if (P->n_pitems)
-        hipLaunchKernelGGL(pb_producer_kernel, dim3(P->n_pitems), dim3(kPbThreads), P->lds_producer, s, P->pitems.as<ProducerItem>(), P->cols, P->H, P->hot_x.as<double>(),
+        hipLaunchKernelGGL(pb_producer_kernel, dim3(P->n_pitems), dim3(kPbThreads), P->lds_producer, s, P->pitems.as<ProducerItem>(), P->cols, P->RB, P->H, P->hot_x.as<double>(),
                            P->p_lcol.as<unsigned short>(), P->p_val.as<double>(), P->masks.as<unsigned char>(), P->mbase.as<int>(), x, P->prod.as<double>());
     if (P->n_citems)
         hipLaunchKernelGGL(pb_consumer_kernel, dim3(P->n_citems), dim3(kPbThreads), P->lds_consumer, s, P->citems.as<ConsumerItem>(), P->rows,

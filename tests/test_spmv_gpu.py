@@ -159,14 +159,11 @@ def test_spmv_full_size_properties():
     assert inf["algorithmic_bytes"] == 12 * A.nnz + 4 * (n + 1) + 16 * n
 
 
-@pytest.mark.parametrize("impl", ["pb", "tb"])
 @pytest.mark.parametrize("kind", ["random", "powerlaw", "lap5", "tiny", "wide"])
-def test_spmv_blocked_path(oracle, kind, impl, monkeypatch):
-    """The blocked paths (G4S_SPMV_BLOCKED; impl pb = propagation-blocked, the default; tb = the tile-blocked experiment, read from
-    G4S_SPMV_IMPL at g4s_csr_create): same parity bar as the streaming path. Matrices larger than one 16K band in both directions, with
+def test_spmv_blocked_path(oracle, kind):
+    """The blocked path (G4S_SPMV_BLOCKED, propagation blocking): same parity bar as the streaming path. Matrices larger than one 16K band in both directions, with
     empty rows, hubs, alpha/beta, and rows/cols that are not multiples of the band."""
     from g4s_amd import capi, host
-    monkeypatch.setenv("G4S_SPMV_IMPL", impl)
     if kind == "random":
         rows, cols = 40000, 50000
         rp, ci, va = random_csr(rows, cols, 0.0004, 3, empty_rows=[0, 17000, 39999])
@@ -183,7 +180,7 @@ def test_spmv_blocked_path(oracle, kind, impl, monkeypatch):
         rows, cols = 100, 100000
         rp, ci, va = random_csr(rows, cols, 0.01, 5)
     A = host.CSR.from_host(rp, ci, va, rows, cols, spmv_flags=capi.SPMV_BLOCKED)
-    assert A.info()["spmv_path"] == (1 if impl == "pb" else 2)
+    assert A.info()["spmv_path"] == 1
     x = np.random.default_rng(2).uniform(-1, 1, cols)
     _check(oracle, A, rp, ci, va, x)
     _check(oracle, A, rp, ci, va, x, alpha=-1.5, beta=0.25, y0=np.random.default_rng(3).uniform(-1, 1, rows))
@@ -199,7 +196,7 @@ def test_spmv_path_selection():
     assert host.banded_csr(6_000_000, 5, 1).info()["spmv_path"] == 3      # diagonal-structured → index-free path
     assert host.banded_csr(6_000_000, 5, 1, spmv_flags=16).info()["spmv_path"] == 0   # G4S_SPMV_STREAM forces the CSR kernel
     A = host.rmat_csr(6_000_000, 23, 30_000_000, 5)
-    assert A.info()["spmv_path"] in (1, 2)
+    assert A.info()["spmv_path"] == 1
 
 
 @pytest.mark.parametrize("flags", [16, 8])
@@ -275,7 +272,7 @@ def test_spmv_blocked_hot_column_bands(oracle, monkeypatch, hot):
         ci[rp[r]:rp[r + 1]] = np.sort(c)
     va = rng.uniform(-1, 1, rp[-1])
     A = host.CSR.from_host(rp, ci, va, rows, cols, spmv_flags=capi.SPMV_BLOCKED)
-    assert A.info()["spmv_path"] in (1, 2)
+    assert A.info()["spmv_path"] == 1
     x = rng.uniform(-1, 1, cols)
     _check(oracle, A, rp, ci, va, x)
     _check(oracle, A, rp, ci, va, x, alpha=0.75, beta=-2.0, y0=rng.uniform(-1, 1, rows))
@@ -333,19 +330,11 @@ def test_spmv_randomised_structures():
     assert r.returncode == 0 and "all ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("groups,lag", [("1", None), ("6", "1"), ("16", None), ("16", "16"), ("0", None)])
-def test_spmv_blocked_one_launch_fresh_vectors(oracle, monkeypatch, groups, lag):
-    """The one-launch form of the blocked path (pb_fused_kernel: producer and consumer items of one product in one persistent launch, handed over
-    through agent-scope counters). A stale hand-off — a consumer reading last launch's partial sums, or a producer staging last launch's hot x —
-    is invisible while x stays the same, so every launch gets a NEW x and is compared with the oracle. lag 1 makes consumers wait for their
-    producers (the dependency is exercised, not just ordered away); groups 0 = the three-launch form (G4S_PB_FUSED=0)."""
+def test_spmv_blocked_fresh_vectors_every_launch(oracle):
+    """The blocked path keeps state between launches (the gathered hot x values, the partial-sum buffer, the pre-scaled split row bands): a launch
+    that read any of it from the previous product would go unnoticed while x stays the same, so every launch gets a NEW x and is compared with
+    the oracle; alpha / beta alternate so that the split row bands' pre-scale is exercised too."""
     from g4s_amd import capi, host
-    if groups == "0":
-        monkeypatch.setenv("G4S_PB_FUSED", "0")
-    else:
-        monkeypatch.setenv("G4S_PB_GROUPS", groups)
-    if lag:
-        monkeypatch.setenv("G4S_PB_LAG", lag)
     n = 1_500_000
     G = host.rmat_csr(n, 21, 24_000_000, 77)
     A = host.CSR(G.rowptr, G.colids, G.values, n, n, spmv_flags=capi.SPMV_BLOCKED)
@@ -353,7 +342,7 @@ def test_spmv_blocked_one_launch_fresh_vectors(oracle, monkeypatch, groups, lag)
     rp, ci, va = A.to_host()
     y = torch.empty(n, dtype=torch.float64, device="cuda")
     y0 = host.synth_vector(99, n)
-    for it in range(6):
+    for it in range(4):
         x = host.synth_vector(100 + it, n)
         xh = x.cpu().numpy()
         alpha, beta = (1.0, 0.0) if it % 2 == 0 else (-0.5, 1.25)

@@ -14,7 +14,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
         for row in csv.DictReader(fh):
             k = row["Kernel_Name"]
             short = None
-            for key in ("spmv_csr_adaptive", "spmv_long_fixup", "pb_producer", "pb_consumer", "pb_scale_rows", "pb_gather_hot", "pb_prepare", "pb_fused"):
+            for key in ("spmv_csr_adaptive", "spmv_long_fixup", "pb_producer", "pb_consumer", "pb_scale_rows", "pb_gather_hot", "pb_prepare"):
                 if key in k:
                     short = key
             if short is None:
