@@ -12,9 +12,14 @@
 //   DENSE_ROW_TIMES_MATRIX  DeePMD OptMatmul lambda, deepmd/source/op/opt_matmul.cc:52-58 — a dense fp64 GEMM
 //                           result[M×K] = xx[M×N]·w[N×K]: the dense-tile case, on v_mfma_f64_16x16x4_f64.
 //   SYM_QUADRATIC_FORM      Cantera gather1/apply1, gather2/apply2, cantera/src/thermo/RedlichKwongMFTP.cpp:927-970.
-// An unregistered callback pair is refused (G4S_ERR_UNSUPPORTED): there is no host fallback in this library.
+// Any OTHER callback pair gets the interface's own semantics — the reference's driver loop, on the host, in the reference's order
+// (g4s_spmm_dense below; g4s_set_host_callback_policy chooses serial / threadNum threads for race-free gathers / refusal). That loop is what
+// "gather degree times per vertex, then apply" means for host code; it is not a CPU twin of any kernel and never calls oracle/.
 #include "common.hpp"
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -693,6 +698,7 @@ struct Pattern {
 };
 
 std::mutex g_mu;
+std::atomic<int> g_host_policy{G4S_HOST_CALLBACKS_SERIAL};
 std::map<std::pair<void *, void *>, std::unique_ptr<Pattern>> g_patterns;
 
 std::pair<void *, void *> key_of(fun_gather g, fun_apply a) { return {reinterpret_cast<void *>(g), reinterpret_cast<void *>(a)}; }
@@ -728,6 +734,13 @@ G4S_API g4s_status g4s_register_pattern(fun_gather gather, fun_apply apply, cons
     return G4S_OK;
 }
 
+G4S_API g4s_status g4s_set_host_callback_policy(int32_t policy)
+{
+    G4S_REQUIRE(policy == G4S_HOST_CALLBACKS_SERIAL || policy == G4S_HOST_CALLBACKS_PARALLEL || policy == G4S_HOST_CALLBACKS_REFUSE, "unknown policy");
+    g_host_policy.store(policy);
+    return G4S_OK;
+}
+
 G4S_API g4s_status g4s_unregister_pattern(fun_gather gather, fun_apply apply)
 {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -738,12 +751,41 @@ G4S_API g4s_status g4s_unregister_pattern(fun_gather gather, fun_apply apply)
 G4S_API g4s_status g4s_spmm_dense(uint32_t numNodes, uint32_t degree, const double **edgeWeight, const double *vertexStates,
                                   double *temp, double *result, fun_gather gather, fun_apply apply, double *time, int threadNum)
 {
-    (void)threadNum; // CPU thread count of the reference; the device needs none
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::unique_lock<std::mutex> lk(g_mu);
     auto it = g_patterns.find(key_of(gather, apply));
-    if (it == g_patterns.end())
-        return g4s::set_error(G4S_ERR_UNSUPPORTED, "spmm_dense: this (gather, apply) pair is not registered with g4s_register_pattern; "
-                                                   "host callbacks cannot run on the GPU and this library has no CPU fallback");
+    if (it == g_patterns.end()) {
+        // An arbitrary callback pair is host code the device cannot run. It is not an error of the caller either: the interface promises
+        // "gather degree times per vertex, then apply" for ANY pair (deepmd/source/op/graph.h:21-32; citcoms/lib/global_defs.h:48-49,854-857),
+        // so the general case runs the reference's driver loop on the host, in the reference's order. This is the interface's semantics for
+        // callbacks, not a CPU version of a device kernel: the three patterns with kernels never come here.
+        const int policy = g_host_policy.load();
+        lk.unlock();                                               // callbacks may call back into the library
+        if (policy == G4S_HOST_CALLBACKS_REFUSE)
+            return g4s::set_error(G4S_ERR_UNSUPPORTED, "spmm_dense: this (gather, apply) pair is not registered with g4s_register_pattern and "
+                                                       "host callbacks are refused (g4s_set_host_callback_policy(G4S_HOST_CALLBACKS_REFUSE))");
+        if (!gather) return g4s::set_error(G4S_ERR_INVALID, "spmm_dense: gather is NULL");
+        const auto t0 = std::chrono::steady_clock::now();
+        // the reference runs 8 OpenMP threads whatever the gather does (graph.h:23); here more than one thread only when the caller has
+        // declared its gathers race-free, and then threadNum of them, vertices handed out one at a time (schedule(dynamic, 1), graph.h:24)
+        const int threads = policy == G4S_HOST_CALLBACKS_PARALLEL ? std::max(1, std::min(threadNum, (int)std::min<uint32_t>(numNodes, 256u))) : 1;
+        std::atomic<uint32_t> next{0};
+        auto worker = [&]() {
+            for (uint32_t vi = next.fetch_add(1); vi < numNodes; vi = next.fetch_add(1)) {
+                for (uint32_t nb = 0; nb < degree; ++nb) gather((int)vi, (int)nb, edgeWeight, vertexStates, result);
+                if (apply) apply((int)vi, edgeWeight, vertexStates, result);
+            }
+        };
+        if (threads == 1) worker();
+        else {
+            std::vector<std::thread> pool;
+            for (int i = 1; i < threads; ++i) pool.emplace_back(worker);
+            worker();
+            for (auto &th : pool) th.join();
+        }
+        (void)temp;                                                // the reference's callbacks receive result only (global_defs.h:48-49)
+        if (time) *time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return G4S_OK;
+    }
     Pattern &P = *it->second;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     G4S_HIP_TRY(hipEventCreate(&e0));

@@ -235,9 +235,22 @@ typedef struct g4s_pattern_desc {
 g4s_status g4s_register_pattern(fun_gather gather, fun_apply apply, const g4s_pattern_desc *desc);
 g4s_status g4s_unregister_pattern(fun_gather gather, fun_apply apply);
 
+/* What an UNREGISTERED (gather, apply) pair gets. Callbacks are host code the device cannot execute, and the interface
+ * promises every pair "gather degree times per vertex, then apply" (deepmd/source/op/graph.h:21-32), so by default the
+ * reference's driver loop runs on the host, one thread, vertices in ascending order (the reference itself hard-codes
+ * 8 OpenMP threads, graph.h:23, racing on gathers that scatter — e.g. CitcomS' Au[aa] +=, Element_calculations.c:466).
+ *   SERIAL    (default) one host thread;
+ *   PARALLEL  the caller declares its gathers race-free: threadNum threads, vertices handed out one at a time
+ *             (schedule(dynamic,1), graph.h:24);
+ *   REFUSE    G4S_ERR_UNSUPPORTED (spmm_dense: abort) — for deployments that must never fall off the device. */
+#define G4S_HOST_CALLBACKS_SERIAL   0
+#define G4S_HOST_CALLBACKS_PARALLEL 1
+#define G4S_HOST_CALLBACKS_REFUSE   2
+g4s_status g4s_set_host_callback_policy(int32_t policy);
+
 /* The reference symbol, exactly (citcoms/lib/global_defs.h:854-857; bound at citcoms/bin/Citcom.c:93).
- * Registered pairs run as HIP kernels; unregistered pairs abort with a message on stderr (callbacks are
- * host code the device cannot execute — see g4s_spmm_dense for the status-returning form). */
+ * Registered pairs run as HIP kernels; any other pair runs the reference's host loop (policy above). spmm_dense returns
+ * void as the reference's does, so a failure aborts with a message — g4s_spmm_dense is the status-returning form. */
 void spmm_dense(uint32_t numNodes, uint32_t degree, const double **edgeWeight, const double *vertexStates,
                 double *temp, double *result, fun_gather gather, fun_apply apply, double *time, int threadNum);
 g4s_status g4s_spmm_dense(uint32_t numNodes, uint32_t degree, const double **edgeWeight, const double *vertexStates,

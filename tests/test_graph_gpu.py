@@ -220,13 +220,18 @@ def test_spmm_dense_with_registered_callbacks(oracle):
     want2 = oracle.sym_quadratic_form(m, 2, a2, x)
     assert np.all(np.abs(out2 - want2) <= 1e-12 * np.abs(want2))
 
-    # ---- an unregistered pair is refused, not run on the host
+    # ---- an unregistered pair gets the reference's host loop (tests/test_host_callbacks_cpu.py pins it to the reference build); with the
+    # REFUSE policy it is turned away before any callback runs
     @capi.FUN_GATHER
     def gather_unknown(e, a, ew, st, res):
-        raise RuntimeError("host callback must not run")
+        raise RuntimeError("host callback must not run under the REFUSE policy")
 
-    st = lib.g4s_spmm_dense(M, Kc, C.cast(_rows(xx), C.c_void_p), w.ctypes.data, None, res.ctypes.data, gather_unknown, apply_dense, None, 1)
-    assert st == capi.ERR_UNSUPPORTED and b"no CPU fallback" in lib.g4s_last_error()
+    capi.check(lib.g4s_set_host_callback_policy(capi.HOST_CALLBACKS_REFUSE))
+    try:
+        st = lib.g4s_spmm_dense(M, Kc, C.cast(_rows(xx), C.c_void_p), w.ctypes.data, None, res.ctypes.data, gather_unknown, apply_dense, None, 1)
+        assert st == capi.ERR_UNSUPPORTED and b"refused" in lib.g4s_last_error()
+    finally:
+        capi.check(lib.g4s_set_host_callback_policy(capi.HOST_CALLBACKS_SERIAL))
     for g, a in ((gather_elem, apply_elem), (gather_dense, apply_dense), (gather_q, apply_q)):
         capi.check(lib.g4s_unregister_pattern(g, a))
 
