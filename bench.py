@@ -7,7 +7,7 @@ are split by equal work (the rule of mm/inc/BIN.h:101-122), every rank owns its 
 {exchange x over RCCL/xGMI, local SpMV} — total work is fixed, so scaling is "strong". Inputs are resident in HBM before
 the timed region. Prints ONE JSON line (rank 0).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload rmat|banded|lap5|lap7] [--exchange auto|dist|allgatherv|allgather|needed|compact]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload rmat|banded|lap5|lap7] [--exchange auto|dist|allgather]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -267,9 +267,9 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="rmat", choices=sorted(WORKLOADS))
-    ap.add_argument("--exchange", default="auto", choices=["auto", "dist", "allgatherv", "allgather", "needed", "compact"],
-                    help="auto = dist: the C-ABI multi-GPU product (g4s_spmv_dist_*: RCCL send/recv of the referenced x entries, overlapped with the own-column "
-                         "product); the others are round 1's torch.distributed variants, kept for A/B runs")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "dist", "allgather"],
+                    help="auto = dist: the C-ABI multi-GPU product (g4s_spmv_dist_*) with the packed exchange (RCCL send/recv of the referenced x entries, overlapped with "
+                         "the own-column product); allgather: the same product with ONE ncclAllGather of the whole vector (also the fallback when the packed wiring fails)")
     ap.add_argument("--small", action="store_true", help="reduced sizes for plumbing checks (not a valid benchmark)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary configs[3] (7-point Laplacian 431^3) measurement reported under `also`")
@@ -321,53 +321,36 @@ def main():
         torch.cuda.empty_cache()
         x_local = host.synth_vector(7, r1 - r0, i0=r0)
         y_local = torch.empty(r1 - r0, dtype=torch.float64, device="cuda")
-        if mode == "dist":
-            # the library's multi-GPU product (g4s_spmv_dist_*, csrc/dist.hip): own / remote column split, packed exchange of the referenced x
-            # entries by ncclSend/ncclRecv on the library's own RCCL communicator, own-column product overlapped with it. DistSpMV agrees
-            # after every set-up phase whether it succeeded on ALL ranks and raises everywhere at the same point if not; the ranks then fall
-            # back — together — to round 1's padded all-gather on torch.distributed.
-            err = ""
-            try:
-                D = gdist.DistSpMV(offs, rank, world, rp, ci, va, n_cols, spmv_flags=flags)
-            except Exception as e:                                  # noqa: BLE001 — reported below, decided collectively
-                D, err = None, f"{type(e).__name__}: {e}"
-            okf = torch.tensor([1 if D is not None else 0], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
-            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
-            if int(okf.item()) == 0:
-                if err:
-                    print(f"[bench rank {rank}] g4s_spmv_dist set-up failed ({err}); every rank falls back to --exchange allgather", file=sys.stderr, flush=True)
-                D, mode = None, "allgather"
-        if mode == "dist":
-            dinfo = D.info()
-            recv_bytes = dinfo["recv_bytes"]
-            info = {"spmv_path": dinfo["rem_path"] if dinfo["reserved"] else dinfo["own_path"], "dist_form": "merged (one product on a compact x)" if dinfo["reserved"] else "own + remote columns",
-                    "algorithmic_bytes": 12 * int(rp[-1].item()) + 4 * (r1 - r0 + 1) + 8 * (r1 - r0) + 8 * (r1 - r0 + dinfo["n_ref"]),
-                    "rows": r1 - r0, "nnz": int(rp[-1].item())}
+        # the library's multi-GPU product (g4s_spmv_dist_*, csrc/dist.hip): own / remote column split; exchange "dist" = packed ncclSend/ncclRecv of the
+        # referenced x entries on the library's own RCCL communicator, own-column product overlapped with it; "allgather" = ONE in-place ncclAllGather of
+        # the padded slabs (north_star's "RCCL all-gather of the dense vector"). DistSpMV agrees after every set-up phase whether it succeeded on ALL
+        # ranks and raises everywhere at the same point if not; the ranks then fall back — together — to the all-gather exchange, which needs no wiring.
+        err = ""
+        try:
+            D = gdist.DistSpMV(offs, rank, world, rp, ci, va, n_cols, spmv_flags=flags, exchange="packed" if mode == "dist" else "allgather")
+        except Exception as e:                                  # noqa: BLE001 — reported below, decided collectively
+            D, err = None, f"{type(e).__name__}: {e}"
+        okf = torch.tensor([1 if D is not None else 0], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        if int(okf.item()) == 0:
+            if err:
+                print(f"[bench rank {rank}] g4s_spmv_dist set-up failed ({err}); every rank falls back to --exchange allgather", file=sys.stderr, flush=True)
+            if D is not None:
+                D.close()
+            if mode == "allgather":
+                raise SystemExit("the all-gather exchange could not be set up either")
+            mode = "allgather"
+            D = gdist.DistSpMV(offs, rank, world, rp, ci, va, n_cols, spmv_flags=flags, exchange="allgather")
+        dinfo = D.info()
+        recv_bytes = dinfo["recv_bytes"]
+        merged = bool(dinfo["reserved"] & 1)
+        info = {"spmv_path": dinfo["rem_path"] if merged else dinfo["own_path"], "dist_form": "merged (one product on the gathered x)" if merged else "own + remote columns",
+                "algorithmic_bytes": 12 * int(rp[-1].item()) + 4 * (r1 - r0 + 1) + 8 * (r1 - r0) + 8 * (r1 - r0 + dinfo["n_ref"]),
+                "rows": r1 - r0, "nnz": int(rp[-1].item()), "plan_bytes": None}
 
-            def product():
-                D(x_local, y_local)
-            step = product
-        else:
-            # the torch.distributed variants of round 1 (g4s_amd/dist.py), kept for A/B runs: --exchange allgatherv | allgather | needed | compact
-            if mode == "compact":
-                exchange = gdist.CompactExchange(offs, rank, world, ci)
-                A = host.CSR(rp, exchange.local_colids, va, r1 - r0, exchange.n_ref, spmv_flags=flags)
-                x_cols = exchange.n_ref
-            else:
-                A = host.CSR(rp, ci, va, r1 - r0, n_cols, spmv_flags=flags)
-                exchange = gdist.VectorExchange(offs, rank, world, colids=A.colids, mode=mode)
-                x_cols = n_cols
-            x_full = torch.zeros(x_cols, dtype=torch.float64, device="cuda")
-            exchange(x_local, x_full)
-            info = A.info()
-            recv_bytes = exchange.recv_bytes
-
-            def product():
-                A.spmv(x_full, y_local)
-
-            def step():
-                exchange(x_local, x_full)
-                A.spmv(x_full, y_local)
+        def product():
+            D(x_local, y_local)
+        step = product
     else:
         A = host.CSR(A_full.rowptr, A_full.colids, A_full.values, n_rows, n_cols, spmv_flags=flags)
         torch.cuda.synchronize()
@@ -448,8 +431,8 @@ def main():
                    "rows": n_rows, "cols": n_cols, "nnz": nnz_total, "index": "int32",
                    "partition": f"1-D rows by equal nnz+rows over {world} rank(s)",
                    "exchange": ("none (single GPU)" if world == 1 else
-                                (f"dist: g4s_spmv_dist_* ({info.get('dist_form')}; packed ncclSend/ncclRecv of the referenced x entries"
-                                 f"{'' if dinfo['reserved'] else ', overlapped with the own-column product'}), {recv_bytes} B received by rank 0 per step" if mode == "dist" else f"{mode} over torch.distributed, {recv_bytes} B received by rank 0 per step")),
+                                (f"g4s_spmv_dist_* ({info.get('dist_form')}; " + ("packed ncclSend/ncclRecv of the referenced x entries" if mode == "dist" else "one in-place ncclAllGather of the padded slabs")
+                                 + f"{'' if merged else ', overlapped with the own-column product'}), {recv_bytes} B received by rank 0 per step")),
                    "matrix_loads": "plain" if args.no_nt else "nontemporal",
                    "spmv_path": {0: "stream", 1: "blocked", 3: "diagonal (index-free)"}[info["spmv_path"]],
                    "reproducible": ("yes: fixed summation order, no atomics" if info["spmv_path"] in (0, 3) else

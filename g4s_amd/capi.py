@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libg4s_hip.so")
 
 OK, ERR_INVALID, ERR_NOMEM, ERR_HIP, ERR_OVERFLOW, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
-HOST_POINTERS, DEVICE_POINTERS, SORT_OUTPUT, SPMV_NO_NT, SPMV_BLOCKED, SPMV_STREAM, DIST_LOOPBACK = 0, 1, 2, 4, 8, 16, 32
+HOST_POINTERS, DEVICE_POINTERS, SORT_OUTPUT, SPMV_NO_NT, SPMV_BLOCKED, SPMV_STREAM, DIST_LOOPBACK, DIST_ALLGATHER = 0, 1, 2, 4, 8, 16, 32, 64
 PATTERN_ELEMENT_BLOCK_MATVEC, PATTERN_DENSE_ROW_TIMES_MATRIX, PATTERN_SYM_QUADRATIC_FORM = 1, 2, 3
 DENSE_DGEMM, DENSE_DSYMM, DENSE_DTRMM, DENSE_DGEMV, DENSE_DSYMV, DENSE_DTRMV, DENSE_DSPMV = 1, 2, 3, 4, 5, 6, 7
 
@@ -34,6 +34,15 @@ class DistInfo(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("local_rows", C.c_int32), ("n_ref", C.c_int32), ("nnz_own", C.c_int64), ("nnz_rem", C.c_int64),
                 ("send_bytes", C.c_int64), ("recv_bytes", C.c_int64), ("own_path", C.c_int32), ("rem_path", C.c_int32), ("connected", C.c_int32),
                 ("reserved", C.c_int32)]
+
+
+class DistSplit(C.Structure):
+    """g4s_dist_split: one rank's rows cut into own-column and remote-column parts (host arrays from g4s_malloc)."""
+    _fields_ = [("local_rows", C.c_int32), ("n_ref", C.c_int32), ("merged", C.c_int32), ("allgather", C.c_int32),
+                ("nnz_own", C.c_int64), ("nnz_rem", C.c_int64), ("pad", C.c_int64),
+                ("own_rowptr", C.POINTER(C.c_int32)), ("own_colids", C.POINTER(C.c_int32)), ("own_values", C.POINTER(C.c_double)),
+                ("rem_rowptr", C.POINTER(C.c_int32)), ("rem_colids", C.POINTER(C.c_int32)), ("rem_values", C.POINTER(C.c_double)),
+                ("want", C.POINTER(C.c_int32)), ("recv_cut", C.POINTER(C.c_int64))]
 
 
 class Timings(C.Structure):
@@ -80,6 +89,9 @@ SIGNATURES = {
     "g4s_csr_device_arrays": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
     "g4s_spmv": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, vp]),
     "g4s_spmv_csr_i32_f64": (C.c_int, [C.c_int32, C.c_int32, vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_uint]),
+    "g4s_row_partition": (C.c_int, [C.c_int32, vp, vp, C.c_int64, C.c_int32, i64p, C.c_uint]),
+    "g4s_dist_split_rows": (C.c_int, [C.c_int32, C.c_int32, i64p, C.c_int64, vp, vp, vp, C.c_uint, C.POINTER(DistSplit)]),
+    "g4s_dist_split_free": (None, [C.POINTER(DistSplit)]),
     "g4s_spmv_dist_create": (C.c_int, [C.POINTER(vp), C.c_int32, C.c_int32, i64p, C.c_int64, vp, vp, vp, C.c_uint]),
     "g4s_spmv_dist_destroy": (C.c_int, [vp]),
     "g4s_spmv_dist_get_info": (C.c_int, [vp, C.POINTER(DistInfo)]),

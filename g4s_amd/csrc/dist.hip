@@ -16,11 +16,21 @@
 //     segment of x_rem, no unpack) ‖ y = A_own·x_local on the caller's stream → wait → y += A_rem·x_rem.
 // RCCL is loaded with dlopen at first use (librccl.so.1: the copy the host framework already mapped, or ROCm's), so libg4s_hip.so has
 // no link-time dependency on it and single-GPU users never touch it.
+//   * G4S_DIST_ALLGATHER (north_star's "RCCL all-gather of the dense vector"; also what bench.py falls back to): no index lists at all —
+//     every rank's slab of x, padded to the longest slab, lands in one buffer of world·pad entries by a single in-place ncclAllGather;
+//     remote column c of owner k is renumbered k·pad + (c − off[k]). More bytes than the packed exchange (the whole vector travels to
+//     everyone), one collective instead of 2·(world − 1) messages, and nothing to wire at set-up.
+// The split itself (own / remote columns, renumbering, want lists) is host-side set-up logic and is exported as g4s_dist_split_rows
+// (no GPU needed: a host with its own transport can use it, and the CPU tests run it under gloo); so is the equal-work row partition
+// g4s_row_partition (mm/inc/BIN.h:101-122).
 #include "common.hpp"
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <algorithm>
+#include <chrono>
 #include <mutex>
+#include <new>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -34,6 +44,8 @@ struct Rccl {
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;   // optional
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -59,7 +71,9 @@ int rccl_load()
     G4S_RCCL_SYM(GetUniqueId, "ncclGetUniqueId") G4S_RCCL_SYM(CommInitRank, "ncclCommInitRank") G4S_RCCL_SYM(CommDestroy, "ncclCommDestroy")
     G4S_RCCL_SYM(Send, "ncclSend") G4S_RCCL_SYM(Recv, "ncclRecv") G4S_RCCL_SYM(AllReduce, "ncclAllReduce")
     G4S_RCCL_SYM(GroupStart, "ncclGroupStart") G4S_RCCL_SYM(GroupEnd, "ncclGroupEnd") G4S_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+    G4S_RCCL_SYM(AllGather, "ncclAllGather")
 #undef G4S_RCCL_SYM
+    r.CommGetAsyncError = reinterpret_cast<decltype(r.CommGetAsyncError)>(dlsym(h, "ncclCommGetAsyncError"));
     g_rccl = r;
     return G4S_OK;
 }
@@ -82,6 +96,8 @@ struct g4s_spmv_dist_s {
     int rank = 0, world = 1;
     bool loopback = false;
     bool merged = false;                        // the own columns are few: one product on a compact x that holds own and remote entries alike
+    bool allgather = false;                     // the remote x is the whole vector, slab by slab, padded to `pad` entries per rank
+    int64_t pad = 0;
     std::vector<int64_t> off;                   // row (= x) partition, world+1
     int32_t local_rows = 0;
     int64_t nnz_own = 0, nnz_rem = 0;
@@ -118,102 +134,237 @@ int owner_of(const std::vector<int64_t> &off, int64_t col)
     return (int)(std::upper_bound(off.begin(), off.end(), col) - off.begin()) - 1;
 }
 
+// One rank's rows cut into the own-column and the remote-column part (host arrays; set-up logic, runs once per matrix).
+struct Split {
+    bool merged = false, allgather = false;
+    int64_t pad = 0;
+    int32_t n_ref = 0;                                              // length of the remote x (packed: referenced columns; all-gather: world·pad)
+    std::vector<int32_t> orp, oci, rrp, rci, want;
+    std::vector<double> ova, rva;
+    std::vector<int64_t> recv_cut;
+};
+
+// Everything is validated before it is used as an index (a crash here would be a host crash across the C boundary): rowptr[0] == 0,
+// non-decreasing, nnz inside int32, every column inside [0, n_cols).
+int split_rows(int rank, int world, const std::vector<int64_t> &off, int64_t n_cols, int32_t m, const int32_t *rp, const int32_t *ci, const double *va,
+               bool loopback, bool allgather, Split &S)
+{
+    if (rp[0] != 0) return g4s::set_error(G4S_ERR_INVALID, "rowptr[0] != 0");
+    for (int32_t i = 0; i < m; ++i)
+        if (rp[i + 1] < rp[i]) return g4s::set_error(G4S_ERR_INVALID, "rowptr decreases at row %d", i);
+    const int64_t nnz = rp[m];
+    if (nnz < 0) return g4s::set_error(G4S_ERR_INVALID, "rowptr[rows] is negative");
+    if (nnz && (!ci || !va)) return g4s::set_error(G4S_ERR_INVALID, "colids/values NULL with nnz > 0");
+    for (int64_t k = 0; k < nnz; ++k)
+        if (ci[k] < 0 || ci[k] >= n_cols) return g4s::set_error(G4S_ERR_INVALID, "a column index is outside [0, n_cols)");
+    const int64_t r0 = off[rank], r1 = off[(size_t)rank + 1];
+    // own range of columns (loopback: only the first half of the slab counts as own, the rest travels rank 0 → rank 0 through RCCL).
+    // Merged form: when fewer than a quarter of the entries sit in own columns (a power-law graph cut into row slabs: ≈10 %), two products
+    // cost more than the overlap buys (tools/dist_probe.py: 0.12–0.16 ms against 0.07–0.09 ms for one product on an eighth of configs[1]),
+    // so the own columns are renumbered into the remote x like everybody else's (packed: filled by a local gather instead of a message).
+    int64_t own_lo = r0, own_hi = loopback ? r0 + (r1 - r0) / 2 : r1;
+    if (!loopback && world > 1 && !getenv("G4S_DIST_NO_MERGE")) {
+        int64_t in_own = 0;
+        for (int64_t k = 0; k < nnz; ++k) in_own += ci[k] >= own_lo && ci[k] < own_hi;
+        if (getenv("G4S_DIST_MERGE") || 4 * in_own < nnz) { S.merged = true; own_hi = own_lo; }
+    }
+    S.allgather = allgather;
+    S.recv_cut.assign((size_t)world + 1, 0);
+    std::vector<int32_t> ref;                                       // packed mode: the referenced remote columns, ascending
+    if (allgather) {
+        for (int k = 0; k < world; ++k) S.pad = std::max(S.pad, off[(size_t)k + 1] - off[k]);
+        if (S.pad * world > INT32_MAX) return g4s::set_error(G4S_ERR_UNSUPPORTED, "all-gather exchange: world * longest slab exceeds the int32 column type");
+        S.n_ref = (int32_t)(S.pad * world);
+        for (int k = 0; k <= world; ++k) S.recv_cut[k] = S.pad * k;
+    } else {
+        for (int64_t k = 0; k < nnz; ++k)
+            if (ci[k] < own_lo || ci[k] >= own_hi) ref.push_back(ci[k]);
+        std::sort(ref.begin(), ref.end());
+        ref.erase(std::unique(ref.begin(), ref.end()), ref.end());
+        S.n_ref = (int32_t)ref.size();
+        // what this rank wants from every owner: ref is sorted, so owner k's columns are one segment
+        S.want.resize(ref.size());
+        for (int32_t i = 0; i < S.n_ref; ++i) {
+            const int k = loopback ? 0 : owner_of(off, ref[i]);
+            S.recv_cut[(size_t)k + 1]++;
+            S.want[i] = (int32_t)(ref[i] - off[k]);
+        }
+        for (int k = 0; k < world; ++k) S.recv_cut[(size_t)k + 1] += S.recv_cut[k];
+        if (!loopback && !S.merged && S.recv_cut[(size_t)rank + 1] != S.recv_cut[rank]) return g4s::set_error(G4S_ERR_INVALID, "internal: own columns among the remote ones");
+    }
+    S.orp.assign((size_t)m + 1, 0); S.rrp.assign((size_t)m + 1, 0);
+    S.oci.reserve((size_t)nnz); S.ova.reserve((size_t)nnz);
+    for (int32_t i = 0; i < m; ++i) {
+        for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
+            const int32_t c = ci[k];
+            if (c >= own_lo && c < own_hi) { S.oci.push_back((int32_t)(c - r0)); S.ova.push_back(va[k]); }
+            else {
+                int32_t rc;
+                if (allgather) { const int o = loopback ? 0 : owner_of(off, c); rc = (int32_t)(S.pad * o + (c - off[o])); }
+                else rc = (int32_t)(std::lower_bound(ref.begin(), ref.end(), c) - ref.begin());
+                S.rci.push_back(rc); S.rva.push_back(va[k]);
+            }
+        }
+        S.orp[(size_t)i + 1] = (int32_t)S.oci.size(); S.rrp[(size_t)i + 1] = (int32_t)S.rci.size();
+    }
+    return G4S_OK;
+}
+
+int check_partition(int32_t rank, int32_t world, const int64_t *row_offsets, int64_t n_cols)
+{
+    G4S_REQUIRE(world >= 1 && rank >= 0 && rank < world && row_offsets, "bad partition arguments");
+    for (int k = 0; k < world; ++k) G4S_REQUIRE(row_offsets[k] <= row_offsets[k + 1], "row_offsets must not decrease");
+    G4S_REQUIRE(row_offsets[0] == 0 && row_offsets[world] == n_cols, "square operator expected: x is partitioned like the rows (row_offsets[world] == n_cols)");
+    G4S_REQUIRE(n_cols <= INT32_MAX, "n_cols exceeds the int32 index type");
+    return G4S_OK;
+}
+
+template <typename T>
+T *dup_array(const std::vector<T> &v)
+{
+    T *p = static_cast<T *>(g4s_malloc(sizeof(T) * std::max<size_t>(v.size(), 1)));
+    if (p && !v.empty()) std::memcpy(p, v.data(), sizeof(T) * v.size());
+    return p;
+}
+
 } // namespace
+
+// Equal-work contiguous row partition: BIN::set_rows_offset (mm/inc/BIN.h:101-122) — prefix-sum the per-row work, average share
+// avg = ceil(total / parts), boundary t = lower_bound(prefix, avg·t); the last boundary is `rows`. The reference splits rows over OpenMP
+// threads with work = flop per row; here the same rule splits rows over GPUs. Host-side set-up logic (no GPU needed).
+G4S_API g4s_status g4s_row_partition(int32_t rows, const int32_t *rowptr, const int64_t *row_work, int64_t row_weight, int32_t parts,
+                                     int64_t *row_offsets, unsigned flags)
+{
+    G4S_REQUIRE(rows >= 0 && parts >= 1 && row_offsets && (rowptr || row_work || rows == 0), "bad argument");
+    try {
+        std::vector<int64_t> prefix((size_t)rows + 1, 0);
+        if (row_work) {
+            for (int32_t i = 0; i < rows; ++i) { G4S_REQUIRE(row_work[i] >= 0, "negative row work"); prefix[(size_t)i + 1] = prefix[i] + row_work[i]; }
+        } else if (rows) {
+            std::vector<int32_t> rp((size_t)rows + 1);
+            if (flags & G4S_DEVICE_POINTERS) G4S_HIP_TRY(hipMemcpy(rp.data(), rowptr, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost));
+            else std::copy(rowptr, rowptr + rows + 1, rp.begin());
+            for (int32_t i = 0; i < rows; ++i) {
+                G4S_REQUIRE(rp[(size_t)i + 1] >= rp[i], "rowptr decreases");
+                prefix[(size_t)i + 1] = prefix[i] + (rp[(size_t)i + 1] - rp[i]) + row_weight;
+            }
+        }
+        const int64_t total = prefix[rows], avg = (total + parts - 1) / parts;
+        row_offsets[0] = 0;
+        for (int32_t t = 1; t <= parts; ++t)
+            row_offsets[t] = std::min<int64_t>(rows, std::lower_bound(prefix.begin(), prefix.end(), avg * t) - prefix.begin());
+        row_offsets[parts] = rows;                                  // BIN.h:120
+        for (int32_t t = 1; t <= parts; ++t) row_offsets[t] = std::max(row_offsets[t], row_offsets[t - 1]);
+    } catch (const std::bad_alloc &) {
+        return g4s::set_error(G4S_ERR_NOMEM, "host allocation failed");
+    }
+    return G4S_OK;
+}
+
+G4S_API g4s_status g4s_dist_split_rows(int32_t rank, int32_t world, const int64_t *row_offsets, int64_t n_cols,
+                                       const int32_t *rowptr, const int32_t *colids, const double *values, unsigned flags, g4s_dist_split *out)
+{
+    G4S_REQUIRE(out && rowptr, "NULL argument");
+    std::memset(out, 0, sizeof(*out));
+    G4S_REQUIRE(!(flags & G4S_DEVICE_POINTERS), "g4s_dist_split_rows works on host arrays");
+    G4S_TRY(check_partition(rank, world, row_offsets, n_cols));
+    const bool loopback = (flags & G4S_DIST_LOOPBACK) != 0;
+    G4S_REQUIRE(!loopback || world == 1, "G4S_DIST_LOOPBACK is a single-rank rehearsal mode");
+    try {
+        const std::vector<int64_t> off(row_offsets, row_offsets + world + 1);
+        const int32_t m = (int32_t)(off[(size_t)rank + 1] - off[rank]);
+        Split S;
+        G4S_TRY(split_rows(rank, world, off, n_cols, m, rowptr, colids, values, loopback, (flags & G4S_DIST_ALLGATHER) != 0, S));
+        out->local_rows = m; out->n_ref = S.n_ref; out->merged = S.merged; out->allgather = S.allgather; out->pad = S.pad;
+        out->nnz_own = (int64_t)S.oci.size(); out->nnz_rem = (int64_t)S.rci.size();
+        out->own_rowptr = dup_array(S.orp); out->own_colids = dup_array(S.oci); out->own_values = dup_array(S.ova);
+        out->rem_rowptr = dup_array(S.rrp); out->rem_colids = dup_array(S.rci); out->rem_values = dup_array(S.rva);
+        out->want = dup_array(S.want); out->recv_cut = dup_array(S.recv_cut);
+        if (!out->own_rowptr || !out->own_colids || !out->own_values || !out->rem_rowptr || !out->rem_colids || !out->rem_values || !out->want || !out->recv_cut) {
+            g4s_dist_split_free(out);
+            return g4s::set_error(G4S_ERR_NOMEM, "host allocation failed");
+        }
+    } catch (const std::bad_alloc &) {
+        g4s_dist_split_free(out);
+        return g4s::set_error(G4S_ERR_NOMEM, "host allocation failed");
+    }
+    return G4S_OK;
+}
+
+G4S_API void g4s_dist_split_free(g4s_dist_split *s)
+{
+    if (!s) return;
+    g4s_free(s->own_rowptr); g4s_free(s->own_colids); g4s_free(s->own_values);
+    g4s_free(s->rem_rowptr); g4s_free(s->rem_colids); g4s_free(s->rem_values);
+    g4s_free(s->want); g4s_free(s->recv_cut);
+    std::memset(s, 0, sizeof(*s));
+}
 
 G4S_API g4s_status g4s_spmv_dist_create(g4s_spmv_dist_t *out, int32_t rank, int32_t world, const int64_t *row_offsets, int64_t n_cols,
                                         const int32_t *rowptr, const int32_t *colids, const double *values, unsigned flags)
 {
     G4S_REQUIRE(out, "out is NULL");
     *out = nullptr;
-    G4S_REQUIRE(world >= 1 && rank >= 0 && rank < world && row_offsets && rowptr, "bad partition arguments");
-    for (int k = 0; k < world; ++k) G4S_REQUIRE(row_offsets[k] <= row_offsets[k + 1], "row_offsets must not decrease");
-    G4S_REQUIRE(row_offsets[0] == 0 && row_offsets[world] == n_cols, "square operator expected: x is partitioned like the rows (row_offsets[world] == n_cols)");
-    G4S_REQUIRE(n_cols <= INT32_MAX, "n_cols exceeds the int32 index type");
+    G4S_REQUIRE(rowptr, "rowptr is NULL");
+    G4S_TRY(check_partition(rank, world, row_offsets, n_cols));
     const int64_t r0 = row_offsets[rank], r1 = row_offsets[rank + 1];
     const int32_t m = (int32_t)(r1 - r0);
     auto h = new (std::nothrow) g4s_spmv_dist_s();
     if (!h) return g4s::set_error(G4S_ERR_NOMEM, "host allocation failed");
     auto fail = [&](int code) { dist_release(h); return code; };
-    h->rank = rank; h->world = world; h->local_rows = m;
-    h->off.assign(row_offsets, row_offsets + world + 1);
-    h->loopback = (flags & G4S_DIST_LOOPBACK) != 0;
-    if (h->loopback && world != 1) return fail(g4s::set_error(G4S_ERR_INVALID, "G4S_DIST_LOOPBACK is a single-rank rehearsal mode"));
+    try {
+        h->rank = rank; h->world = world; h->local_rows = m;
+        h->off.assign(row_offsets, row_offsets + world + 1);
+        h->loopback = (flags & G4S_DIST_LOOPBACK) != 0;
+        if (h->loopback && world != 1) return fail(g4s::set_error(G4S_ERR_INVALID, "G4S_DIST_LOOPBACK is a single-rank rehearsal mode"));
+        const bool allgather = (flags & G4S_DIST_ALLGATHER) != 0 || (getenv("G4S_DIST_EXCHANGE") && !strcmp(getenv("G4S_DIST_EXCHANGE"), "allgather"));
 
-    // ---- the local rows on the host (set-up runs once per matrix)
-    std::vector<int32_t> rp((size_t)m + 1);
-    const bool dp = (flags & G4S_DEVICE_POINTERS) != 0;
-    if (dp) { if (hipMemcpy(rp.data(), rowptr, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost) != hipSuccess) return fail(g4s::set_error(G4S_ERR_HIP, "D2H copy of rowptr failed")); }
-    else std::copy(rowptr, rowptr + m + 1, rp.begin());
-    if (rp[0] != 0) return fail(g4s::set_error(G4S_ERR_INVALID, "rowptr[0] != 0"));
-    const int64_t nnz = rp[m];
-    G4S_REQUIRE(nnz == 0 || (colids && values), "colids/values NULL with nnz > 0");
-    std::vector<int32_t> ci((size_t)nnz);
-    std::vector<double> va((size_t)nnz);
-    if (nnz) {
-        if (dp) {
-            if (hipMemcpy(ci.data(), colids, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost) != hipSuccess ||
-                hipMemcpy(va.data(), values, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost) != hipSuccess)
-                return fail(g4s::set_error(G4S_ERR_HIP, "D2H copy of the matrix failed"));
-        } else { std::copy(colids, colids + nnz, ci.begin()); std::copy(values, values + nnz, va.begin()); }
-    }
-    // own range of columns (loopback: only the first half of the slab counts as own, the rest travels rank 0 → rank 0 through RCCL).
-    // Merged form: when fewer than a quarter of the entries sit in own columns (a power-law graph cut into row slabs: ≈10 %), two products
-    // cost more than the overlap buys (tools/dist_probe.py: 0.12–0.16 ms against 0.07–0.09 ms for one product on an eighth of configs[1]),
-    // so the own columns are renumbered into the compact x like everybody else's and filled by a local gather instead of a message.
-    int64_t own_lo = r0, own_hi = h->loopback ? r0 + (r1 - r0) / 2 : r1;
-    if (!h->loopback && world > 1 && !getenv("G4S_DIST_NO_MERGE")) {
-        int64_t in_own = 0;
-        for (int64_t k = 0; k < nnz; ++k) in_own += ci[k] >= own_lo && ci[k] < own_hi;
-        if (getenv("G4S_DIST_MERGE") || 4 * in_own < nnz) { h->merged = true; own_hi = own_lo; }
-    }
-    std::vector<int32_t> ref;                                       // referenced remote columns
-    for (int64_t k = 0; k < nnz; ++k) {
-        const int32_t c = ci[k];
-        if (c < 0 || c >= n_cols) return fail(g4s::set_error(G4S_ERR_INVALID, "a column index is outside [0, n_cols)"));
-        if (c < own_lo || c >= own_hi) ref.push_back(c);
-    }
-    std::sort(ref.begin(), ref.end());
-    ref.erase(std::unique(ref.begin(), ref.end()), ref.end());
-    h->n_ref = (int32_t)ref.size();
-    std::vector<int32_t> orp((size_t)m + 1, 0), rrp((size_t)m + 1, 0), oci, rci;
-    std::vector<double> ova, rva;
-    oci.reserve((size_t)nnz); ova.reserve((size_t)nnz);
-    for (int32_t i = 0; i < m; ++i) {
-        for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
-            const int32_t c = ci[k];
-            if (c >= own_lo && c < own_hi) { oci.push_back((int32_t)(c - r0)); ova.push_back(va[k]); }
-            else { rci.push_back((int32_t)(std::lower_bound(ref.begin(), ref.end(), c) - ref.begin())); rva.push_back(va[k]); }
+        // ---- the local rows on the host (set-up runs once per matrix)
+        std::vector<int32_t> rp((size_t)m + 1);
+        const bool dp = (flags & G4S_DEVICE_POINTERS) != 0;
+        if (dp) { if (hipMemcpy(rp.data(), rowptr, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost) != hipSuccess) return fail(g4s::set_error(G4S_ERR_HIP, "D2H copy of rowptr failed")); }
+        else std::copy(rowptr, rowptr + m + 1, rp.begin());
+        const int64_t nnz = rp[m];
+        if (nnz < 0) return fail(g4s::set_error(G4S_ERR_INVALID, "rowptr[rows] is negative"));
+        if (nnz && !(colids && values)) return fail(g4s::set_error(G4S_ERR_INVALID, "colids/values NULL with nnz > 0"));
+        std::vector<int32_t> ci((size_t)nnz);
+        std::vector<double> va((size_t)nnz);
+        if (nnz) {
+            if (dp) {
+                if (hipMemcpy(ci.data(), colids, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost) != hipSuccess ||
+                    hipMemcpy(va.data(), values, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost) != hipSuccess)
+                    return fail(g4s::set_error(G4S_ERR_HIP, "D2H copy of the matrix failed"));
+            } else { std::copy(colids, colids + nnz, ci.begin()); std::copy(values, values + nnz, va.begin()); }
         }
-        orp[i + 1] = (int32_t)oci.size(); rrp[i + 1] = (int32_t)rci.size();
+        Split S;
+        int st = split_rows(rank, world, h->off, n_cols, m, rp.data(), ci.data(), va.data(), h->loopback, allgather, S);
+        if (st != G4S_OK) return fail(st);
+        h->merged = S.merged; h->allgather = S.allgather; h->pad = S.pad; h->n_ref = S.n_ref;
+        h->nnz_own = (int64_t)S.oci.size(); h->nnz_rem = (int64_t)S.rci.size();
+        h->recv_cut = S.recv_cut;
+        const unsigned path_flags = flags & (G4S_SPMV_NO_NT | G4S_SPMV_BLOCKED | G4S_SPMV_STREAM);
+        st = g4s_csr_create(&h->A_own, m, (int32_t)(r1 - r0), h->nnz_own, S.orp.data(), S.oci.data(), S.ova.data(), G4S_HOST_POINTERS | path_flags);
+        if (st != G4S_OK) return fail(st);
+        st = g4s_csr_create(&h->A_rem, m, std::max(h->n_ref, 1), h->nnz_rem, S.rrp.data(), S.rci.data(), S.rva.data(), G4S_HOST_POINTERS | path_flags);
+        if (st != G4S_OK) return fail(st);
+        h->give_cut.assign((size_t)world + 1, 0);
+        h->give_set.assign((size_t)world, 0);
+        if (g4s::device_malloc((void **)&h->d_want, sizeof(int32_t) * std::max<size_t>(S.want.size(), 1)) != hipSuccess ||
+            g4s::device_malloc((void **)&h->d_xrem, sizeof(double) * (size_t)std::max(h->n_ref, 1)) != hipSuccess)
+            return fail(g4s::set_error(G4S_ERR_NOMEM, "device allocation failed"));
+        if (!S.want.empty() && hipMemcpy(h->d_want, S.want.data(), sizeof(int32_t) * S.want.size(), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(g4s::set_error(G4S_ERR_HIP, "H2D copy failed"));
+        if (hipMemset(h->d_xrem, 0, sizeof(double) * (size_t)std::max(h->n_ref, 1)) != hipSuccess) return fail(g4s::set_error(G4S_ERR_HIP, "memset failed"));
+        if (hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming) != hipSuccess)
+            return fail(g4s::set_error(G4S_ERR_HIP, "stream / event creation failed"));
+        if (h->allgather) {                                        // nothing to wire: every rank sends its slab, every rank knows where each slab lands
+            std::fill(h->give_set.begin(), h->give_set.end(), 1);
+            h->give_cut[(size_t)world] = h->pad;                   // the one send segment: this rank's slot of the gathered vector, for every peer alike
+        } else if (world == 1 && !h->loopback) h->give_set[0] = 1;  // nothing to exchange
+    } catch (const std::bad_alloc &) {
+        return fail(g4s::set_error(G4S_ERR_NOMEM, "host allocation failed"));
     }
-    h->nnz_own = (int64_t)oci.size(); h->nnz_rem = (int64_t)rci.size();
-    const unsigned path_flags = flags & (G4S_SPMV_NO_NT | G4S_SPMV_BLOCKED | G4S_SPMV_STREAM);
-    int st = g4s_csr_create(&h->A_own, m, (int32_t)(r1 - r0), h->nnz_own, orp.data(), oci.data(), ova.data(), G4S_HOST_POINTERS | path_flags);
-    if (st != G4S_OK) return fail(st);
-    st = g4s_csr_create(&h->A_rem, m, std::max(h->n_ref, 1), h->nnz_rem, rrp.data(), rci.data(), rva.data(), G4S_HOST_POINTERS | path_flags);
-    if (st != G4S_OK) return fail(st);
-    // what this rank wants from every owner: ref is sorted, so owner k's columns are one segment
-    h->recv_cut.assign((size_t)world + 1, 0);
-    std::vector<int32_t> want((size_t)h->n_ref);
-    for (int32_t i = 0; i < h->n_ref; ++i) {
-        const int k = h->loopback ? 0 : owner_of(h->off, ref[i]);
-        h->recv_cut[(size_t)k + 1]++;
-        want[i] = (int32_t)(ref[i] - h->off[k]);
-    }
-    for (int k = 0; k < world; ++k) h->recv_cut[(size_t)k + 1] += h->recv_cut[k];
-    if (!h->loopback && !h->merged && h->recv_cut[(size_t)rank + 1] != h->recv_cut[rank]) return fail(g4s::set_error(G4S_ERR_INVALID, "internal: own columns among the remote ones"));
-    h->give_cut.assign((size_t)world + 1, 0);
-    h->give_set.assign((size_t)world, 0);
-    if (g4s::device_malloc((void **)&h->d_want, sizeof(int32_t) * (size_t)std::max(h->n_ref, 1)) != hipSuccess ||
-        g4s::device_malloc((void **)&h->d_xrem, sizeof(double) * (size_t)std::max(h->n_ref, 1)) != hipSuccess)
-        return fail(g4s::set_error(G4S_ERR_NOMEM, "device allocation failed"));
-    if (h->n_ref && hipMemcpy(h->d_want, want.data(), sizeof(int32_t) * (size_t)h->n_ref, hipMemcpyHostToDevice) != hipSuccess)
-        return fail(g4s::set_error(G4S_ERR_HIP, "H2D copy failed"));
-    if (hipMemset(h->d_xrem, 0, sizeof(double) * (size_t)std::max(h->n_ref, 1)) != hipSuccess) return fail(g4s::set_error(G4S_ERR_HIP, "memset failed"));
-    if (hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming) != hipSuccess)
-        return fail(g4s::set_error(G4S_ERR_HIP, "stream / event creation failed"));
-    if (world == 1 && !h->loopback) h->give_set[0] = 1;            // nothing to exchange
     *out = h;
     return G4S_OK;
 }
@@ -230,9 +381,14 @@ G4S_API g4s_status g4s_spmv_dist_get_info(g4s_spmv_dist_t h, g4s_spmv_dist_info 
     G4S_REQUIRE(h && info, "NULL argument");
     info->rank = h->rank; info->world = h->world; info->local_rows = h->local_rows; info->n_ref = h->n_ref;
     info->nnz_own = h->nnz_own; info->nnz_rem = h->nnz_rem;
-    info->recv_bytes = 8 * (h->recv_cut[h->world] - (h->merged ? h->recv_cut[(size_t)h->rank + 1] - h->recv_cut[h->rank] : 0));
-    info->reserved = h->merged ? 1 : 0;
-    info->send_bytes = 8 * h->give_cut[h->world];
+    if (h->allgather) {                                             // every slab, padded, from every other rank; this rank's slot to every other rank
+        info->recv_bytes = 8 * h->pad * (h->world - 1);
+        info->send_bytes = 8 * h->pad * (h->world - 1);
+    } else {
+        info->recv_bytes = 8 * (h->recv_cut[h->world] - (h->merged ? h->recv_cut[(size_t)h->rank + 1] - h->recv_cut[h->rank] : 0));
+        info->send_bytes = 8 * h->give_cut[h->world];
+    }
+    info->reserved = (h->merged ? 1 : 0) | (h->allgather ? 2 : 0);
     g4s_csr_info ci;
     G4S_TRY(g4s_csr_get_info(h->A_own, &ci)); info->own_path = ci.spmv_path;
     G4S_TRY(g4s_csr_get_info(h->A_rem, &ci)); info->rem_path = ci.spmv_path;
@@ -254,6 +410,7 @@ G4S_API g4s_status g4s_spmv_dist_want(g4s_spmv_dist_t h, int32_t peer, int64_t *
 G4S_API g4s_status g4s_spmv_dist_set_give(g4s_spmv_dist_t h, int32_t peer, int64_t count, const int32_t *idx, unsigned flags)
 {
     G4S_REQUIRE(h && peer >= 0 && peer < h->world && count >= 0 && (idx || count == 0), "bad argument");
+    G4S_REQUIRE(!h->allgather, "the all-gather exchange has no give lists");
     G4S_REQUIRE(!h->d_send, "the give lists are final once a product has run");
     std::vector<int32_t> list((size_t)count);
     if (count) {
@@ -282,43 +439,98 @@ G4S_API g4s_status g4s_spmv_dist_set_give(g4s_spmv_dist_t h, int32_t peer, int64
     return G4S_OK;
 }
 
+namespace {
+
+// Waits for `stream` with a deadline instead of an unbounded hipStreamSynchronize: a peer that failed before entering the same
+// collective would otherwise leave this rank blocked for ever (G4S_DIST_TIMEOUT_S, default 120). Also surfaces asynchronous RCCL errors.
+int wait_stream(hipStream_t stream, ncclComm_t comm, const char *what)
+{
+    const char *e = getenv("G4S_DIST_TIMEOUT_S");
+    const double limit = e ? atof(e) : 120.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(stream);
+        if (q == hipSuccess) return G4S_OK;
+        if (q != hipErrorNotReady) return g4s::set_error(G4S_ERR_HIP, "%s: %s", what, hipGetErrorString(q));
+        if (comm && g_rccl.CommGetAsyncError) {
+            ncclResult_t ar = ncclSuccess;
+            if (g_rccl.CommGetAsyncError(comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress)
+                return g4s::set_error(G4S_ERR_HIP, "%s: RCCL reports %s", what, g_rccl.GetErrorString(ar));
+        }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
+            return g4s::set_error(G4S_ERR_HIP, "%s: no completion within %.0f s (a peer that never entered the exchange?)", what, limit);
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+}
+
+// One grouped point-to-point round. ncclGroupEnd is ALWAYS called once ncclGroupStart has succeeded — returning from inside an open group
+// would leave the thread's group open and every later RCCL call of the process (the host framework's too) queued behind it.
+template <typename Body>
+int rccl_group(Body body, const char *what)
+{
+    ncclResult_t r = g_rccl.GroupStart();
+    if (r != ncclSuccess) return g4s::set_error(G4S_ERR_HIP, "%s: ncclGroupStart failed: %s", what, g_rccl.GetErrorString(r));
+    const ncclResult_t rb = body();
+    const ncclResult_t re = g_rccl.GroupEnd();
+    if (rb != ncclSuccess) return g4s::set_error(G4S_ERR_HIP, "%s failed: %s", what, g_rccl.GetErrorString(rb));
+    if (re != ncclSuccess) return g4s::set_error(G4S_ERR_HIP, "%s: ncclGroupEnd failed: %s", what, g_rccl.GetErrorString(re));
+    return G4S_OK;
+}
+
+struct DevFree {
+    void *p = nullptr;
+    ~DevFree() { if (p) (void)hipFree(p); }
+};
+
+} // namespace
+
 G4S_API g4s_status g4s_spmv_dist_connect_rccl(g4s_spmv_dist_t h, void *comm)
 {
     G4S_REQUIRE(h && comm, "NULL argument");
     G4S_TRY(rccl_load());
     h->comm = reinterpret_cast<ncclComm_t>(comm);
+    if (h->allgather) return G4S_OK;                               // no lists to exchange: the collective itself is the wiring
+    // a send buffer sized from earlier give lists (g4s_spmv_dist_buffers, or a product that ran before the wiring) would be too small for the new ones
+    if (h->d_send) { (void)hipFree(h->d_send); h->d_send = nullptr; }
     const int W = h->world;
     // 1. how many entries does every peer want from me? one 8-byte exchange per pair
     std::vector<long long> want_n((size_t)W), give_n((size_t)W, 0);
     for (int k = 0; k < W; ++k) want_n[k] = h->recv_cut[(size_t)k + 1] - h->recv_cut[k];
-    long long *d_cnt = nullptr;
-    G4S_HIP_TRY(g4s::device_malloc((void **)&d_cnt, sizeof(long long) * 2 * (size_t)W));
+    DevFree cnt;
+    G4S_HIP_TRY(g4s::device_malloc(&cnt.p, sizeof(long long) * 2 * (size_t)W));
+    long long *d_cnt = static_cast<long long *>(cnt.p);
     G4S_HIP_TRY(hipMemcpy(d_cnt, want_n.data(), sizeof(long long) * (size_t)W, hipMemcpyHostToDevice));
-    G4S_RCCL_TRY(g_rccl.GroupStart());
-    for (int k = 0; k < W; ++k) {
-        if (k == h->rank && !h->loopback) continue;
-        G4S_RCCL_TRY(g_rccl.Send(d_cnt + k, 1, ncclInt64, k, h->comm, h->cstream));
-        G4S_RCCL_TRY(g_rccl.Recv(d_cnt + W + k, 1, ncclInt64, k, h->comm, h->cstream));
-    }
-    G4S_RCCL_TRY(g_rccl.GroupEnd());
-    G4S_HIP_TRY(hipStreamSynchronize(h->cstream));
+    G4S_TRY(rccl_group([&]() {
+        for (int k = 0; k < W; ++k) {
+            if (k == h->rank && !h->loopback) continue;
+            ncclResult_t r = g_rccl.Send(d_cnt + k, 1, ncclInt64, k, h->comm, h->cstream);
+            if (r == ncclSuccess) r = g_rccl.Recv(d_cnt + W + k, 1, ncclInt64, k, h->comm, h->cstream);
+            if (r != ncclSuccess) return r;
+        }
+        return ncclSuccess;
+    }, "exchange of the want counts"));
+    G4S_TRY(wait_stream(h->cstream, h->comm, "exchange of the want counts"));
     G4S_HIP_TRY(hipMemcpy(give_n.data(), d_cnt + W, sizeof(long long) * (size_t)W, hipMemcpyDeviceToHost));
-    (void)hipFree(d_cnt);
     if (!h->loopback) give_n[h->rank] = 0;
+    const int64_t slab = h->off[(size_t)h->rank + 1] - h->off[h->rank];
+    for (int k = 0; k < W; ++k) G4S_REQUIRE(give_n[k] >= 0 && give_n[k] <= slab, "a peer asks for more entries than this slab holds");
     // 2. the index lists themselves, received straight into the give list in peer order
     std::vector<int64_t> cut((size_t)W + 1, 0);
     for (int k = 0; k < W; ++k) cut[(size_t)k + 1] = cut[k] + give_n[k];
     (void)hipFree(h->d_give);
     h->d_give = nullptr;
     G4S_HIP_TRY(g4s::device_malloc((void **)&h->d_give, sizeof(int32_t) * (size_t)std::max<int64_t>(cut[W], 1)));
-    G4S_RCCL_TRY(g_rccl.GroupStart());
-    for (int k = 0; k < W; ++k) {
-        if (k == h->rank && !h->loopback) continue;
-        if (want_n[k]) G4S_RCCL_TRY(g_rccl.Send(h->d_want + h->recv_cut[k], (size_t)want_n[k], ncclInt32, k, h->comm, h->cstream));
-        if (give_n[k]) G4S_RCCL_TRY(g_rccl.Recv(h->d_give + cut[k], (size_t)give_n[k], ncclInt32, k, h->comm, h->cstream));
-    }
-    G4S_RCCL_TRY(g_rccl.GroupEnd());
-    G4S_HIP_TRY(hipStreamSynchronize(h->cstream));
+    G4S_TRY(rccl_group([&]() {
+        for (int k = 0; k < W; ++k) {
+            if (k == h->rank && !h->loopback) continue;
+            ncclResult_t r = ncclSuccess;
+            if (want_n[k]) r = g_rccl.Send(h->d_want + h->recv_cut[k], (size_t)want_n[k], ncclInt32, k, h->comm, h->cstream);
+            if (r == ncclSuccess && give_n[k]) r = g_rccl.Recv(h->d_give + cut[k], (size_t)give_n[k], ncclInt32, k, h->comm, h->cstream);
+            if (r != ncclSuccess) return r;
+        }
+        return ncclSuccess;
+    }, "exchange of the want lists"));
+    G4S_TRY(wait_stream(h->cstream, h->comm, "exchange of the want lists"));
     h->give_cut = cut;
     std::fill(h->give_set.begin(), h->give_set.end(), 1);
     return G4S_OK;
@@ -327,6 +539,15 @@ G4S_API g4s_status g4s_spmv_dist_connect_rccl(g4s_spmv_dist_t h, void *comm)
 G4S_API g4s_status g4s_spmv_dist_buffers(g4s_spmv_dist_t h, double **send_dev, const int64_t **send_cut, double **recv_dev, const int64_t **recv_cut)
 {
     G4S_REQUIRE(h, "NULL handle");
+    if (h->allgather) {
+        // send = this rank's slot of the gathered vector (pad entries, the same for every peer: send_cut = {0, …, 0, pad});
+        // recv = the gathered vector, slot k = [k·pad, (k+1)·pad) from rank k
+        if (send_dev) *send_dev = h->d_xrem + h->pad * h->rank;
+        if (send_cut) *send_cut = h->give_cut.data();
+        if (recv_dev) *recv_dev = h->d_xrem;
+        if (recv_cut) *recv_cut = h->recv_cut.data();
+        return G4S_OK;
+    }
     if (!h->d_send) G4S_HIP_TRY(g4s::device_malloc((void **)&h->d_send, sizeof(double) * (size_t)std::max<int64_t>(h->give_cut[h->world], 1)));
     if (send_dev) *send_dev = h->d_send;
     if (send_cut) *send_cut = h->give_cut.data();
@@ -343,6 +564,21 @@ G4S_API g4s_status g4s_spmv_dist_begin(g4s_spmv_dist_t h, const double *x_local_
         if (!(h->give_set[k] || (k == h->rank && !h->loopback)))
             return g4s::set_error(G4S_ERR_INVALID, "g4s_spmv_dist_begin: the give list of peer %d is not set (g4s_spmv_dist_connect_rccl or g4s_spmv_dist_set_give)", k);
     hipStream_t s = g4s::as_stream(stream);
+    h->exchange_posted = false;
+    if (h->allgather) {
+        // own slab into its slot of the gathered vector, then ONE in-place all-gather on the side stream while the own-column product runs
+        const int64_t slab = h->off[(size_t)h->rank + 1] - h->off[h->rank];
+        if (slab) G4S_HIP_TRY(hipMemcpyAsync(h->d_xrem + h->pad * h->rank, x_local_dev, sizeof(double) * (size_t)slab, hipMemcpyDeviceToDevice, s));
+        if (h->comm && (h->world > 1 || h->loopback)) {
+            G4S_HIP_TRY(hipEventRecord(h->ev_packed, s));
+            G4S_HIP_TRY(hipStreamWaitEvent(h->cstream, h->ev_packed, 0));
+            G4S_RCCL_TRY(g_rccl.AllGather(h->d_xrem + h->pad * h->rank, h->d_xrem, (size_t)h->pad, ncclDouble, h->comm, h->cstream));
+            G4S_HIP_TRY(hipEventRecord(h->ev_done, h->cstream));
+            h->exchange_posted = true;
+        }
+        if (h->merged) return G4S_OK;
+        return g4s_spmv(h->A_own, x_local_dev, y_local_dev, 1.0, 0.0, stream);
+    }
     G4S_TRY(g4s_spmv_dist_buffers(h, nullptr, nullptr, nullptr, nullptr));
     const int64_t n_send = h->give_cut[h->world];
     if (n_send) {
@@ -350,18 +586,20 @@ G4S_API g4s_status g4s_spmv_dist_begin(g4s_spmv_dist_t h, const double *x_local_
         hipLaunchKernelGGL(dist_pack_kernel, dim3(grid), dim3(256), 0, s, n_send, h->d_give, x_local_dev, h->d_send);
         G4S_HIP_TRY(hipGetLastError());
     }
-    h->exchange_posted = false;
     if (h->comm && (n_send || h->n_ref)) {
         G4S_HIP_TRY(hipEventRecord(h->ev_packed, s));
         G4S_HIP_TRY(hipStreamWaitEvent(h->cstream, h->ev_packed, 0));
-        G4S_RCCL_TRY(g_rccl.GroupStart());
-        for (int k = 0; k < h->world; ++k) {
-            if (k == h->rank && !h->loopback) continue;
-            const int64_t ns = h->give_cut[(size_t)k + 1] - h->give_cut[k], nr = h->recv_cut[(size_t)k + 1] - h->recv_cut[k];
-            if (ns) G4S_RCCL_TRY(g_rccl.Send(h->d_send + h->give_cut[k], (size_t)ns, ncclDouble, k, h->comm, h->cstream));
-            if (nr) G4S_RCCL_TRY(g_rccl.Recv(h->d_xrem + h->recv_cut[k], (size_t)nr, ncclDouble, k, h->comm, h->cstream));
-        }
-        G4S_RCCL_TRY(g_rccl.GroupEnd());
+        G4S_TRY(rccl_group([&]() {
+            for (int k = 0; k < h->world; ++k) {
+                if (k == h->rank && !h->loopback) continue;
+                const int64_t ns = h->give_cut[(size_t)k + 1] - h->give_cut[k], nr = h->recv_cut[(size_t)k + 1] - h->recv_cut[k];
+                ncclResult_t r = ncclSuccess;
+                if (ns) r = g_rccl.Send(h->d_send + h->give_cut[k], (size_t)ns, ncclDouble, k, h->comm, h->cstream);
+                if (r == ncclSuccess && nr) r = g_rccl.Recv(h->d_xrem + h->recv_cut[k], (size_t)nr, ncclDouble, k, h->comm, h->cstream);
+                if (r != ncclSuccess) return r;
+            }
+            return ncclSuccess;
+        }, "exchange of the x entries"));
         G4S_HIP_TRY(hipEventRecord(h->ev_done, h->cstream));
         h->exchange_posted = true;
     }
@@ -392,7 +630,7 @@ G4S_API g4s_status g4s_spmv_dist_finish(g4s_spmv_dist_t h, double *y_local_dev, 
 G4S_API g4s_status g4s_spmv_dist_apply(g4s_spmv_dist_t h, const double *x_local_dev, double *y_local_dev, void *stream)
 {
     G4S_REQUIRE(h, "NULL handle");
-    if ((h->world > 1 || h->loopback) && !h->comm && (h->n_ref || h->give_cut[h->world]))
+    if ((h->world > 1 || (h->loopback && !h->allgather)) && !h->comm && (h->n_ref || h->give_cut[h->world]))
         return g4s::set_error(G4S_ERR_INVALID, "g4s_spmv_dist_apply needs g4s_spmv_dist_connect_rccl; with another transport use _begin / _buffers / _finish");
     G4S_TRY(g4s_spmv_dist_begin(h, x_local_dev, y_local_dev, stream));
     return g4s_spmv_dist_finish(h, y_local_dev, stream);

@@ -127,16 +127,46 @@ g4s_status g4s_spmv_csr_i32_f64(int32_t rows, int32_t cols, const int32_t *rowpt
  * a rank's rows actually reference travel (halo planes for stencils), each peer pair over its own xGMI link (ncclSend/ncclRecv in one
  * group), while the own-column part of the product runs. */
 #define G4S_DIST_LOOPBACK 32u   /* single-rank rehearsal: half of the own slab is treated as remote and travels rank 0 → rank 0 through RCCL */
+#define G4S_DIST_ALLGATHER 64u  /* exchange = ONE in-place ncclAllGather of the whole vector (every slab padded to the longest; north_star's
+                                 * "RCCL all-gather of the dense vector") instead of packed point-to-point messages: more bytes, no index
+                                 * lists, nothing to wire. Also selected by G4S_DIST_EXCHANGE=allgather in the environment. */
+
+/* Equal-work contiguous row partition — BIN::set_rows_offset, mm/inc/BIN.h:101-122: prefix-sum the per-row work, average share
+ * avg = ceil(total / parts), boundary t = lower_bound(prefix, avg·t), last boundary = rows. The reference splits rows over threads (work =
+ * flop per row); the same rule gives g4s_spmv_dist_create its row_offsets. work_i = row_work[i] when row_work is given (host array, rows
+ * entries — any cost model the caller has), else (rowptr[i+1] − rowptr[i]) + row_weight (bench.py: row_weight = 1). row_offsets: parts+1
+ * entries, host memory. flags: G4S_HOST_POINTERS / G4S_DEVICE_POINTERS for rowptr. Host-side set-up logic: runs without a GPU. */
+g4s_status g4s_row_partition(int32_t rows, const int32_t *rowptr, const int64_t *row_work, int64_t row_weight, int32_t parts,
+                             int64_t *row_offsets, unsigned flags);
+
+/* One rank's rows cut into the own-column part (columns renumbered to the own slab) and the remote-column part (columns renumbered into
+ * the remote x: packed mode — the referenced columns only, ascending, segment [recv_cut[k], recv_cut[k+1]) from owner k, `want` = their
+ * indices local to the owner's slab; all-gather mode — k·pad + (c − row_offsets[k])). What g4s_spmv_dist_create does before it uploads;
+ * exported for hosts that bring their own transport or device set-up. Host arrays in, g4s_malloc'ed host arrays out (g4s_dist_split_free);
+ * needs no GPU. flags: G4S_DIST_ALLGATHER, G4S_DIST_LOOPBACK. merged = 1: fewer than a quarter of the entries sit in own columns and ALL
+ * columns went to the remote part (one product per step). */
+typedef struct g4s_dist_split {
+    int32_t local_rows, n_ref, merged, allgather;
+    int64_t nnz_own, nnz_rem, pad;
+    int32_t *own_rowptr, *own_colids; double *own_values;
+    int32_t *rem_rowptr, *rem_colids; double *rem_values;
+    int32_t *want;            /* packed mode: n_ref entries */
+    int64_t *recv_cut;        /* world+1 entries */
+} g4s_dist_split;
+g4s_status g4s_dist_split_rows(int32_t rank, int32_t world, const int64_t *row_offsets, int64_t n_cols,
+                               const int32_t *rowptr, const int32_t *colids, const double *values, unsigned flags, g4s_dist_split *out);
+void g4s_dist_split_free(g4s_dist_split *s);
+
 typedef struct g4s_spmv_dist_s *g4s_spmv_dist_t;
 typedef struct g4s_spmv_dist_info {
     int32_t rank, world, local_rows, n_ref;     /* n_ref: distinct remote columns this rank's rows reference (length of the compact remote x) */
     int64_t nnz_own, nnz_rem;                   /* nonzeros in own / remote columns */
     int64_t send_bytes, recv_bytes;             /* per product */
     int32_t own_path, rem_path;                 /* g4s_csr_info.spmv_path of the two parts */
-    int32_t connected, reserved;                /* connected: every peer's give list is known; reserved: 1 = merged form (own columns are few and live in
-                                                 * the compact x with the remote ones: one product per step instead of two) */
+    int32_t connected, reserved;                /* connected: every peer's give list is known; reserved: bit 0 = merged form (own columns are few and live in
+                                                 * the remote x with the remote ones: one product per step instead of two), bit 1 = all-gather exchange */
 } g4s_spmv_dist_info;
-/* flags: G4S_HOST_POINTERS / G4S_DEVICE_POINTERS for the three matrix arrays, the G4S_SPMV_* path flags, G4S_DIST_LOOPBACK.
+/* flags: G4S_HOST_POINTERS / G4S_DEVICE_POINTERS for the three matrix arrays, the G4S_SPMV_* path flags, G4S_DIST_LOOPBACK, G4S_DIST_ALLGATHER.
  * row_offsets: world+1 entries, host memory; row_offsets[world] == n_cols. Collective only in the sense that every rank creates its own. */
 g4s_status g4s_spmv_dist_create(g4s_spmv_dist_t *out, int32_t rank, int32_t world, const int64_t *row_offsets, int64_t n_cols,
                                 const int32_t *rowptr, const int32_t *colids, const double *values, unsigned flags);
@@ -156,6 +186,8 @@ g4s_status g4s_spmv_dist_apply(g4s_spmv_dist_t h, const double *x_local_dev, dou
  * send_dev[send_cut[k]..send_cut[k+1]) to peer k and receives peer k's entries into recv_dev[recv_cut[k]..recv_cut[k+1]) (both ordered after
  * _begin on `stream`); _finish adds the remote-column part. */
 g4s_status g4s_spmv_dist_begin(g4s_spmv_dist_t h, const double *x_local_dev, double *y_local_dev, void *stream);
+/* All-gather mode: send_dev = this rank's slot (pad entries) and goes to EVERY peer (send_cut = {0, …, 0, pad}); recv_dev = the gathered vector,
+ * slot k = [k·pad, (k+1)·pad) comes from rank k. */
 g4s_status g4s_spmv_dist_buffers(g4s_spmv_dist_t h, double **send_dev, const int64_t **send_cut, double **recv_dev, const int64_t **recv_cut);
 g4s_status g4s_spmv_dist_finish(g4s_spmv_dist_t h, double *y_local_dev, void *stream);
 /* RCCL communicator for hosts that have none (rank 0 makes the 128-byte id, every rank gets it by its own means and calls _create), and

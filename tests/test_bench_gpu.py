@@ -55,7 +55,7 @@ def test_bench_self_launch_two_ranks():
     assert d["n_gpus"] == 2 and d["value"] > 0 and "dist" in d["config"]["exchange"]
 
 
-@pytest.mark.parametrize("workload,exchange", [("rmat", "dist"), ("lap7", "dist"), ("rmat", "allgatherv"), ("rmat", "compact"), ("rmat", "allgather"), ("lap7", "needed")])
+@pytest.mark.parametrize("workload,exchange", [("rmat", "dist"), ("lap7", "dist"), ("rmat", "allgather"), ("lap7", "allgather")])
 def test_bench_two_ranks_rehearsal(workload, exchange):
     env = dict(os.environ, G4S_BENCH_SAME_DEVICE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_port()),
@@ -65,16 +65,17 @@ def test_bench_two_ranks_rehearsal(workload, exchange):
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["scaling"] == "strong"
-    assert "2 rank(s)" in d["config"]["partition"] and exchange in d["config"]["exchange"]
+    assert "2 rank(s)" in d["config"]["partition"] and ("packed ncclSend" if exchange == "dist" else "ncclAllGather") in d["config"]["exchange"]
 
 
 def test_bench_two_ranks_fall_back_together():
-    """One rank's g4s_spmv_dist set-up fails: every rank takes the torch.distributed all-gather (agreed through one all-reduce), none hangs."""
-    env = dict(os.environ, G4S_BENCH_SAME_DEVICE="1", G4S_DIST_FAIL="create:1")
+    """One rank's wiring of the packed exchange fails: every rank takes the library's all-gather exchange instead (agreed through one all-reduce;
+    it needs no wiring), none hangs."""
+    env = dict(os.environ, G4S_BENCH_SAME_DEVICE="1", G4S_DIST_FAIL="wire:1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_port()),
            "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--small", "--backend", "gloo", "--no-cpu-baseline"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     d = _last_json(r.stdout)
-    assert d["n_gpus"] == 2 and d["value"] > 0 and "allgather over torch.distributed" in d["config"]["exchange"]
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "ncclAllGather" in d["config"]["exchange"]
     assert "falls back" in r.stderr

@@ -46,6 +46,9 @@ def _worker(rank, world, port, kind, out_dir):
     if kind.endswith("+merged"):
         os.environ["G4S_DIST_MERGE"] = "1"                          # force the one-product form (own columns inside the compact x)
         kind = kind[:-7]
+    exchange = "packed"
+    if kind.endswith("+allgather"):
+        exchange, kind = "allgather", kind[:-10]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -57,7 +60,7 @@ def _worker(rank, world, port, kind, out_dir):
     offs = gdist.row_partition(rpt, world)
     r0, r1 = offs[rank], offs[rank + 1]
     lrp, lci, lva = gdist.slice_rows(rpt, torch.from_numpy(ci).cuda(), torch.from_numpy(va).cuda(), r0, r1)
-    D = gdist.DistSpMV(offs, rank, world, lrp, lci, lva, n)
+    D = gdist.DistSpMV(offs, rank, world, lrp, lci, lva, n, exchange=exchange)
     x = np.random.default_rng(3).uniform(-1, 1, n)
     xl = torch.from_numpy(x[r0:r1]).cuda()
     y1 = D(xl).clone()
@@ -71,11 +74,14 @@ def _worker(rank, world, port, kind, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,kind", [(1, "powerlaw"), (2, "powerlaw"), (3, "powerlaw"), (2, "lap7"), (3, "banded"), (3, "powerlaw+merged"), (2, "lap7+merged")])
+@pytest.mark.parametrize("world,kind", [(1, "powerlaw"), (2, "powerlaw"), (3, "powerlaw"), (2, "lap7"), (3, "banded"), (3, "powerlaw+merged"), (2, "lap7+merged"),
+                                        (2, "powerlaw+allgather"), (3, "lap7+allgather"), (3, "powerlaw+allgather+merged"), (1, "powerlaw+allgather")])
 def test_dist_spmv_capi_matches_oracle(tmp_path, oracle, world, kind):
     mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
     merged = kind.endswith("+merged")
     kind = kind[:-7] if merged else kind
+    allgather = kind.endswith("+allgather")
+    kind = kind[:-10] if allgather else kind
     rp, ci, va, n = _matrix(kind, oracle)
     x = np.random.default_rng(3).uniform(-1, 1, n)
     want = oracle.spmv(rp, ci, va, x)
@@ -86,11 +92,14 @@ def test_dist_spmv_capi_matches_oracle(tmp_path, oracle, world, kind):
     metas = [np.load(tmp_path / f"i{r}.npy") for r in range(world)]
     assert sum(int(m[3] + m[4]) for m in metas) == len(ci)          # every nonzero is in exactly one of the two parts
     assert sum(int(m[5]) for m in metas) == sum(int(m[6]) for m in metas)   # what is received was sent
-    assert all(int(m[7]) == (1 if merged else 0) for m in metas)
+    assert all(int(m[7]) == (1 if merged else 0) + (2 if allgather else 0) for m in metas)
     if merged:
         assert all(int(m[3]) == 0 for m in metas)                   # everything is in the one compact product
     if world == 1:
-        assert int(metas[0][2]) == 0 and int(metas[0][5]) == 0
+        assert int(metas[0][5]) == 0 and (allgather or int(metas[0][2]) == 0)
+    if allgather:
+        pad = max(int(m[1] - m[0]) for m in metas)
+        assert all(int(m[2]) == pad * world and int(m[5]) == 8 * pad * (world - 1) for m in metas)
     if kind == "lap7" and world == 2 and not merged:
         # the halo of a slab cut along z is one plane of 40·30 columns per neighbour
         assert [int(m[2]) for m in metas] == [1200, 1200]
@@ -113,6 +122,14 @@ def test_dist_spmv_rccl_loopback_single_rank(oracle):
     for _ in range(3):
         y = D(xl).cpu().numpy()
         assert np.all(np.abs(y - want) <= TOL * asum + 1e-300)
+    # the all-gather exchange through RCCL itself (one rank: the collective is a copy, the event hand-over and the side stream are real)
+    G = gdist.DistSpMV([0, n], 0, 1, torch.from_numpy(rp).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(va).cuda(), n, loopback=True, exchange="allgather")
+    gi = G.info()
+    assert gi["reserved"] == 2 and gi["nnz_rem"] > 0 and gi["n_ref"] == n
+    for _ in range(2):
+        y = G(xl).cpu().numpy()
+        assert np.all(np.abs(y - want) <= TOL * asum + 1e-300)
+    G.close()
     # the all-reduce the Krylov dots use
     t = torch.arange(8, dtype=torch.float64, device="cuda")
     D.allreduce_sum(t)

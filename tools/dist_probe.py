@@ -45,7 +45,6 @@ worst = 0.0
 for r in range(W):
     r0, r1 = offs[r], offs[r + 1]
     rp, ci, va = gdist.slice_rows(A.rowptr, A.colids, A.values, r0, r1)
-    D = gdist.DistSpMV.__new__(gdist.DistSpMV)           # the handle alone: no communicator, no peers on this box
     h = C.c_void_p()
     o = (C.c_int64 * (W + 1))(*offs)
     torch.cuda.synchronize()
