@@ -168,9 +168,9 @@ class DistSpMV:
     def _phase(self, name, fn):
         err = None
         try:
-            if os.environ.get("G4S_DIST_FAIL") == f"{name}:{self.rank}":      # test hook: this phase "fails" on this rank
-                raise RuntimeError("G4S_DIST_FAIL")
             fn()
+            if os.environ.get("G4S_DIST_FAIL") == f"{name}:{self.rank}":      # test hook: this phase "fails" on this rank — after its collectives,
+                raise RuntimeError("G4S_DIST_FAIL")                           # so that the ranks still meet in the agreement all-reduce below
         except Exception as e:                                               # noqa: BLE001 — re-raised below, on every rank
             err = e
         if self.world > 1 and dist.is_initialized():
