@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libg4s_hip.so")
+LIB_PATH = os.environ.get("G4S_LIB") or os.path.join(_HERE, "lib", "libg4s_hip.so")   # G4S_LIB: the host-sanitized build (tools/run_sanitized_cpu_tests.sh)
 
 OK, ERR_INVALID, ERR_NOMEM, ERR_HIP, ERR_OVERFLOW, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 HOST_POINTERS, DEVICE_POINTERS, SORT_OUTPUT, SPMV_NO_NT, SPMV_BLOCKED, SPMV_STREAM, DIST_LOOPBACK, DIST_ALLGATHER = 0, 1, 2, 4, 8, 16, 32, 64
@@ -89,6 +89,9 @@ SIGNATURES = {
     "g4s_csr_device_arrays": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
     "g4s_spmv": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, vp]),
     "g4s_spmv_csr_i32_f64": (C.c_int, [C.c_int32, C.c_int32, vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_uint]),
+    "g4s_prim_exclusive_scan_i32": (C.c_int, [vp, vp, C.c_int64, vp]),
+    "g4s_prim_exclusive_scan_i64": (C.c_int, [vp, vp, C.c_int64, vp]),
+    "g4s_prim_sort_pairs_desc_i32": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int32, vp]),
     "g4s_row_partition": (C.c_int, [C.c_int32, vp, vp, C.c_int64, C.c_int32, i64p, C.c_uint]),
     "g4s_dist_split_rows": (C.c_int, [C.c_int32, C.c_int32, i64p, C.c_int64, vp, vp, vp, C.c_uint, C.POINTER(DistSplit)]),
     "g4s_dist_split_free": (None, [C.POINTER(DistSplit)]),

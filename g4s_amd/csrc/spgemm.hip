@@ -29,7 +29,7 @@
 #ifndef G4S_SPGEMM_UPR
 #define G4S_SPGEMM_UPR 4
 #endif
-#include <hipcub/hipcub.hpp>
+#include "prims.hpp"
 #include <algorithm>
 #include <chrono>
 #include <mutex>
@@ -532,7 +532,15 @@ inline int window_max_n() { const char *e = getenv("G4S_SPGEMM_WINDOW_MAX_N"); r
 // grid of the persistent big-row kernels: one workgroup per CU (their LDS allows no more), fewer when the class is small
 inline int big_grid(int nrows, int wgs_per_cu = 1)
 {
-    static const int cus = [] { int d = 0; hipDeviceProp_t p; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }();
+    // CU count of the CURRENT device (a process may drive several): cached per device id, not once per process
+    static int cus_of[64] = {0};
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
+    if (cus_of[d] == 0) {
+        hipDeviceProp_t p;
+        cus_of[d] = (hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    }
+    const int cus = cus_of[d];
     const char *e = getenv("G4S_SPGEMM_BIG_GRID");
     const int g = (e ? atoi(e) : cus) * wgs_per_cu;
     return nrows < g ? nrows : g;
@@ -1430,11 +1438,12 @@ struct ColumnMap {
     int width(int N) const { return n2 ? n2 : N; }
     const int *inverse() const { return n2 ? inv.as<int>() : nullptr; }
 };
-__global__ void colmap_mark_kernel(long long nnz, const int *__restrict__ bcol, unsigned *__restrict__ bm)
+__global__ void colmap_mark_kernel(long long nnz, int N, const int *__restrict__ bcol, unsigned *__restrict__ bm)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nnz) return;
     const int c = bcol[k];
+    if (c < 0 || c >= N) return;                                   // the numeric-only call does not range-check B again: never write outside the bitmap
     const unsigned bit = 1u << (c & 31);
     if (!(bm[c >> 5] & bit)) atomicOr(&bm[c >> 5], bit);
 }
@@ -1468,17 +1477,14 @@ int build_column_map(int N, long long bnnz, const int *bcol, ColumnMap &cm, hipS
     cm.n2 = 0;
     if (N < (1 << 16) || bnnz <= 0 || getenv("G4S_SPGEMM_NO_COLMAP")) return G4S_OK;   // a single small window either way
     const int W = (N + 31) >> 5;
-    DevBuf bm, cnt, prefix, tmp;
+    DevBuf bm, cnt, prefix;
     G4S_TRY(bm.alloc(sizeof(unsigned) * (size_t)W));
     G4S_TRY(cnt.alloc(sizeof(int) * ((size_t)W + 1)));
     G4S_TRY(prefix.alloc(sizeof(int) * ((size_t)W + 1)));
     G4S_HIP_TRY(hipMemsetAsync(bm.p, 0, sizeof(unsigned) * (size_t)W, s));
-    hipLaunchKernelGGL(colmap_mark_kernel, dim3((unsigned)((bnnz + 255) / 256)), dim3(256), 0, s, bnnz, bcol, bm.as<unsigned>());
+    hipLaunchKernelGGL(colmap_mark_kernel, dim3((unsigned)((bnnz + 255) / 256)), dim3(256), 0, s, bnnz, N, bcol, bm.as<unsigned>());
     hipLaunchKernelGGL(colmap_popc_kernel, dim3((W + 256) / 256), dim3(256), 0, s, W, bm.as<unsigned>(), cnt.as<int>());
-    size_t tb = 0;
-    G4S_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt.as<int>(), prefix.as<int>(), W + 1, s));
-    G4S_TRY(tmp.alloc(tb));
-    G4S_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, cnt.as<int>(), prefix.as<int>(), W + 1, s));
+    G4S_TRY(g4s::prims::exclusive_scan(cnt.as<int>(), prefix.as<int>(), (long long)W + 1, s));
     int n2 = 0;
     G4S_HIP_TRY(hipMemcpyAsync(&n2, prefix.as<int>() + W, sizeof(int), hipMemcpyDeviceToHost, s));
     G4S_HIP_TRY(hipStreamSynchronize(s));
@@ -1549,7 +1555,7 @@ __global__ void row_size_keys_kernel(int n, const int *__restrict__ rows, const 
 }
 struct SortedRows {
     DevBuf keys, keys_sorted, rows, tmp, counter;
-    int build(int n, const int *list, const long long *size, const int *crpt, hipStream_t s)
+    int build(int n, const int *list, const long long *size, const int *crpt, long long key_bound, hipStream_t s)
     {
         G4S_TRY(keys.alloc(sizeof(int) * (size_t)n));
         G4S_TRY(keys_sorted.alloc(sizeof(int) * (size_t)n));
@@ -1557,10 +1563,10 @@ struct SortedRows {
         G4S_TRY(counter.alloc(sizeof(int)));
         G4S_HIP_TRY(hipMemsetAsync(counter.p, 0, sizeof(int), s));
         hipLaunchKernelGGL(row_size_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, list, size, crpt, keys.as<int>());
-        size_t tb = 0;
-        G4S_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, keys.as<int>(), keys_sorted.as<int>(), list, rows.as<int>(), n, 0, 32, s));
-        G4S_TRY(tmp.alloc(tb));
-        G4S_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp.p, tb, keys.as<int>(), keys_sorted.as<int>(), list, rows.as<int>(), n, 0, 32, s));
+        G4S_TRY(tmp.alloc(sizeof(int) * 2 * (size_t)n));
+        int bits = 1;
+        while (bits < 31 && (1ll << bits) <= key_bound) ++bits;    // an upper bound of the keys' significant bits: fewer radix passes
+        G4S_TRY(g4s::prims::sort_pairs_descending(keys.as<int>(), list, keys_sorted.as<int>(), rows.as<int>(), tmp.as<int>(), tmp.as<int>() + n, n, bits, s));
         return G4S_OK;
     }
 };
@@ -1656,16 +1662,13 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     if (pre && !getenv("G4S_SPGEMM_NO_PRESORT")) {
         // which classes the window kernel counts in this call: M2 always, MEDIUM / LARGE while B is narrow enough
         const unsigned class_mask = (1u << CLS_M2) | (x_med ? (1u << CLS_MEDIUM) : 0u) | (x_large ? (1u << CLS_LARGE) : 0u);
-        DevBuf need, tmp;
+        DevBuf need;
         G4S_TRY(need.alloc(sizeof(long long) * ((size_t)M + 1)));
         G4S_TRY(pre->off.alloc(sizeof(long long) * ((size_t)M + 1)));
         G4S_HIP_TRY(hipMemsetAsync(need.p, 0, sizeof(long long) * ((size_t)M + 1), s));
         const long long min_flop = getenv("G4S_SPGEMM_PRESORT_MIN") ? atoll(getenv("G4S_SPGEMM_PRESORT_MIN")) : kPresortMinFlop;
         hipLaunchKernelGGL(presorted_need_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, rc.cls.as<int>(), class_mask, row_flop.as<long long>(), N2, min_flop, need.as<long long>());
-        size_t tb = 0;
-        G4S_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, need.as<long long>(), pre->off.as<long long>(), M + 1, s));
-        G4S_TRY(tmp.alloc(tb));
-        G4S_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, need.as<long long>(), pre->off.as<long long>(), M + 1, s));
+        G4S_TRY(g4s::prims::exclusive_scan(need.as<long long>(), pre->off.as<long long>(), (long long)M + 1, s));
         long long total_cols = 0;
         G4S_HIP_TRY(hipMemcpyAsync(&total_cols, pre->off.as<long long>() + M, sizeof(long long), hipMemcpyDeviceToHost, s));
         G4S_HIP_TRY(hipStreamSynchronize(s));
@@ -1700,7 +1703,7 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
         int *next_row = nullptr;
         if (longest_first && n > 1 && !getenv("G4S_SPGEMM_STATIC_ROWS")) {
             SortedRows &sr = sorted[n_sorted++];
-            G4S_TRY(sr.build(n, rows, row_flop.as<long long>(), nullptr, s));
+            G4S_TRY(sr.build(n, rows, row_flop.as<long long>(), nullptr, INT_MAX, s));
             rows = sr.rows.as<int>(); next_row = sr.counter.as<int>();
         }
         if (threads == 256) return window_t(std::integral_constant<int, 256>{}, rows, n, poff, pcols, next_row);
@@ -1802,6 +1805,9 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
     if (!pre) {
         int bnnz = 0;
         G4S_TRY(read_last(brpt, K, &bnnz, s));
+        // the numeric-only call may be handed a B that is not the one the symbolic call checked: the column map and the window kernels
+        // index by column id, so the ids are range-checked here too (the one-shot call checked them in its symbolic phase)
+        G4S_TRY(check_ids(bcol, bnnz, N, "a column id of B", s));
         G4S_TRY(build_column_map(N, bnnz, bcol, local_map, s));
     }
     const ColumnMap &cmap = pre ? pre->cmap : local_map;
@@ -1854,7 +1860,7 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         else {
             // The class spans 4 K … 1 M outputs per row (a 250-fold range of work): longest rows first, handed out one at a time.
             SortedRows sr;
-            G4S_TRY(sr.build(n, rc.list(CLS_M3), nullptr, crpt, s));
+            G4S_TRY(sr.build(n, rc.list(CLS_M3), nullptr, crpt, N, s));   // a row has at most N outputs
             G4S_TRY(big(1024, sr.rows.as<int>(), n, 0, INT_MAX, sr.counter.as<int>()));
             G4S_HIP_TRY(hipStreamSynchronize(s));                 // the sorted list and the counter die with this block
         }

@@ -16,7 +16,7 @@
 // Stream blocks are dealt to the 8 XCDs in contiguous runs (blockIdx%8 selects the run) so that neighbouring row
 // blocks, which touch neighbouring parts of x on banded/stencil matrices, share one L2.
 #include "common.hpp"
-#include <hipcub/hipcub.hpp>
+#include "prims.hpp"
 #include "spmv_pb.hpp"
 #include <algorithm>
 #include <vector>
@@ -173,7 +173,7 @@ __global__ void spmv_long_fixup_kernel(const LongRow *__restrict__ lrows, int n_
 constexpr int kMaxDiags = 32;
 struct DiaOffsets { int off[kMaxDiags]; };
 
-template <int ND>
+template <int ND, bool NT>
 __global__ __launch_bounds__(WG) void spmv_dia_kernel(int rows, int cols, int nd, DiaOffsets offs, long long ld, const double *__restrict__ dia,
                                                        const unsigned *__restrict__ mask, const double *__restrict__ x, double *__restrict__ y,
                                                        double alpha, double beta, int blocks_per_xcd)
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(WG) void spmv_dia_kernel(int rows, int cols, int nd
 #pragma unroll
     for (int d = 0; d < ND; ++d)
         if (d < nd) {
-            v[d] = __builtin_nontemporal_load(dia + (long long)d * ld + row);
+            v[d] = NT ? __builtin_nontemporal_load(dia + (long long)d * ld + row) : dia[(long long)d * ld + row];   // G4S_SPMV_NO_NT is honoured here too
             const int c = min(max(row + offs.off[d], 0), cols - 1);       // absent entries read a clamped (unused) position
             xv[d] = x[c];
         }
@@ -199,19 +199,22 @@ __global__ __launch_bounds__(WG) void spmv_dia_kernel(int rows, int cols, int nd
     store_y(y, row, s, alpha, beta);
 }
 
-// One thread per row scatters the row's entries into their diagonals; fail |= 1 when an offset is not in the candidate set or a row holds
-// the same column twice (a diagonal has one slot per row).
+// One thread per row scatters the row's entries into their diagonals; fail |= 1 when an offset is not in the candidate set, a row holds
+// the same column twice (a diagonal has one slot per row), or a row's columns are not ascending — the kernel adds the products in offset
+// order, which is the oracle's (stored) order only for sorted rows, and "bit-identical" is what this path promises.
 __global__ void dia_fill_kernel(int rows, int nd, DiaOffsets offs, long long ld, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colids,
                                 const double *__restrict__ values, double *__restrict__ dia, unsigned *__restrict__ mask, int *__restrict__ fail)
 {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= rows) return;
     unsigned m = 0;
+    int prev = -1;
     for (int k = rowptr[row]; k < rowptr[row + 1]; ++k) {
         const int o = colids[k] - row;
         int lo = 0, hi = nd;                                       // offs.off is ascending
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (offs.off[mid] < o) lo = mid + 1; else hi = mid; }
-        if (lo >= nd || offs.off[lo] != o || ((m >> lo) & 1u)) { atomicOr(fail, 1); return; }
+        if (lo >= nd || offs.off[lo] != o || lo <= prev) { atomicOr(fail, 1); return; }   // lo <= prev: a repeated or a descending column
+        prev = lo;
         m |= 1u << lo;
         dia[(long long)lo * ld + row] = values[k];
     }
@@ -379,8 +382,7 @@ int build_plan_device(g4s_csr_s *A)
     const int long_cap = (int)std::min<int64_t>(A->nnz / TILE_NNZ + 1, rows);
     int *d_cnt = nullptr, *d_off = nullptr, *d_scalars = nullptr;   // scalars: [0] n_long, [1] fail (row + 1)
     PlanLong *d_longs = nullptr;
-    void *d_tmp = nullptr;
-    auto cleanup = [&]() { (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_scalars); (void)hipFree(d_longs); (void)hipFree(d_tmp); };
+    auto cleanup = [&]() { (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_scalars); (void)hipFree(d_longs); };
 #define PLAN_TRY(expr) do { if ((expr) != hipSuccess) { const hipError_t e_ = hipGetLastError(); cleanup(); return g4s::set_error(G4S_ERR_HIP, "g4s_csr_create (device plan): %s", hipGetErrorString(e_)); } } while (0)
     PLAN_TRY(g4s::device_malloc((void **)&d_cnt, sizeof(int) * ((size_t)nruns + 1)));
     PLAN_TRY(g4s::device_malloc((void **)&d_off, sizeof(int) * ((size_t)nruns + 1)));
@@ -394,10 +396,8 @@ int build_plan_device(g4s_csr_s *A)
     if (h_scalars[1]) { cleanup(); return g4s::set_error(G4S_ERR_INVALID, "g4s_csr_create: rowptr decreases at row %d", h_scalars[1] - 1); }
     hipLaunchKernelGGL(plan_walk_kernel<false>, dim3((nruns + 63) / 64), dim3(64), 0, nullptr, rows, nruns, A->d_rowptr, (const int *)nullptr, d_cnt, (int4 *)nullptr, d_longs,
                        long_cap, d_scalars, d_scalars + 1);
-    size_t tb = 0;
-    PLAN_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_cnt, d_off, nruns + 1));
-    PLAN_TRY(g4s::device_malloc(&d_tmp, tb ? tb : 1));
-    PLAN_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_cnt, d_off, nruns + 1));
+    PLAN_TRY(hipGetLastError());                                   // the two plan kernels' launches were never checked
+    if (g4s::prims::exclusive_scan(d_cnt, d_off, (long long)nruns + 1, nullptr) != G4S_OK) { cleanup(); return G4S_ERR_HIP; }
     int n_blocks = 0;
     PLAN_TRY(hipMemcpy(&n_blocks, d_off + nruns, sizeof(int), hipMemcpyDeviceToHost));
     PLAN_TRY(hipMemcpy(h_scalars, d_scalars, sizeof(int) * 2, hipMemcpyDeviceToHost));
@@ -478,10 +478,15 @@ int try_build_dia(g4s_csr_s *A)
     if (g4s::device_malloc((void **)&mask, sizeof(unsigned) * (size_t)rows) != hipSuccess || g4s::device_malloc((void **)&d_fail, sizeof(int)) != hipSuccess) {
         (void)hipGetLastError(); (void)hipFree(dia); (void)hipFree(mask); return G4S_OK;
     }
-    G4S_HIP_TRY(hipMemset(dia, 0, sizeof(double) * (size_t)(ld * nd)));
-    G4S_HIP_TRY(hipMemset(d_fail, 0, sizeof(int)));
+    hipError_t e = hipMemset(dia, 0, sizeof(double) * (size_t)(ld * nd));
+    if (e == hipSuccess) e = hipMemset(d_fail, 0, sizeof(int));
+    if (e != hipSuccess) {                                          // (the three buffers used to leak on this path)
+        (void)hipFree(dia); (void)hipFree(mask); (void)hipFree(d_fail);
+        return g4s::set_error(G4S_ERR_HIP, "diagonal form: hipMemset failed: %s", hipGetErrorString(e));
+    }
     hipLaunchKernelGGL(dia_fill_kernel, dim3((rows + 255) / 256), dim3(256), 0, nullptr, rows, nd, D, ld, A->d_rowptr, A->d_colids, A->d_values, dia, mask, d_fail);
-    hipError_t e = hipMemcpy(&h_fail, d_fail, sizeof(int), hipMemcpyDeviceToHost);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(&h_fail, d_fail, sizeof(int), hipMemcpyDeviceToHost);
     (void)hipFree(d_fail);
     if (e != hipSuccess || h_fail) { (void)hipFree(dia); (void)hipFree(mask); return e == hipSuccess ? G4S_OK : g4s::set_error(G4S_ERR_HIP, "diagonal fill failed: %s", hipGetErrorString(e)); }
     A->d_dia = dia; A->d_dia_mask = mask; A->dia_nd = nd; A->dia_ld = ld; A->dia_offs = D;
@@ -611,7 +616,11 @@ G4S_API g4s_status g4s_spmv(g4s_csr_t A, const double *x_dev, double *y_dev, dou
     if (A->d_dia) {
         const int nblocks = (A->rows + WG - 1) / WG, per_xcd = (nblocks + g4s::kXcds - 1) / g4s::kXcds;
         const dim3 grid(per_xcd * g4s::kXcds), block(WG);
-#define G4S_DIA_LAUNCH(ND) hipLaunchKernelGGL(spmv_dia_kernel<ND>, grid, block, 0, s, A->rows, A->cols, A->dia_nd, A->dia_offs, A->dia_ld, A->d_dia, A->d_dia_mask, x_dev, y_dev, alpha, beta, per_xcd)
+#define G4S_DIA_LAUNCH(ND)                                                                                                                                            \
+    do {                                                                                                                                                          \
+        if (A->use_nt) hipLaunchKernelGGL((spmv_dia_kernel<ND, true>), grid, block, 0, s, A->rows, A->cols, A->dia_nd, A->dia_offs, A->dia_ld, A->d_dia, A->d_dia_mask, x_dev, y_dev, alpha, beta, per_xcd);  \
+        else hipLaunchKernelGGL((spmv_dia_kernel<ND, false>), grid, block, 0, s, A->rows, A->cols, A->dia_nd, A->dia_offs, A->dia_ld, A->d_dia, A->d_dia_mask, x_dev, y_dev, alpha, beta, per_xcd);           \
+    } while (0)
         if (A->dia_nd <= 8) G4S_DIA_LAUNCH(8);
         else if (A->dia_nd <= 16) G4S_DIA_LAUNCH(16);
         else G4S_DIA_LAUNCH(32);

@@ -14,12 +14,12 @@
 // ≈62 B/nonzero of 128-byte line fetches.
 // The cell (column band c, row band r) holds its entries in CSR order (a stable regrouping), so the micro-runs of a cell are
 // numbered consecutively on both sides and one per-cell offset maps a producer micro-run to its consumer slot.
-// The regrouping is built once per matrix (g4s_csr_create) with a rocPRIM radix sort and scan; the values are stored a second
+// The regrouping is built once per matrix (g4s_csr_create) with rocPRIM's radix sort and scan (called directly); the values are stored a second
 // time in producer order. Sums are accumulated by LDS atomics: equal to the oracle within the fp64 tolerance, not bit for bit,
 // and the last bits may differ from run to run.
 #include "common.hpp"
 #include "spmv_pb.hpp"
-#include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 #include <algorithm>
 #include <memory>
 #include <vector>
@@ -439,9 +439,9 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
             hipLaunchKernelGGL(pb_iota_kernel, dim3((cols + 255) / 256), dim3(256), 0, nullptr, cols, order_in.as<int>());
             G4S_HIP_TRY(hipGetLastError());
             size_t tb = 0;
-            G4S_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, deg.as<int>(), deg_s.as<int>(), order_in.as<int>(), order.as<int>(), cols, 0, 32, nullptr));
+            G4S_HIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, tb, deg.as<int>(), deg_s.as<int>(), order_in.as<int>(), order.as<int>(), (size_t)cols, 0, 32, nullptr));
             G4S_TRY(tmp0.alloc(tb));
-            G4S_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp0.p, tb, deg.as<int>(), deg_s.as<int>(), order_in.as<int>(), order.as<int>(), cols, 0, 32, nullptr));
+            G4S_HIP_TRY(rocprim::radix_sort_pairs_desc(tmp0.p, tb, deg.as<int>(), deg_s.as<int>(), order_in.as<int>(), order.as<int>(), (size_t)cols, 0, 32, nullptr));
             std::vector<int> top((size_t)Hmax * kBand);
             G4S_HIP_TRY(hipMemcpy(top.data(), deg_s.p, sizeof(int) * top.size(), hipMemcpyDeviceToHost));
             if (want > 0) H = std::min(want, Hmax);
@@ -486,11 +486,11 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
                        rowid.as<int>(), idx.as<unsigned>());
     G4S_HIP_TRY(hipGetLastError());
     size_t tmp_bytes = 0;
-    G4S_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, key.as<unsigned>(), key_s.as<unsigned>(), idx.as<unsigned>(), perm.as<unsigned>(),
-                                                   (int)nnz, 0, 2 * bits, nullptr));
+    G4S_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key.as<unsigned>(), key_s.as<unsigned>(), idx.as<unsigned>(), perm.as<unsigned>(),
+                                             (size_t)nnz, 0, 2 * bits, nullptr));
     G4S_TRY(tmp.alloc(tmp_bytes));
-    G4S_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, key.as<unsigned>(), key_s.as<unsigned>(), idx.as<unsigned>(), perm.as<unsigned>(),
-                                                   (int)nnz, 0, 2 * bits, nullptr));
+    G4S_HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, key.as<unsigned>(), key_s.as<unsigned>(), idx.as<unsigned>(), perm.as<unsigned>(),
+                                             (size_t)nnz, 0, 2 * bits, nullptr));
     G4S_HIP_TRY(hipDeviceSynchronize());
     key.release(); idx.release();
     G4S_TRY(startP.alloc(sizeof(int) * (size_t)(ncells + 1)));
@@ -537,9 +537,9 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     G4S_HIP_TRY(hipMemset(counts.p, 0, counts.bytes));
     hipLaunchKernelGGL(pb_span_heads_kernel, dim3(grid_for(nspans)), dim3(256), 0, nullptr, nspans, t_row.as<int>(), t_cell.as<int>(), P->masks.as<unsigned char>(), counts.as<int>());
     G4S_HIP_TRY(hipGetLastError());
-    G4S_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, counts.as<int>(), P->mbase.as<int>(), (int)nspans + 1, nullptr));
+    G4S_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, counts.as<int>(), P->mbase.as<int>(), 0, (size_t)nspans + 1, rocprim::plus<int>(), nullptr));
     G4S_TRY(tmp.alloc(tmp_bytes));
-    G4S_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, counts.as<int>(), P->mbase.as<int>(), (int)nspans + 1, nullptr));
+    G4S_HIP_TRY(rocprim::exclusive_scan(tmp.p, tmp_bytes, counts.as<int>(), P->mbase.as<int>(), 0, (size_t)nspans + 1, rocprim::plus<int>(), nullptr));
 
     // 4. micro-run index at every cell start → consumer layout (host): row band segments at multiples of 4
     std::vector<int> span_of_cell((size_t)ncells + 1), mstart((size_t)ncells + 1);

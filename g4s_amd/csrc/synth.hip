@@ -181,3 +181,28 @@ G4S_API g4s_status g4s_synth_banded(int32_t n, int32_t hb, uint64_t seed, int32_
     G4S_HIP_TRY(hipGetLastError());
     return G4S_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- the library's primitives, testable on their own
+#include "prims.hpp"
+G4S_API g4s_status g4s_prim_exclusive_scan_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, void *stream)
+{
+    G4S_REQUIRE(n >= 0 && (n == 0 || (in_dev && out_dev)), "bad argument");
+    return g4s::prims::exclusive_scan<int>(in_dev, out_dev, n, g4s::as_stream(stream));
+}
+G4S_API g4s_status g4s_prim_exclusive_scan_i64(const int64_t *in_dev, int64_t *out_dev, int64_t n, void *stream)
+{
+    G4S_REQUIRE(n >= 0 && (n == 0 || (in_dev && out_dev)), "bad argument");
+    return g4s::prims::exclusive_scan<long long>(reinterpret_cast<const long long *>(in_dev), reinterpret_cast<long long *>(out_dev), n, g4s::as_stream(stream));
+}
+G4S_API g4s_status g4s_prim_sort_pairs_desc_i32(const int32_t *keys_in_dev, const int32_t *vals_in_dev, int32_t *keys_out_dev, int32_t *vals_out_dev,
+                                                int32_t n, int32_t key_bits, void *stream)
+{
+    G4S_REQUIRE(n >= 0 && (n == 0 || (keys_in_dev && vals_in_dev && keys_out_dev && vals_out_dev)), "bad argument");
+    if (n == 0) return G4S_OK;
+    hipStream_t s = g4s::as_stream(stream);
+    void *tmp = nullptr;
+    G4S_TRY(g4s::scratch_alloc(&tmp, sizeof(int) * 2 * (size_t)n, s));
+    const int st = g4s::prims::sort_pairs_descending(keys_in_dev, vals_in_dev, keys_out_dev, vals_out_dev, static_cast<int *>(tmp), static_cast<int *>(tmp) + n, n, key_bits, s);
+    g4s::scratch_free(tmp, s);
+    return st;
+}

@@ -33,6 +33,14 @@ g4s_status g4s_synth_laplacian_rows(int32_t kind, int32_t nx, int32_t ny, int32_
 g4s_status g4s_synth_banded(int32_t n, int32_t hb, uint64_t seed, int32_t *rowptr_dev, int32_t *colids_dev,
                             double *values_dev, void *stream);
 
+/* The library's own device-wide primitives (csrc/prims.hpp: exclusive prefix sum; stable key-value radix sort, descending keys, 4-bit
+ * digits), exposed so that they can be tested on their own. out[i] = sum of in[0..i); keys are non-negative ints with at most key_bits
+ * significant bits; inputs are left untouched. Device pointers, asynchronous on `stream`. */
+g4s_status g4s_prim_exclusive_scan_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, void *stream);
+g4s_status g4s_prim_exclusive_scan_i64(const int64_t *in_dev, int64_t *out_dev, int64_t n, void *stream);
+g4s_status g4s_prim_sort_pairs_desc_i32(const int32_t *keys_in_dev, const int32_t *vals_in_dev, int32_t *keys_out_dev, int32_t *vals_out_dev,
+                                        int32_t n, int32_t key_bits, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

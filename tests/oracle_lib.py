@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+ORACLE_SO = os.environ.get("G4S_ORACLE_SO") or os.path.join(ROOT, "oracle", "liboracle.so")   # G4S_ORACLE_SO: the ASan/UBSan build (make -C oracle asan)
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref_graph.so")
 
 FUN_GATHER = C.CFUNCTYPE(None, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_double), C.POINTER(C.c_double))

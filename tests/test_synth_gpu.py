@@ -60,3 +60,41 @@ def test_device_allocator_round_trip():
     capi.check(lib.g4s_shutdown())
     capi.check(lib.g4s_dev_alloc(C.byref(a), 4096))                # the library keeps working after a shutdown
     capi.check(lib.g4s_dev_free(a))
+
+
+@pytest.mark.parametrize("n", [1, 63, 2048, 2049, 100_000, 3_000_001])
+def test_own_exclusive_scan_equals_cumsum(n):
+    """csrc/prims.hpp: the library's exclusive prefix sum (three kernels, DPP/shuffle wave scans) that replaced hipcub::DeviceScan on the SpGEMM call
+    path and in the SpMV plan — int32 and int64, tile boundaries, more tiles than one offsets pass."""
+    import ctypes as C
+    from g4s_amd import capi, host
+    lib = capi.load()
+    g = torch.Generator(device="cuda").manual_seed(n)
+    a = torch.randint(0, 1000, (n,), dtype=torch.int32, device="cuda", generator=g)
+    out = torch.empty_like(a)
+    capi.check(lib.g4s_prim_exclusive_scan_i32(a.data_ptr(), out.data_ptr(), n, host._stream()))
+    want = torch.cumsum(a.long(), 0) - a.long()
+    assert torch.equal(out.long(), want)
+    b = torch.randint(0, 1 << 40, (n,), dtype=torch.int64, device="cuda", generator=g)
+    out64 = torch.empty_like(b)
+    capi.check(lib.g4s_prim_exclusive_scan_i64(b.data_ptr(), out64.data_ptr(), n, host._stream()))
+    assert torch.equal(out64, torch.cumsum(b, 0) - b)
+
+
+@pytest.mark.parametrize("n,bits", [(1, 31), (255, 4), (2049, 9), (70_000, 21), (1_000_003, 31), (300_000, 1)])
+def test_own_radix_sort_is_stable_and_descending(n, bits):
+    """csrc/prims.hpp: key-value radix sort, descending keys, ties in input order (what orders a row class longest-first for the persistent SpGEMM
+    kernels; replaced hipcub::DeviceRadixSort there). Checked against torch's stable sort; inputs must be left untouched."""
+    from g4s_amd import capi, host
+    lib = capi.load()
+    g = torch.Generator(device="cuda").manual_seed(n + bits)
+    keys = torch.randint(0, min(1 << bits, (1 << 31) - 1), (n,), dtype=torch.int32, device="cuda", generator=g)
+    if n > 1000:
+        keys[::7] = keys[0]                                          # many ties
+    vals = torch.arange(n, dtype=torch.int32, device="cuda")
+    k0, v0 = keys.clone(), vals.clone()
+    ko, vo = torch.empty_like(keys), torch.empty_like(vals)
+    capi.check(lib.g4s_prim_sort_pairs_desc_i32(keys.data_ptr(), vals.data_ptr(), ko.data_ptr(), vo.data_ptr(), n, bits, host._stream()))
+    order = torch.sort(keys.long(), descending=True, stable=True).indices
+    assert torch.equal(ko, keys[order]) and torch.equal(vo, vals[order])
+    assert torch.equal(keys, k0) and torch.equal(vals, v0)
