@@ -45,6 +45,15 @@ class DistSplit(C.Structure):
                 ("want", C.POINTER(C.c_int32)), ("recv_cut", C.POINTER(C.c_int64))]
 
 
+ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)      # g4s_transport.allreduce_sum_f64(ctx, buf_dev, count, stream)
+EXCHANGE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)                  # g4s_transport.exchange(ctx, h, stream)
+
+
+class Transport(C.Structure):
+    """g4s_transport: the two collectives of a partitioned Krylov solver as callbacks."""
+    _fields_ = [("ctx", C.c_void_p), ("allreduce_sum_f64", ALLREDUCE_CB), ("exchange", EXCHANGE_CB)]
+
+
 class Timings(C.Structure):
     """mm/inc/Timings.h:4-23 — seven stage times in milliseconds."""
     _fields_ = [(n, C.c_double) for n in ("create", "spmm", "convert", "order", "export_csr", "destroy", "total")]
@@ -96,6 +105,7 @@ SIGNATURES = {
     "g4s_dist_split_rows": (C.c_int, [C.c_int32, C.c_int32, i64p, C.c_int64, vp, vp, vp, C.c_uint, C.POINTER(DistSplit)]),
     "g4s_dist_split_free": (None, [C.POINTER(DistSplit)]),
     "g4s_spmv_dist_create": (C.c_int, [C.POINTER(vp), C.c_int32, C.c_int32, i64p, C.c_int64, vp, vp, vp, C.c_uint]),
+    "g4s_spmv_dist_create_rect": (C.c_int, [C.POINTER(vp), C.c_int32, C.c_int32, i64p, i64p, vp, vp, vp, C.c_uint]),
     "g4s_spmv_dist_destroy": (C.c_int, [vp]),
     "g4s_spmv_dist_get_info": (C.c_int, [vp, C.POINTER(DistInfo)]),
     "g4s_spmv_dist_connect_rccl": (C.c_int, [vp, vp]),
@@ -105,6 +115,10 @@ SIGNATURES = {
     "g4s_spmv_dist_begin": (C.c_int, [vp, vp, vp, vp]),
     "g4s_spmv_dist_buffers": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64p), C.POINTER(vp), C.POINTER(i64p)]),
     "g4s_spmv_dist_finish": (C.c_int, [vp, vp, vp]),
+    "g4s_transport_rccl": (C.c_int, [vp, C.POINTER(Transport)]),
+    "g4s_conj_grad_dist_tr": (C.c_int, [vp, C.POINTER(Transport), C.c_int32, vp, vp, C.c_int32, vp, vp, C.c_double, C.c_int32, C.POINTER(C.c_int32), f64p, vp]),
+    "g4s_stokes_uzawa_cg_dist": (C.c_int, [vp, vp, vp, C.POINTER(Transport), C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_double, vp, C.c_int32, vp, vp, vp,
+                                           C.POINTER(StokesParams), C.POINTER(StokesResult), vp, C.c_int32, vp]),
     "g4s_comm_unique_id": (C.c_int, [vp]),
     "g4s_comm_create": (C.c_int, [C.POINTER(vp), C.c_int32, C.c_int32, vp]),
     "g4s_comm_destroy": (C.c_int, [vp]),

@@ -427,18 +427,43 @@ G4S_API g4s_status g4s_cg_end(g4s_cg_ws_t ws, double *d0_dev, const int32_t *zer
 // element-wise by g4s_comm_allreduce_sum_f64 on the same communicator (every rank then adds the same 256 numbers in the same order
 // and reaches the same α, β and verdict) — the two collectives of the CitcomS loop it replaces (Regional_parallel_related.c:744-789
 // neighbour exchange, Global_operations.c:534-562 MPI_Allreduce). One host read of (count, done, residual) per iteration.
-G4S_API g4s_status g4s_conj_grad_dist(g4s_spmv_dist_t A, void *comm, int32_t n_local, const double *BI_dev, const int32_t *zero_resid_dev, int32_t n_zero,
-                                      const double *F_dev, double *d0_dev, double acc, int32_t steps, int32_t *cycles, double *residual, void *stream)
+namespace {
+g4s_status rccl_allreduce_cb(void *ctx, double *buf, int64_t count, void *stream) { return g4s_comm_allreduce_sum_f64(ctx, buf, count, stream); }
+} // namespace
+
+G4S_API g4s_status g4s_transport_rccl(void *comm, g4s_transport *out)
 {
-    G4S_REQUIRE(A && comm && BI_dev && F_dev && d0_dev, "NULL argument");
-    G4S_REQUIRE(n_local >= 0 && n_zero >= 0 && (n_zero == 0 || zero_resid_dev), "bad size");
+    G4S_REQUIRE(comm && out, "NULL argument");
+    out->ctx = comm;
+    out->allreduce_sum_f64 = rccl_allreduce_cb;
+    out->exchange = nullptr;                                       // the handles' own RCCL wiring (g4s_spmv_dist_connect_rccl)
+    return G4S_OK;
+}
+
+namespace g4s {
+// one distributed product through a transport
+int dist_product(g4s_spmv_dist_t A, const g4s_transport *tr, const double *x, double *y, void *stream)
+{
+    if (!tr->exchange) return g4s_spmv_dist_apply(A, x, y, stream);
+    G4S_TRY(g4s_spmv_dist_begin(A, x, y, stream));
+    G4S_TRY(tr->exchange(tr->ctx, A, stream));
+    return g4s_spmv_dist_finish(A, y, stream);
+}
+} // namespace g4s
+
+G4S_API g4s_status g4s_conj_grad_dist_tr(g4s_spmv_dist_t A, const g4s_transport *tr, int32_t n_local, const double *BI_dev, const int32_t *zero_resid_dev,
+                                         int32_t n_zero, const double *F_dev, double *d0_dev, double acc, int32_t steps, int32_t *cycles, double *residual,
+                                         void *stream)
+{
+    G4S_REQUIRE(A && tr && tr->allreduce_sum_f64 && BI_dev && F_dev && d0_dev, "NULL argument");
+    G4S_REQUIRE(n_local > 0 && n_zero >= 0 && (n_zero == 0 || zero_resid_dev), "bad size");
     g4s_cg_ws_t ws = nullptr;
     G4S_TRY(g4s_cg_ws_create(&ws, n_local));
     auto run = [&]() -> int {
         G4S_TRY(g4s_cg_begin(ws, F_dev, BI_dev, d0_dev, zero_resid_dev, n_zero, stream));
         double *p = nullptr, *Ap = nullptr, *part = nullptr;
         G4S_TRY(g4s_cg_buffers(ws, &p, &Ap, &part));
-        G4S_TRY(g4s_comm_allreduce_sum_f64(comm, part, 3 * kDotBlocks, stream));            // r·z and r·r of the start vector
+        G4S_TRY(tr->allreduce_sum_f64(tr->ctx, part, 3 * kDotBlocks, stream));              // r·z and r·r of the start vector
         int32_t count = 0, done = 0;
         double res = 0.0;
         for (;;) {
@@ -446,11 +471,11 @@ G4S_API g4s_status g4s_conj_grad_dist(g4s_spmv_dist_t A, void *comm, int32_t n_l
             G4S_TRY(g4s_cg_state(ws, &count, &done, &res, stream));
             if (done) break;
             G4S_TRY(g4s_cg_buffers(ws, &p, &Ap, nullptr));
-            G4S_TRY(g4s_spmv_dist_apply(A, p, Ap, stream));
+            G4S_TRY(g4s::dist_product(A, tr, p, Ap, stream));
             G4S_TRY(g4s_cg_reduce_pAp(ws, stream));
-            G4S_TRY(g4s_comm_allreduce_sum_f64(comm, part + kDotBlocks, kDotBlocks, stream));
+            G4S_TRY(tr->allreduce_sum_f64(tr->ctx, part + kDotBlocks, kDotBlocks, stream));
             G4S_TRY(g4s_cg_update(ws, BI_dev, d0_dev, stream));
-            G4S_TRY(g4s_comm_allreduce_sum_f64(comm, part, 3 * kDotBlocks, stream));        // [0, 256) r·z and [512, 768) r·r; the middle third is rewritten before its next use
+            G4S_TRY(tr->allreduce_sum_f64(tr->ctx, part, 3 * kDotBlocks, stream));          // [0, 256) r·z and [512, 768) r·r; the middle third is rewritten before its next use
         }
         G4S_TRY(g4s_cg_end(ws, d0_dev, zero_resid_dev, n_zero, stream));
         if (cycles) *cycles = count;
@@ -460,4 +485,13 @@ G4S_API g4s_status g4s_conj_grad_dist(g4s_spmv_dist_t A, void *comm, int32_t n_l
     const int st = run();
     (void)g4s_cg_ws_destroy(ws);
     return st;
+}
+
+G4S_API g4s_status g4s_conj_grad_dist(g4s_spmv_dist_t A, void *comm, int32_t n_local, const double *BI_dev, const int32_t *zero_resid_dev, int32_t n_zero,
+                                      const double *F_dev, double *d0_dev, double acc, int32_t steps, int32_t *cycles, double *residual, void *stream)
+{
+    G4S_REQUIRE(A && comm, "NULL argument");
+    g4s_transport tr;
+    G4S_TRY(g4s_transport_rccl(comm, &tr));
+    return g4s_conj_grad_dist_tr(A, &tr, n_local, BI_dev, zero_resid_dev, n_zero, F_dev, d0_dev, acc, steps, cycles, residual, stream);
 }

@@ -98,7 +98,7 @@ struct g4s_spmv_dist_s {
     bool merged = false;                        // the own columns are few: one product on a compact x that holds own and remote entries alike
     bool allgather = false;                     // the remote x is the whole vector, slab by slab, padded to `pad` entries per rank
     int64_t pad = 0;
-    std::vector<int64_t> off;                   // row (= x) partition, world+1
+    std::vector<int64_t> off;                   // partition of x (= of the rows for a square operator), world+1
     int32_t local_rows = 0;
     int64_t nnz_own = 0, nnz_rem = 0;
     g4s_csr_t A_own = nullptr, A_rem = nullptr;
@@ -300,21 +300,26 @@ G4S_API void g4s_dist_split_free(g4s_dist_split *s)
     std::memset(s, 0, sizeof(*s));
 }
 
-G4S_API g4s_status g4s_spmv_dist_create(g4s_spmv_dist_t *out, int32_t rank, int32_t world, const int64_t *row_offsets, int64_t n_cols,
-                                        const int32_t *rowptr, const int32_t *colids, const double *values, unsigned flags)
+// Rows partitioned by row_offsets, x (the columns) by col_offsets: the square operator has both alike; a rectangular one (the discrete
+// divergence / gradient of the Stokes iteration: elements × equations and back) has two different partitions.
+G4S_API g4s_status g4s_spmv_dist_create_rect(g4s_spmv_dist_t *out, int32_t rank, int32_t world, const int64_t *row_offsets, const int64_t *col_offsets,
+                                             const int32_t *rowptr, const int32_t *colids, const double *values, unsigned flags)
 {
     G4S_REQUIRE(out, "out is NULL");
     *out = nullptr;
-    G4S_REQUIRE(rowptr, "rowptr is NULL");
-    G4S_TRY(check_partition(rank, world, row_offsets, n_cols));
-    const int64_t r0 = row_offsets[rank], r1 = row_offsets[rank + 1];
-    const int32_t m = (int32_t)(r1 - r0);
+    G4S_REQUIRE(rowptr && row_offsets && col_offsets && world >= 1, "NULL argument");
+    const int64_t n_cols = col_offsets[world];
+    G4S_TRY(check_partition(rank, world, col_offsets, n_cols));
+    for (int k = 0; k < world; ++k) G4S_REQUIRE(row_offsets[k] <= row_offsets[k + 1], "row_offsets must not decrease");
+    G4S_REQUIRE(row_offsets[0] == 0 && row_offsets[world] <= INT32_MAX, "bad row_offsets");
+    const int64_t r0 = col_offsets[rank], r1 = col_offsets[rank + 1];      // this rank's slab of x
+    const int32_t m = (int32_t)(row_offsets[rank + 1] - row_offsets[rank]);
     auto h = new (std::nothrow) g4s_spmv_dist_s();
     if (!h) return g4s::set_error(G4S_ERR_NOMEM, "host allocation failed");
     auto fail = [&](int code) { dist_release(h); return code; };
     try {
         h->rank = rank; h->world = world; h->local_rows = m;
-        h->off.assign(row_offsets, row_offsets + world + 1);
+        h->off.assign(col_offsets, col_offsets + world + 1);        // the partition of x: what the exchange is about
         h->loopback = (flags & G4S_DIST_LOOPBACK) != 0;
         if (h->loopback && world != 1) return fail(g4s::set_error(G4S_ERR_INVALID, "G4S_DIST_LOOPBACK is a single-rank rehearsal mode"));
         const bool allgather = (flags & G4S_DIST_ALLGATHER) != 0 || (getenv("G4S_DIST_EXCHANGE") && !strcmp(getenv("G4S_DIST_EXCHANGE"), "allgather"));
@@ -367,6 +372,15 @@ G4S_API g4s_status g4s_spmv_dist_create(g4s_spmv_dist_t *out, int32_t rank, int3
     }
     *out = h;
     return G4S_OK;
+}
+
+G4S_API g4s_status g4s_spmv_dist_create(g4s_spmv_dist_t *out, int32_t rank, int32_t world, const int64_t *row_offsets, int64_t n_cols,
+                                        const int32_t *rowptr, const int32_t *colids, const double *values, unsigned flags)
+{
+    G4S_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    G4S_TRY(check_partition(rank, world, row_offsets, n_cols));    // square: x is partitioned like the rows
+    return g4s_spmv_dist_create_rect(out, rank, world, row_offsets, row_offsets, rowptr, colids, values, flags);
 }
 
 G4S_API g4s_status g4s_spmv_dist_destroy(g4s_spmv_dist_t h)

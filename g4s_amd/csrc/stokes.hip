@@ -325,3 +325,155 @@ G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, g4s_csr_t K_csr, const 
     res->dpressure = dpressure;
     return G4S_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ the same iteration on a partitioned operator
+namespace g4s { int dist_product(g4s_spmv_dist_t A, const g4s_transport *tr, const double *x, double *y, void *stream); }   // cg.hip
+
+namespace {
+// the raw local sums of a reduction, before the all-reduce (the derived scalars are formed after it, by one thread)
+__global__ __launch_bounds__(kThreads) void finish_raw_kernel(const double *__restrict__ part, double *__restrict__ raw)
+{
+    __shared__ double sh[4];
+    double r[3];
+    for (int k = 0; k < 3; ++k) r[k] = block_sum(part[k * kBlocks + threadIdx.x], sh);
+    if (threadIdx.x == 0) { raw[0] = r[0]; raw[1] = r[1]; raw[2] = r[2]; }
+}
+template <typename E>
+__global__ void scalar_kernel(E ep) { if (threadIdx.x == 0 && blockIdx.x == 0) ep(); }
+} // namespace
+
+G4S_API g4s_status g4s_stokes_uzawa_cg_dist(g4s_spmv_dist_t K, g4s_spmv_dist_t D, g4s_spmv_dist_t Dt, const g4s_transport *tr, int32_t neq, int32_t nel,
+                                            const double *BI, const double *BPI, const double *vmass, const double *area, double volume,
+                                            const int32_t *zero_resid, int32_t n_zero, const double *FF, double *V, double *P,
+                                            const g4s_stokes_params *prm, g4s_stokes_result *res, double *hist, int32_t hist_lines, void *stream)
+{
+    G4S_REQUIRE(K && D && Dt && tr && tr->allreduce_sum_f64 && prm && res, "NULL argument");
+    G4S_REQUIRE(neq > 0 && nel > 0, "every rank must own at least one equation and one element");
+    G4S_REQUIRE(BI && BPI && vmass && area && FF && V && P, "NULL argument");
+    G4S_REQUIRE(volume > 0.0, "volume must be positive");
+    G4S_REQUIRE(n_zero >= 0 && (n_zero == 0 || zero_resid), "zero_resid is NULL");
+    G4S_REQUIRE(hist_lines >= 0 && (hist_lines == 0 || hist), "hist is NULL");
+    hipStream_t s = g4s::as_stream(stream);
+    const size_t nq = ((size_t)neq * 8 + 255) / 256 * 256, np = ((size_t)nel * 8 + 255) / 256 * 256;
+    Scratch scr; scr.s = s;
+    G4S_TRY(g4s::scratch_alloc(&scr.p, 3 * nq + 6 * np + sizeof(double) * (3 * kBlocks + 32), s));
+    char *base = static_cast<char *>(scr.p);
+    double *F = reinterpret_cast<double *>(base), *u1 = reinterpret_cast<double *>(base + nq), *tmp = reinterpret_cast<double *>(base + 2 * nq);
+    double *r1 = reinterpret_cast<double *>(base + 3 * nq), *r2 = reinterpret_cast<double *>(base + 3 * nq + np),
+           *z1 = reinterpret_cast<double *>(base + 3 * nq + 2 * np), *s1 = reinterpret_cast<double *>(base + 3 * nq + 3 * np),
+           *s2 = reinterpret_cast<double *>(base + 3 * nq + 4 * np), *Fp = reinterpret_cast<double *>(base + 3 * nq + 5 * np);
+    double *part = reinterpret_cast<double *>(base + 3 * nq + 6 * np), *sc = part + 3 * kBlocks, *raw = sc + 16;
+    enum { R1Z1, R0Z0, DELTA, ALPHA, VDOTV, U1DOTU1, PDOTP, S2S2, DIVN, NSC };
+    double hsc[NSC] = {0};
+    // a reduction: local partial sums in the fixed two-level shape → three raw sums → summed over the ranks → the derived scalars
+    auto reduce = [&](int n, auto f, auto ep) -> int {
+        hipLaunchKernelGGL(map_sum_kernel, dim3(kBlocks), dim3(kThreads), 0, s, n, f, part);
+        hipLaunchKernelGGL(finish_raw_kernel, dim3(1), dim3(kThreads), 0, s, part, raw);
+        G4S_TRY(tr->allreduce_sum_f64(tr->ctx, raw, 3, stream));
+        hipLaunchKernelGGL(scalar_kernel, dim3(1), dim3(64), 0, s, ep);
+        return G4S_OK;
+    };
+    auto fetch = [&]() -> int {
+        G4S_HIP_TRY(hipGetLastError());
+        G4S_HIP_TRY(hipMemcpyAsync(hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, s));
+        G4S_HIP_TRY(hipStreamSynchronize(s));
+        return G4S_OK;
+    };
+    auto each = [&](int n, auto f) { hipLaunchKernelGGL(map_kernel, dim3(grid_for(n)), dim3(kThreads), 0, s, n, f); };
+    auto strip = [&](double *x) { if (n_zero) hipLaunchKernelGGL(zero_rows_kernel, dim3(grid_for(n_zero)), dim3(kThreads), 0, s, n_zero, zero_resid, x); };
+    auto grad_p = [&](const double *p_in, double *out) -> int { G4S_TRY(g4s::dist_product(Dt, tr, p_in, out, stream)); strip(out); return G4S_OK; };   // assemble_grad_p + strip_bcs
+    auto div_u = [&](const double *u_in, double *out) -> int { return g4s::dist_product(D, tr, u_in, out, stream); };                                   // assemble_div_u
+    int64_t inner_total = 0;
+    const double inner_acc = prm->imp * prm->inner_accuracy_scale * prm->v_res;
+    auto solve_del2_u = [&](const double *rhs, double *d0, int *valid) -> int {
+        int32_t cycles = 0;
+        double residual = 0.0;
+        G4S_TRY(g4s_conj_grad_dist_tr(K, tr, neq, BI, zero_resid, n_zero, rhs, d0, inner_acc, prm->v_steps_low, &cycles, &residual, stream));
+        inner_total += cycles;
+        *valid = residual < inner_acc ? 1 : 0;
+        return G4S_OK;
+    };
+
+    // ---- initial_vel_residual (:839-881): F = FF − grad(P) − K·V, stripped; K·u1 = F; V += u1
+    int valid = 0;
+    G4S_TRY(grad_p(P, u1));
+    each(neq, [=] __device__(int i) { F[i] = FF[i] - u1[i]; });
+    G4S_TRY(g4s::dist_product(K, tr, V, u1, stream));
+    strip(u1);
+    each(neq, [=] __device__(int i) { F[i] = F[i] - u1[i]; });
+    strip(F);
+    G4S_TRY(solve_del2_u(F, u1, &valid));
+    strip(u1);
+    each(neq, [=] __device__(int i) { V[i] = V[i] + u1[i]; });
+
+    G4S_TRY(div_u(V, r1));
+    G4S_HIP_TRY(hipMemsetAsync(sc, 0, sizeof(double) * NSC, s));
+    G4S_TRY(reduce(std::max(neq, nel), [=] __device__(int i) {
+        Sum3 o{0.0, 0.0, 0.0};
+        if (i < neq) o.a = V[i] * V[i] * vmass[i];
+        if (i < nel) { o.b = r1[i] * r1[i] / area[i]; o.c = P[i] * P[i] * area[i]; }
+        return o;
+    }, [=] __device__() { sc[VDOTV] = raw[0]; sc[DIVN] = raw[1]; sc[PDOTP] = raw[2]; }));
+    G4S_TRY(fetch());
+    double vdotv = hsc[VDOTV] / volume, pdotp = hsc[PDOTP] / volume;
+    double incompressibility = std::sqrt(hsc[DIVN] / volume / (1e-32 + vdotv));
+    double dvelocity = 1.0, dpressure = 1.0;
+    int count = 0, converging = 0, lines = 0;
+    auto record = [&]() {
+        if (lines < hist_lines) { double *h = hist + 5 * (size_t)lines; h[0] = std::sqrt(vdotv); h[1] = std::sqrt(pdotp); h[2] = dvelocity; h[3] = dpressure; h[4] = incompressibility; }
+        ++lines;
+    };
+    record();
+    for (;;) {
+        const bool keep = prm->check_continuity_convergence ? (incompressibility > prm->imp || converging < 2)
+                                                            : (incompressibility > prm->imp && converging < 2);   // keep_iterating :150-162
+        if (!(count < prm->steps_max && keep)) break;              // every rank holds the same all-reduced scalars: the same verdict everywhere
+        G4S_TRY(reduce(nel, [=] __device__(int i) { const double z = BPI[i] * r1[i]; z1[i] = z; return Sum3{r1[i] * z, 0.0, 0.0}; },
+                       [=] __device__() { sc[R1Z1] = raw[0]; sc[DELTA] = raw[0] / sc[R0Z0]; }));
+        const bool first = count == 0;
+        each(nel, [=] __device__(int i) { s2[i] = first ? z1[i] : z1[i] + sc[DELTA] * s1[i]; });
+        G4S_TRY(grad_p(s2, tmp));
+        G4S_TRY(solve_del2_u(tmp, u1, &valid));
+        strip(u1);
+        G4S_TRY(div_u(u1, Fp));
+        G4S_TRY(reduce(nel, [=] __device__(int i) { return Sum3{s2[i] * Fp[i], 0.0, 0.0}; }, [=] __device__() { sc[ALPHA] = sc[R1Z1] / raw[0]; }));
+        each(nel, [=] __device__(int i) { const double alpha = sc[ALPHA]; r2[i] = r1[i] - alpha * Fp[i]; P[i] += alpha * s2[i]; });
+        each(neq, [=] __device__(int i) { V[i] -= sc[ALPHA] * u1[i]; });
+        G4S_TRY(div_u(V, z1));
+        G4S_TRY(reduce(std::max(neq, nel), [=] __device__(int i) {
+            Sum3 o{0.0, 0.0, 0.0};
+            if (i < neq) { o.a = V[i] * V[i] * vmass[i]; o.b = u1[i] * u1[i] * vmass[i]; }
+            if (i < nel) o.c = P[i] * P[i] * area[i];
+            return o;
+        }, [=] __device__() { sc[VDOTV] = raw[0]; sc[U1DOTU1] = raw[1]; sc[PDOTP] = raw[2]; }));
+        G4S_TRY(reduce(nel, [=] __device__(int i) { return Sum3{s2[i] * s2[i] * area[i], z1[i] * z1[i] / area[i], 0.0}; },
+                       [=] __device__() { sc[S2S2] = raw[0]; sc[DIVN] = raw[1]; sc[R0Z0] = sc[R1Z1]; }));
+        G4S_TRY(fetch());
+        if (hsc[R1Z1] == 0.0) return g4s::set_error(G4S_ERR_INVALID, "g4s_stokes_uzawa_cg_dist: <r1, z1> = 0 at the head of iteration %d (the source asserts)", count);
+        const double alpha = hsc[ALPHA];
+        vdotv = hsc[VDOTV] / volume;
+        pdotp = hsc[PDOTP] / volume;
+        dvelocity = alpha * std::sqrt(hsc[U1DOTU1] / volume / (1e-32 + vdotv));
+        dpressure = alpha * std::sqrt(hsc[S2S2] / volume / (1e-32 + pdotp));
+        incompressibility = std::sqrt(hsc[DIVN] / volume / (1e-32 + vdotv));
+        ++count;
+        record();
+        if (!valid) converging = 0;
+        else if (prm->check_pressure_convergence) converging = (dvelocity < prm->imp && dpressure < prm->imp) ? converging + 1 : 0;
+        else converging = dvelocity < prm->imp ? converging + 1 : 0;
+        std::swap(s1, s2);
+        std::swap(r1, r2);
+    }
+    G4S_HIP_TRY(hipGetLastError());
+    G4S_HIP_TRY(hipStreamSynchronize(s));
+    res->outer_iterations = count;
+    res->inner_iterations = inner_total;
+    res->last_solve_valid = valid;
+    res->incompressibility = incompressibility;
+    res->v_norm = std::sqrt(vdotv);
+    res->p_norm = std::sqrt(pdotp);
+    res->dvelocity = dvelocity;
+    res->dpressure = dpressure;
+    return G4S_OK;
+}
+

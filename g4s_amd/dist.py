@@ -117,6 +117,59 @@ def dist_conj_grad(D, BI_local, F_local, zero_resid_local, acc, steps):
         lib.g4s_cg_ws_destroy(ws)
 
 
+class TorchTransport:
+    """g4s_transport over torch.distributed for process groups that are not RCCL (gloo rehearsals): the C loops of the library
+    (g4s_conj_grad_dist_tr, g4s_stokes_uzawa_cg_dist) call back here for the dot products' all-reduce and for the exchange half of a
+    distributed product. With RCCL use g4s_transport_rccl instead — no Python in the loop."""
+
+    def __init__(self, group=None):
+        from . import capi, host
+        self.group = group
+
+        def allreduce(ctx, buf, count, stream):
+            try:
+                t = host.view_f64(C.c_void_p(buf), int(count), torch.device("cuda", torch.cuda.current_device()))
+                torch.cuda.current_stream().synchronize()
+                _all_reduce_sum(t, self.group)
+                return 0
+            except Exception as e:                                 # noqa: BLE001 — a Python exception must not unwind through C
+                print(f"TorchTransport.allreduce failed: {e}", flush=True)
+                return capi.ERR_HIP
+
+        def exchange(ctx, h, stream):
+            try:
+                DistSpMV._by_handle[h].exchange_by_torch()
+                return 0
+            except Exception as e:                                 # noqa: BLE001
+                print(f"TorchTransport.exchange failed: {e}", flush=True)
+                return capi.ERR_HIP
+
+        self._cbs = (capi.ALLREDUCE_CB(allreduce), capi.EXCHANGE_CB(exchange))   # kept alive with the object
+        self.struct = capi.Transport(None, self._cbs[0], self._cbs[1])
+
+
+def rccl_transport(comm):
+    from . import capi
+    t = capi.Transport()
+    capi.check(capi.load().g4s_transport_rccl(comm, C.byref(t)))
+    return t
+
+
+def stokes_uzawa_dist(K, D, Dt, transport, BI, BPI, vmass, area, volume, zero_resid, F, V, P, params, hist_lines=0):
+    """g4s_stokes_uzawa_cg_dist on this rank's slabs (device tensors; K, D, Dt: DistSpMV over the equation / element partitions).
+    Returns (StokesResult, hist array or None); V and P are updated in place."""
+    from . import capi, host
+    res = capi.StokesResult()
+    hist = np.zeros(5 * hist_lines) if hist_lines else None
+    zr = zero_resid if zero_resid is not None and zero_resid.numel() else None
+    tr = transport.struct if hasattr(transport, "struct") else transport
+    capi.check(capi.load().g4s_stokes_uzawa_cg_dist(K.h, D.h, Dt.h, C.byref(tr), K.n_local, D.n_local, host._ptr(BI), host._ptr(BPI), host._ptr(vmass), host._ptr(area),
+                                                    float(volume), host._ptr(zr) if zr is not None else None, int(zr.numel()) if zr is not None else 0, host._ptr(F),
+                                                    host._ptr(V), host._ptr(P), C.byref(params), C.byref(res), hist.ctypes.data if hist is not None else None, hist_lines,
+                                                    host._stream()))
+    return res, hist
+
+
 class DistSpMV:
     """The row-partitioned product behind the C-ABI (g4s_spmv_dist_*, csrc/dist.hip): own-column / remote-column split, packed exchange of
     only the referenced x entries, own-column product overlapped with the exchange. This class only wires it to a transport:
@@ -128,7 +181,10 @@ class DistSpMV:
 
     rowptr / colids / values: this rank's rows [offsets[rank], offsets[rank+1]) with GLOBAL column ids, device tensors."""
 
-    def __init__(self, offsets, rank, world, rowptr, colids, values, n_cols, spmv_flags=0, group=None, loopback=False, exchange="packed"):
+    _by_handle = {}                                                # handle value → DistSpMV, for the transport's exchange callback
+
+    def __init__(self, offsets, rank, world, rowptr, colids, values, n_cols, spmv_flags=0, group=None, loopback=False, exchange="packed", col_offsets=None):
+        """col_offsets: the partition of x when it differs from the rows' (a rectangular operator, g4s_spmv_dist_create_rect)."""
         from . import capi, host
         self._capi, self._host = capi, host
         self.lib = capi.load()
@@ -144,8 +200,15 @@ class DistSpMV:
         self.rccl = dist.is_initialized() and dist.get_backend(group) == "nccl" if (world > 1) else bool(loopback)
         # Set-up is a sequence of phases, the later ones collective. After each one the ranks agree (one all-reduce of a flag) whether it
         # succeeded EVERYWHERE; if not, every rank raises at the same point — none is left waiting inside a collective the others never enter.
-        self._phase("create", lambda: capi.check(self.lib.g4s_spmv_dist_create(
-            C.byref(self.h), rank, world, offs, int(n_cols), host._ptr(rowptr), host._ptr(colids), host._ptr(values), flags)))
+        if col_offsets is None:
+            self._phase("create", lambda: capi.check(self.lib.g4s_spmv_dist_create(
+                C.byref(self.h), rank, world, offs, int(n_cols), host._ptr(rowptr), host._ptr(colids), host._ptr(values), flags)))
+        else:
+            assert int(col_offsets[-1]) == int(n_cols)
+            coffs = (C.c_int64 * (world + 1))(*[int(v) for v in col_offsets])
+            self._phase("create", lambda: capi.check(self.lib.g4s_spmv_dist_create_rect(
+                C.byref(self.h), rank, world, offs, coffs, host._ptr(rowptr), host._ptr(colids), host._ptr(values), flags)))
+        DistSpMV._by_handle[self.h.value] = self
         if self.rccl:
             idbuf = torch.zeros(128, dtype=torch.uint8)
             if rank == 0:
@@ -239,10 +302,20 @@ class DistSpMV:
             capi.check(self.lib.g4s_spmv_dist_apply(self.h, host._ptr(x_local), host._ptr(y_local), st))
             return y_local
         capi.check(self.lib.g4s_spmv_dist_begin(self.h, host._ptr(x_local), host._ptr(y_local), st))
+        self.exchange_by_torch()
+        capi.check(self.lib.g4s_spmv_dist_finish(self.h, host._ptr(y_local), st))
+        return y_local
+
+    def exchange_by_torch(self):
+        """The transport half of one product when the process group is not RCCL: between g4s_spmv_dist_begin and _finish, carry the library's
+        send buffer to the peers and fill its receive buffer through torch.distributed."""
         send, scut, recv, rcut = self._buffers()
+        on_dev = _gloo_on_device(send, self.group)
         if self.allgather:                                         # every rank's slot (pad entries) to everybody: one all_gather over the views
             pad = scut[-1]
-            if _gloo_on_device(x_local, self.group):
+            if self.world == 1:
+                return
+            if on_dev:
                 torch.cuda.synchronize()
                 mine = send[:pad].cpu()
                 slots = [torch.empty(pad, dtype=torch.float64) for _ in range(self.world)]
@@ -250,8 +323,7 @@ class DistSpMV:
                 recv[:pad * self.world].copy_(torch.cat(slots))
             else:
                 dist.all_gather_into_tensor(recv[:pad * self.world], send[:pad].clone(), group=self.group)
-            capi.check(self.lib.g4s_spmv_dist_finish(self.h, host._ptr(y_local), st))
-            return y_local
+            return
         ops = []
         for k in range(self.world):
             if k == self.rank:
@@ -261,12 +333,10 @@ class DistSpMV:
             if rcut[k + 1] > rcut[k]:
                 ops.append(dist.P2POp(dist.irecv, recv[rcut[k]:rcut[k + 1]], k, group=self.group))
         if ops:
-            if _gloo_on_device(x_local, self.group):
+            if on_dev:
                 torch.cuda.synchronize()
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
-        capi.check(self.lib.g4s_spmv_dist_finish(self.h, host._ptr(y_local), st))
-        return y_local
 
     def allreduce_sum(self, t):
         """Sum over the ranks, in place: the library's RCCL communicator when there is one, torch.distributed otherwise."""
@@ -291,6 +361,7 @@ class DistSpMV:
 
     def close(self):
         if self.h:
+            DistSpMV._by_handle.pop(self.h.value, None)
             self.lib.g4s_spmv_dist_destroy(self.h)
             self.h = None
         if self.comm is not None:

@@ -170,6 +170,10 @@ typedef struct g4s_spmv_dist_info {
  * row_offsets: world+1 entries, host memory; row_offsets[world] == n_cols. Collective only in the sense that every rank creates its own. */
 g4s_status g4s_spmv_dist_create(g4s_spmv_dist_t *out, int32_t rank, int32_t world, const int64_t *row_offsets, int64_t n_cols,
                                 const int32_t *rowptr, const int32_t *colids, const double *values, unsigned flags);
+/* Rectangular operator: rows partitioned by row_offsets (y), columns by col_offsets (x) — the discrete divergence / gradient of the Stokes
+ * iteration (elements × equations and back, citcoms/lib/Element_calculations.c:701-779) next to the square stiffness operator. */
+g4s_status g4s_spmv_dist_create_rect(g4s_spmv_dist_t *out, int32_t rank, int32_t world, const int64_t *row_offsets, const int64_t *col_offsets,
+                                     const int32_t *rowptr, const int32_t *colids, const double *values, unsigned flags);
 g4s_status g4s_spmv_dist_destroy(g4s_spmv_dist_t h);
 g4s_status g4s_spmv_dist_get_info(g4s_spmv_dist_t h, g4s_spmv_dist_info *info);
 /* Wiring, RCCL: comm is an ncclComm_t over the same ranks (the caller's own, or g4s_comm_create below); the want / give index lists
@@ -402,6 +406,40 @@ g4s_status g4s_cg_end(g4s_cg_ws_t ws, double *d0_dev, const int32_t *zero_resid_
  * and residual. A must be connected to comm (g4s_spmv_dist_connect_rccl). */
 g4s_status g4s_conj_grad_dist(g4s_spmv_dist_t A, void *comm, int32_t n_local, const double *BI_dev, const int32_t *zero_resid_dev, int32_t n_zero,
                               const double *F_dev, double *d0_dev, double acc, int32_t steps, int32_t *cycles, double *residual, void *stream);
+
+/* The two collectives a partitioned Krylov solver needs, as a pair of callbacks, so that ONE loop in C serves RCCL and any transport the
+ * host already has (MPI in CitcomS; gloo in the tests): the sum all-reduce of the dot products (Global_operations.c:534-562) and the
+ * exchange of the x entries of one distributed product (Regional_parallel_related.c:744-789).
+ *   allreduce_sum_f64(ctx, buf_dev, count, stream): element-wise sum over the ranks, in place, device buffer, ordered on `stream`.
+ *   exchange(ctx, h, stream): called between g4s_spmv_dist_begin(h) and g4s_spmv_dist_finish(h): carry h's send buffer to the peers and fill
+ *   its receive buffer (g4s_spmv_dist_buffers). NULL: the handle's own RCCL wiring does it (g4s_spmv_dist_apply).
+ * g4s_transport_rccl fills the pair for an RCCL communicator the handles are connected to. */
+typedef struct g4s_transport {
+    void *ctx;
+    g4s_status (*allreduce_sum_f64)(void *ctx, double *buf_dev, int64_t count, void *stream);
+    g4s_status (*exchange)(void *ctx, g4s_spmv_dist_t h, void *stream);
+} g4s_transport;
+g4s_status g4s_transport_rccl(void *comm, g4s_transport *out);
+/* g4s_conj_grad_dist over a transport. */
+g4s_status g4s_conj_grad_dist_tr(g4s_spmv_dist_t A, const g4s_transport *tr, int32_t n_local, const double *BI_dev, const int32_t *zero_resid_dev,
+                                 int32_t n_zero, const double *F_dev, double *d0_dev, double acc, int32_t steps, int32_t *cycles, double *residual,
+                                 void *stream);
+
+/* The Uzawa / Schur-complement CG iteration of g4s_stokes_uzawa_cg on a PARTITIONED operator (BASELINE configs[4] "1 vs 8 GPUs";
+ * solve_Ahat_p_fhat_CG, citcoms/lib/Stokes_flow_Incomp.c:188-452, with the reductions of Global_operations.c:591-656 over the ranks).
+ * The velocity unknowns (equations) and the pressure unknowns (elements) each have a 1-D partition; every rank holds its slabs of all
+ * vectors and three distributed operators over those partitions:
+ *   K   equations × equations   the assembled stiffness matrix (square; the inner solves are g4s_conj_grad_dist_tr on it);
+ *   D   elements × equations    assemble_div_u:  divU[e] = Σ_p g[e][p]·U[eq(e,p)]      (Element_calculations.c:744-779), as a CSR matrix;
+ *   Dt  equations × elements    assemble_grad_p: its transpose                           (:701-741)            (g4s_spmv_dist_create_rect).
+ * On one rank the element-ordered sums of g4s_stokes_uzawa_cg become CSR row sums: same terms, same order within a part, the own-column
+ * and remote-column parts added separately — results agree to rounding, iteration counts normally exactly.
+ * vmass_dev[neq_local] = NMass of the node that owns the equation (the weight of global_v_norm2), area_dev[nel_local], volume = mesh volume,
+ * zero_resid: LOCAL equation indices; BI / BPI: the two preconditioner diagonals, local slabs. V / P updated in place. */
+g4s_status g4s_stokes_uzawa_cg_dist(g4s_spmv_dist_t K, g4s_spmv_dist_t D, g4s_spmv_dist_t Dt, const g4s_transport *tr, int32_t neq_local, int32_t nel_local,
+                                    const double *BI_dev, const double *BPI_dev, const double *vmass_dev, const double *area_dev, double volume,
+                                    const int32_t *zero_resid_dev, int32_t n_zero, const double *F_dev, double *V_dev, double *P_dev,
+                                    const g4s_stokes_params *params, g4s_stokes_result *result, double *hist, int32_t hist_lines, void *stream);
 
 /* result[M×K] = xx[M×N] · w[N×K], row-major fp64, device pointers (opt_matmul.cc:24-62). */
 g4s_status g4s_dense_rows_times_matrix(int32_t M, int32_t N, int32_t K, const double *xx_dev, const double *w_dev,

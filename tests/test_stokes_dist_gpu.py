@@ -1,0 +1,151 @@
+"""The Uzawa / Schur-complement CG iteration on a PARTITIONED operator (BASELINE configs[4] "1 vs 8 GPUs"): g4s_stokes_uzawa_cg_dist — the
+loop of solve_Ahat_p_fhat_CG (citcoms/lib/Stokes_flow_Incomp.c:188-452) in C, with the stiffness matrix, the discrete divergence and the
+discrete gradient as three row-partitioned distributed operators, the velocity solves by g4s_conj_grad_dist_tr and every norm / dot product
+summed over the ranks (Global_operations.c:591-656). One GPU box cannot run RCCL between ranks, so 1, 2 and 3 gloo ranks share the GPU and
+carry the library's buffers through torch.distributed (g4s_transport callbacks); the RCCL half is rehearsed with one rank. Against the
+oracle's single-process restatement: the same outer iteration count, the solution to round-off growth."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests.helpers import assemble_csr, stokes_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def div_grad_csr(ien, idmap, g, neq):
+    """assemble_div_u as a CSR matrix D (nel × neq: row e holds g[e][p] at column eq(e, p), p in the element's own order — the order the
+    reference adds the terms in) and its transpose Dt (row = equation, terms in ascending element order: the order of assemble_grad_p)."""
+    nel = len(ien)
+    cols = idmap[ien].reshape(nel, 24).astype(np.int32)            # eq(e, p), p = 3·a + d
+    drp = (24 * np.arange(nel + 1)).astype(np.int32)
+    dci, dva = cols.ravel().copy(), g.ravel().copy()
+    order = np.argsort(dci, kind="stable")                         # by equation, then by element (and p): ascending element order per equation
+    trp = np.zeros(neq + 1, np.int32)
+    np.add.at(trp, dci + 1, 1)
+    trp = np.cumsum(trp).astype(np.int32)
+    tci = np.repeat(np.arange(nel, dtype=np.int32), 24)[order]
+    return (drp, dci, dva), (trp, tci, dva[order])
+
+
+def _setup(ex, ey, ez, seed, oracle):
+    pr = stokes_problem(ex, ey, ez, seed)
+    ien, idmap, nno, neq, nel = pr["ien"], pr["id"], pr["nno"], pr["neq"], len(pr["ien"])
+    BI = oracle.element_inverse_diagonal(ien, idmap, pr["K"], neq)
+    BPI = oracle.build_diagonal_of_Ahat(ien, idmap, pr["g"], BI)
+    return pr, BI, BPI
+
+
+def _slice(csr, r0, r1):
+    rp, ci, va = csr
+    k0, k1 = rp[r0], rp[r1]
+    return (rp[r0:r1 + 1] - rp[r0]).astype(np.int32), ci[k0:k1].copy(), va[k0:k1].copy()
+
+
+def _worker(rank, world, port, shape, exchange, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from g4s_amd import capi, dist as gdist
+    from tests import oracle_lib
+    o = oracle_lib.load()
+    pr, BI, BPI = _setup(*shape, o)
+    ien, idmap, nno, neq, nel = pr["ien"], pr["id"], pr["nno"], pr["neq"], len(pr["ien"])
+    Kc = assemble_csr(ien, idmap, pr["K"], neq)
+    Dc, Dtc = div_grad_csr(ien, idmap, pr["g"], neq)
+    # partitions: nodes by equal stiffness work (3 equations each, so that a node's equations stay together), elements by equal count
+    node_work = np.add.reduceat(np.diff(Kc[0]).astype(np.int64) + 1, np.arange(0, neq, 3))
+    noff = gdist.row_partition(torch.zeros(nno + 1, dtype=torch.int32), world, row_work=node_work)
+    eoff = [3 * v for v in noff]
+    loff = [(nel * k) // world for k in range(world + 1)]
+    e0, e1, l0, l1 = eoff[rank], eoff[rank + 1], loff[rank], loff[rank + 1]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    mk = lambda csr, roff, coff, r0, r1: gdist.DistSpMV(roff, rank, world, *[dev(a) for a in _slice(csr, r0, r1)], coff[-1], exchange=exchange, col_offsets=coff)
+    K = mk(Kc, eoff, eoff, e0, e1)
+    D = mk(Dc, loff, eoff, l0, l1)
+    Dt = mk(Dtc, eoff, loff, e0, e1)
+    vmass = np.repeat(pr["nmass"], 3)
+    bc = pr["bc"]
+    bcl = dev((bc[(bc >= e0) & (bc < e1)] - e0).astype(np.int32))
+    imp, scale, vlow, steps = 1e-6, 1.0, 500, 40
+    v_res = float(np.linalg.norm(pr["F"]))
+    prm = capi.StokesParams(imp, scale, v_res, vlow, steps, 0, 0)
+    V, P = torch.zeros(e1 - e0, dtype=torch.float64, device="cuda"), torch.zeros(l1 - l0, dtype=torch.float64, device="cuda")
+    tr = gdist.TorchTransport()
+    res, hist = gdist.stokes_uzawa_dist(K, D, Dt, tr, dev(BI[e0:e1]), dev(BPI[l0:l1]), dev(vmass[e0:e1]), dev(pr["area"][l0:l1]), pr["volume"], bcl,
+                                        dev(pr["F"][e0:e1]), V, P, prm, hist_lines=steps + 1)
+    np.save(os.path.join(out_dir, f"V{rank}.npy"), V.cpu().numpy())
+    np.save(os.path.join(out_dir, f"P{rank}.npy"), P.cpu().numpy())
+    np.save(os.path.join(out_dir, f"m{rank}.npy"), np.array([res.outer_iterations, res.inner_iterations, res.incompressibility, res.last_solve_valid, e0, e1, l0, l1]))
+    np.save(os.path.join(out_dir, f"h{rank}.npy"), hist)
+    dist.barrier()
+    for h in (K, D, Dt):
+        h.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape,exchange", [(1, (6, 6, 4, 1), "packed"), (2, (6, 6, 4, 1), "packed"), (3, (6, 6, 4, 1), "packed"), (3, (8, 6, 5, 2), "allgather"),
+                                                  (2, (16, 16, 8, 3), "packed")])
+def test_uzawa_on_the_partitioned_operator_matches_oracle(tmp_path, oracle, world, shape, exchange):
+    mp.spawn(_worker, args=(world, _free_port(), shape, exchange, str(tmp_path)), nprocs=world, join=True)
+    pr, BI, BPI = _setup(*shape, oracle)
+    ien, idmap, nno, neq, nel = pr["ien"], pr["id"], pr["nno"], pr["neq"], len(pr["ien"])
+    imp, scale, vlow, steps = 1e-6, 1.0, 500, 40
+    v_res = float(np.linalg.norm(pr["F"]))
+    Vo, Po, cnt_o, inc_o, hist_o, inner_o = oracle.solve_Ahat_p_fhat_CG(ien, idmap, nno, neq, pr["K"], pr["g"], BI, BPI, pr["nmass"], pr["area"], pr["volume"],
+                                                                       pr["bc"], pr["F"], np.zeros(neq), np.zeros(nel), imp, scale, v_res, vlow, steps, 0, 0)
+    metas = [np.load(tmp_path / f"m{r}.npy") for r in range(world)]
+    assert len({int(m[0]) for m in metas}) == 1 and len({int(m[1]) for m in metas}) == 1, "every rank must take the same decisions"
+    assert metas[0][4] == 0 and metas[-1][5] == neq and metas[0][6] == 0 and metas[-1][7] == nel
+    assert int(metas[0][0]) == cnt_o, (int(metas[0][0]), cnt_o)
+    assert abs(int(metas[0][1]) - inner_o) <= 2 * (cnt_o + 1)
+    V = np.concatenate([np.load(tmp_path / f"V{r}.npy") for r in range(world)])
+    P = np.concatenate([np.load(tmp_path / f"P{r}.npy") for r in range(world)])
+    assert np.all(V[pr["bc"]] == 0.0)
+    assert np.allclose(V, Vo, rtol=0, atol=1e-8 * np.abs(Vo).max())
+    assert np.allclose(P, Po, rtol=0, atol=1e-7 * np.abs(Po).max())
+    hist = np.load(tmp_path / "h0.npy").reshape(-1, 5)
+    assert np.allclose(hist[:cnt_o + 1, :2], hist_o[:, :2], rtol=1e-8)
+    assert np.isclose(metas[0][2], inc_o, rtol=1e-4, atol=1e-14)
+
+
+def test_uzawa_dist_over_rccl_one_rank(oracle):
+    """The RCCL half on one GPU: the library's own communicator of one rank, g4s_transport_rccl (ncclAllReduce for every norm and dot
+    product, the handles' RCCL wiring for the products). Same bar as above."""
+    from g4s_amd import capi, dist as gdist
+    shape = (6, 6, 4, 1)
+    pr, BI, BPI = _setup(*shape, oracle)
+    ien, idmap, nno, neq, nel = pr["ien"], pr["id"], pr["nno"], pr["neq"], len(pr["ien"])
+    Kc = assemble_csr(ien, idmap, pr["K"], neq)
+    Dc, Dtc = div_grad_csr(ien, idmap, pr["g"], neq)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    K = gdist.DistSpMV([0, neq], 0, 1, *[dev(a) for a in Kc], neq, loopback=True)           # half of the slab travels rank 0 → rank 0 through RCCL
+    D = gdist.DistSpMV([0, nel], 0, 1, *[dev(a) for a in Dc], neq, col_offsets=[0, neq])
+    Dt = gdist.DistSpMV([0, neq], 0, 1, *[dev(a) for a in Dtc], nel, col_offsets=[0, nel])
+    imp, scale, vlow, steps = 1e-6, 1.0, 500, 40
+    v_res = float(np.linalg.norm(pr["F"]))
+    prm = capi.StokesParams(imp, scale, v_res, vlow, steps, 0, 0)
+    V, P = torch.zeros(neq, dtype=torch.float64, device="cuda"), torch.zeros(nel, dtype=torch.float64, device="cuda")
+    res, _ = gdist.stokes_uzawa_dist(K, D, Dt, gdist.rccl_transport(K.comm), dev(BI), dev(BPI), dev(np.repeat(pr["nmass"], 3)), dev(pr["area"]), pr["volume"],
+                                     dev(pr["bc"]), dev(pr["F"]), V, P, prm)
+    Vo, Po, cnt_o, inc_o, hist_o, inner_o = oracle.solve_Ahat_p_fhat_CG(ien, idmap, nno, neq, pr["K"], pr["g"], BI, BPI, pr["nmass"], pr["area"], pr["volume"],
+                                                                       pr["bc"], pr["F"], np.zeros(neq), np.zeros(nel), imp, scale, v_res, vlow, steps, 0, 0)
+    assert res.outer_iterations == cnt_o
+    assert np.allclose(V.cpu().numpy(), Vo, rtol=0, atol=1e-8 * np.abs(Vo).max()) and np.allclose(P.cpu().numpy(), Po, rtol=0, atol=1e-7 * np.abs(Po).max())
+    for h in (K, D, Dt):
+        h.close()
