@@ -182,7 +182,7 @@ def config3_lap7(world, rank, steps, warmup, small, host, gdist, dist, torch):
             extra.update({"bytes_model": "csr-algorithmic (12*nnz + 4*(rows+1) + 8*rows + 8*cols); the diagonal kernel itself moves kernel_own_bytes",
                           "kernel_own_bytes": own, "kernel_own_gbs": round(own * steps / el / 1e9, 1), "kernel_own_frac_of_8TBs": round(own * steps / el / 1e9 / 8000.0, 4)})
     return {**extra, "workload": WORKLOADS["lap7"] + (" [--small size]" if small else ""), "n_gpus": world, "rows": n, "nnz": nnz, "steps": steps, "ms_per_step": round(el / steps * 1e3, 5),
-            "value": round(nnz * steps / el / 1e9, 3), "unit": "GEdges/s", "spmv_path": {0: "stream", 1: "blocked", 3: "diagonal (index-free)"}.get(path, str(path)),
+            "value": round(nnz * steps / el / 1e9, 3), "unit": "GEdges/s", "spmv_path": {0: "stream", 1: "blocked", 3: "diagonal (index-free)", 4: "block-row"}.get(path, str(path)),
             "hbm_gbs_algorithmic_whole_job": round(alg * steps / el / 1e9, 1), "frac_of_n_gpus_x_8TBs": round(alg * steps / el / 1e9 / (8000.0 * world), 4)}
 
 
@@ -434,15 +434,15 @@ def main():
                                 (f"g4s_spmv_dist_* ({info.get('dist_form')}; " + ("packed ncclSend/ncclRecv of the referenced x entries" if mode == "dist" else "one in-place ncclAllGather of the padded slabs")
                                  + f"{'' if merged else ', overlapped with the own-column product'}), {recv_bytes} B received by rank 0 per step")),
                    "matrix_loads": "plain" if args.no_nt else "nontemporal",
-                   "spmv_path": {0: "stream", 1: "blocked", 3: "diagonal (index-free)"}[info["spmv_path"]],
-                   "reproducible": ("yes: fixed summation order, no atomics" if info["spmv_path"] in (0, 3) else
+                   "spmv_path": {0: "stream", 1: "blocked", 3: "diagonal (index-free)", 4: "block-row"}[info["spmv_path"]],
+                   "reproducible": ("yes: fixed summation order, no atomics" if info["spmv_path"] in (0, 3, 4) else
                                     "no: fp64 sums meet in LDS / global atomics, last bits may differ run to run (inside the 1e-10 tolerance)"),
                    **({"backend": "gloo (rehearsal, not a valid multi-GPU number)"} if args.backend != "nccl" else {})},
         "hbm_gbs_algorithmic_whole_job": round((12 * nnz_total + 4 * (n_rows + 1) + 8 * n_rows + 8 * n_cols) * args.steps / elapsed / 1e9, 2),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": {0: "spmv_csr_adaptive_kernel", 1: "pb_prepare_kernel+pb_producer_kernel+pb_consumer_kernel (propagation-blocked SpMV)",
-                                3: "spmv_dia_kernel"}[info["spmv_path"]], "kernel_ms": round(kernel_ms, 5),
+                                3: "spmv_dia_kernel", 4: "spmv_bcsr_kernel"}[info["spmv_path"]], "kernel_ms": round(kernel_ms, 5),
                      "algorithmic_bytes_per_launch": info["algorithmic_bytes"],
                      "launch_rows": info["rows"], "launch_nnz": info["nnz"],
                      **({"kernel_ms_includes_exchange": True, "note": "N > 1: kernel_ms is one distributed product on rank 0 — pack, ncclSend/ncclRecv and both local products — not a single kernel"} if world > 1 else {})},

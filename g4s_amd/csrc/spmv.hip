@@ -18,6 +18,7 @@
 #include "common.hpp"
 #include "prims.hpp"
 #include "spmv_pb.hpp"
+#include "spmv_bcsr.hpp"
 #include <algorithm>
 #include <vector>
 
@@ -257,6 +258,7 @@ struct g4s_csr_s {
     long long dia_ld = 0;
     DiaOffsets dia_offs{};
     g4s::PbPlan *pb = nullptr;      // propagation-blocked path (spmv_pb.hip) for matrices without gather locality
+    g4s::BcsrPlan *bcsr = nullptr;  // block-row form of an assembled FE matrix (spmv_bcsr.hip)
 };
 
 namespace {
@@ -441,6 +443,7 @@ void release(g4s_csr_s *A)
     (void)hipFree(A->d_dia);
     (void)hipFree(A->d_dia_mask);
     g4s::pb_destroy(A->pb);
+    g4s::bcsr_destroy(A->bcsr);
     delete A;
 }
 
@@ -573,6 +576,12 @@ G4S_API g4s_status g4s_csr_create(g4s_csr_t *out, int32_t rows, int32_t cols, in
         st = try_build_dia(A);
         if (st != G4S_OK) return fail(st);
     }
+    // assembled FE matrices (aligned b×b blocks, b rows with one column list): one block-column id per block instead of b² column ids
+    if (!A->pb && !A->d_dia && !(flags & G4S_SPMV_STREAM) && nnz > 0) {
+        st = g4s::bcsr_try_build(&A->bcsr, rows, cols, nnz, A->d_rowptr, A->d_colids, A->d_values, A->use_nt);
+        if (st != G4S_OK) return fail(st);
+        A->plan_bytes += g4s::bcsr_bytes(A->bcsr);
+    }
     *out = A;
     return G4S_OK;
 }
@@ -591,7 +600,7 @@ G4S_API g4s_status g4s_csr_get_info(g4s_csr_t A, g4s_csr_info *info)
     info->tile_nnz = TILE_NNZ; info->tile_rows = TILE_ROWS; info->long_chunk_nnz = LONG_CHUNK;
     info->algorithmic_bytes = 12 * A->nnz + 4 * ((int64_t)A->rows + 1) + 8 * (int64_t)A->rows + 8 * (int64_t)A->cols;
     info->plan_bytes = A->plan_bytes;
-    info->spmv_path = A->pb ? 1 : (A->d_dia ? 3 : 0);
+    info->spmv_path = A->pb ? 1 : (A->d_dia ? 3 : (A->bcsr ? 4 : 0));
     return G4S_OK;
 }
 
@@ -613,6 +622,7 @@ G4S_API g4s_status g4s_spmv(g4s_csr_t A, const double *x_dev, double *y_dev, dou
     G4S_REQUIRE((const void *)x_dev != (const void *)y_dev, "x and y must not alias");
     hipStream_t s = g4s::as_stream(stream);
     if (A->pb) return g4s::pb_spmv(A->pb, x_dev, y_dev, alpha, beta, s);
+    if (A->bcsr) return g4s::bcsr_spmv(A->bcsr, x_dev, y_dev, alpha, beta, s);
     if (A->d_dia) {
         const int nblocks = (A->rows + WG - 1) / WG, per_xcd = (nblocks + g4s::kXcds - 1) / g4s::kXcds;
         const dim3 grid(per_xcd * g4s::kXcds), block(WG);

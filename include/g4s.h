@@ -85,7 +85,8 @@ typedef struct g4s_csr_info {
     int64_t algorithmic_bytes;/* 12·nnz + 4·(rows+1) + 8·rows + 8·cols                      */
     int64_t plan_bytes;       /* extra device bytes the plan itself occupies                               */
     int32_t spmv_path;        /* 0 = row-streaming CSR kernel, 1 = propagation-blocked (regrouped copy of the matrix), 2 = unused (was round 2's tile-blocked experiment, removed),
-                               * 3 = diagonal-structured, index-free (stencil / banded matrices: values by diagonal + a presence mask per row) */
+                               * 3 = diagonal-structured, index-free (stencil / banded matrices: values by diagonal + a presence mask per row),
+                               * 4 = block-row (assembled FE matrices: aligned b×b blocks, one block-column id per block, one lane per row) */
     int32_t reserved;
 } g4s_csr_info;
 

@@ -354,3 +354,46 @@ def test_spmv_blocked_fresh_vectors_every_launch(oracle):
         scale = abs(alpha) * asum + abs(beta) * np.abs(y0.cpu().numpy())
         err = np.abs(y.cpu().numpy() - want)
         assert np.all(err <= TOL * scale + 1e-300), f"launch {it}: max rel err {np.max(err / (scale + 1e-300))}"
+
+
+def test_spmv_block_row_path_for_assembled_fe_matrices(oracle):
+    """An assembled finite-element stiffness matrix handed over as plain CSR (BASELINE configs[4]: 3 unknowns per node, so the matrix is made of
+    aligned 3×3 blocks) takes the block-row path (spmv_path 4: one block-column id per block, one lane per row) and every row is BIT-identical to
+    the oracle — the CSR kernel reduces 81-entry rows with several lanes. Matrices that only look similar (a perturbed column, rows of unequal
+    length, unsorted block columns) must stay on the CSR kernel; 2×2 and 4×4 blocks are recognised too."""
+    from g4s_amd import capi, host
+    from tests.helpers import assemble_csr, hex_mesh, spd_blocks
+    ien, idmap, nno, neq = hex_mesh(12, 10, 6)
+    K = spd_blocks(len(ien), 24, 3)
+    rp, ci, va = assemble_csr(ien, idmap, K, neq)
+    A = host.CSR.from_host(rp, ci, va, neq, neq)
+    assert A.info()["spmv_path"] == 4 and A.info()["plan_bytes"] > 8 * len(ci)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, neq)
+    _check(oracle, A, rp, ci, va, x, exact=True)
+    _check(oracle, A, rp, ci, va, x, alpha=-0.75, beta=1.5, y0=rng.uniform(-1, 1, neq), exact=True)
+    S = host.CSR.from_host(rp, ci, va, neq, neq, spmv_flags=capi.SPMV_STREAM)
+    assert S.info()["spmv_path"] == 0
+    _check(oracle, S, rp, ci, va, x)
+    # near misses stay on the CSR kernel
+    ci2 = ci.copy()
+    k = rp[300]                                                       # swap two columns inside one row: the b rows of a node no longer agree
+    ci2[k], ci2[k + 1] = ci2[k + 1], ci2[k]
+    assert host.CSR.from_host(rp, ci2, va, neq, neq).info()["spmv_path"] == 0
+    keep = np.ones(len(ci), bool)
+    keep[rp[7]] = False                                               # one entry less in one row
+    rp3 = np.concatenate([[0], np.cumsum(np.add.reduceat(keep.astype(np.int64), rp[:-1]))]).astype(np.int32)
+    assert host.CSR.from_host(rp3, ci[keep], va[keep], neq, neq).info()["spmv_path"] == 0
+    # generic block sizes: a random block-sparse pattern expanded to b×b dense blocks
+    for b in (2, 4):
+        nb = 3000
+        brp, bci, _ = random_csr(nb, nb, 0.002, 11 + b)
+        lens = np.diff(brp)
+        rows = nb * b
+        rp_b = np.concatenate([[0], np.cumsum(np.repeat(lens * b, b))]).astype(np.int32)
+        ci_b = np.concatenate([np.tile((bci[brp[n]:brp[n + 1], None] * b + np.arange(b)[None, :]).ravel(), b) for n in range(nb)]).astype(np.int32)
+        va_b = rng.uniform(-1, 1, len(ci_b))
+        B = host.CSR.from_host(rp_b, ci_b, va_b, rows, rows)
+        if len(ci_b) >= 2 * b * rows:
+            assert B.info()["spmv_path"] == 4
+        _check(oracle, B, rp_b, ci_b, va_b, rng.uniform(-1, 1, rows), exact=B.info()["spmv_path"] == 4)

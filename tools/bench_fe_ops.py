@@ -20,13 +20,17 @@ hn = C.c_void_p()
 capi.check(lib.g4s_node_op_create(C.byref(hn), nno, neq, max_eqn, np.ascontiguousarray(nm).ctypes.data, np.ascontiguousarray(idmap).ctypes.data, ks[0].ctypes.data, ks[1].ctypes.data, ks[2].ctypes.data))
 rp, ci, va = assemble_csr(ien, idmap, K, neq)
 A = host.CSR.from_host(rp, ci, va, neq, neq)
+S = host.CSR.from_host(rp, ci, va, neq, neq, spmv_flags=capi.SPMV_STREAM)     # the same matrix on the row-streaming CSR kernel
+S.handle
 u = torch.from_numpy(np.random.default_rng(0).uniform(-1, 1, neq)).cuda()
-outs = [torch.empty_like(u) for _ in range(3)]
+outs = [torch.empty_like(u) for _ in range(4)]
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 calls = {"element-by-element": lambda y: lib.g4s_elem_op_apply(h, u.data_ptr(), y.data_ptr(), st),
          "node-assembled blocks": lambda y: lib.g4s_node_op_apply(hn, u.data_ptr(), y.data_ptr(), None, 0, st),
-         "assembled CSR (g4s_spmv)": lambda y: lib.g4s_spmv(A.handle, u.data_ptr(), y.data_ptr(), 1.0, 0.0, st)}
-bytes_ = {"element-by-element": len(ien) * 576 * 8 + 16 * neq, "node-assembled blocks": nno * 27 * 76 + 16 * neq, "assembled CSR (g4s_spmv)": 12 * len(ci) + 4 * (neq + 1) + 16 * neq}
+         "assembled CSR (g4s_spmv)": lambda y: lib.g4s_spmv(A.handle, u.data_ptr(), y.data_ptr(), 1.0, 0.0, st),
+         "assembled CSR, G4S_SPMV_STREAM": lambda y: lib.g4s_spmv(S.handle, u.data_ptr(), y.data_ptr(), 1.0, 0.0, st)}
+bytes_ = {"element-by-element": len(ien) * 576 * 8 + 16 * neq, "node-assembled blocks": nno * 27 * 76 + 16 * neq, "assembled CSR (g4s_spmv)": 12 * len(ci) + 4 * (neq + 1) + 16 * neq,
+          "assembled CSR, G4S_SPMV_STREAM": 12 * len(ci) + 4 * (neq + 1) + 16 * neq}
 res = {}
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for (name, f), y in zip(calls.items(), outs):
@@ -41,4 +45,4 @@ for (name, f), y in zip(calls.items(), outs):
 ref = outs[0].cpu().numpy()
 for name, y in zip(calls, outs):
     res[name]["max_rel_diff_vs_elements"] = float(np.max(np.abs(y.cpu().numpy() - ref)) / np.max(np.abs(ref)))
-print(json.dumps({"mesh": f"32x32x{ez}", "neq": neq, "nnz_assembled": int(len(ci)), "matvec": res}))
+print(json.dumps({"mesh": f"32x32x{ez}", "neq": neq, "nnz_assembled": int(len(ci)), "g4s_spmv_path": A.info()["spmv_path"], "matvec": res}))

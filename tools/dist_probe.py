@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="rmat")
 ap.add_argument("--ranks", type=int, default=8)
 ap.add_argument("--reps", type=int, default=30)
+ap.add_argument("--row-weight", type=int, default=1, help="work per row on top of its nonzeros in the equal-work partition (g4s_row_partition)")
 args = ap.parse_args()
 lib = capi.load()
 A = bench.build_matrix(args.workload, host, False)
@@ -40,7 +41,8 @@ def timed(fn):
 full = timed(lambda: A.spmv(x, y))
 print(f"{args.workload}: whole matrix on one GPU {full:.4f} ms (path {A.info()['spmv_path']}), nnz {A.nnz}")
 W = args.ranks
-offs = gdist.row_partition(A.rowptr, W)
+offs = gdist.row_partition(A.rowptr, W, row_weight=args.row_weight)
+print(f"row partition: work = nnz + {args.row_weight} per row")
 worst = 0.0
 for r in range(W):
     r0, r1 = offs[r], offs[r + 1]
