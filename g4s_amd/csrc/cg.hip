@@ -12,6 +12,7 @@
 // (sized from the previous solve and a geometric fit of the residual) and reads 40 bytes of state after each batch, so the GPU runs launches back to back instead of idling across a
 // D2H round trip per iteration (62 → see DESIGN.md §4.4 µs per Cookbook2 iteration).
 #include "common.hpp"
+#include "cg_async.hpp"
 #include <algorithm>
 #include <cmath>
 #include <functional>
@@ -203,92 +204,187 @@ G4S_API g4s_status g4s_elem_op_inverse_diagonal(g4s_elem_op_t op, double *BI_dev
     return G4S_OK;
 }
 
-namespace {
-// matvec(p, Ap, done_flag, stream): Ap = K·p, free to return at once when *done_flag != 0
-using MatVec = std::function<int(const double *, double *, const int *, hipStream_t)>;
+namespace g4s {
+// One conjugate-gradient solve as an object, so that a caller can enqueue its first batch of iterations, go on enqueuing work that uses the
+// result SPECULATIVELY, and read the solve's state together with its own scalars in one host synchronisation (stokes.hip: the Uzawa loop was two
+// synchronisations per outer iteration — this one and its nine scalars — with the host's launches and the device's execution taking turns).
+//   start(batch)  arena, boundary mask, r/z/d0 initialised, `batch` iterations and the loop test enqueued; no synchronisation
+//   read_state_async(&h) copies the state to the host (caller synchronises); complete(h) runs further batches (synchronising) until done;
+//   finish() strips the boundary rows of d0 (conj_grad :409) — harmless to enqueue speculatively, enqueued again after a continued solve.
+// Iterations past the one that meets the test are no-ops on the device, so a batch that overshoots costs launches, never results.
+using MatVec = std::function<int(const double *, double *, const int *, hipStream_t)>;   // matvec(p, Ap, done_flag, stream); free to return at once when *done_flag != 0
 
-int conj_grad_impl(const MatVec &matvec, int32_t neq, const double *BI, const int32_t *zero_resid, int32_t n_zero,
-                   const double *F, double *d0, double acc, int32_t *cycles, double *residual_out, void *stream)
-{
-    G4S_REQUIRE(neq > 0 && BI && F && d0 && cycles, "bad argument");
-    G4S_REQUIRE(n_zero >= 0 && (n_zero == 0 || zero_resid), "zero_resid is NULL");
-    hipStream_t s = g4s::as_stream(stream);
-    const size_t nb = sizeof(double) * (size_t)neq;
-    // one stream-ordered arena for the six work vectors, the partial sums, the state and the boundary mask: after the first solve
-    // the pool hands the same pages back without a driver call (nine hipMalloc/hipFree pairs cost more than a short solve)
-    const size_t nbp = (nb + 255) / 256 * 256;
-    const size_t arena_bytes = 6 * nbp + sizeof(double) * 3 * kDotBlocks + 256 + (n_zero ? ((size_t)neq + 255) / 256 * 256 : 0);
-    struct Arena {
-        void *p = nullptr; hipStream_t s = nullptr;
-        ~Arena() { g4s::scratch_free(p, s); }
-    } arena;
-    arena.s = s;
-    G4S_TRY(g4s::scratch_alloc(&arena.p, arena_bytes, s));
-    char *base = static_cast<char *>(arena.p);
-    double *r1 = reinterpret_cast<double *>(base), *r2 = reinterpret_cast<double *>(base + nbp), *z = reinterpret_cast<double *>(base + 2 * nbp),
-           *p1 = reinterpret_cast<double *>(base + 3 * nbp), *p2 = reinterpret_cast<double *>(base + 4 * nbp), *Ap = reinterpret_cast<double *>(base + 5 * nbp);
-    double *part_rz = reinterpret_cast<double *>(base + 6 * nbp), *part_pAp = part_rz + kDotBlocks, *part_rr = part_pAp + kDotBlocks;
-    CgState *st = reinterpret_cast<CgState *>(part_rr + kDotBlocks);
-    static_assert(sizeof(CgState) <= 256, "state slot");
-    G4S_HIP_TRY(hipMemsetAsync(part_rz, 0, sizeof(double) * 3 * kDotBlocks + sizeof(CgState), s));   // partial sums of unused workgroup slots stay zero; state
+struct CgRun {
+    MatVec matvec;
+    int neq = 0, n_zero = 0, steps = 0, enqueued = 0;
+    const double *BI = nullptr;
+    const int32_t *zero_resid = nullptr;
+    double *d0 = nullptr, acc = 0.0;
+    hipStream_t s = nullptr;
+    void *arena = nullptr;
+    double *r1 = nullptr, *r2 = nullptr, *z = nullptr, *p1 = nullptr, *p2 = nullptr, *Ap = nullptr, *part_rz = nullptr, *part_pAp = nullptr, *part_rr = nullptr;
+    CgState *st = nullptr;
     unsigned char *bc_mask = nullptr;
-    if (n_zero) {
-        bc_mask = reinterpret_cast<unsigned char *>(st) + 256;
-        G4S_HIP_TRY(hipMemsetAsync(bc_mask, 0, (size_t)neq, s));
-        hipLaunchKernelGGL(cg_mask_kernel, dim3((n_zero + kThreads - 1) / kThreads), dim3(kThreads), 0, s, n_zero, zero_resid, bc_mask);
-    }
-    const int steps = *cycles;
-    hipLaunchKernelGGL(cg_init_kernel, dim3(dot_blocks(neq)), dim3(kThreads), 0, s, neq, F, BI, r1, d0, z, part_rr, part_rz);
-    CgState h{};
-    // first batch: one more than the previous solve of this thread needed — consecutive velocity solves of an Uzawa iteration take
-    // nearly the same number of iterations, so the whole solve is usually one batch, one read-back and no wasted launches
-    static thread_local int last_iterations = 3;
-    int batch = std::max(2, std::min(32, last_iterations + 1)), enqueued = 0;
-    while (!h.done) {
-        // iterations past the one that meets the test are no-ops on the device (and the pointer rotation of :398-402 below is then
-        // irrelevant: nothing reads r1/r2/p1/p2 again)
-        const int todo = std::max(1, std::min(batch, steps - enqueued + 1));
+    ~CgRun() { g4s::scratch_free(arena, s); }
+
+    int enqueue(int todo)
+    {
         for (int it = 0; it < todo; ++it) {
             hipLaunchKernelGGL(cg_direction_kernel, dim3(dot_blocks(neq)), dim3(kThreads), 0, s, neq, steps, acc, part_rr, part_rz, st, z, p1, p2);
             G4S_TRY(matvec(p2, Ap, &st->done, s));
             hipLaunchKernelGGL(cg_pAp_kernel, dim3(dot_blocks(neq)), dim3(kThreads), 0, s, neq, st, bc_mask, p2, Ap, part_pAp);
             hipLaunchKernelGGL(cg_update_kernel, dim3(dot_blocks(neq)), dim3(kThreads), 0, s, neq, part_pAp, st, BI, p2, Ap, r1, r2, d0, z, part_rr, part_rz);
-            std::swap(r1, r2);
+            std::swap(r1, r2);      // the pointer rotation of General_matrix_functions.c:398-402 (irrelevant for no-op iterations: nothing reads them again)
             std::swap(p1, p2);
         }
         enqueued += todo;
         hipLaunchKernelGGL(cg_peek_kernel, dim3(1), dim3(kThreads), 0, s, steps, acc, part_rr, st);
         G4S_HIP_TRY(hipGetLastError());
-        G4S_HIP_TRY(hipMemcpyAsync(&h, st, sizeof(CgState), hipMemcpyDeviceToHost, s));
-        G4S_HIP_TRY(hipStreamSynchronize(s));
-        // next batch: the iterations a geometric fit of the residual history says are left (+1), between 2 and 32
-        batch = std::min(32, batch * 2);
-        if (!h.done && h.count > 0 && h.residual > acc && acc > 0.0 && h.residual0 > h.residual) {
-            const double rate = std::log(h.residual / h.residual0) / h.count;        // < 0
-            const double left = std::log(acc / h.residual) / rate;
-            if (left > 0.0 && left < 1e6) batch = std::max(2, std::min(32, (int)std::ceil(left) + 1));
-        }
+        return G4S_OK;
     }
-    if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s conj_grad: %d iterations, %d enqueued, residual %.3e (acc %.3e)\n", h.count, enqueued, h.residual, acc);
-    last_iterations = h.count;
-    const double residual = h.residual;
-    *cycles = h.count;
-    if (n_zero) hipLaunchKernelGGL(cg_strip_kernel, dim3((n_zero + kThreads - 1) / kThreads), dim3(kThreads), 0, s, n_zero, zero_resid, d0);   // :409
-    G4S_HIP_TRY(hipGetLastError());
+
+    int start(const MatVec &mv, int32_t neq_, const double *BI_, const int32_t *zero_resid_, int32_t n_zero_, const double *F, double *d0_, double acc_, int32_t steps_,
+              int batch, hipStream_t stream)
+    {
+        G4S_REQUIRE(neq_ > 0 && BI_ && F && d0_, "bad argument");
+        G4S_REQUIRE(n_zero_ >= 0 && (n_zero_ == 0 || zero_resid_), "zero_resid is NULL");
+        matvec = mv; neq = neq_; BI = BI_; zero_resid = zero_resid_; n_zero = n_zero_; d0 = d0_; acc = acc_; steps = steps_; s = stream;
+        const size_t nb = sizeof(double) * (size_t)neq;
+        // one stream-ordered arena for the six work vectors, the partial sums, the state and the boundary mask: after the first solve
+        // the pool hands the same pages back without a driver call (nine hipMalloc/hipFree pairs cost more than a short solve)
+        const size_t nbp = (nb + 255) / 256 * 256;
+        const size_t arena_bytes = 6 * nbp + sizeof(double) * 3 * kDotBlocks + 256 + (n_zero ? ((size_t)neq + 255) / 256 * 256 : 0);
+        G4S_TRY(g4s::scratch_alloc(&arena, arena_bytes, s));
+        char *base = static_cast<char *>(arena);
+        r1 = reinterpret_cast<double *>(base); r2 = reinterpret_cast<double *>(base + nbp); z = reinterpret_cast<double *>(base + 2 * nbp);
+        p1 = reinterpret_cast<double *>(base + 3 * nbp); p2 = reinterpret_cast<double *>(base + 4 * nbp); Ap = reinterpret_cast<double *>(base + 5 * nbp);
+        part_rz = reinterpret_cast<double *>(base + 6 * nbp); part_pAp = part_rz + kDotBlocks; part_rr = part_pAp + kDotBlocks;
+        st = reinterpret_cast<CgState *>(part_rr + kDotBlocks);
+        static_assert(sizeof(CgState) <= 256, "state slot");
+        G4S_HIP_TRY(hipMemsetAsync(part_rz, 0, sizeof(double) * 3 * kDotBlocks + sizeof(CgState), s));   // partial sums of unused workgroup slots stay zero; state
+        if (n_zero) {
+            bc_mask = reinterpret_cast<unsigned char *>(st) + 256;
+            G4S_HIP_TRY(hipMemsetAsync(bc_mask, 0, (size_t)neq, s));
+            hipLaunchKernelGGL(cg_mask_kernel, dim3((n_zero + kThreads - 1) / kThreads), dim3(kThreads), 0, s, n_zero, zero_resid, bc_mask);
+        }
+        hipLaunchKernelGGL(cg_init_kernel, dim3(dot_blocks(neq)), dim3(kThreads), 0, s, neq, F, BI, r1, d0, z, part_rr, part_rz);
+        return enqueue(std::max(1, std::min(batch, steps + 1)));
+    }
+
+    int read_state_async(CgState *h) { G4S_HIP_TRY(hipMemcpyAsync(h, st, sizeof(CgState), hipMemcpyDeviceToHost, s)); return G4S_OK; }
+
+    // h: the state after the batches enqueued so far (read by the caller after a synchronisation). Runs on until the loop test is met.
+    int complete(CgState &h)
+    {
+        int batch = std::min(32, std::max(2, enqueued * 2));
+        while (!h.done) {
+            // next batch: the iterations a geometric fit of the residual history says are left (+1), between 2 and 32
+            if (h.count > 0 && h.residual > acc && acc > 0.0 && h.residual0 > h.residual) {
+                const double rate = std::log(h.residual / h.residual0) / h.count;        // < 0
+                const double left = std::log(acc / h.residual) / rate;
+                if (left > 0.0 && left < 1e6) batch = std::max(2, std::min(32, (int)std::ceil(left) + 1));
+            }
+            G4S_TRY(enqueue(std::max(1, std::min(batch, steps - enqueued + 1))));
+            G4S_TRY(read_state_async(&h));
+            G4S_HIP_TRY(hipStreamSynchronize(s));
+            batch = std::min(32, batch * 2);
+        }
+        return G4S_OK;
+    }
+
+    int finish()
+    {
+        if (n_zero) hipLaunchKernelGGL(cg_strip_kernel, dim3((n_zero + kThreads - 1) / kThreads), dim3(kThreads), 0, s, n_zero, zero_resid, d0);   // :409
+        G4S_HIP_TRY(hipGetLastError());
+        return G4S_OK;
+    }
+};
+
+// first batch: one more than the previous solve of this thread needed — consecutive velocity solves of an Uzawa iteration take nearly the same
+// number of iterations, so the whole solve is usually one batch, one read-back and no wasted launches
+int &cg_last_iterations() { static thread_local int last = 3; return last; }
+int cg_first_batch()
+{
+    if (const char *e = getenv("G4S_CG_FIRST_BATCH")) return std::max(1, atoi(e));   // tests: 1 makes every longer solve outrun its first batch
+    return std::max(2, std::min(32, cg_last_iterations() + 1));
+}
+
+MatVec cg_matvec_for(g4s_elem_op_t op, g4s_csr_t A)
+{
+    if (op) return [op](const double *p, double *Ap, const int *done, hipStream_t s) { return g4s_elem_op_apply_unless(op, p, Ap, done, s); };
+    return [A](const double *p, double *Ap, const int *, hipStream_t s) { return g4s_spmv(A, p, Ap, 1.0, 0.0, s); };
+}
+
+// the synchronous solve: start, read, continue until done, strip, synchronise
+int conj_grad_impl(const MatVec &matvec, int32_t neq, const double *BI, const int32_t *zero_resid, int32_t n_zero,
+                   const double *F, double *d0, double acc, int32_t *cycles, double *residual_out, void *stream)
+{
+    G4S_REQUIRE(cycles, "cycles is NULL");
+    hipStream_t s = g4s::as_stream(stream);
+    CgRun run;
+    G4S_TRY(run.start(matvec, neq, BI, zero_resid, n_zero, F, d0, acc, *cycles, cg_first_batch(), s));
+    CgState h{};
+    G4S_TRY(run.read_state_async(&h));
     G4S_HIP_TRY(hipStreamSynchronize(s));
-    if (residual_out) *residual_out = residual;
+    G4S_TRY(run.complete(h));
+    if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s conj_grad: %d iterations, %d enqueued, residual %.3e (acc %.3e)\n", h.count, run.enqueued, h.residual, acc);
+    cg_last_iterations() = h.count;
+    *cycles = h.count;
+    G4S_TRY(run.finish());
+    G4S_HIP_TRY(hipStreamSynchronize(s));
+    if (residual_out) *residual_out = h.residual;
     return G4S_OK;
 }
+} // namespace g4s
+
+namespace {
+using g4s::MatVec;
+using g4s::conj_grad_impl;
 } // namespace
+namespace g4s {
+struct CgAsync {
+    CgRun run;
+    CgState h{};
+};
+
+int cg_async_start(CgAsync **out, g4s_elem_op_t op, g4s_csr_t A, int32_t neq, const double *BI, const int32_t *zero_resid, int32_t n_zero,
+                   const double *F, double *d0, double acc, int32_t steps, hipStream_t s)
+{
+    *out = nullptr;
+    G4S_REQUIRE((op != nullptr) != (A != nullptr), "exactly one of op / A must be given");
+    auto c = new (std::nothrow) CgAsync();
+    if (!c) return set_error(G4S_ERR_NOMEM, "host allocation failed");
+    int st = c->run.start(cg_matvec_for(op, A), neq, BI, zero_resid, n_zero, F, d0, acc, steps, cg_first_batch(), s);
+    if (st == G4S_OK) st = c->run.finish();
+    if (st != G4S_OK) { delete c; return st; }
+    *out = c;
+    return G4S_OK;
+}
+
+int cg_async_read(CgAsync *c) { return c->run.read_state_async(&c->h); }
+
+int cg_async_settle(CgAsync *c, bool *speculation_held, int32_t *cycles, double *residual)
+{
+    *speculation_held = c->h.done != 0;
+    if (!c->h.done) {
+        G4S_TRY(c->run.complete(c->h));
+        G4S_TRY(c->run.finish());
+    }
+    cg_last_iterations() = c->h.count;
+    if (cycles) *cycles = c->h.count;
+    if (residual) *residual = c->h.residual;
+    return G4S_OK;
+}
+
+void cg_async_free(CgAsync *c) { delete c; }
+} // namespace g4s
+
 
 G4S_API g4s_status g4s_conj_grad(g4s_elem_op_t op, g4s_csr_t A, int32_t neq, const double *BI, const int32_t *zero_resid, int32_t n_zero,
                                  const double *F, double *d0, double acc, int32_t *cycles, double *residual_out, void *stream)
 {
     G4S_REQUIRE((op != nullptr) != (A != nullptr), "exactly one of op / A must be given");
-    MatVec mv;
-    if (op) mv = [op](const double *p, double *Ap, const int *done, hipStream_t s) { return g4s_elem_op_apply_unless(op, p, Ap, done, s); };
-    else mv = [A](const double *p, double *Ap, const int *, hipStream_t s) { return g4s_spmv(A, p, Ap, 1.0, 0.0, s); };
-    return conj_grad_impl(mv, neq, BI, zero_resid, n_zero, F, d0, acc, cycles, residual_out, stream);
+    return conj_grad_impl(g4s::cg_matvec_for(op, A), neq, BI, zero_resid, n_zero, F, d0, acc, cycles, residual_out, stream);
 }
 
 G4S_API g4s_status g4s_conj_grad_node(g4s_node_op_t op, int32_t neq, const double *BI, const int32_t *zero_resid, int32_t n_zero,

@@ -1,0 +1,16 @@
+// cg_async.hpp — a conjugate-gradient solve whose first batch of iterations is only ENQUEUED (cg.hip: CgRun), for callers that go on enqueuing
+// dependent work speculatively and read the solve's state with their own scalars in one host synchronisation (stokes.hip).
+#pragma once
+#include "common.hpp"
+
+namespace g4s {
+struct CgAsync;
+// Enqueues: set-up, the first batch of iterations (one more than this thread's previous solve needed), the loop test, the strip of d0's boundary rows.
+int cg_async_start(CgAsync **out, g4s_elem_op_t op, g4s_csr_t A, int32_t neq, const double *BI, const int32_t *zero_resid, int32_t n_zero,
+                   const double *F, double *d0, double acc, int32_t steps, hipStream_t s);
+int cg_async_read(CgAsync *c);                      // enqueues the copy of the solve's state into the object (the caller synchronises)
+// After that synchronisation. *speculation_held = the first batch met the loop test, so everything enqueued behind it used the final d0. If it did
+// not, the solve is run to its end here (synchronising) and d0 stripped again; the caller must redo what it had enqueued behind the solve.
+int cg_async_settle(CgAsync *c, bool *speculation_held, int32_t *cycles, double *residual);
+void cg_async_free(CgAsync *c);
+} // namespace g4s

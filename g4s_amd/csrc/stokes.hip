@@ -9,6 +9,7 @@
 // (keep_iterating :150-162, the "two consecutive converging iterations" rule); δ, α and the norms are computed on the device and
 // nine doubles come back once per outer iteration.
 #include "common.hpp"
+#include "cg_async.hpp"
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -202,6 +203,13 @@ G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, g4s_csr_t K_csr, const 
            *s2 = reinterpret_cast<double *>(base + 3 * nq + 4 * np), *Fp = reinterpret_cast<double *>(base + 3 * nq + 5 * np);
     double *part = reinterpret_cast<double *>(base + 3 * nq + 6 * np), *sums_dev = part + 3 * kBlocks;
     const int *node_eq = v.node_eq;
+    // V and P of the NEXT outer iteration are written beside the current ones (ping-pong): an iteration that was enqueued behind a velocity
+    // solve which turns out not to have met its test can then simply be enqueued again, from unchanged inputs
+    Scratch scr2; scr2.s = s;
+    G4S_TRY(g4s::scratch_alloc(&scr2.p, nq + np, s));
+    double *Vc = V, *Vn = reinterpret_cast<double *>(scr2.p), *Pc = P, *Pn = reinterpret_cast<double *>(static_cast<char *>(scr2.p) + nq);
+    // G4S_STOKES_SYNC=1: wait for every velocity solve before enqueuing what follows it (the round-2 behaviour, for A/B)
+    const bool speculate = !(getenv("G4S_STOKES_SYNC") && atoi(getenv("G4S_STOKES_SYNC")) != 0);
 
     // sc: device scalars of the loop. A reduction = map_sum over the vectors + a one-workgroup finish whose epilogue writes the
     // derived scalars; nothing comes to the host until fetch() at the end of an outer iteration.
@@ -278,26 +286,50 @@ G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, g4s_csr_t K_csr, const 
                [=] __device__(double a, double, double) { sc[R1Z1] = a; sc[DELTA] = a / sc[R0Z0]; });
         const bool first = count == 0;
         each(nel, [=] __device__(int i) { s2[i] = first ? z1[i] : z1[i] + sc[DELTA] * s1[i]; });
-        // K·u1 = grad(s2)
+        // K·u1 = grad(s2). The solve's first batch (one iteration more than the previous solve needed) is only enqueued; everything that follows it
+        // in this outer iteration is enqueued behind it at once, and ONE synchronisation brings back the solve's state and the nine scalars.
+        // Before round 3 the host waited for the solve, then enqueued the rest and waited again: at Cookbook2's size the loop was host-bound
+        // (38 launches of 3–11 µs and two read-backs per outer iteration: 0.21 ms, of which the device needs 0.13 — tools/uzawa_graph_probe.py).
         G4S_TRY(g4s_elem_op_grad_p(op, g, s2, tmp, zero_resid, n_zero, s));
-        G4S_TRY(solve_del2_u(tmp, u1, &valid));
-        strip(u1);
-        G4S_TRY(g4s_elem_op_div_u(op, g, u1, Fp, s));
-        // α = <r1, z1> / <s2, div(u1)>; r2, P, V (:336-354)
-        reduce(nel, [=] __device__(int i) { return Sum3{s2[i] * Fp[i], 0.0, 0.0}; },
-               [=] __device__(double a, double, double) { sc[ALPHA] = sc[R1Z1] / a; });
-        each(nel, [=] __device__(int i) { const double alpha = sc[ALPHA]; r2[i] = r1[i] - alpha * Fp[i]; P[i] += alpha * s2[i]; });
-        each(neq, [=] __device__(int i) { V[i] -= sc[ALPHA] * u1[i]; });
-        G4S_TRY(g4s_elem_op_div_u(op, g, V, z1, s));
-        reduce(std::max(nno, nel), [=] __device__(int i) {
-            Sum3 o{0.0, 0.0, 0.0};
-            if (i < nno) { o.a = v_terms(V, i); o.b = v_terms(u1, i); }
-            if (i < nel) o.c = P[i] * P[i] * area[i];
-            return o;
-        }, [=] __device__(double a, double b, double c) { sc[VDOTV] = a; sc[U1DOTU1] = b; sc[PDOTP] = c; });
-        reduce(nel, [=] __device__(int i) { return Sum3{s2[i] * s2[i] * area[i], z1[i] * z1[i] / area[i], 0.0}; },
-               [=] __device__(double a, double b, double) { sc[S2S2] = a; sc[DIVN] = b; sc[R0Z0] = sc[R1Z1]; });   // shift <r0, z0> = <r1, z1> (:405)
-        G4S_TRY(fetch());                                          // the one read-back of the iteration: 9 doubles
+        g4s::CgAsync *cg = nullptr;
+        G4S_TRY(g4s::cg_async_start(&cg, K_csr ? nullptr : op, K_csr, neq, BI, zero_resid, n_zero, tmp, u1, inner_acc, prm->v_steps_low, s));
+        struct CgFree { g4s::CgAsync *c; ~CgFree() { g4s::cg_async_free(c); } } cg_guard{cg};
+        int32_t cycles = 0;
+        double residual = 0.0;
+        bool held = true;
+        if (!speculate) {
+            G4S_TRY(g4s::cg_async_read(cg));
+            G4S_HIP_TRY(hipStreamSynchronize(s));
+            G4S_TRY(g4s::cg_async_settle(cg, &held, &cycles, &residual));
+        }
+        auto rest_of_iteration = [&]() -> int {
+            G4S_TRY(g4s_elem_op_div_u(op, g, u1, Fp, s));
+            // α = <r1, z1> / <s2, div(u1)>; r2, P, V (:336-354)
+            reduce(nel, [=] __device__(int i) { return Sum3{s2[i] * Fp[i], 0.0, 0.0}; },
+                   [=] __device__(double a, double, double) { sc[ALPHA] = sc[R1Z1] / a; });
+            each(nel, [=] __device__(int i) { const double alpha = sc[ALPHA]; r2[i] = r1[i] - alpha * Fp[i]; Pn[i] = Pc[i] + alpha * s2[i]; });
+            each(neq, [=] __device__(int i) { Vn[i] = Vc[i] - sc[ALPHA] * u1[i]; });
+            G4S_TRY(g4s_elem_op_div_u(op, g, Vn, z1, s));
+            reduce(std::max(nno, nel), [=] __device__(int i) {
+                Sum3 o{0.0, 0.0, 0.0};
+                if (i < nno) { o.a = v_terms(Vn, i); o.b = v_terms(u1, i); }
+                if (i < nel) o.c = Pn[i] * Pn[i] * area[i];
+                return o;
+            }, [=] __device__(double a, double b, double c) { sc[VDOTV] = a; sc[U1DOTU1] = b; sc[PDOTP] = c; });
+            reduce(nel, [=] __device__(int i) { return Sum3{s2[i] * s2[i] * area[i], z1[i] * z1[i] / area[i], 0.0}; },
+                   [=] __device__(double a, double b, double) { sc[S2S2] = a; sc[DIVN] = b; sc[R0Z0] = sc[R1Z1]; });   // shift <r0, z0> = <r1, z1> (:405)
+            return G4S_OK;
+        };
+        G4S_TRY(rest_of_iteration());
+        if (speculate) {
+            G4S_TRY(g4s::cg_async_read(cg));
+            G4S_TRY(fetch());
+            G4S_TRY(g4s::cg_async_settle(cg, &held, &cycles, &residual));
+            if (!held) G4S_TRY(rest_of_iteration());              // the first batch did not meet the test: u1 is final only now — once more, from the same V, P, r1, s2
+        }
+        inner_total += cycles;
+        valid = residual < inner_acc ? 1 : 0;
+        if (!speculate || !held) G4S_TRY(fetch());                 // (speculation that held: the scalars came back with the solve's state)
         if (hsc[R1Z1] == 0.0) return g4s::set_error(G4S_ERR_INVALID, "g4s_stokes_uzawa_cg: <r1, z1> = 0 at the head of iteration %d (the source asserts)", count);
         const double alpha = hsc[ALPHA];
         vdotv = hsc[VDOTV] / volume;
@@ -312,6 +344,12 @@ G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, g4s_csr_t K_csr, const 
         else converging = dvelocity < prm->imp ? converging + 1 : 0;
         std::swap(s1, s2);
         std::swap(r1, r2);
+        std::swap(Vc, Vn);
+        std::swap(Pc, Pn);
+    }
+    if (Vc != V) {                                                 // an odd number of iterations: the result sits in the scratch pair
+        G4S_HIP_TRY(hipMemcpyAsync(V, Vc, sizeof(double) * (size_t)neq, hipMemcpyDeviceToDevice, s));
+        G4S_HIP_TRY(hipMemcpyAsync(P, Pc, sizeof(double) * (size_t)nel, hipMemcpyDeviceToDevice, s));
     }
     G4S_HIP_TRY(hipGetLastError());
     G4S_HIP_TRY(hipStreamSynchronize(s));

@@ -95,3 +95,44 @@ def test_uzawa_iteration_matches_oracle(oracle, ex, ey, ez, seed, check_cont, ch
     mom -= Kv
     mom[pr["bc"]] = 0.0
     assert np.linalg.norm(mom) <= 50 * imp * v_res
+
+
+@pytest.mark.parametrize("stiffness", ["elements", "csr"])
+def test_uzawa_speculation_and_its_fallback_are_bit_identical(oracle, monkeypatch, stiffness):
+    """Round 3: the Uzawa loop enqueues the rest of an outer iteration behind the velocity solve's first batch and reads everything back in one
+    synchronisation; when that batch was too short the solve is finished and the rest enqueued again from unchanged inputs. Three ways through the
+    same arithmetic — speculation that holds (default), speculation that never holds (G4S_CG_FIRST_BATCH=1), no speculation (G4S_STOKES_SYNC=1) —
+    must give the same iteration counts and bit-identical V, P, also for an odd and an even number of outer iterations (the ping-pong copy-back)."""
+    from g4s_amd import capi, host
+    lib = capi.load()
+    pr = stokes_problem(8, 6, 4, 5)
+    ien, idmap, nno, neq, nel = pr["ien"], pr["id"], pr["nno"], pr["neq"], len(pr["ien"])
+    BI = oracle.element_inverse_diagonal(ien, idmap, pr["K"], neq)
+    BPI = oracle.build_diagonal_of_Ahat(ien, idmap, pr["g"], BI)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    Kd, gd, BId, BPId, nmd, ard, bcd, Fd = (dev(pr["K"]), dev(pr["g"]), dev(BI), dev(BPI), dev(pr["nmass"]), dev(pr["area"]), dev(pr["bc"]), dev(pr["F"]))
+    h = _op(lib, capi, ien, idmap, nno, neq, Kd)
+    Acsr = host.CSR.from_host(*assemble_csr(ien, idmap, pr["K"], neq), neq, neq) if stiffness == "csr" else None
+    v_res = float(np.linalg.norm(pr["F"]))
+    outs = {}
+    for steps in (40, 3, 4):                                       # converged, capped at an odd and at an even count
+        for mode in ("default", "never_holds", "sync"):
+            monkeypatch.delenv("G4S_CG_FIRST_BATCH", raising=False)
+            monkeypatch.delenv("G4S_STOKES_SYNC", raising=False)
+            if mode == "never_holds":
+                monkeypatch.setenv("G4S_CG_FIRST_BATCH", "1")
+            if mode == "sync":
+                monkeypatch.setenv("G4S_STOKES_SYNC", "1")
+            prm = capi.StokesParams(1e-6, 1.0, v_res, 500, steps, 0, 0)
+            res = capi.StokesResult()
+            Vd, Pd = torch.zeros(neq, dtype=torch.float64, device="cuda"), torch.zeros(nel, dtype=torch.float64, device="cuda")
+            capi.check(lib.g4s_stokes_uzawa_cg(h, Acsr.handle if Acsr is not None else None, gd.data_ptr(), BId.data_ptr(), BPId.data_ptr(), nmd.data_ptr(), ard.data_ptr(),
+                                               pr["volume"], bcd.data_ptr(), len(pr["bc"]), Fd.data_ptr(), Vd.data_ptr(), Pd.data_ptr(), C.byref(prm), C.byref(res), None, 0, None))
+            outs[(steps, mode)] = (res.outer_iterations, res.inner_iterations, Vd.cpu().numpy(), Pd.cpu().numpy())
+        a, b, c = outs[(steps, "default")], outs[(steps, "never_holds")], outs[(steps, "sync")]
+        assert a[0] == b[0] == c[0] and a[1] == b[1] == c[1], (steps, a[:2], b[:2], c[:2])
+        if stiffness == "csr":                                     # the CSR product is reproducible: bit-identical; the element operator too (no atomics)
+            pass
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[2], c[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[3], c[3])
+    assert outs[(3, "default")][0] == 3 and outs[(4, "default")][0] == 4 and outs[(40, "default")][0] > 4
+    lib.g4s_elem_op_destroy(h)
