@@ -53,9 +53,11 @@ __device__ __forceinline__ double sum_partials(const double *__restrict__ part, 
 // r1 = F; d0 = 0; z = BI∘r1; partial r1·r1 and r1·z   (General_matrix_functions.c:345-362, first pass of :365-367)
 __global__ __launch_bounds__(kThreads) void cg_init_kernel(int n, const double *__restrict__ F, const double *__restrict__ BI, double *__restrict__ r1,
                                                             double *__restrict__ d0, double *__restrict__ z, double *__restrict__ part_rr,
-                                                            double *__restrict__ part_rz)
+                                                            double *__restrict__ part_rz, CgState *__restrict__ st)
 {
     __shared__ double sh[4];
+    // the state of a new solve (no other block of this kernel reads it; a memset launch less per solve)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->r1z1 = 0.0; st->r0z0 = 0.0; st->residual = 0.0; st->residual0 = 0.0; st->count = 0; st->done = 0; }
     double rr = 0.0, rz = 0.0;
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
         const double f = F[i], zi = BI[i] * f;
@@ -214,6 +216,15 @@ namespace g4s {
 // Iterations past the one that meets the test are no-ops on the device, so a batch that overshoots costs launches, never results.
 using MatVec = std::function<int(const double *, double *, const int *, hipStream_t)>;   // matvec(p, Ap, done_flag, stream); free to return at once when *done_flag != 0
 
+// byte mask of the boundary equations (strip_bcs_from_residual through cg_pAp_kernel): neq bytes
+int cg_build_mask(int32_t neq, const int32_t *zero_resid, int32_t n_zero, unsigned char *mask, hipStream_t s)
+{
+    G4S_HIP_TRY(hipMemsetAsync(mask, 0, (size_t)neq, s));
+    if (n_zero) hipLaunchKernelGGL(cg_mask_kernel, dim3((n_zero + kThreads - 1) / kThreads), dim3(kThreads), 0, s, n_zero, zero_resid, mask);
+    G4S_HIP_TRY(hipGetLastError());
+    return G4S_OK;
+}
+
 struct CgRun {
     MatVec matvec;
     int neq = 0, n_zero = 0, steps = 0, enqueued = 0;
@@ -244,7 +255,7 @@ struct CgRun {
     }
 
     int start(const MatVec &mv, int32_t neq_, const double *BI_, const int32_t *zero_resid_, int32_t n_zero_, const double *F, double *d0_, double acc_, int32_t steps_,
-              int batch, hipStream_t stream)
+              int batch, hipStream_t stream, const unsigned char *shared_mask = nullptr)
     {
         G4S_REQUIRE(neq_ > 0 && BI_ && F && d0_, "bad argument");
         G4S_REQUIRE(n_zero_ >= 0 && (n_zero_ == 0 || zero_resid_), "zero_resid is NULL");
@@ -261,13 +272,13 @@ struct CgRun {
         part_rz = reinterpret_cast<double *>(base + 6 * nbp); part_pAp = part_rz + kDotBlocks; part_rr = part_pAp + kDotBlocks;
         st = reinterpret_cast<CgState *>(part_rr + kDotBlocks);
         static_assert(sizeof(CgState) <= 256, "state slot");
-        G4S_HIP_TRY(hipMemsetAsync(part_rz, 0, sizeof(double) * 3 * kDotBlocks + sizeof(CgState), s));   // partial sums of unused workgroup slots stay zero; state
-        if (n_zero) {
+        // no memset: cg_init_kernel resets the state, and every kernel that writes partial sums zeroes the slots of workgroups that do not exist
+        if (n_zero && shared_mask) bc_mask = const_cast<unsigned char *>(shared_mask);   // built once by the caller for all its solves (cg_build_mask)
+        else if (n_zero) {
             bc_mask = reinterpret_cast<unsigned char *>(st) + 256;
-            G4S_HIP_TRY(hipMemsetAsync(bc_mask, 0, (size_t)neq, s));
-            hipLaunchKernelGGL(cg_mask_kernel, dim3((n_zero + kThreads - 1) / kThreads), dim3(kThreads), 0, s, n_zero, zero_resid, bc_mask);
+            G4S_TRY(cg_build_mask(neq, zero_resid, n_zero, bc_mask, s));
         }
-        hipLaunchKernelGGL(cg_init_kernel, dim3(dot_blocks(neq)), dim3(kThreads), 0, s, neq, F, BI, r1, d0, z, part_rr, part_rz);
+        hipLaunchKernelGGL(cg_init_kernel, dim3(dot_blocks(neq)), dim3(kThreads), 0, s, neq, F, BI, r1, d0, z, part_rr, part_rz, st);
         return enqueue(std::max(1, std::min(batch, steps + 1)));
     }
 
@@ -348,13 +359,13 @@ struct CgAsync {
 };
 
 int cg_async_start(CgAsync **out, g4s_elem_op_t op, g4s_csr_t A, int32_t neq, const double *BI, const int32_t *zero_resid, int32_t n_zero,
-                   const double *F, double *d0, double acc, int32_t steps, hipStream_t s)
+                   const double *F, double *d0, double acc, int32_t steps, hipStream_t s, const unsigned char *bc_mask)
 {
     *out = nullptr;
     G4S_REQUIRE((op != nullptr) != (A != nullptr), "exactly one of op / A must be given");
     auto c = new (std::nothrow) CgAsync();
     if (!c) return set_error(G4S_ERR_NOMEM, "host allocation failed");
-    int st = c->run.start(cg_matvec_for(op, A), neq, BI, zero_resid, n_zero, F, d0, acc, steps, cg_first_batch(), s);
+    int st = c->run.start(cg_matvec_for(op, A), neq, BI, zero_resid, n_zero, F, d0, acc, steps, cg_first_batch(), s, bc_mask);
     if (st == G4S_OK) st = c->run.finish();
     if (st != G4S_OK) { delete c; return st; }
     *out = c;
@@ -451,7 +462,7 @@ G4S_API g4s_status g4s_cg_begin(g4s_cg_ws_t ws, const double *F_dev, const doubl
         G4S_HIP_TRY(hipMemsetAsync(ws->mask, 0, (size_t)ws->n, s));
         hipLaunchKernelGGL(cg_mask_kernel, dim3((n_zero + kThreads - 1) / kThreads), dim3(kThreads), 0, s, n_zero, zero_resid_dev, ws->mask);
     }
-    hipLaunchKernelGGL(cg_init_kernel, dim3(dot_blocks(ws->n)), dim3(kThreads), 0, s, ws->n, F_dev, BI_dev, ws->r1, d0_dev, ws->z, ws->part + 2 * kDotBlocks, ws->part);
+    hipLaunchKernelGGL(cg_init_kernel, dim3(dot_blocks(ws->n)), dim3(kThreads), 0, s, ws->n, F_dev, BI_dev, ws->r1, d0_dev, ws->z, ws->part + 2 * kDotBlocks, ws->part, ws->st);
     G4S_HIP_TRY(hipGetLastError());
     return G4S_OK;
 }

@@ -7,7 +7,9 @@ namespace g4s {
 struct CgAsync;
 // Enqueues: set-up, the first batch of iterations (one more than this thread's previous solve needed), the loop test, the strip of d0's boundary rows.
 int cg_async_start(CgAsync **out, g4s_elem_op_t op, g4s_csr_t A, int32_t neq, const double *BI, const int32_t *zero_resid, int32_t n_zero,
-                   const double *F, double *d0, double acc, int32_t steps, hipStream_t s);
+                   const double *F, double *d0, double acc, int32_t steps, hipStream_t s, const unsigned char *bc_mask = nullptr);
+// the boundary-equation byte mask a solve needs (neq bytes): a caller with many solves on one set of boundary rows builds it once and passes it in
+int cg_build_mask(int32_t neq, const int32_t *zero_resid, int32_t n_zero, unsigned char *mask, hipStream_t s);
 int cg_async_read(CgAsync *c);                      // enqueues the copy of the solve's state into the object (the caller synchronises)
 // After that synchronisation. *speculation_held = the first batch met the loop test, so everything enqueued behind it used the final d0. If it did
 // not, the solve is run to its end here (synchronising) and d0 stripped again; the caller must redo what it had enqueued behind the solve.

@@ -30,6 +30,7 @@ __device__ __forceinline__ double block_sum(double v, double *sh)
 }
 
 struct Sum3 { double a, b, c; };
+struct Sum6 { double v[6]; };
 
 // f(i) does the element-wise work of index i and returns up to three terms to be summed over i. Two-level sums with a fixed
 // shape (grid-stride partials per workgroup → finish_sums_kernel): reproducible.
@@ -56,6 +57,32 @@ __global__ __launch_bounds__(kThreads) void finish_sums_kernel(const double *__r
     double r[3];
     for (int k = 0; k < 3; ++k) r[k] = block_sum(part[k * kBlocks + threadIdx.x], sh);
     if (threadIdx.x == 0) ep(r[0], r[1], r[2]);
+}
+
+// the same with six terms (the five norms at the end of an outer iteration in one pass instead of two)
+template <typename F>
+__global__ __launch_bounds__(kThreads) void map_sum6_kernel(int n, F f, double *__restrict__ part)
+{
+    __shared__ double sh[4];
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += kBlocks * kThreads) {
+        const Sum6 v = f(i);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] += v.v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double t = block_sum(acc[k], sh);
+        if (threadIdx.x == 0) part[k * kBlocks + blockIdx.x] = t;
+    }
+}
+template <typename E>
+__global__ __launch_bounds__(kThreads) void finish_sums6_kernel(const double *__restrict__ part, E ep)
+{
+    __shared__ double sh[4];
+    double r[6];
+    for (int k = 0; k < 6; ++k) r[k] = block_sum(part[k * kBlocks + threadIdx.x], sh);
+    if (threadIdx.x == 0) ep(r);
 }
 
 template <typename F>
@@ -195,18 +222,21 @@ G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, g4s_csr_t K_csr, const 
     const int neq = v.neq, nel = v.nel, nno = v.nno, dof = v.dof;
     const size_t nq = ((size_t)neq * 8 + 255) / 256 * 256, np = ((size_t)nel * 8 + 255) / 256 * 256;
     Scratch scr; scr.s = s;
-    G4S_TRY(g4s::scratch_alloc(&scr.p, 3 * nq + 6 * np + sizeof(double) * (3 * kBlocks + 16), s));
+    G4S_TRY(g4s::scratch_alloc(&scr.p, 3 * nq + 6 * np + sizeof(double) * (6 * kBlocks + 16), s));
     char *base = static_cast<char *>(scr.p);
     double *F = reinterpret_cast<double *>(base), *u1 = reinterpret_cast<double *>(base + nq), *tmp = reinterpret_cast<double *>(base + 2 * nq);
     double *r1 = reinterpret_cast<double *>(base + 3 * nq), *r2 = reinterpret_cast<double *>(base + 3 * nq + np),
            *z1 = reinterpret_cast<double *>(base + 3 * nq + 2 * np), *s1 = reinterpret_cast<double *>(base + 3 * nq + 3 * np),
            *s2 = reinterpret_cast<double *>(base + 3 * nq + 4 * np), *Fp = reinterpret_cast<double *>(base + 3 * nq + 5 * np);
-    double *part = reinterpret_cast<double *>(base + 3 * nq + 6 * np), *sums_dev = part + 3 * kBlocks;
+    double *part = reinterpret_cast<double *>(base + 3 * nq + 6 * np), *sums_dev = part + 6 * kBlocks;
     const int *node_eq = v.node_eq;
     // V and P of the NEXT outer iteration are written beside the current ones (ping-pong): an iteration that was enqueued behind a velocity
     // solve which turns out not to have met its test can then simply be enqueued again, from unchanged inputs
     Scratch scr2; scr2.s = s;
-    G4S_TRY(g4s::scratch_alloc(&scr2.p, nq + np, s));
+    const size_t nm = ((size_t)neq + 255) / 256 * 256;
+    G4S_TRY(g4s::scratch_alloc(&scr2.p, nq + np + nm, s));
+    unsigned char *bc_mask = reinterpret_cast<unsigned char *>(static_cast<char *>(scr2.p) + nq + np);   // boundary-equation mask of every velocity solve of this call
+    G4S_TRY(g4s::cg_build_mask(neq, zero_resid, n_zero, bc_mask, s));
     double *Vc = V, *Vn = reinterpret_cast<double *>(scr2.p), *Pc = P, *Pn = reinterpret_cast<double *>(static_cast<char *>(scr2.p) + nq);
     // G4S_STOKES_SYNC=1: wait for every velocity solve before enqueuing what follows it (the round-2 behaviour, for A/B)
     const bool speculate = !(getenv("G4S_STOKES_SYNC") && atoi(getenv("G4S_STOKES_SYNC")) != 0);
@@ -292,7 +322,7 @@ G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, g4s_csr_t K_csr, const 
         // (38 launches of 3–11 µs and two read-backs per outer iteration: 0.21 ms, of which the device needs 0.13 — tools/uzawa_graph_probe.py).
         G4S_TRY(g4s_elem_op_grad_p(op, g, s2, tmp, zero_resid, n_zero, s));
         g4s::CgAsync *cg = nullptr;
-        G4S_TRY(g4s::cg_async_start(&cg, K_csr ? nullptr : op, K_csr, neq, BI, zero_resid, n_zero, tmp, u1, inner_acc, prm->v_steps_low, s));
+        G4S_TRY(g4s::cg_async_start(&cg, K_csr ? nullptr : op, K_csr, neq, BI, zero_resid, n_zero, tmp, u1, inner_acc, prm->v_steps_low, s, n_zero ? bc_mask : nullptr));
         struct CgFree { g4s::CgAsync *c; ~CgFree() { g4s::cg_async_free(c); } } cg_guard{cg};
         int32_t cycles = 0;
         double residual = 0.0;
@@ -307,17 +337,22 @@ G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, g4s_csr_t K_csr, const 
             // α = <r1, z1> / <s2, div(u1)>; r2, P, V (:336-354)
             reduce(nel, [=] __device__(int i) { return Sum3{s2[i] * Fp[i], 0.0, 0.0}; },
                    [=] __device__(double a, double, double) { sc[ALPHA] = sc[R1Z1] / a; });
-            each(nel, [=] __device__(int i) { const double alpha = sc[ALPHA]; r2[i] = r1[i] - alpha * Fp[i]; Pn[i] = Pc[i] + alpha * s2[i]; });
-            each(neq, [=] __device__(int i) { Vn[i] = Vc[i] - sc[ALPHA] * u1[i]; });
+            each(std::max(nel, neq), [=] __device__(int i) {        // one launch for the three updates
+                const double alpha = sc[ALPHA];
+                if (i < nel) { r2[i] = r1[i] - alpha * Fp[i]; Pn[i] = Pc[i] + alpha * s2[i]; }
+                if (i < neq) Vn[i] = Vc[i] - alpha * u1[i];
+            });
             G4S_TRY(g4s_elem_op_div_u(op, g, Vn, z1, s));
-            reduce(std::max(nno, nel), [=] __device__(int i) {
-                Sum3 o{0.0, 0.0, 0.0};
-                if (i < nno) { o.a = v_terms(Vn, i); o.b = v_terms(u1, i); }
-                if (i < nel) o.c = Pn[i] * Pn[i] * area[i];
+            // the five norms of the iteration in one two-level pass (they were two passes of three: two launches less)
+            hipLaunchKernelGGL(map_sum6_kernel, dim3(kBlocks), dim3(kThreads), 0, s, std::max(nno, nel), [=] __device__(int i) {
+                Sum6 o{{0.0, 0.0, 0.0, 0.0, 0.0, 0.0}};
+                if (i < nno) { o.v[0] = v_terms(Vn, i); o.v[1] = v_terms(u1, i); }
+                if (i < nel) { o.v[2] = Pn[i] * Pn[i] * area[i]; o.v[3] = s2[i] * s2[i] * area[i]; o.v[4] = z1[i] * z1[i] / area[i]; }
                 return o;
-            }, [=] __device__(double a, double b, double c) { sc[VDOTV] = a; sc[U1DOTU1] = b; sc[PDOTP] = c; });
-            reduce(nel, [=] __device__(int i) { return Sum3{s2[i] * s2[i] * area[i], z1[i] * z1[i] / area[i], 0.0}; },
-                   [=] __device__(double a, double b, double) { sc[S2S2] = a; sc[DIVN] = b; sc[R0Z0] = sc[R1Z1]; });   // shift <r0, z0> = <r1, z1> (:405)
+            }, part);
+            hipLaunchKernelGGL(finish_sums6_kernel, dim3(1), dim3(kThreads), 0, s, part, [=] __device__(const double (&r)[6]) {
+                sc[VDOTV] = r[0]; sc[U1DOTU1] = r[1]; sc[PDOTP] = r[2]; sc[S2S2] = r[3]; sc[DIVN] = r[4]; sc[R0Z0] = sc[R1Z1];   // shift <r0, z0> = <r1, z1> (:405)
+            });
             return G4S_OK;
         };
         G4S_TRY(rest_of_iteration());
