@@ -573,7 +573,7 @@ G4S_API g4s_status g4s_spmv_dist_buffers(g4s_spmv_dist_t h, double **send_dev, c
 // Pack the send segments, start the exchange (RCCL mode) on the side stream, run the own-column product on the caller's stream.
 G4S_API g4s_status g4s_spmv_dist_begin(g4s_spmv_dist_t h, const double *x_local_dev, double *y_local_dev, void *stream)
 {
-    G4S_REQUIRE(h && y_local_dev && (x_local_dev || h->local_rows == 0), "NULL argument");
+    G4S_REQUIRE(h && (y_local_dev || h->local_rows == 0) && (x_local_dev || h->off[(size_t)h->rank + 1] == h->off[h->rank]), "NULL argument");   // (a rectangular operator may own rows but no x entries, or the reverse)
     for (int k = 0; k < h->world; ++k)
         if (!(h->give_set[k] || (k == h->rank && !h->loopback)))
             return g4s::set_error(G4S_ERR_INVALID, "g4s_spmv_dist_begin: the give list of peer %d is not set (g4s_spmv_dist_connect_rccl or g4s_spmv_dist_set_give)", k);
