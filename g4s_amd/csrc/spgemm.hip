@@ -1551,7 +1551,11 @@ __global__ void row_size_keys_kernel(int n, const int *__restrict__ rows, const 
     if (i >= n) return;
     const int r = rows[i];
     const long long v = size ? size[r] : (long long)crpt[r + 1] - crpt[r];
-    keys[i] = v > INT_MAX ? INT_MAX : (int)v;
+    // The order only decides which rows the persistent kernels take first (longest first, for the tail): an 11-bit logarithmic key —
+    // position of the leading one, then the six bits behind it — is monotone in the size and sorts in 3 radix passes instead of 8.
+    const unsigned u = v > INT_MAX ? (unsigned)INT_MAX : (v < 0 ? 0u : (unsigned)v);
+    const int e = u ? 31 - __clz(u) : 0;
+    keys[i] = u ? ((e + 1) << 6) | (int)(((unsigned long long)u << (32 - e)) >> 26 & 63u) : 0;
 }
 struct SortedRows {
     DevBuf keys, keys_sorted, rows, tmp, counter;
@@ -1564,9 +1568,8 @@ struct SortedRows {
         G4S_HIP_TRY(hipMemsetAsync(counter.p, 0, sizeof(int), s));
         hipLaunchKernelGGL(row_size_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, list, size, crpt, keys.as<int>());
         G4S_TRY(tmp.alloc(sizeof(int) * 2 * (size_t)n));
-        int bits = 1;
-        while (bits < 31 && (1ll << bits) <= key_bound) ++bits;    // an upper bound of the keys' significant bits: fewer radix passes
-        G4S_TRY(g4s::prims::sort_pairs_descending(keys.as<int>(), list, keys_sorted.as<int>(), rows.as<int>(), tmp.as<int>(), tmp.as<int>() + n, n, bits, s));
+        (void)key_bound;
+        G4S_TRY(g4s::prims::sort_pairs_descending(keys.as<int>(), list, keys_sorted.as<int>(), rows.as<int>(), tmp.as<int>(), tmp.as<int>() + n, n, 11, s));   // (31 + 1) << 6 | 63 < 2^11
         return G4S_OK;
     }
 };
