@@ -95,6 +95,9 @@ __global__ void dist_pack_kernel(long long n, const int32_t *__restrict__ idx, c
 struct g4s_spmv_dist_s {
     int rank = 0, world = 1;
     bool loopback = false;
+    int nseg = 1;                               // segments of the exchange buffers: one per rank — or, in loopback, G4S_DIST_LOOPBACK_PEERS (default 7) pieces of
+                                                // the "remote" half of the slab, each travelling rank 0 → rank 0 as its own ncclSend / ncclRecv pair: the
+                                                // message pattern of an 8-GPU node's rank, rehearsed on one GPU
     bool merged = false;                        // the own columns are few: one product on a compact x that holds own and remote entries alike
     bool allgather = false;                     // the remote x is the whole vector, slab by slab, padded to `pad` entries per rank
     int64_t pad = 0;
@@ -136,6 +139,7 @@ int owner_of(const std::vector<int64_t> &off, int64_t col)
 
 // One rank's rows cut into the own-column and the remote-column part (host arrays; set-up logic, runs once per matrix).
 struct Split {
+    int nseg = 1;
     bool merged = false, allgather = false;
     int64_t pad = 0;
     int32_t n_ref = 0;                                              // length of the remote x (packed: referenced columns; all-gather: world·pad)
@@ -169,7 +173,13 @@ int split_rows(int rank, int world, const std::vector<int64_t> &off, int64_t n_c
         if (getenv("G4S_DIST_MERGE") || 4 * in_own < nnz) { S.merged = true; own_hi = own_lo; }
     }
     S.allgather = allgather;
-    S.recv_cut.assign((size_t)world + 1, 0);
+    S.nseg = world;
+    if (loopback && !allgather) {
+        const char *e = getenv("G4S_DIST_LOOPBACK_PEERS");
+        S.nseg = std::max(1, std::min(64, e ? atoi(e) : 7));
+    }
+    const int nseg = S.nseg;
+    S.recv_cut.assign((size_t)nseg + 1, 0);
     std::vector<int32_t> ref;                                       // packed mode: the referenced remote columns, ascending
     if (allgather) {
         for (int k = 0; k < world; ++k) S.pad = std::max(S.pad, off[(size_t)k + 1] - off[k]);
@@ -185,11 +195,12 @@ int split_rows(int rank, int world, const std::vector<int64_t> &off, int64_t n_c
         // what this rank wants from every owner: ref is sorted, so owner k's columns are one segment
         S.want.resize(ref.size());
         for (int32_t i = 0; i < S.n_ref; ++i) {
-            const int k = loopback ? 0 : owner_of(off, ref[i]);
+            // loopback: the remote half [own_hi, r1) in nseg equal column ranges, every one of them "owned" by rank 0
+            const int k = loopback ? (int)std::min<int64_t>(nseg - 1, (ref[i] - own_hi) * nseg / std::max<int64_t>(1, r1 - own_hi)) : owner_of(off, ref[i]);
             S.recv_cut[(size_t)k + 1]++;
-            S.want[i] = (int32_t)(ref[i] - off[k]);
+            S.want[i] = (int32_t)(ref[i] - off[loopback ? 0 : k]);
         }
-        for (int k = 0; k < world; ++k) S.recv_cut[(size_t)k + 1] += S.recv_cut[k];
+        for (int k = 0; k < nseg; ++k) S.recv_cut[(size_t)k + 1] += S.recv_cut[k];
         if (!loopback && !S.merged && S.recv_cut[(size_t)rank + 1] != S.recv_cut[rank]) return g4s::set_error(G4S_ERR_INVALID, "internal: own columns among the remote ones");
     }
     S.orp.assign((size_t)m + 1, 0); S.rrp.assign((size_t)m + 1, 0);
@@ -279,7 +290,7 @@ G4S_API g4s_status g4s_dist_split_rows(int32_t rank, int32_t world, const int64_
         out->nnz_own = (int64_t)S.oci.size(); out->nnz_rem = (int64_t)S.rci.size();
         out->own_rowptr = dup_array(S.orp); out->own_colids = dup_array(S.oci); out->own_values = dup_array(S.ova);
         out->rem_rowptr = dup_array(S.rrp); out->rem_colids = dup_array(S.rci); out->rem_values = dup_array(S.rva);
-        out->want = dup_array(S.want); out->recv_cut = dup_array(S.recv_cut);
+        out->want = dup_array(S.want); out->recv_cut = dup_array(S.recv_cut);   // (nseg + 1 entries: world + 1 outside the loopback rehearsal)
         if (!out->own_rowptr || !out->own_colids || !out->own_values || !out->rem_rowptr || !out->rem_colids || !out->rem_values || !out->want || !out->recv_cut) {
             g4s_dist_split_free(out);
             return g4s::set_error(G4S_ERR_NOMEM, "host allocation failed");
@@ -344,7 +355,7 @@ G4S_API g4s_status g4s_spmv_dist_create_rect(g4s_spmv_dist_t *out, int32_t rank,
         Split S;
         int st = split_rows(rank, world, h->off, n_cols, m, rp.data(), ci.data(), va.data(), h->loopback, allgather, S);
         if (st != G4S_OK) return fail(st);
-        h->merged = S.merged; h->allgather = S.allgather; h->pad = S.pad; h->n_ref = S.n_ref;
+        h->merged = S.merged; h->allgather = S.allgather; h->pad = S.pad; h->n_ref = S.n_ref; h->nseg = S.nseg;
         h->nnz_own = (int64_t)S.oci.size(); h->nnz_rem = (int64_t)S.rci.size();
         h->recv_cut = S.recv_cut;
         const unsigned path_flags = flags & (G4S_SPMV_NO_NT | G4S_SPMV_BLOCKED | G4S_SPMV_STREAM);
@@ -352,8 +363,8 @@ G4S_API g4s_status g4s_spmv_dist_create_rect(g4s_spmv_dist_t *out, int32_t rank,
         if (st != G4S_OK) return fail(st);
         st = g4s_csr_create(&h->A_rem, m, std::max(h->n_ref, 1), h->nnz_rem, S.rrp.data(), S.rci.data(), S.rva.data(), G4S_HOST_POINTERS | path_flags);
         if (st != G4S_OK) return fail(st);
-        h->give_cut.assign((size_t)world + 1, 0);
-        h->give_set.assign((size_t)world, 0);
+        h->give_cut.assign((size_t)h->nseg + 1, 0);
+        h->give_set.assign((size_t)h->nseg, 0);
         if (g4s::device_malloc((void **)&h->d_want, sizeof(int32_t) * std::max<size_t>(S.want.size(), 1)) != hipSuccess ||
             g4s::device_malloc((void **)&h->d_xrem, sizeof(double) * (size_t)std::max(h->n_ref, 1)) != hipSuccess)
             return fail(g4s::set_error(G4S_ERR_NOMEM, "device allocation failed"));
@@ -365,7 +376,7 @@ G4S_API g4s_status g4s_spmv_dist_create_rect(g4s_spmv_dist_t *out, int32_t rank,
             return fail(g4s::set_error(G4S_ERR_HIP, "stream / event creation failed"));
         if (h->allgather) {                                        // nothing to wire: every rank sends its slab, every rank knows where each slab lands
             std::fill(h->give_set.begin(), h->give_set.end(), 1);
-            h->give_cut[(size_t)world] = h->pad;                   // the one send segment: this rank's slot of the gathered vector, for every peer alike
+            h->give_cut[(size_t)h->nseg] = h->pad;                   // the one send segment: this rank's slot of the gathered vector, for every peer alike
         } else if (world == 1 && !h->loopback) h->give_set[0] = 1;  // nothing to exchange
     } catch (const std::bad_alloc &) {
         return fail(g4s::set_error(G4S_ERR_NOMEM, "host allocation failed"));
@@ -399,22 +410,22 @@ G4S_API g4s_status g4s_spmv_dist_get_info(g4s_spmv_dist_t h, g4s_spmv_dist_info 
         info->recv_bytes = 8 * h->pad * (h->world - 1);
         info->send_bytes = 8 * h->pad * (h->world - 1);
     } else {
-        info->recv_bytes = 8 * (h->recv_cut[h->world] - (h->merged ? h->recv_cut[(size_t)h->rank + 1] - h->recv_cut[h->rank] : 0));
-        info->send_bytes = 8 * h->give_cut[h->world];
+        info->recv_bytes = 8 * (h->recv_cut[h->nseg] - (h->merged ? h->recv_cut[(size_t)h->rank + 1] - h->recv_cut[h->rank] : 0));
+        info->send_bytes = 8 * h->give_cut[h->nseg];
     }
     info->reserved = (h->merged ? 1 : 0) | (h->allgather ? 2 : 0);
     g4s_csr_info ci;
     G4S_TRY(g4s_csr_get_info(h->A_own, &ci)); info->own_path = ci.spmv_path;
     G4S_TRY(g4s_csr_get_info(h->A_rem, &ci)); info->rem_path = ci.spmv_path;
     int ready = 1;
-    for (int k = 0; k < h->world; ++k) ready &= h->give_set[k] || (k == h->rank && !h->loopback);
+    for (int k = 0; k < h->nseg; ++k) ready &= h->give_set[k] || (k == h->rank && !h->loopback);
     info->connected = ready;
     return G4S_OK;
 }
 
 G4S_API g4s_status g4s_spmv_dist_want(g4s_spmv_dist_t h, int32_t peer, int64_t *count, const int32_t **idx_dev)
 {
-    G4S_REQUIRE(h && peer >= 0 && peer < h->world && count, "bad argument");
+    G4S_REQUIRE(h && peer >= 0 && peer < h->nseg && count, "bad argument");
     *count = h->recv_cut[(size_t)peer + 1] - h->recv_cut[peer];
     if (idx_dev) *idx_dev = h->d_want + h->recv_cut[peer];
     return G4S_OK;
@@ -423,7 +434,7 @@ G4S_API g4s_status g4s_spmv_dist_want(g4s_spmv_dist_t h, int32_t peer, int64_t *
 // The give lists arrive peer by peer, in any order; the send buffer is laid out in peer order once all of them are known.
 G4S_API g4s_status g4s_spmv_dist_set_give(g4s_spmv_dist_t h, int32_t peer, int64_t count, const int32_t *idx, unsigned flags)
 {
-    G4S_REQUIRE(h && peer >= 0 && peer < h->world && count >= 0 && (idx || count == 0), "bad argument");
+    G4S_REQUIRE(h && peer >= 0 && peer < h->nseg && count >= 0 && (idx || count == 0), "bad argument");
     G4S_REQUIRE(!h->allgather, "the all-gather exchange has no give lists");
     G4S_REQUIRE(!h->d_send, "the give lists are final once a product has run");
     std::vector<int32_t> list((size_t)count);
@@ -434,16 +445,16 @@ G4S_API g4s_status g4s_spmv_dist_set_give(g4s_spmv_dist_t h, int32_t peer, int64
         for (int32_t v : list) G4S_REQUIRE(v >= 0 && v < slab, "a requested index is outside this rank's slab");
     }
     // append to the device list: rebuild it in peer order from what is known so far
-    std::vector<int32_t> all((size_t)h->give_cut[h->world]);
+    std::vector<int32_t> all((size_t)h->give_cut[h->nseg]);
     if (!all.empty()) G4S_HIP_TRY(hipMemcpy(all.data(), h->d_give, sizeof(int32_t) * all.size(), hipMemcpyDeviceToHost));
     std::vector<int32_t> next;
-    std::vector<int64_t> cut((size_t)h->world + 1, 0);
-    for (int k = 0; k < h->world; ++k) {
+    std::vector<int64_t> cut((size_t)h->nseg + 1, 0);
+    for (int k = 0; k < h->nseg; ++k) {
         cut[k] = (int64_t)next.size();
         if (k == peer) next.insert(next.end(), list.begin(), list.end());
         else next.insert(next.end(), all.begin() + h->give_cut[k], all.begin() + h->give_cut[(size_t)k + 1]);
     }
-    cut[h->world] = (int64_t)next.size();
+    cut[h->nseg] = (int64_t)next.size();
     (void)hipFree(h->d_give);
     h->d_give = nullptr;
     if (g4s::device_malloc((void **)&h->d_give, sizeof(int32_t) * std::max<size_t>(next.size(), 1)) != hipSuccess) return g4s::set_error(G4S_ERR_NOMEM, "device allocation failed");
@@ -506,7 +517,8 @@ G4S_API g4s_status g4s_spmv_dist_connect_rccl(g4s_spmv_dist_t h, void *comm)
     if (h->allgather) return G4S_OK;                               // no lists to exchange: the collective itself is the wiring
     // a send buffer sized from earlier give lists (g4s_spmv_dist_buffers, or a product that ran before the wiring) would be too small for the new ones
     if (h->d_send) { (void)hipFree(h->d_send); h->d_send = nullptr; }
-    const int W = h->world;
+    const int W = h->nseg;                                         // segments; segment k talks to rank k (loopback: every segment to rank 0)
+    auto peer = [&](int k) { return h->loopback ? 0 : k; };
     // 1. how many entries does every peer want from me? one 8-byte exchange per pair
     std::vector<long long> want_n((size_t)W), give_n((size_t)W, 0);
     for (int k = 0; k < W; ++k) want_n[k] = h->recv_cut[(size_t)k + 1] - h->recv_cut[k];
@@ -517,8 +529,8 @@ G4S_API g4s_status g4s_spmv_dist_connect_rccl(g4s_spmv_dist_t h, void *comm)
     G4S_TRY(rccl_group([&]() {
         for (int k = 0; k < W; ++k) {
             if (k == h->rank && !h->loopback) continue;
-            ncclResult_t r = g_rccl.Send(d_cnt + k, 1, ncclInt64, k, h->comm, h->cstream);
-            if (r == ncclSuccess) r = g_rccl.Recv(d_cnt + W + k, 1, ncclInt64, k, h->comm, h->cstream);
+            ncclResult_t r = g_rccl.Send(d_cnt + k, 1, ncclInt64, peer(k), h->comm, h->cstream);
+            if (r == ncclSuccess) r = g_rccl.Recv(d_cnt + W + k, 1, ncclInt64, peer(k), h->comm, h->cstream);
             if (r != ncclSuccess) return r;
         }
         return ncclSuccess;
@@ -538,8 +550,8 @@ G4S_API g4s_status g4s_spmv_dist_connect_rccl(g4s_spmv_dist_t h, void *comm)
         for (int k = 0; k < W; ++k) {
             if (k == h->rank && !h->loopback) continue;
             ncclResult_t r = ncclSuccess;
-            if (want_n[k]) r = g_rccl.Send(h->d_want + h->recv_cut[k], (size_t)want_n[k], ncclInt32, k, h->comm, h->cstream);
-            if (r == ncclSuccess && give_n[k]) r = g_rccl.Recv(h->d_give + cut[k], (size_t)give_n[k], ncclInt32, k, h->comm, h->cstream);
+            if (want_n[k]) r = g_rccl.Send(h->d_want + h->recv_cut[k], (size_t)want_n[k], ncclInt32, peer(k), h->comm, h->cstream);
+            if (r == ncclSuccess && give_n[k]) r = g_rccl.Recv(h->d_give + cut[k], (size_t)give_n[k], ncclInt32, peer(k), h->comm, h->cstream);
             if (r != ncclSuccess) return r;
         }
         return ncclSuccess;
@@ -562,7 +574,7 @@ G4S_API g4s_status g4s_spmv_dist_buffers(g4s_spmv_dist_t h, double **send_dev, c
         if (recv_cut) *recv_cut = h->recv_cut.data();
         return G4S_OK;
     }
-    if (!h->d_send) G4S_HIP_TRY(g4s::device_malloc((void **)&h->d_send, sizeof(double) * (size_t)std::max<int64_t>(h->give_cut[h->world], 1)));
+    if (!h->d_send) G4S_HIP_TRY(g4s::device_malloc((void **)&h->d_send, sizeof(double) * (size_t)std::max<int64_t>(h->give_cut[h->nseg], 1)));
     if (send_dev) *send_dev = h->d_send;
     if (send_cut) *send_cut = h->give_cut.data();
     if (recv_dev) *recv_dev = h->d_xrem;
@@ -574,7 +586,7 @@ G4S_API g4s_status g4s_spmv_dist_buffers(g4s_spmv_dist_t h, double **send_dev, c
 G4S_API g4s_status g4s_spmv_dist_begin(g4s_spmv_dist_t h, const double *x_local_dev, double *y_local_dev, void *stream)
 {
     G4S_REQUIRE(h && (y_local_dev || h->local_rows == 0) && (x_local_dev || h->off[(size_t)h->rank + 1] == h->off[h->rank]), "NULL argument");   // (a rectangular operator may own rows but no x entries, or the reverse)
-    for (int k = 0; k < h->world; ++k)
+    for (int k = 0; k < h->nseg; ++k)
         if (!(h->give_set[k] || (k == h->rank && !h->loopback)))
             return g4s::set_error(G4S_ERR_INVALID, "g4s_spmv_dist_begin: the give list of peer %d is not set (g4s_spmv_dist_connect_rccl or g4s_spmv_dist_set_give)", k);
     hipStream_t s = g4s::as_stream(stream);
@@ -594,7 +606,7 @@ G4S_API g4s_status g4s_spmv_dist_begin(g4s_spmv_dist_t h, const double *x_local_
         return g4s_spmv(h->A_own, x_local_dev, y_local_dev, 1.0, 0.0, stream);
     }
     G4S_TRY(g4s_spmv_dist_buffers(h, nullptr, nullptr, nullptr, nullptr));
-    const int64_t n_send = h->give_cut[h->world];
+    const int64_t n_send = h->give_cut[h->nseg];
     if (n_send) {
         const int grid = (int)std::min<int64_t>((n_send + 255) / 256, 4096);
         hipLaunchKernelGGL(dist_pack_kernel, dim3(grid), dim3(256), 0, s, n_send, h->d_give, x_local_dev, h->d_send);
@@ -604,12 +616,13 @@ G4S_API g4s_status g4s_spmv_dist_begin(g4s_spmv_dist_t h, const double *x_local_
         G4S_HIP_TRY(hipEventRecord(h->ev_packed, s));
         G4S_HIP_TRY(hipStreamWaitEvent(h->cstream, h->ev_packed, 0));
         G4S_TRY(rccl_group([&]() {
-            for (int k = 0; k < h->world; ++k) {
+            for (int k = 0; k < h->nseg; ++k) {
                 if (k == h->rank && !h->loopback) continue;
+                const int pk = h->loopback ? 0 : k;
                 const int64_t ns = h->give_cut[(size_t)k + 1] - h->give_cut[k], nr = h->recv_cut[(size_t)k + 1] - h->recv_cut[k];
                 ncclResult_t r = ncclSuccess;
-                if (ns) r = g_rccl.Send(h->d_send + h->give_cut[k], (size_t)ns, ncclDouble, k, h->comm, h->cstream);
-                if (r == ncclSuccess && nr) r = g_rccl.Recv(h->d_xrem + h->recv_cut[k], (size_t)nr, ncclDouble, k, h->comm, h->cstream);
+                if (ns) r = g_rccl.Send(h->d_send + h->give_cut[k], (size_t)ns, ncclDouble, pk, h->comm, h->cstream);
+                if (r == ncclSuccess && nr) r = g_rccl.Recv(h->d_xrem + h->recv_cut[k], (size_t)nr, ncclDouble, pk, h->comm, h->cstream);
                 if (r != ncclSuccess) return r;
             }
             return ncclSuccess;
@@ -644,7 +657,7 @@ G4S_API g4s_status g4s_spmv_dist_finish(g4s_spmv_dist_t h, double *y_local_dev, 
 G4S_API g4s_status g4s_spmv_dist_apply(g4s_spmv_dist_t h, const double *x_local_dev, double *y_local_dev, void *stream)
 {
     G4S_REQUIRE(h, "NULL handle");
-    if ((h->world > 1 || (h->loopback && !h->allgather)) && !h->comm && (h->n_ref || h->give_cut[h->world]))
+    if ((h->world > 1 || (h->loopback && !h->allgather)) && !h->comm && (h->n_ref || h->give_cut[h->nseg]))
         return g4s::set_error(G4S_ERR_INVALID, "g4s_spmv_dist_apply needs g4s_spmv_dist_connect_rccl; with another transport use _begin / _buffers / _finish");
     G4S_TRY(g4s_spmv_dist_begin(h, x_local_dev, y_local_dev, stream));
     return g4s_spmv_dist_finish(h, y_local_dev, stream);

@@ -127,7 +127,9 @@ g4s_status g4s_spmv_csr_i32_f64(int32_t rows, int32_t cols, const int32_t *rowpt
  * (citcoms/lib/Regional_parallel_related.c:744-789) with the equal-work row split of mm/inc/BIN.h:101-122. Per product only the x entries
  * a rank's rows actually reference travel (halo planes for stencils), each peer pair over its own xGMI link (ncclSend/ncclRecv in one
  * group), while the own-column part of the product runs. */
-#define G4S_DIST_LOOPBACK 32u   /* single-rank rehearsal: half of the own slab is treated as remote and travels rank 0 → rank 0 through RCCL */
+#define G4S_DIST_LOOPBACK 32u   /* single-rank rehearsal: half of the own slab is treated as remote and travels rank 0 → rank 0 through RCCL, cut into
+                                 * G4S_DIST_LOOPBACK_PEERS (default 7) segments with their own ncclSend / ncclRecv pair each — the message pattern
+                                 * one rank of an 8-GPU node has, on one GPU */
 #define G4S_DIST_ALLGATHER 64u  /* exchange = ONE in-place ncclAllGather of the whole vector (every slab padded to the longest; north_star's
                                  * "RCCL all-gather of the dense vector") instead of packed point-to-point messages: more bytes, no index
                                  * lists, nothing to wire. Also selected by G4S_DIST_EXCHANGE=allgather in the environment. */

@@ -122,6 +122,18 @@ def test_dist_spmv_rccl_loopback_single_rank(oracle):
     for _ in range(3):
         y = D(xl).cpu().numpy()
         assert np.all(np.abs(y - want) <= TOL * asum + 1e-300)
+    # the remote half travels as SEVEN segments by default (seven ncclSend / ncclRecv pairs per product in one group, as one rank of an 8-GPU node has);
+    # one segment and sixteen give the same product
+    for peers in ("1", "16"):
+        os.environ["G4S_DIST_LOOPBACK_PEERS"] = peers
+        try:
+            E = gdist.DistSpMV([0, n], 0, 1, torch.from_numpy(rp).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(va).cuda(), n, loopback=True)
+        finally:
+            del os.environ["G4S_DIST_LOOPBACK_PEERS"]
+        assert E.info()["n_ref"] == info["n_ref"] and E.info()["connected"] == 1
+        y = E(xl).cpu().numpy()
+        assert np.all(np.abs(y - want) <= TOL * asum + 1e-300)
+        E.close()
     # the all-gather exchange through RCCL itself (one rank: the collective is a copy, the event hand-over and the side stream are real)
     G = gdist.DistSpMV([0, n], 0, 1, torch.from_numpy(rp).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(va).cuda(), n, loopback=True, exchange="allgather")
     gi = G.info()
