@@ -573,17 +573,29 @@ G4S_API g4s_status g4s_conj_grad_dist_tr(g4s_spmv_dist_t A, const g4s_transport 
         G4S_TRY(tr->allreduce_sum_f64(tr->ctx, part, 3 * kDotBlocks, stream));              // r·z and r·r of the start vector
         int32_t count = 0, done = 0;
         double res = 0.0;
+        // Iterations are enqueued in batches with ONE read of (count, done, residual) behind each batch — the first as long as the previous solve of
+        // this thread plus one (g4s::cg_first_batch, as the single-GPU solve): with an RCCL transport nothing inside a batch waits for the host.
+        // Iterations past the one that meets the test are no-ops in the CG kernels; their product and all-reduces still run, on data nothing
+        // reads again (the partial sums are rewritten by the next solve's first kernel).
+        int batch = g4s::cg_first_batch(), enqueued = 0;
         for (;;) {
-            G4S_TRY(g4s_cg_direction(ws, steps, acc, stream));
+            const int todo = std::max(1, std::min(batch, steps - enqueued + 1));
+            for (int it = 0; it < todo; ++it) {
+                G4S_TRY(g4s_cg_direction(ws, steps, acc, stream));
+                G4S_TRY(g4s_cg_buffers(ws, &p, &Ap, nullptr));
+                G4S_TRY(g4s::dist_product(A, tr, p, Ap, stream));
+                G4S_TRY(g4s_cg_reduce_pAp(ws, stream));
+                G4S_TRY(tr->allreduce_sum_f64(tr->ctx, part + kDotBlocks, kDotBlocks, stream));
+                G4S_TRY(g4s_cg_update(ws, BI_dev, d0_dev, stream));
+                G4S_TRY(tr->allreduce_sum_f64(tr->ctx, part, 3 * kDotBlocks, stream));      // [0, 256) r·z and [512, 768) r·r; the middle third is rewritten before its next use
+            }
+            enqueued += todo;
+            G4S_TRY(g4s_cg_direction(ws, steps, acc, stream));                              // the loop test behind the batch (a no-op once done)
             G4S_TRY(g4s_cg_state(ws, &count, &done, &res, stream));
             if (done) break;
-            G4S_TRY(g4s_cg_buffers(ws, &p, &Ap, nullptr));
-            G4S_TRY(g4s::dist_product(A, tr, p, Ap, stream));
-            G4S_TRY(g4s_cg_reduce_pAp(ws, stream));
-            G4S_TRY(tr->allreduce_sum_f64(tr->ctx, part + kDotBlocks, kDotBlocks, stream));
-            G4S_TRY(g4s_cg_update(ws, BI_dev, d0_dev, stream));
-            G4S_TRY(tr->allreduce_sum_f64(tr->ctx, part, 3 * kDotBlocks, stream));          // [0, 256) r·z and [512, 768) r·r; the middle third is rewritten before its next use
+            batch = std::min(32, batch * 2);
         }
+        g4s::cg_last_iterations() = count;
         G4S_TRY(g4s_cg_end(ws, d0_dev, zero_resid_dev, n_zero, stream));
         if (cycles) *cycles = count;
         if (residual) *residual = res;
