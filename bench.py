@@ -449,6 +449,12 @@ def main():
         "plan": {"plan_bytes": info.get("plan_bytes"), "build_ms": None if plan_ms is None else round(plan_ms, 2),
                  "build_in_products": None if plan_ms is None else round(plan_ms / (elapsed / args.steps * 1e3), 1)},
     }
+    if info["spmv_path"] == 3 and world == 1 and info.get("plan_bytes"):
+        # the index-free diagonal kernel does not move the CSR arrays the algorithmic model counts: its own bytes beside them
+        own = info["plan_bytes"] + 8 * n_rows + 8 * n_cols
+        result["roofline"].update({"bytes_model": "csr-algorithmic; the diagonal kernel itself moves kernel_own_bytes (diagonals + row masks + x + y)",
+                                   "kernel_own_bytes": own, "kernel_own_gbs": round(own / (kernel_ms * 1e-3) / 1e9, 1),
+                                   "kernel_own_frac": round(own / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, y_cpu, asum = cpu_baseline(A, x_full)
         result["cpu_baseline"] = base

@@ -290,6 +290,10 @@ def test_spmv_diagonal_path(oracle):
         cases.append((rp, ci, rng.uniform(-1, 1, len(ci)), nx * ny * nz, nx * ny * nz, 7))
     rp, ci, va = oracle.banded(40000, 9, 4)
     cases.append((rp, ci, va, 40000, 40000, 19))
+    rp, ci, va = oracle.laplacian7(21, 13, 9)                          # an ODD number of rows: the two-rows-per-lane kernel + the one-row kernel for the last row
+    cases.append((rp, ci, rng.uniform(-1, 1, len(ci)), 21 * 13 * 9, 21 * 13 * 9, 7))
+    rp, ci, va = oracle.banded(30001, 2, 9)                            # odd, and the last row's entries reach back (offset −2, −1)
+    cases.append((rp, ci, va, 30001, 30001, 5))
     # rectangular: rows × (rows + 50), offsets {0, 3, 50}, the last rows lose entries
     rows, cols = 30000, 30020
     M = sp.diags([rng.uniform(-1, 1, rows), rng.uniform(-1, 1, rows), rng.uniform(-1, 1, rows)], [0, 3, 50], shape=(rows, cols), format="csr")
@@ -298,6 +302,11 @@ def test_spmv_diagonal_path(oracle):
     for rp, ci, va, rows, cols, nd in cases:
         A = host.CSR.from_host(rp, ci, va, rows, cols)
         assert A.info()["spmv_path"] == 3
+        # y that is only 8-byte aligned takes the one-row kernel for every row: same bits
+        xm = torch.from_numpy(rng.uniform(-1, 1, cols)).cuda()
+        buf = torch.zeros(rows + 1, dtype=torch.float64, device="cuda")
+        assert buf.data_ptr() % 16 == 0
+        assert torch.equal(A.spmv(xm, buf[1:]), A.spmv(xm))
         x = rng.uniform(-1, 1, cols)
         _check(oracle, A, rp, ci, va, x, exact=True)
         _check(oracle, A, rp, ci, va, x, alpha=-0.5, beta=2.0, y0=rng.uniform(-1, 1, rows), exact=True)
