@@ -123,15 +123,29 @@ def reference_library_baseline(rp, ci, va, xh, rows, cols, nnz, y_oracle, asum, 
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-def config3_lap7(world, rank, steps, warmup, small, host, gdist, dist, torch):
-    """BASELINE configs[3] beside the headline number: the 431^3 7-point Laplacian (80M rows), rows split evenly over the ranks, every rank
-    generating only its slab; N = 1: one g4s_spmv handle; N > 1: the library's distributed product (halo planes travel, overlapped with the
-    own-column part). Same timing protocol as the main measurement. Reported as `also`, never as `value`."""
-    s = 431 if not small else 48
-    n = s ** 3
-    offs = [(n * k) // world for k in range(world + 1)]
-    r0, r1 = offs[rank], offs[rank + 1]
-    A = host.laplacian_csr(7, s, s, s, r0=r0, r1=r1)
+def config_secondary(kind, world, rank, steps, warmup, small, host, gdist, dist, torch):
+    """A secondary workload beside the headline number, same ranks, same timing protocol; reported under `also` / `also_banded`, never as `value`.
+    kind "lap7": BASELINE configs[3], the 431^3 7-point Laplacian (80M rows), rows split evenly over the ranks, every rank generating only its slab.
+    kind "banded": north_star's banded matrix (10M x 10M, half-bandwidth 5), rows split evenly. N = 1: one g4s_spmv handle; N > 1: the library's
+    distributed product (halo planes / halo rows travel, overlapped with the own-column part)."""
+    if kind == "lap7":
+        s = 431 if not small else 48
+        n = s ** 3
+        offs = [(n * k) // world for k in range(world + 1)]
+        r0, r1 = offs[rank], offs[rank + 1]
+        A = host.laplacian_csr(7, s, s, s, r0=r0, r1=r1)
+    else:
+        n = 10_000_000 if not small else 200_000
+        offs = [(n * k) // world for k in range(world + 1)]
+        r0, r1 = offs[rank], offs[rank + 1]
+        full = host.banded_csr(n, 5, 20240521)
+        if world > 1:
+            rp, ci, va = gdist.slice_rows(full.rowptr, full.colids, full.values, r0, r1)
+            A = host.CSR(rp, ci, va, r1 - r0, n)
+            del full
+            torch.cuda.empty_cache()
+        else:
+            A = full
     x_local = host.synth_vector(7, r1 - r0, i0=r0)
     y_local = torch.empty(r1 - r0, dtype=torch.float64, device="cuda")
     nnz_local = A.nnz
@@ -181,7 +195,7 @@ def config3_lap7(world, rank, steps, warmup, small, host, gdist, dist, torch):
             own = inf["plan_bytes"] + 8 * n + 8 * n
             extra.update({"bytes_model": "csr-algorithmic (12*nnz + 4*(rows+1) + 8*rows + 8*cols); the diagonal kernel itself moves kernel_own_bytes",
                           "kernel_own_bytes": own, "kernel_own_gbs": round(own * steps / el / 1e9, 1), "kernel_own_frac_of_8TBs": round(own * steps / el / 1e9 / 8000.0, 4)})
-    return {**extra, "workload": WORKLOADS["lap7"] + (" [--small size]" if small else ""), "n_gpus": world, "rows": n, "nnz": nnz, "steps": steps, "ms_per_step": round(el / steps * 1e3, 5),
+    return {**extra, "workload": WORKLOADS[kind] + (" [--small size]" if small else ""), "n_gpus": world, "rows": n, "nnz": nnz, "steps": steps, "ms_per_step": round(el / steps * 1e3, 5),
             "value": round(nnz * steps / el / 1e9, 3), "unit": "GEdges/s", "spmv_path": {0: "stream", 1: "blocked", 3: "diagonal (index-free)", 4: "block-row"}.get(path, str(path)),
             "hbm_gbs_algorithmic_whole_job": round(alg * steps / el / 1e9, 1), "frac_of_n_gpus_x_8TBs": round(alg * steps / el / 1e9 / (8000.0 * world), 4)}
 
@@ -470,10 +484,16 @@ def main():
         # scaling is exchange-bound by construction; the stencil shows what the row partition does when only halos travel
         torch.cuda.empty_cache()
         try:                                                       # a failure here (raised on every rank alike, see DistSpMV) must not cost the headline line
-            also = config3_lap7(world, rank, max(10, args.steps // 2), min(args.warmup, 5), args.small, host, gdist, dist, torch)
+            also = config_secondary("lap7", world, rank, max(10, args.steps // 2), min(args.warmup, 5), args.small, host, gdist, dist, torch)
         except Exception as e:                                     # noqa: BLE001
             also = {"error": f"{type(e).__name__}: {e}"}
         result["also"] = also
+        torch.cuda.empty_cache()
+        try:                                                       # north_star: "GEdges/s on synthetic power-law AND banded matrices"
+            also_b = config_secondary("banded", world, rank, max(10, args.steps // 2), min(args.warmup, 5), args.small, host, gdist, dist, torch)
+        except Exception as e:                                     # noqa: BLE001
+            also_b = {"error": f"{type(e).__name__}: {e}"}
+        result["also_banded"] = also_b
     if not args.no_also and args.workload == "rmat" and world == 1:
         # BASELINE configs[2] in the driver's own line ("driver-timed SpGEMM"); guarded like `also`
         try:
