@@ -90,6 +90,13 @@ __global__ void dist_pack_kernel(long long n, const int32_t *__restrict__ idx, c
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) send[i] = x[idx[i]];
 }
 
+// y[rows[i]] += t[i]: the remote-column part of the few rows that have one
+__global__ void dist_add_rows_kernel(int n, const int32_t *__restrict__ rows, const double *__restrict__ t, double *__restrict__ y)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[rows[i]] += t[i];
+}
+
 } // namespace
 
 struct g4s_spmv_dist_s {
@@ -112,6 +119,11 @@ struct g4s_spmv_dist_s {
     int32_t *d_want = nullptr;                  // n_ref indices, local to their owner's slab (what this rank asks for), in x_rem order
     int32_t *d_give = nullptr;                  // indices into x_local, concatenated per peer
     double *d_send = nullptr, *d_xrem = nullptr;
+    // own + remote form: rows that hold remote-column entries, when they are few (the two boundary planes of a stencil slab): A_rem then has only those
+    // rows, its product lands in d_rem_y and is added into y by row index — instead of a read-modify-write of every row of y for a handful of entries
+    int32_t n_rem_rows = 0;
+    int32_t *d_rem_rows = nullptr;
+    double *d_rem_y = nullptr;
     hipStream_t cstream = nullptr;
     hipEvent_t ev_packed = nullptr, ev_done = nullptr;
     ncclComm_t comm = nullptr;
@@ -125,7 +137,7 @@ void dist_release(g4s_spmv_dist_s *h)
     if (!h) return;
     if (h->A_own) g4s_csr_destroy(h->A_own);
     if (h->A_rem) g4s_csr_destroy(h->A_rem);
-    (void)hipFree(h->d_want); (void)hipFree(h->d_give); (void)hipFree(h->d_send); (void)hipFree(h->d_xrem);
+    (void)hipFree(h->d_want); (void)hipFree(h->d_give); (void)hipFree(h->d_send); (void)hipFree(h->d_xrem); (void)hipFree(h->d_rem_rows); (void)hipFree(h->d_rem_y);
     if (h->ev_packed) (void)hipEventDestroy(h->ev_packed);
     if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     if (h->cstream) (void)hipStreamDestroy(h->cstream);
@@ -361,8 +373,28 @@ G4S_API g4s_status g4s_spmv_dist_create_rect(g4s_spmv_dist_t *out, int32_t rank,
         const unsigned path_flags = flags & (G4S_SPMV_NO_NT | G4S_SPMV_BLOCKED | G4S_SPMV_STREAM);
         st = g4s_csr_create(&h->A_own, m, (int32_t)(r1 - r0), h->nnz_own, S.orp.data(), S.oci.data(), S.ova.data(), G4S_HOST_POINTERS | path_flags);
         if (st != G4S_OK) return fail(st);
-        st = g4s_csr_create(&h->A_rem, m, std::max(h->n_ref, 1), h->nnz_rem, S.rrp.data(), S.rci.data(), S.rva.data(), G4S_HOST_POINTERS | path_flags);
-        if (st != G4S_OK) return fail(st);
+        // remote-column part: only the rows that have one, when they are under a quarter of the slab (never in the merged form, whose one product writes all of y)
+        std::vector<int32_t> rem_rows;
+        if (!h->merged && h->nnz_rem > 0 && !getenv("G4S_DIST_NO_ROW_COMPACTION")) {
+            for (int32_t i = 0; i < m; ++i)
+                if (S.rrp[(size_t)i + 1] > S.rrp[i]) rem_rows.push_back(i);
+            if ((int64_t)rem_rows.size() * 4 >= m) rem_rows.clear();
+        }
+        if (!rem_rows.empty()) {
+            std::vector<int32_t> crp(rem_rows.size() + 1, 0);
+            for (size_t i = 0; i < rem_rows.size(); ++i) crp[i + 1] = S.rrp[(size_t)rem_rows[i] + 1];   // the entries stay where they are: empty rows hold none
+            h->n_rem_rows = (int32_t)rem_rows.size();
+            st = g4s_csr_create(&h->A_rem, h->n_rem_rows, std::max(h->n_ref, 1), h->nnz_rem, crp.data(), S.rci.data(), S.rva.data(), G4S_HOST_POINTERS | path_flags);
+            if (st != G4S_OK) return fail(st);
+            if (g4s::device_malloc((void **)&h->d_rem_rows, sizeof(int32_t) * rem_rows.size()) != hipSuccess ||
+                g4s::device_malloc((void **)&h->d_rem_y, sizeof(double) * rem_rows.size()) != hipSuccess)
+                return fail(g4s::set_error(G4S_ERR_NOMEM, "device allocation failed"));
+            if (hipMemcpy(h->d_rem_rows, rem_rows.data(), sizeof(int32_t) * rem_rows.size(), hipMemcpyHostToDevice) != hipSuccess)
+                return fail(g4s::set_error(G4S_ERR_HIP, "H2D copy failed"));
+        } else {
+            st = g4s_csr_create(&h->A_rem, m, std::max(h->n_ref, 1), h->nnz_rem, S.rrp.data(), S.rci.data(), S.rva.data(), G4S_HOST_POINTERS | path_flags);
+            if (st != G4S_OK) return fail(st);
+        }
         h->give_cut.assign((size_t)h->nseg + 1, 0);
         h->give_set.assign((size_t)h->nseg, 0);
         if (g4s::device_malloc((void **)&h->d_want, sizeof(int32_t) * std::max<size_t>(S.want.size(), 1)) != hipSuccess ||
@@ -651,6 +683,12 @@ G4S_API g4s_status g4s_spmv_dist_finish(g4s_spmv_dist_t h, double *y_local_dev, 
     h->exchange_posted = false;
     if (h->merged) return g4s_spmv(h->A_rem, h->d_xrem, y_local_dev, 1.0, 0.0, stream);
     if (h->nnz_rem == 0) return G4S_OK;
+    if (h->n_rem_rows) {
+        G4S_TRY(g4s_spmv(h->A_rem, h->d_xrem, h->d_rem_y, 1.0, 0.0, stream));
+        hipLaunchKernelGGL(dist_add_rows_kernel, dim3((h->n_rem_rows + 255) / 256), dim3(256), 0, s, h->n_rem_rows, h->d_rem_rows, h->d_rem_y, y_local_dev);
+        G4S_HIP_TRY(hipGetLastError());
+        return G4S_OK;
+    }
     return g4s_spmv(h->A_rem, h->d_xrem, y_local_dev, 1.0, 1.0, stream);
 }
 
