@@ -677,10 +677,11 @@ G4S_API g4s_status g4s_spmv_dist_begin(g4s_spmv_dist_t h, const double *x_local_
 
 G4S_API g4s_status g4s_spmv_dist_finish(g4s_spmv_dist_t h, double *y_local_dev, void *stream)
 {
-    G4S_REQUIRE(h && y_local_dev, "NULL argument");
+    G4S_REQUIRE(h && (y_local_dev || h->local_rows == 0), "NULL argument");   // (a rank of a rectangular operator may own x entries but no rows)
     hipStream_t s = g4s::as_stream(stream);
     if (h->exchange_posted) G4S_HIP_TRY(hipStreamWaitEvent(s, h->ev_done, 0));
     h->exchange_posted = false;
+    if (h->local_rows == 0) return G4S_OK;
     if (h->merged) return g4s_spmv(h->A_rem, h->d_xrem, y_local_dev, 1.0, 0.0, stream);
     if (h->nnz_rem == 0) return G4S_OK;
     if (h->n_rem_rows) {

@@ -148,3 +148,23 @@ def test_dist_spmv_rccl_loopback_single_rank(oracle):
     torch.cuda.synchronize()
     assert torch.equal(t.cpu(), torch.arange(8, dtype=torch.float64))
     D.close()
+
+
+def test_dist_rect_rank_without_rows():
+    """A rectangular operator whose rank owns entries of x but no rows (the coarse side of a restriction, a tail rank of the divergence operator):
+    begin / finish accept y = NULL and do nothing."""
+    import ctypes as C
+    from g4s_amd import capi
+    lib = capi.load()
+    n = 64
+    row_off = (C.c_int64 * 2)(0, 0)
+    col_off = (C.c_int64 * 2)(0, n)
+    rp = (C.c_int32 * 1)(0)
+    h = C.c_void_p()
+    capi.check(lib.g4s_spmv_dist_create_rect(C.byref(h), 0, 1, row_off, col_off, C.cast(rp, C.c_void_p), None, None, 0))
+    x = torch.ones(n, dtype=torch.float64, device="cuda")
+    capi.check(lib.g4s_spmv_dist_begin(h, C.c_void_p(x.data_ptr()), None, None))
+    capi.check(lib.g4s_spmv_dist_finish(h, None, None))
+    capi.check(lib.g4s_spmv_dist_apply(h, C.c_void_p(x.data_ptr()), None, None))
+    torch.cuda.synchronize()
+    capi.check(lib.g4s_spmv_dist_destroy(h))
