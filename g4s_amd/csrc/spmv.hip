@@ -173,17 +173,33 @@ __global__ void spmv_long_fixup_kernel(const LongRow *__restrict__ lrows, int n_
 // indices — a 2-flop-per-entry product gains nothing from the matrix cores).
 constexpr int kMaxDiags = 32;
 struct DiaOffsets { int off[kMaxDiags]; };
+// A 3-D stencil in natural ordering has two diagonals one PLANE away (±431² for the 431³ Laplacian): x[row + plane] is needed again a plane later as the
+// centre and two planes later as x[row − plane]. With every XCD walking a contiguous eighth of the rows that reuse distance is three planes of x (4.5 MB) plus
+// the streams in between — more than an XCD's 4 MiB L2, so x crossed the fabric three times (PMC: 6.7 GB fetched for 5.4 GB of own reads). Instead XCD j takes
+// the j-th eighth of EVERY plane, plane after plane: the three slices it needs are 0.56 MB and stay in its L2; the neighbours one grid line away (±431) cross
+// a slice border for 2·431 of 23 221 rows. Chosen at plan time when the largest offset is far (≥ 16 K rows) and symmetric and the rows hold ≥ 8 planes.
+struct DiaFar { int stride, slice, blocks_per_slice; };   // stride 0: the contiguous walk
 
 template <int ND, bool NT>
 __global__ __launch_bounds__(WG) void spmv_dia_kernel(int rows, int cols, int nd, DiaOffsets offs, long long ld, const double *__restrict__ dia,
                                                        const unsigned *__restrict__ mask, const double *__restrict__ x, double *__restrict__ y,
-                                                       double alpha, double beta, int blocks_per_xcd, int row0 /* first row of this launch */)
+                                                       double alpha, double beta, int blocks_per_xcd, int row0 /* first row of this launch */, DiaFar far)
 {
-    // blocks of one XCD walk a contiguous range of rows: neighbouring row blocks read neighbouring parts of x through the same L2
+    // blocks of one XCD walk a contiguous range of rows: neighbouring row blocks read neighbouring parts of x through the same L2 —
+    // or, with far planes, the XCD's eighth of every plane (DiaFar; one row per lane: blocks_per_slice counts WG rows)
     const int b = (int)blockIdx.x;
-    const int lb = (b % g4s::kXcds) * blocks_per_xcd + b / g4s::kXcds;
-    const int row = row0 + lb * WG + (int)threadIdx.x;
-    if (row >= rows) return;
+    int row;
+    if (far.stride) {
+        const int j = b % g4s::kXcds, l = b / g4s::kXcds, z = l / far.blocks_per_slice, w = l - z * far.blocks_per_slice;
+        const long long base = (long long)z * far.stride;
+        const long long r = base + min(j * far.slice, far.stride) + w * WG + (int)threadIdx.x;
+        if (r >= base + min((j + 1) * far.slice, far.stride) || r >= rows) return;
+        row = (int)r;
+    } else {
+        const int lb = (b % g4s::kXcds) * blocks_per_xcd + b / g4s::kXcds;
+        row = row0 + lb * WG + (int)threadIdx.x;
+        if (row >= rows) return;
+    }
     const unsigned m = mask[row];
     double v[ND], xv[ND];
 #pragma unroll
@@ -208,12 +224,23 @@ typedef unsigned dia_uint2 __attribute__((ext_vector_type(2)));
 template <int ND, bool NT>
 __global__ __launch_bounds__(WG) void spmv_dia2_kernel(int rows2 /* even part of the row count */, int cols, int nd, DiaOffsets offs, long long ld, const double *__restrict__ dia,
                                                         const unsigned *__restrict__ mask, const double *__restrict__ x, double *__restrict__ y,
-                                                        double alpha, double beta, int blocks_per_xcd)
+                                                        double alpha, double beta, int blocks_per_xcd, DiaFar far)
 {
     const int b = (int)blockIdx.x;
-    const int lb = (b % g4s::kXcds) * blocks_per_xcd + b / g4s::kXcds;
-    const int row = 2 * (lb * WG + (int)threadIdx.x);
-    if (row >= rows2) return;
+    int row;
+    if (far.stride) {
+        // plane-sliced walk (see DiaFar): XCD j takes the j-th eighth of every plane, plane after plane
+        const int j = b % g4s::kXcds, l = b / g4s::kXcds, z = l / far.blocks_per_slice, w = l - z * far.blocks_per_slice;
+        const long long base = (long long)z * far.stride;
+        const long long lo = (base + min(j * far.slice, far.stride) + 1) & ~1ll, hi = (base + min((j + 1) * far.slice, far.stride) + 1) & ~1ll;   // even: 16-byte accesses
+        const long long r = lo + 2 * (w * WG + (int)threadIdx.x);
+        if (r >= hi || r >= rows2) return;
+        row = (int)r;
+    } else {
+        const int lb = (b % g4s::kXcds) * blocks_per_xcd + b / g4s::kXcds;
+        row = 2 * (lb * WG + (int)threadIdx.x);
+        if (row >= rows2) return;
+    }
     const dia_uint2 m = *reinterpret_cast<const dia_uint2 *>(mask + row);
     dia_double2 v[ND];
     double x0[ND], x1[ND];
@@ -299,6 +326,7 @@ struct g4s_csr_s {
     int dia_nd = 0;
     long long dia_ld = 0;
     DiaOffsets dia_offs{};
+    DiaFar dia_far{0, 0, 0};
     g4s::PbPlan *pb = nullptr;      // propagation-blocked path (spmv_pb.hip) for matrices without gather locality
     g4s::BcsrPlan *bcsr = nullptr;  // block-row form of an assembled FE matrix (spmv_bcsr.hip)
 };
@@ -535,6 +563,18 @@ int try_build_dia(g4s_csr_s *A)
     (void)hipFree(d_fail);
     if (e != hipSuccess || h_fail) { (void)hipFree(dia); (void)hipFree(mask); return e == hipSuccess ? G4S_OK : g4s::set_error(G4S_ERR_HIP, "diagonal fill failed: %s", hipGetErrorString(e)); }
     A->d_dia = dia; A->d_dia_mask = mask; A->dia_nd = nd; A->dia_ld = ld; A->dia_offs = D;
+    // plane-sliced walk (DiaFar): the outermost diagonals are ±stride with stride ≥ 16 K rows, every other offset is well inside a slice, ≥ 8 planes
+    A->dia_far = DiaFar{0, 0, 0};
+    if (nd >= 3 && !getenv("G4S_SPMV_DIA_CONTIGUOUS")) {
+        const long long stride = D.off[nd - 1];
+        const long long inner = std::max<long long>(std::abs((long long)D.off[1]), std::abs((long long)D.off[nd - 2]));
+        const long long slice = (stride + g4s::kXcds - 1) / g4s::kXcds;
+        if (stride >= 16384 && D.off[0] == -stride && 8 * inner <= slice && (long long)rows >= 8 * stride) {
+            A->dia_far.stride = (int)stride;
+            A->dia_far.slice = (int)slice;
+            A->dia_far.blocks_per_slice = (int)((slice + 2 + 2 * WG - 1) / (2 * WG));
+        }
+    }
     A->plan_bytes += (int64_t)(sizeof(double) * (size_t)(ld * nd) + sizeof(unsigned) * (size_t)rows);
     return G4S_OK;
 }
@@ -671,11 +711,13 @@ G4S_API g4s_status g4s_spmv(g4s_csr_t A, const double *x_dev, double *y_dev, dou
         const int rows2 = two ? (A->rows & ~1) : 0;
         if (rows2) {
             const int nblocks = (rows2 / 2 + WG - 1) / WG, per_xcd = (nblocks + g4s::kXcds - 1) / g4s::kXcds;
-            const dim3 grid(per_xcd * g4s::kXcds), block(WG);
+            const DiaFar far = A->dia_far;
+            const long long planes = far.stride ? ((long long)rows2 + far.stride - 1) / far.stride : 0;
+            const dim3 grid(far.stride ? (unsigned)(planes * far.blocks_per_slice * g4s::kXcds) : (unsigned)(per_xcd * g4s::kXcds)), block(WG);
 #define G4S_DIA2_LAUNCH(ND)                                                                                                                                           \
     do {                                                                                                                                                          \
-        if (A->use_nt) hipLaunchKernelGGL((spmv_dia2_kernel<ND, true>), grid, block, 0, s, rows2, A->cols, A->dia_nd, A->dia_offs, A->dia_ld, A->d_dia, A->d_dia_mask, x_dev, y_dev, alpha, beta, per_xcd);  \
-        else hipLaunchKernelGGL((spmv_dia2_kernel<ND, false>), grid, block, 0, s, rows2, A->cols, A->dia_nd, A->dia_offs, A->dia_ld, A->d_dia, A->d_dia_mask, x_dev, y_dev, alpha, beta, per_xcd);           \
+        if (A->use_nt) hipLaunchKernelGGL((spmv_dia2_kernel<ND, true>), grid, block, 0, s, rows2, A->cols, A->dia_nd, A->dia_offs, A->dia_ld, A->d_dia, A->d_dia_mask, x_dev, y_dev, alpha, beta, per_xcd, far);  \
+        else hipLaunchKernelGGL((spmv_dia2_kernel<ND, false>), grid, block, 0, s, rows2, A->cols, A->dia_nd, A->dia_offs, A->dia_ld, A->d_dia, A->d_dia_mask, x_dev, y_dev, alpha, beta, per_xcd, far);           \
     } while (0)
             if (A->dia_nd <= 8) G4S_DIA2_LAUNCH(8);
             else G4S_DIA2_LAUNCH(16);
@@ -685,11 +727,15 @@ G4S_API g4s_status g4s_spmv(g4s_csr_t A, const double *x_dev, double *y_dev, dou
         if (tail0 < A->rows) {
             const int n_tail = A->rows - tail0;
             const int nblocks = (n_tail + WG - 1) / WG, per_xcd = (nblocks + g4s::kXcds - 1) / g4s::kXcds;
-            const dim3 grid(per_xcd * g4s::kXcds), block(WG);
+            DiaFar far = A->dia_far;
+            if (tail0 != 0) far.stride = 0;                          // the odd last row behind the two-row kernel
+            if (far.stride) far.blocks_per_slice = (far.slice + WG - 1) / WG;
+            const long long planes = far.stride ? ((long long)A->rows + far.stride - 1) / far.stride : 0;
+            const dim3 grid(far.stride ? (unsigned)(planes * far.blocks_per_slice * g4s::kXcds) : (unsigned)(per_xcd * g4s::kXcds)), block(WG);
 #define G4S_DIA_LAUNCH(ND)                                                                                                                                            \
     do {                                                                                                                                                          \
-        if (A->use_nt) hipLaunchKernelGGL((spmv_dia_kernel<ND, true>), grid, block, 0, s, A->rows, A->cols, A->dia_nd, A->dia_offs, A->dia_ld, A->d_dia, A->d_dia_mask, x_dev, y_dev, alpha, beta, per_xcd, tail0);  \
-        else hipLaunchKernelGGL((spmv_dia_kernel<ND, false>), grid, block, 0, s, A->rows, A->cols, A->dia_nd, A->dia_offs, A->dia_ld, A->d_dia, A->d_dia_mask, x_dev, y_dev, alpha, beta, per_xcd, tail0);           \
+        if (A->use_nt) hipLaunchKernelGGL((spmv_dia_kernel<ND, true>), grid, block, 0, s, A->rows, A->cols, A->dia_nd, A->dia_offs, A->dia_ld, A->d_dia, A->d_dia_mask, x_dev, y_dev, alpha, beta, per_xcd, tail0, far);  \
+        else hipLaunchKernelGGL((spmv_dia_kernel<ND, false>), grid, block, 0, s, A->rows, A->cols, A->dia_nd, A->dia_offs, A->dia_ld, A->d_dia, A->d_dia_mask, x_dev, y_dev, alpha, beta, per_xcd, tail0, far);           \
     } while (0)
             if (A->dia_nd <= 8) G4S_DIA_LAUNCH(8);
             else if (A->dia_nd <= 16) G4S_DIA_LAUNCH(16);

@@ -4,6 +4,7 @@ Tolerance (fp64): |y_gpu − y_oracle|_i ≤ 1e-10 · Σ_k |a_ik x_k|  (north_st
 (blocks with > 128 rows) are summed in the oracle's order and must be BIT-identical.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -294,6 +295,13 @@ def test_spmv_diagonal_path(oracle):
     cases.append((rp, ci, rng.uniform(-1, 1, len(ci)), 21 * 13 * 9, 21 * 13 * 9, 7))
     rp, ci, va = oracle.banded(30001, 2, 9)                            # odd, and the last row's entries reach back (offset −2, −1)
     cases.append((rp, ci, va, 30001, 30001, 5))
+    # planes of >= 16 K rows, >= 8 of them: the plane-sliced walk (every XCD an eighth of every plane) — an ODD plane (slices start on either parity),
+    # an even one, and both again with G4S_SPMV_DIA_CONTIGUOUS below
+    far_cases = []
+    for (nx, ny, nz) in [(131, 127, 9), (128, 130, 8)]:
+        rp, ci, va = oracle.laplacian7(nx, ny, nz)
+        far_cases.append((rp, ci, rng.uniform(-1, 1, len(ci)), nx * ny * nz, nx * ny * nz, 7))
+    cases += far_cases
     # rectangular: rows × (rows + 50), offsets {0, 3, 50}, the last rows lose entries
     rows, cols = 30000, 30020
     M = sp.diags([rng.uniform(-1, 1, rows), rng.uniform(-1, 1, rows), rng.uniform(-1, 1, rows)], [0, 3, 50], shape=(rows, cols), format="csr")
@@ -310,6 +318,15 @@ def test_spmv_diagonal_path(oracle):
         x = rng.uniform(-1, 1, cols)
         _check(oracle, A, rp, ci, va, x, exact=True)
         _check(oracle, A, rp, ci, va, x, alpha=-0.5, beta=2.0, y0=rng.uniform(-1, 1, rows), exact=True)
+    # the contiguous walk on the same far-plane matrices: the same bits
+    os.environ["G4S_SPMV_DIA_CONTIGUOUS"] = "1"
+    try:
+        for rp, ci, va, rows, cols, nd in far_cases:
+            A = host.CSR.from_host(rp, ci, va, rows, cols)
+            assert A.info()["spmv_path"] == 3
+            _check(oracle, A, rp, ci, va, rng.uniform(-1, 1, cols), exact=True)
+    finally:
+        del os.environ["G4S_SPMV_DIA_CONTIGUOUS"]
     # not diagonal-structured: a random matrix, and a band with one stray entry → the CSR kernel
     rp, ci, va = random_csr(20000, 20000, 0.0005, 3)
     assert host.CSR.from_host(rp, ci, va, 20000, 20000).info()["spmv_path"] == 0
