@@ -263,13 +263,10 @@ def config2_spgemm(small, host, capi, torch, runs=10, mkl_threads=14):
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as fresh child processes (this process has not
     touched the GPU yet and never will), relay rank 0's JSON line, return the children's exit code."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher binds a free port itself and keeps it (a port picked here and handed over could be taken in between)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.run(cmd, env=env).returncode

@@ -119,3 +119,10 @@ def assemble_csr(ien, idmap, K, neq):
     A.sum_duplicates()
     A.sort_indices()
     return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+
+
+def init_gloo(rank, world, rendezvous_file):
+    """Process group for the spawned multi-rank tests through a FILE store: a TCP port picked beforehand can be taken by somebody else before
+    rank 0 binds it (seen once on a GPU box: EADDRINUSE); a file in the test's tmp_path cannot."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"file://{rendezvous_file}", rank=rank, world_size=world)

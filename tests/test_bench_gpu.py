@@ -21,6 +21,18 @@ def _port():
     return p
 
 
+def _launch_two_ranks(extra_args, env):
+    """The driver's launch line for N > 1 (`--master-addr 127.0.0.1 --master-port P`). The port is picked just before the launch; if somebody else takes it
+    in between (EADDRINUSE: a race in the test, not a bench failure) the launch is repeated once with another port."""
+    for attempt in range(2):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_port()),
+               "bench.py", "--gpus", "2"] + extra_args
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        if r.returncode == 0 or "EADDRINUSE" not in r.stderr or attempt == 1:
+            return r
+    return r
+
+
 def _last_json(out):
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out[-2000:]
@@ -58,10 +70,7 @@ def test_bench_self_launch_two_ranks():
 @pytest.mark.parametrize("workload,exchange", [("rmat", "dist"), ("lap7", "dist"), ("rmat", "allgather"), ("lap7", "allgather")])
 def test_bench_two_ranks_rehearsal(workload, exchange):
     env = dict(os.environ, G4S_BENCH_SAME_DEVICE="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_port()),
-           "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--small", "--backend", "gloo", "--workload", workload, "--exchange", exchange,
-           "--no-cpu-baseline"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    r = _launch_two_ranks(["--steps", "4", "--warmup", "1", "--small", "--backend", "gloo", "--workload", workload, "--exchange", exchange, "--no-cpu-baseline"], env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["scaling"] == "strong"
@@ -72,9 +81,7 @@ def test_bench_two_ranks_fall_back_together():
     """One rank's wiring of the packed exchange fails: every rank takes the library's all-gather exchange instead (agreed through one all-reduce;
     it needs no wiring), none hangs."""
     env = dict(os.environ, G4S_BENCH_SAME_DEVICE="1", G4S_DIST_FAIL="wire:1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_port()),
-           "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--small", "--backend", "gloo", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    r = _launch_two_ranks(["--steps", "3", "--warmup", "1", "--small", "--backend", "gloo", "--no-cpu-baseline"], env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["value"] > 0 and "ncclAllGather" in d["config"]["exchange"]

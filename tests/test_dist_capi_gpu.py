@@ -8,25 +8,16 @@ A one-GPU test box cannot run RCCL between ranks, so two things are rehearsed se
     event hand-over) — with ONE rank in loopback mode: half of its own slab is treated as remote and travels rank 0 → rank 0.
 Every y must equal the single-rank oracle within 1e-10 · Σ|terms|."""
 import os
-import socket
 
 import numpy as np
 import pytest
 import torch
 import torch.multiprocessing as mp
 
-from tests.helpers import power_law_csr
+from tests.helpers import power_law_csr, init_gloo
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
 
 
 def _matrix(kind, oracle):
@@ -49,9 +40,7 @@ def _worker(rank, world, port, kind, out_dir):
     exchange = "packed"
     if kind.endswith("+allgather"):
         exchange, kind = "allgather", kind[:-10]
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    init_gloo(rank, world, port)                                   # (a rendezvous FILE, tests/helpers.py)
     torch.cuda.set_device(0)
     from g4s_amd import dist as gdist
     from tests import oracle_lib
@@ -77,7 +66,7 @@ def _worker(rank, world, port, kind, out_dir):
 @pytest.mark.parametrize("world,kind", [(1, "powerlaw"), (2, "powerlaw"), (3, "powerlaw"), (2, "lap7"), (3, "banded"), (3, "powerlaw+merged"), (2, "lap7+merged"),
                                         (2, "powerlaw+allgather"), (3, "lap7+allgather"), (3, "powerlaw+allgather+merged"), (1, "powerlaw+allgather")])
 def test_dist_spmv_capi_matches_oracle(tmp_path, oracle, world, kind):
-    mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, os.path.join(str(tmp_path), "rendezvous"), kind, str(tmp_path)), nprocs=world, join=True)
     merged = kind.endswith("+merged")
     kind = kind[:-7] if merged else kind
     allgather = kind.endswith("+allgather")

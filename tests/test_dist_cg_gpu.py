@@ -2,24 +2,15 @@
 ranks share this box's GPU and talk through gloo (the collectives are what is being rehearsed; RCCL takes their place on a multi-GPU
 node). Every rank runs g4s_amd.dist.dist_conj_grad (the library's CG step API around the library's distributed product) on its slab; the stacked solution must match the single-rank oracle CG."""
 import os
-import socket
 
 import numpy as np
 import pytest
 import torch
 import torch.multiprocessing as mp
 
-from tests.helpers import assemble_csr, hex_mesh, spd_blocks
+from tests.helpers import assemble_csr, hex_mesh, spd_blocks, init_gloo
 
 pytestmark = pytest.mark.gpu
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
 
 
 def _problem():
@@ -34,9 +25,7 @@ def _problem():
 
 def _worker(rank, world, port, mode, out_dir):
     import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    init_gloo(rank, world, port)                                   # (a rendezvous FILE, tests/helpers.py)
     torch.cuda.set_device(0)
     from g4s_amd import dist as gdist, host
     ien, idmap, nno, neq, K, bc, F = _problem()
@@ -64,7 +53,7 @@ def _worker(rank, world, port, mode, out_dir):
 
 @pytest.mark.parametrize("world,mode", [(1, "packed"), (2, "packed"), (3, "packed"), (3, "allgather"), (2, "allgather")])
 def test_dist_conj_grad_matches_oracle(tmp_path, oracle, world, mode):
-    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, os.path.join(str(tmp_path), "rendezvous"), mode, str(tmp_path)), nprocs=world, join=True)
     ien, idmap, nno, neq, K, bc, F = _problem()
     BI = oracle.element_inverse_diagonal(ien, idmap, K, neq)
     acc = 1e-8 * float(np.linalg.norm(F))

@@ -3,7 +3,6 @@ half of g4s_spmv_dist_create (csrc/dist.hip) — with the exchange carried by gl
 GPU box through RCCL is the same split, the same want lists and the same buffer layout; only the transport and the product kernels differ."""
 import ctypes as C
 import os
-import socket
 
 import numpy as np
 import pytest
@@ -11,15 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from tests.helpers import power_law_csr
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+from tests.helpers import power_law_csr, init_gloo
 
 
 def _matrix(kind, o):
@@ -31,9 +22,7 @@ def _matrix(kind, o):
 
 
 def _worker(rank, world, port, mode, kind, out_dir):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    init_gloo(rank, world, port)                                   # (a rendezvous FILE, tests/helpers.py)
     from g4s_amd import dist as gdist
     from tests import oracle_lib
     o = oracle_lib.load()
@@ -103,7 +92,7 @@ def _worker(rank, world, port, mode, kind, out_dir):
 @pytest.mark.parametrize("world,mode,kind", [(2, "packed", "powerlaw"), (2, "packed", "lap7"), (3, "packed", "powerlaw"), (3, "packed", "hubs"),
                                              (1, "packed", "powerlaw"), (2, "allgather", "lap7"), (3, "allgather", "powerlaw"), (3, "allgather", "hubs")])
 def test_partitioned_spmv_matches_single(tmp_path, oracle, world, mode, kind):
-    mp.spawn(_worker, args=(world, _free_port(), mode, kind, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, os.path.join(str(tmp_path), "rendezvous"), mode, kind, str(tmp_path)), nprocs=world, join=True)
     rp, ci, va = _matrix(kind, oracle)
     n = len(rp) - 1
     x = oracle.vector(7, n)

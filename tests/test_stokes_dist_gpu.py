@@ -6,24 +6,15 @@ carry the library's buffers through torch.distributed (g4s_transport callbacks);
 oracle's single-process restatement: the same outer iteration count, the solution to round-off growth."""
 import ctypes as C
 import os
-import socket
 
 import numpy as np
 import pytest
 import torch
 import torch.multiprocessing as mp
 
-from tests.helpers import assemble_csr, stokes_problem
+from tests.helpers import assemble_csr, stokes_problem, init_gloo
 
 pytestmark = pytest.mark.gpu
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
 
 
 def div_grad_csr(ien, idmap, g, neq):
@@ -57,9 +48,7 @@ def _slice(csr, r0, r1):
 
 def _worker(rank, world, port, shape, exchange, out_dir):
     import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    init_gloo(rank, world, port)                                   # (a rendezvous FILE, tests/helpers.py)
     torch.cuda.set_device(0)
     from g4s_amd import capi, dist as gdist
     from tests import oracle_lib
@@ -102,7 +91,7 @@ def _worker(rank, world, port, shape, exchange, out_dir):
 @pytest.mark.parametrize("world,shape,exchange", [(1, (6, 6, 4, 1), "packed"), (2, (6, 6, 4, 1), "packed"), (3, (6, 6, 4, 1), "packed"), (3, (8, 6, 5, 2), "allgather"),
                                                   (2, (16, 16, 8, 3), "packed")])
 def test_uzawa_on_the_partitioned_operator_matches_oracle(tmp_path, oracle, world, shape, exchange):
-    mp.spawn(_worker, args=(world, _free_port(), shape, exchange, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, os.path.join(str(tmp_path), "rendezvous"), shape, exchange, str(tmp_path)), nprocs=world, join=True)
     pr, BI, BPI = _setup(*shape, oracle)
     ien, idmap, nno, neq, nel = pr["ien"], pr["id"], pr["nno"], pr["neq"], len(pr["ien"])
     imp, scale, vlow, steps = 1e-6, 1.0, 500, 40
