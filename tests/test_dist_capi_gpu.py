@@ -64,7 +64,8 @@ def _worker(rank, world, port, kind, out_dir):
 
 
 @pytest.mark.parametrize("world,kind", [(1, "powerlaw"), (2, "powerlaw"), (3, "powerlaw"), (2, "lap7"), (3, "banded"), (3, "powerlaw+merged"), (2, "lap7+merged"),
-                                        (2, "powerlaw+allgather"), (3, "lap7+allgather"), (3, "powerlaw+allgather+merged"), (1, "powerlaw+allgather")])
+                                        (2, "powerlaw+allgather"), (3, "lap7+allgather"), (3, "powerlaw+allgather+merged"), (1, "powerlaw+allgather"),
+                                        (5, "powerlaw+merged"), (5, "lap7")])   # five ranks + this process: the box's limit of six GPU processes
 def test_dist_spmv_capi_matches_oracle(tmp_path, oracle, world, kind):
     mp.spawn(_worker, args=(world, os.path.join(str(tmp_path), "rendezvous"), kind, str(tmp_path)), nprocs=world, join=True)
     merged = kind.endswith("+merged")

@@ -90,7 +90,8 @@ def _worker(rank, world, port, mode, kind, out_dir):
 
 
 @pytest.mark.parametrize("world,mode,kind", [(2, "packed", "powerlaw"), (2, "packed", "lap7"), (3, "packed", "powerlaw"), (3, "packed", "hubs"),
-                                             (1, "packed", "powerlaw"), (2, "allgather", "lap7"), (3, "allgather", "powerlaw"), (3, "allgather", "hubs")])
+                                             (1, "packed", "powerlaw"), (2, "allgather", "lap7"), (3, "allgather", "powerlaw"), (3, "allgather", "hubs"),
+                                             (8, "packed", "powerlaw"), (8, "packed", "lap7"), (8, "allgather", "hubs")])   # the driver's widest launch: eight ranks
 def test_partitioned_spmv_matches_single(tmp_path, oracle, world, mode, kind):
     mp.spawn(_worker, args=(world, os.path.join(str(tmp_path), "rendezvous"), mode, kind, str(tmp_path)), nprocs=world, join=True)
     rp, ci, va = _matrix(kind, oracle)
