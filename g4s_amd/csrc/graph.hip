@@ -419,6 +419,97 @@ __global__ __launch_bounds__(512) void dense_rows_times_matrix_resident_kernel(i
     }
 }
 
+// The resident kernel rewritten for the memory pipeline (round 3). The ISA of the version above showed: every A-fragment load under its own
+// per-lane branch (32 of them per strip), an s_waitcnt vmcnt(0) in front of the first MFMA — i.e. the "prefetch" of the next strip was waited for on the
+// spot, behind the result stores just issued — and an lgkmcnt(0) between each pair of MFMAs and the LDS read of their B fragments. Here:
+//   * a lane loads PAIRS of consecutive k (16-byte loads: 16 rows × 64 B per instruction instead of 16 × 32 B); pair g of lane (row i, kk) holds
+//     k = 8g + 2kk + j, j = 0, 1, and MFMA step (g, j) takes element j — so the rows of w sit in LDS in the order 8g + 4j + kk (a lane's four kk are
+//     consecutive LDS rows, as before: no bank conflict). N must be even; GT = ceil(N/8) pairs, a template parameter (4, 7, 13, 16 ↔ N ≤ 32, 50–56, 98–104, 122–128);
+//   * all loads are unconditional (row clamped to M − 1, a pair past N clamped to the row's first pair and replaced by zeros when it is used);
+//   * EVERY lane issues all 4·KT stores of a strip (a lane outside M × K writes to its wave's dump slot): no per-lane branches around the stores;
+//   * the B fragments of step s + 1 are read from LDS before the MFMAs of step s are issued.
+typedef double double2_t __attribute__((ext_vector_type(2)));
+template <int KT, int GT, bool WT>
+__global__ __launch_bounds__(512) void dense_rows_times_matrix_resident2_kernel(int M, int N, int K, const double *__restrict__ xx, const double *__restrict__ w,
+                                                                                 double *__restrict__ result, double *__restrict__ dump)
+{
+    extern __shared__ double wres[];                               // [8·G][16·KT] in the permuted row order, zero padded
+    constexpr int KP = 16 * KT;
+    constexpr int G = GT;                                          // = ceil(N/8): the launcher picks the instantiation (a runtime bound would put every load under a branch)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kk = lane >> 4, cl = lane & 15;
+    for (int idx = threadIdx.x; idx < 8 * G * KP; idx += 512) {
+        const int rp = idx / KP, c = idx - rp * KP;                // LDS row rp = 8g + 4j + kk' holds k = 8g + 2kk' + j
+        const int g = rp >> 3, j = (rp >> 2) & 1, k2 = rp & 3, r = 8 * g + 2 * k2 + j;
+        wres[idx] = (r < N && c < K) ? (WT ? w[(size_t)c * N + r] : w[(size_t)r * K + c]) : 0.0;
+    }
+    __syncthreads();
+    const int nstrips = (M + 15) / 16, stride = gridDim.x * 8;
+    double *const my_dump = dump + (blockIdx.x * 8 + wave);
+    struct Tile { double2_t a[GT]; };
+    auto request = [&](Tile &T, int sp) {
+        const int row = min(sp * 16 + cl, M - 1);                  // (a strip past the end repeats the last row: loaded, never stored)
+        const double *base = xx + (size_t)row * N;
+#pragma unroll
+        for (int g = 0; g < GT; ++g) {
+            const int k0 = 8 * g + 2 * kk;
+            T.a[g] = *reinterpret_cast<const double2_t *>(base + (k0 < N ? k0 : 0));
+        }
+    };
+    auto work = [&](const Tile &T, int sp) {
+        double4_t acc[KT];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+        double bf[2][KT];
+        auto read_b = [&](double (&b)[KT], int step) {             // step = 2g + j → LDS rows 8g + 4j + kk
+            const double *src = wres + (size_t)(4 * step + kk) * KP + cl;
+#pragma unroll
+            for (int t = 0; t < KT; ++t) b[t] = src[t * 16];
+        };
+        read_b(bf[0], 0);
+#pragma unroll
+        for (int g = 0; g < GT; ++g) {
+            const bool in = 8 * g + 2 * kk < N;                    // (only the last group can hold pairs past N)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int step = 2 * g + j;
+                if (step + 1 < 2 * G) read_b(bf[(step + 1) & 1], step + 1);   // compile time; issued before this step's MFMAs
+                __builtin_amdgcn_sched_barrier(0);                 // (… and kept there: left alone the scheduler sinks the reads behind the MFMAs)
+                const double a = (g + 1 < GT || in) ? T.a[g][j] : 0.0;
+#pragma unroll
+                for (int t = 0; t < KT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bf[step & 1][t], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);                 // without it the scheduler hoists all 2·GT·KT LDS reads to the top and spills
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            const int col = t * 16 + cl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = sp * 16 + kk + 4 * r;
+                double *dst = (row < M && col < K) ? result + (size_t)row * K + col : my_dump;
+                *dst = acc[t][r];
+            }
+        }
+    };
+    // two A tiles take turns (no register copies): the next strip is requested before the current one's MFMAs; with every store issued by every lane the number
+    // of memory operations between a tile's request and its first use is static, and hipcc's waits leave exactly those in flight
+    int strip = blockIdx.x * 8 + wave;
+    if (strip >= nstrips) return;                                  // (after the only barrier)
+    Tile A, B;
+    request(A, strip);
+    for (;;) {
+        request(B, strip + stride);
+        work(A, strip);
+        strip += stride;
+        if (strip >= nstrips) break;
+        request(A, strip + stride);
+        work(B, strip);
+        strip += stride;
+        if (strip >= nstrips) break;
+    }
+}
+
 // dw[N×K] = xxᵀ·grad: a reduction over the M rows (1e5–1e6) into a small matrix. One workgroup per (row range, 128×128 block
 // of dw). The rows go through LDS in slabs of 32 — [32][128 xx columns | 128 grad columns | 8 pad] doubles — double buffered:
 // thread t owns LDS column t and fetches its 32 rows of slab s+1 into registers (one base pointer + row stride per thread, all 32
@@ -566,6 +657,41 @@ int dense_rows_times_matrix_launch(int32_t M, int32_t N, int32_t K, const double
 {
     const int KT = (K + 15) / 16, NS = (N + 3) / 4;
     const size_t lds = sizeof(double) * 4 * (size_t)NS * 16 * KT;
+    // the rewritten resident kernel: even N (16-byte pairs of xx), the column-tile counts of the embedding-net sizes (K = 25/50/100/128 → 2/4/7/8 tiles)
+    const int G = (N + 7) / 8, GT = G;
+    const size_t lds2 = sizeof(double) * 8 * (size_t)G * 16 * KT;
+    if (N >= 2 && N % 2 == 0 && N <= 128 && K <= 128 && M >= 4096 && (KT == 2 || KT == 4 || KT == 7 || KT == 8) && (G == 4 || G == 7 || G == 13 || (G == 16 && KT <= 4)) /* (7–8 tiles × 16 groups would spill) */ && lds2 <= 140 * 1024 &&
+        (reinterpret_cast<uintptr_t>(xx_dev) & 15u) == 0 && !getenv("G4S_DENSE_RESIDENT_V1")) {
+        hipStream_t s = g4s::as_stream(stream);
+        const int strips = (M + 15) / 16, grid = std::min(256, (strips + 7) / 8);
+        double *dump = nullptr;
+        G4S_TRY(g4s::scratch_alloc(reinterpret_cast<void **>(&dump), sizeof(double) * 8 * (size_t)grid, s));
+        auto launch = [&](auto kern) -> int {
+            G4S_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds2, s, M, N, K, xx_dev, w_dev, result_dev, dump);
+            return G4S_OK;
+        };
+        int st = G4S_OK;
+#define G4S_DENSE2_GT(KT_)                                                                                           \
+        switch (GT) {                                                                                                \
+        case 4: st = launch(dense_rows_times_matrix_resident2_kernel<KT_, 4, WT>); break;                            \
+        case 7: st = launch(dense_rows_times_matrix_resident2_kernel<KT_, 7, WT>); break;                            \
+        case 13: st = launch(dense_rows_times_matrix_resident2_kernel<KT_, 13, WT>); break;                          \
+        default: st = launch(dense_rows_times_matrix_resident2_kernel<KT_, 16, WT>); break;                          \
+        }
+        switch (KT) {
+        case 2: G4S_DENSE2_GT(2) break;
+        case 4: G4S_DENSE2_GT(4) break;
+        case 7: G4S_DENSE2_GT(7) break;
+        default: G4S_DENSE2_GT(8) break;
+        }
+#undef G4S_DENSE2_GT
+        const hipError_t le = hipGetLastError();
+        g4s::scratch_free(dump, s);
+        G4S_TRY(st);
+        G4S_HIP_TRY(le);
+        return G4S_OK;
+    }
     if (N >= 1 && N <= 128 && K <= 128 && lds <= 96 * 1024 && M >= 4096) {
         // embedding-net shapes: w resident in LDS, persistent strips
         const int strips = (M + 15) / 16, grid = std::min(256 * 1, (strips + 7) / 8);

@@ -20,9 +20,15 @@ for (M, N, K) in [(100000, 25, 50), (100000, 50, 100), (100000, 100, 100), (1000
     ms = e0.elapsed_time(e1) / 50
     ref = xx @ w
     err = (r - ref).abs().max().item()
+    e0.record()
+    for _ in range(20):
+        torch.matmul(xx, w, out=ref)                               # rocBLAS / hipBLASLt beside it (not in the product: a yardstick for the shape)
+    e1.record(); torch.cuda.synchronize()
+    lib_ms = e0.elapsed_time(e1) / 20
     byt = 8 * (M * N + N * K + M * K)
     print(json.dumps({"M": M, "N": N, "K": K, "ms": round(ms, 4), "TFLOPs": round(2 * M * N * K / ms / 1e9, 2), "GBps": round(byt / ms / 1e6, 1),
-                      "frac_hbm_8TBps": round(byt / ms / 1e6 / 8000, 3), "max_abs_diff_vs_torch": err}))
+                      "frac_hbm_8TBps": round(byt / ms / 1e6 / 8000, 3), "max_abs_diff_vs_torch": err,
+                      "vendor_gemm_ms": round(lib_ms, 4), "vendor_gemm_TFLOPs": round(2 * M * N * K / lib_ms / 1e9, 2)}))
 
     # gradient (_opt_matmul_grad.py): dxx = grad·wᵀ, dw = xxᵀ·grad
     g = torch.rand(M, K, dtype=torch.float64, device="cuda") - 0.5
