@@ -32,6 +32,7 @@
 #include "prims.hpp"
 #include <algorithm>
 #include <chrono>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -637,8 +638,11 @@ constexpr size_t big_lds_bytes() { return sizeof(unsigned) * BigCfg<T>::kWindowW
 template <int T, bool WITH_VAL, int UPR, typename Body>
 __device__ __forceinline__ void flat_products(int a0, int a1, const int *__restrict__ acol, const double *__restrict__ aval,
                                               const int *__restrict__ lo, const int *__restrict__ hi, const int *__restrict__ bcol,
-                                              const double *__restrict__ bval, const BigSide<T> &sd, int t, Body body)
+                                              const double *__restrict__ bval, const BigSide<T> &sd, int t, Body body,
+                                              const int *__restrict__ xlo = nullptr, const int *__restrict__ xhi = nullptr, int xs = 0)
 {
+    // xlo / xhi (value chunks with exact splits, chunk_splits_kernel): the bounds of A-entry e of the row are xlo[(e − a0)·xs] / xhi[(e − a0)·xs]
+    // instead of lo[c] / hi[c]
     constexpr int kWaves = T / 64, kUB = BigSide<T>::kUnitBatch;
     const int lane = t & 63, wave = t >> 6;
     BIG_PROF_DECL;
@@ -647,7 +651,8 @@ __device__ __forceinline__ void flat_products(int a0, int a1, const int *__restr
         int units = 0;
         if (t < ne) {
             const int c = acol[e0 + t];
-            const int b0 = lo[c], b1 = hi[c];
+            const size_t xi = (size_t)(e0 + t - a0) * (size_t)xs;
+            const int b0 = xlo ? xlo[xi] : lo[c], b1 = xhi ? xhi[xi] : hi[c];
             const long long bits = WITH_VAL ? __double_as_longlong(aval[e0 + t]) : 0ll;
             sd.E[t] = make_int4(b0, b1, (int)(bits & 0xFFFFFFFFll), (int)(bits >> 32));
             units = b1 > b0 ? (b1 - b0 + 63) >> 6 : 0;
@@ -880,6 +885,51 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
 }
 
 
+// Exact splits for the value chunks of rows with more than one chunk (one-shot call: the sorted columns are known before the numeric phase).
+// A chunk holds kChunk consecutive output columns; with the 16 window pieces as the only splits a chunk walked every B-row piece its column range
+// touches — three units visited per unit used, flop-weighted, on R-MAT-21 (each visit: unit look-up, loads, range test). Here, once per product, every
+// (A-entry e, interior chunk boundary b) of such a row gets the position in B row acol[e] of the first column >= C_b = sorted_cols[b · kChunk]: a binary
+// search inside the window piece that holds C_b. Chunk q of entry e is then exactly [split(e, q), split(e, q + 1)) — no over-visit, no range test, and
+// the entry pass reads its bounds by entry index (no acol → wsplit dependence). need[i] = entries · (chunks − 1) of the i-th row of the launch's list (0 for
+// rows of one chunk); ct_off = its exclusive scan, indexed by list position like the kernel's own walk.
+__global__ void chunk_split_need_kernel(int n, const int *__restrict__ rows, const int *__restrict__ arpt, const int *__restrict__ crpt,
+                                        const long long *__restrict__ pre_off, int chunk, int nz_lo, int nz_hi, long long *__restrict__ need)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int row = rows[i], nz = crpt[row + 1] - crpt[row];
+    need[i] = (nz > nz_lo && nz <= nz_hi && nz > chunk && pre_off[row] >= 0) ? (long long)(arpt[row + 1] - arpt[row]) * ((nz + chunk - 1) / chunk - 1) : 0;
+}
+// One thread per (row, entry, boundary) item, the items numbered through ct_off (a hub row alone holds millions of them: one workgroup per row took 2.6 ms
+// per launch for work of a few hundred µs).
+__global__ __launch_bounds__(256) void chunk_splits_kernel(long long total, int n, const int *__restrict__ rows, int K, int N, const int *__restrict__ wsplit,
+                                                           const int *__restrict__ arpt, const int *__restrict__ acol, const int *__restrict__ brpt,
+                                                           const int *__restrict__ bcol /* window ids */, const int *__restrict__ crpt,
+                                                           const long long *__restrict__ pre_off, const int *__restrict__ pre_cols, int chunk,
+                                                           const long long *__restrict__ ct_off /* n + 1 */, int *__restrict__ ct)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int rl = 0, rh = n;                                            // the list position whose items hold i: the last one with ct_off[r] <= i
+    while (rl < rh) {
+        const int mid = (rl + rh) >> 1;
+        if (ct_off[mid + 1] > i) rh = mid; else rl = mid + 1;
+    }
+    const int row = rows[rl], nz = crpt[row + 1] - crpt[row];
+    const long long po = pre_off[row], idx = i - ct_off[rl];
+    const int a0 = arpt[row], nb = (nz + chunk - 1) / chunk - 1;
+    const int e = (int)(idx / nb), b = (int)(idx - (long long)e * nb) + 1;
+    const int c = acol[a0 + e], cb = pre_cols[po + (long long)chunk * b];
+    const int sb = split_bits(N), W = (N + (1 << sb) - 1) >> sb, wf = cb >> sb;
+    int lo = (wsplit && wf > 0) ? wsplit[(size_t)(wf - 1) * K + c] : brpt[c];
+    int hi = (wsplit && wf < W - 1) ? wsplit[(size_t)wf * K + c] : brpt[c + 1];
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (bcol[mid] < cb) lo = mid + 1; else hi = mid;
+    }
+    ct[i] = lo;
+}
+
 template <int T>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void spgemm_numeric_big_kernel(
     const int *__restrict__ rows, int nrows, int nz_lo, int nz_hi /* rows with nz outside (nz_lo, nz_hi] are left to the other shape */,
@@ -887,7 +937,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     const int *__restrict__ brpt, const int *__restrict__ bcol /* window ids: compact when col_of is given */, const int *__restrict__ col_of,
     const double *__restrict__ bval, const long long *__restrict__ row_flop,
     const int *__restrict__ crpt, int *__restrict__ ccol, double *__restrict__ cval,
-    const long long *__restrict__ pre_off, const int *__restrict__ pre_cols)
+    const long long *__restrict__ pre_off, const int *__restrict__ pre_cols,
+    const long long *__restrict__ ct_off /* exact chunk splits (chunk_splits_kernel), or NULL */, const int *__restrict__ ct)
 {
     // No static __shared__ in this kernel: it would sit in front of the dynamic region and push the fp64 table of phase 2 off its
     // 8-byte alignment (cdna_hip_programming.md Guideline 17). Everything is carved from the dynamic region instead.
@@ -965,6 +1016,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     static_assert(4 * kBigChunk <= kBigWindowWords && kBigChunk <= 65536, "phase 2 reuses the bitmap region; slots are packed in 16 bits");
     constexpr int kU = kFlatUnitsPerRound;
     int kfirst = 0, klast = 0, shift = 0;
+    const bool exact = ct && po >= 0 && nz > kBigChunk;            // uniform: this row's chunks have exact splits — every product visited lies in the chunk
+    const int nbnd = exact ? (nz + kBigChunk - 1) / kBigChunk - 1 : 0;
+    const int *ctr = exact ? ct + ct_off[ridx] : nullptr;         // (by position in this launch's row list)
     // One round of a lane's products: their slots are found in lock-step (the dependent LDS reads of the kU searches interleave) for as many
     // halvings as the wave's deepest bucket needs — a unit is 64 consecutive entries of a sorted B row, so a wave's lanes sit in neighbouring
     // buckets — and the atomics come last. A round whose units all lie outside the chunk's column range is skipped by the whole wave.
@@ -973,7 +1027,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         bool in[kU], any_in = false;
 #pragma unroll
         for (int q = 0; q < kU; ++q) {
-            in[q] = ok[q] && col[q] >= kfirst && col[q] <= klast;
+            in[q] = ok[q] && (exact || (col[q] >= kfirst && col[q] <= klast));
             any_in |= in[q];
         }
         if (!__any(any_in)) return;
@@ -1055,7 +1109,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         BIG_PROF(7);
         const int *clo, *chi;
         window_bounds(brpt, wsplit, K, N, kfirst, klast, clo, chi);   // the part of each B row inside the windows this chunk spans
-        flat_products<T, true, kU>(a0, a1, acol, aval, clo, chi, bcol, bval, sd, t, accumulate);
+        const int qi = q0 / kBigChunk;
+        flat_products<T, true, kU>(a0, a1, acol, aval, clo, chi, bcol, bval, sd, t, accumulate,
+                                   (exact && qi > 0) ? ctr + (qi - 1) : nullptr, (exact && qi < nbnd) ? ctr + qi : nullptr, nbnd);
         BIG_PROF(8);
         {   // the chunk's values, and its columns as B's column ids (window ids → ids: a gather whose latency the value stores cover)
             int orig[kPerThread];
@@ -1813,12 +1869,41 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
     if (!(pre && pre->has_wsplit)) G4S_TRY(build_window_splits(K, N2, brpt, wcol, wsplit_buf, &wsplit, s));
     // Rows past 1 K entries: bitmap windows + bucketed slots beat table + in-LDS bitonic sort while the column range is <= 4 windows.
     const bool xn_large = N2 <= window_max_n(), xn_m2 = xn_large;
+    // exact chunk splits (chunk_splits_kernel) for the rows of one launch that hold more than one value chunk: one-shot call only (the sorted columns must
+    // exist before the numeric kernel runs); the buffers live until the end of this call
+    std::vector<std::unique_ptr<DevBuf>> ct_keep;
+    auto chunk_splits = [&](int threads, const int *rows, int n, int nz_lo, int nz_hi, const long long **ct_off, const int **ct) -> int {
+        *ct_off = nullptr; *ct = nullptr;
+        if (!pre || !pre_off || !wsplit || n == 0 || getenv("G4S_SPGEMM_NO_EXACT_SPLITS")) return G4S_OK;
+        if (threads != 1024 && !getenv("G4S_SPGEMM_EXACT_SPLITS_ALL")) return G4S_OK;   // the 256-thread launches hold rows of at most two 2 048-entry chunks: measured no gain (1.22 ms either way), 0.45 ms of splits
+        const int chunk = 8 * threads;                             // BigCfg<T>::kChunk
+        auto need = std::make_unique<DevBuf>(), off = std::make_unique<DevBuf>(), tab = std::make_unique<DevBuf>();
+        G4S_TRY(need->alloc(sizeof(long long) * ((size_t)n + 1)));
+        G4S_TRY(off->alloc(sizeof(long long) * ((size_t)n + 1)));
+        G4S_HIP_TRY(hipMemsetAsync(need->as<long long>() + n, 0, sizeof(long long), s));
+        hipLaunchKernelGGL(chunk_split_need_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, rows, arpt, crpt, pre_off, chunk, nz_lo, nz_hi, need->as<long long>());
+        G4S_TRY(g4s::prims::exclusive_scan(need->as<long long>(), off->as<long long>(), (long long)n + 1, s));
+        long long total = 0;
+        G4S_HIP_TRY(hipMemcpyAsync(&total, off->as<long long>() + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+        G4S_HIP_TRY(hipStreamSynchronize(s));
+        if (total <= 0) return G4S_OK;
+        G4S_TRY(tab->alloc(sizeof(int) * (size_t)total));
+        hipLaunchKernelGGL(chunk_splits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, n, rows, K, N2, wsplit, arpt, acol, brpt, wcol, crpt, pre_off, pre_cols, chunk,
+                           off->as<long long>(), tab->as<int>());
+        G4S_HIP_TRY(hipGetLastError());
+        *ct_off = off->as<long long>(); *ct = tab->as<int>();
+        ct_keep.push_back(std::move(need)); ct_keep.push_back(std::move(off)); ct_keep.push_back(std::move(tab));
+        return G4S_OK;
+    };
     auto big_t = [&](auto shape, const int *rows, int n, int nz_lo, int nz_hi, int *next_row) -> int {
         constexpr int T = decltype(shape)::value;
         auto k = spgemm_numeric_big_kernel<T>;
         const size_t lds = big_lds_bytes<T>();   // the bitmap (phase 2 reuses it) + scan scratch + long-B list + store staging
         G4S_TRY(allow_lds(k, lds));
-        if (n) hipLaunchKernelGGL(k, dim3(big_grid(n, BigCfg<T>::kPerCu)), dim3(T), lds, s, rows, n, nz_lo, nz_hi, next_row, N2, K, wsplit, arpt, acol, aval, brpt, wcol, winv, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols);
+        const long long *ct_off = nullptr;
+        const int *ct = nullptr;
+        if (n) G4S_TRY(chunk_splits(T, rows, n, nz_lo, nz_hi, &ct_off, &ct));
+        if (n) hipLaunchKernelGGL(k, dim3(big_grid(n, BigCfg<T>::kPerCu)), dim3(T), lds, s, rows, n, nz_lo, nz_hi, next_row, N2, K, wsplit, arpt, acol, aval, brpt, wcol, winv, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols, ct_off, ct);
         return G4S_OK;
     };
     auto big = [&](int threads, const int *rows, int n, int nz_lo = 0, int nz_hi = INT_MAX, int *next_row = nullptr) -> int {
