@@ -908,13 +908,16 @@ __global__ __launch_bounds__(256) void chunk_splits_kernel(long long total, int 
                                                            const long long *__restrict__ pre_off, const int *__restrict__ pre_cols, int chunk,
                                                            const long long *__restrict__ ct_off /* n + 1 */, int *__restrict__ ct)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    int rl = 0, rh = n;                                            // the list position whose items hold i: the last one with ct_off[r] <= i
+    const long long i0 = (long long)blockIdx.x * blockDim.x, i = i0 + threadIdx.x;
+    // the list position whose items hold the workgroup's FIRST item — a uniform search (scalar loads, once per 256 items: a search per item was a chain of
+    // 17 dependent loads in front of every 10-step split search) — then a short walk forward for the lanes whose item belongs to a later row
+    int rl = 0, rh = n;
     while (rl < rh) {
         const int mid = (rl + rh) >> 1;
-        if (ct_off[mid + 1] > i) rh = mid; else rl = mid + 1;
+        if (ct_off[mid + 1] > i0) rh = mid; else rl = mid + 1;
     }
+    if (i >= total) return;
+    while (ct_off[rl + 1] <= i) ++rl;
     const int row = rows[rl], nz = crpt[row + 1] - crpt[row];
     const long long po = pre_off[row], idx = i - ct_off[rl];
     const int a0 = arpt[row], nb = (nz + chunk - 1) / chunk - 1;
