@@ -1944,7 +1944,7 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
             // The class spans 4 K … 1 M outputs per row (a 250-fold range of work): longest rows first, handed out one at a time.
             SortedRows sr;
             G4S_TRY(sr.build(n, rc.list(CLS_M3), nullptr, crpt, N, s));   // a row has at most N outputs
-            G4S_TRY(big(1024, sr.rows.as<int>(), n, 0, INT_MAX, sr.counter.as<int>()));
+            G4S_TRY(big(m3_cut <= 0 ? t_m3 : 1024, sr.rows.as<int>(), n, 0, INT_MAX, sr.counter.as<int>()));   // (G4S_SPGEMM_M3_CUT=0 + G4S_SPGEMM_T_NUM_M3: the whole class in another shape)
             G4S_HIP_TRY(hipStreamSynchronize(s));                 // the sorted list and the counter die with this block
         }
     }
@@ -2084,6 +2084,8 @@ G4S_API g4s_status g4s_spgemm_csr_i32_f64(const int32_t *arpt, const int32_t *ac
     t.destroy = ms_since(t0);
     t.total = ms_since(t_total);
     if (timings) *timings = t;
+    if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s one-call: create %.2f spmm %.2f export %.2f destroy %.2f total %.2f ms (the carried state of the two phases is released after this line)\n",
+                                     t.create, t.spmm, t.export_csr, t.destroy, t.total);
     return G4S_OK;
 }
 
