@@ -1889,8 +1889,10 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         long long total = 0;
         G4S_HIP_TRY(hipMemcpyAsync(&total, off->as<long long>() + n, sizeof(long long), hipMemcpyDeviceToHost, s));
         G4S_HIP_TRY(hipStreamSynchronize(s));
-        if (total <= 0) return G4S_OK;
-        G4S_TRY(tab->alloc(sizeof(int) * (size_t)total));
+        // an optimisation, never a reason to fail: entries × chunks can outgrow any sensible table (rows of 10^5 entries and 10^6 outputs) — those products, and
+        // a table that cannot be allocated, run with the window pieces as before
+        if (total <= 0 || total > (1ll << 28)) return G4S_OK;
+        if (tab->alloc(sizeof(int) * (size_t)total) != G4S_OK) { (void)hipGetLastError(); return G4S_OK; }
         hipLaunchKernelGGL(chunk_splits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, n, rows, K, N2, wsplit, arpt, acol, brpt, wcol, crpt, pre_off, pre_cols, chunk,
                            off->as<long long>(), tab->as<int>());
         G4S_HIP_TRY(hipGetLastError());
