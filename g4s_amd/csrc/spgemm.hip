@@ -635,12 +635,16 @@ constexpr size_t big_lds_bytes() { return sizeof(unsigned) * BigCfg<T>::kWindowW
 //      waves striding the unit range, so every wave does the same work whatever the B-row lengths are.
 // body(col[UPR], b_value[UPR], a_value[UPR], valid[UPR]) gets a lane's products of one round together, so that it can interleave their
 // dependent LDS chains. Contains barriers: call from uniform control flow; on return every product has been handed to body.
-template <int T, bool WITH_VAL, int UPR, typename Body>
+struct FlatNoTail { __device__ __forceinline__ void operator()() const {} };
+template <int T, bool WITH_VAL, int UPR, typename Body, typename Tail = FlatNoTail>
 __device__ __forceinline__ void flat_products(int a0, int a1, const int *__restrict__ acol, const double *__restrict__ aval,
                                               const int *__restrict__ lo, const int *__restrict__ hi, const int *__restrict__ bcol,
                                               const double *__restrict__ bval, const BigSide<T> &sd, int t, Body body,
-                                              const int *__restrict__ xlo = nullptr, const int *__restrict__ xhi = nullptr, int xs = 0)
+                                              const int *__restrict__ xlo = nullptr, const int *__restrict__ xhi = nullptr, int xs = 0, Tail tail = Tail())
 {
+    // tail(): called once by every thread in front of the LAST barrier of the walk (or at the end when there is none): loads issued there have the
+    // barrier's skew to arrive in (the numeric kernel starts the column-id gather of its store step there)
+    bool tail_done = false;
     // xlo / xhi (value chunks with exact splits, chunk_splits_kernel): the bounds of A-entry e of the row are xlo[(e − a0)·xs] / xhi[(e − a0)·xs]
     // instead of lo[c] / hi[c]
     constexpr int kWaves = T / 64, kUB = BigSide<T>::kUnitBatch;
@@ -716,10 +720,12 @@ __device__ __forceinline__ void flat_products(int a0, int a1, const int *__restr
                 if (WITH_VAL) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); BIG_PROF(5); }
 #endif
             }
+            if (e0 + T >= a1 && ub0 + kUB >= nu) { tail(); tail_done = true; }   // uniform: the last batch of the last tile
             __syncthreads();                                        // M — and after the last batch E and P — are rewritten next
             if (WITH_VAL) BIG_PROF(14);
         }
     }
+    if (!tail_done) tail();
     BIG_PROF_FLUSH;
 }
 
@@ -1113,11 +1119,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         const int *clo, *chi;
         window_bounds(brpt, wsplit, K, N, kfirst, klast, clo, chi);   // the part of each B row inside the windows this chunk spans
         const int qi = q0 / kBigChunk;
-        flat_products<T, true, kU>(a0, a1, acol, aval, clo, chi, bcol, bval, sd, t, accumulate,
-                                   (exact && qi > 0) ? ctr + (qi - 1) : nullptr, (exact && qi < nbnd) ? ctr + qi : nullptr, nbnd);
-        BIG_PROF(8);
-        {   // the chunk's values, and its columns as B's column ids (window ids → ids: a gather whose latency the value stores cover)
-            int orig[kPerThread];
+        // the chunk's columns as B's column ids (window ids → ids): a gather, started in front of the walk's last barrier so that it arrives under the barrier's skew
+        int orig[kPerThread];
+        auto gather_ids = [&]() {
             if (col_of) {
 #pragma unroll
                 for (int u = 0; u < kPerThread; ++u) orig[u] = col_of[KC[min(t + u * kBigThreads, qn - 1)]];
@@ -1125,6 +1129,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
 #pragma unroll
                 for (int u = 0; u < kPerThread; ++u) orig[u] = KC[min(t + u * kBigThreads, qn - 1)];
             }
+        };
+        flat_products<T, true, kU>(a0, a1, acol, aval, clo, chi, bcol, bval, sd, t, accumulate,
+                                   (exact && qi > 0) ? ctr + (qi - 1) : nullptr, (exact && qi < nbnd) ? ctr + qi : nullptr, nbnd, gather_ids);
+        BIG_PROF(8);
+        {   // the chunk's values and column ids (gathered above)
             double val[kPerThread];
 #pragma unroll
             for (int u = 0; u < kPerThread; ++u) val[u] = V[min(t + u * kBigThreads, qn - 1)];
