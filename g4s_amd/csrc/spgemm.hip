@@ -1105,6 +1105,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         }
     };
     fetch_chunk(0);
+#pragma unroll
+    for (int u = 0; u < kPerThread; ++u) asm volatile("" :: "v"(cc[u]));   // settled on the loop's entry path too (see the store step): the first open needs them at once anyway
     for (int q0 = 0; q0 < nz; q0 += kBigChunk) {
         const int qn = min(kBigChunk, nz - q0);
         open_chunk(qn);
@@ -1133,7 +1135,12 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         flat_products<T, true, kU>(a0, a1, acol, aval, clo, chi, bcol, bval, sd, t, accumulate,
                                    (exact && qi > 0) ? ctr + (qi - 1) : nullptr, (exact && qi < nbnd) ? ctr + qi : nullptr, nbnd, gather_ids);
         BIG_PROF(8);
-        {   // the chunk's values and column ids (gathered above)
+        {   // the chunk's values and column ids (gathered above).
+            // hipcc's wait-count book: a register whose load is consumed only under a per-lane branch (the stores below) stays "pending" on the path that skips the
+            // branch, and the merged state then makes the NEXT chunk wait — at its very top, for the stores just issued — before it may reuse that register. A use
+            // of the prefetched columns and of the gathered ids here, in front of the stores, settles them on every path: the next chunk opens without a wait.
+#pragma unroll
+            for (int u = 0; u < kPerThread; ++u) { asm volatile("" :: "v"(cc[u])); asm volatile("" :: "v"(orig[u])); }
             double val[kPerThread];
 #pragma unroll
             for (int u = 0; u < kPerThread; ++u) val[u] = V[min(t + u * kBigThreads, qn - 1)];
