@@ -175,10 +175,12 @@ constexpr int kMaxDiags = 32;
 struct DiaOffsets { int off[kMaxDiags]; };
 // A 3-D stencil in natural ordering has two diagonals one PLANE away (±431² for the 431³ Laplacian): x[row + plane] is needed again a plane later as the
 // centre and two planes later as x[row − plane]. With every XCD walking a contiguous eighth of the rows that reuse distance is three planes of x (4.5 MB) plus
-// the streams in between — more than an XCD's 4 MiB L2, so x crossed the fabric three times (PMC: 6.7 GB fetched for 5.4 GB of own reads). Instead XCD j takes
-// the j-th eighth of EVERY plane, plane after plane: the three slices it needs are 0.56 MB and stay in its L2; the neighbours one grid line away (±431) cross
-// a slice border for 2·431 of 23 221 rows. Chosen at plan time when the largest offset is far (≥ 16 K rows) and symmetric and the rows hold ≥ 8 planes.
-struct DiaFar { int stride, slice, blocks_per_slice; };   // stride 0: the contiguous walk
+// the streams in between — more than an XCD's 4 MiB L2, so x crosses the fabric three times (PMC: 6.7 GB fetched for 5.4 GB of own reads). In the plane-sliced
+// walk XCD j takes the j-th eighth of EVERY plane, plane after plane: the three slices it needs are 0.56 MB and stay in its L2 (PMC: 5.65 GB fetched). Measured on
+// one handle in one process the sliced walk is NOT faster (1–2 % slower on three boxes; staggered starting planes 5–8 % slower): the kernel is not bound by
+// the fabric bytes. It is therefore opt-in (dia_walk below); the geometry is computed at plan time when the largest offset is far (≥ 16 K rows) and symmetric
+// and the rows hold ≥ 8 planes.
+struct DiaFar { int stride, slice, blocks_per_slice, planes, zshift; };   // stride 0: the contiguous walk; zshift: XCD j starts j·zshift planes further on (wrapping)
 
 template <int ND, bool NT>
 __global__ __launch_bounds__(WG) void spmv_dia_kernel(int rows, int cols, int nd, DiaOffsets offs, long long ld, const double *__restrict__ dia,
@@ -190,7 +192,8 @@ __global__ __launch_bounds__(WG) void spmv_dia_kernel(int rows, int cols, int nd
     const int b = (int)blockIdx.x;
     int row;
     if (far.stride) {
-        const int j = b % g4s::kXcds, l = b / g4s::kXcds, z = l / far.blocks_per_slice, w = l - z * far.blocks_per_slice;
+        const int j = b % g4s::kXcds, l = b / g4s::kXcds, z0 = l / far.blocks_per_slice, w = l - z0 * far.blocks_per_slice;
+        const int z = (z0 + j * far.zshift) % far.planes;
         const long long base = (long long)z * far.stride;
         const long long r = base + min(j * far.slice, far.stride) + w * WG + (int)threadIdx.x;
         if (r >= base + min((j + 1) * far.slice, far.stride) || r >= rows) return;
@@ -230,7 +233,8 @@ __global__ __launch_bounds__(WG) void spmv_dia2_kernel(int rows2 /* even part of
     int row;
     if (far.stride) {
         // plane-sliced walk (see DiaFar): XCD j takes the j-th eighth of every plane, plane after plane
-        const int j = b % g4s::kXcds, l = b / g4s::kXcds, z = l / far.blocks_per_slice, w = l - z * far.blocks_per_slice;
+        const int j = b % g4s::kXcds, l = b / g4s::kXcds, z0 = l / far.blocks_per_slice, w = l - z0 * far.blocks_per_slice;
+        const int z = (z0 + j * far.zshift) % far.planes;          // staggered start: the eight XCDs are never on the same plane
         const long long base = (long long)z * far.stride;
         const long long lo = (base + min(j * far.slice, far.stride) + 1) & ~1ll, hi = (base + min((j + 1) * far.slice, far.stride) + 1) & ~1ll;   // even: 16-byte accesses
         const long long r = lo + 2 * (w * WG + (int)threadIdx.x);
@@ -326,7 +330,7 @@ struct g4s_csr_s {
     int dia_nd = 0;
     long long dia_ld = 0;
     DiaOffsets dia_offs{};
-    DiaFar dia_far{0, 0, 0};
+    DiaFar dia_far{0, 0, 0, 1, 0};
     g4s::PbPlan *pb = nullptr;      // propagation-blocked path (spmv_pb.hip) for matrices without gather locality
     g4s::BcsrPlan *bcsr = nullptr;  // block-row form of an assembled FE matrix (spmv_bcsr.hip)
 };
@@ -564,8 +568,8 @@ int try_build_dia(g4s_csr_s *A)
     if (e != hipSuccess || h_fail) { (void)hipFree(dia); (void)hipFree(mask); return e == hipSuccess ? G4S_OK : g4s::set_error(G4S_ERR_HIP, "diagonal fill failed: %s", hipGetErrorString(e)); }
     A->d_dia = dia; A->d_dia_mask = mask; A->dia_nd = nd; A->dia_ld = ld; A->dia_offs = D;
     // plane-sliced walk (DiaFar): the outermost diagonals are ±stride with stride ≥ 16 K rows, every other offset is well inside a slice, ≥ 8 planes
-    A->dia_far = DiaFar{0, 0, 0};
-    if (nd >= 3 && !getenv("G4S_SPMV_DIA_CONTIGUOUS")) {
+    A->dia_far = DiaFar{0, 0, 0, 1, 0};
+    if (nd >= 3) {
         const long long stride = D.off[nd - 1];
         const long long inner = std::max<long long>(std::abs((long long)D.off[1]), std::abs((long long)D.off[nd - 2]));
         const long long slice = (stride + g4s::kXcds - 1) / g4s::kXcds;
@@ -695,6 +699,21 @@ G4S_API g4s_status g4s_csr_device_arrays(g4s_csr_t A, const int32_t **rowptr, co
     return G4S_OK;
 }
 
+namespace {
+// Which rows an XCD walks on the diagonal path (read per launch, so that tools/ab_lap7_walks.py can compare the walks on ONE handle and one pair of vectors —
+// the same walk varies by ±8 % from process to process with the placement of its pages): contiguous eighths (default), or — G4S_SPMV_DIA_WALK=l — its eighth of
+// every plane of a 3-D stencil, plane after plane (15 % fewer bytes across the fabric, PMC; not faster: DESIGN §4.1), =s the same with the XCDs' starting planes
+// staggered. The plan holds the geometry (DiaFar) whenever the matrix has far planes.
+DiaFar dia_walk(DiaFar geometry)
+{
+    const char *wk = getenv("G4S_SPMV_DIA_WALK");
+    const char mode = wk ? wk[0] : 'c';
+    if (mode != 'l' && mode != 's') geometry.stride = 0;
+    geometry.zshift = mode == 's' ? 1 : 0;
+    return geometry;
+}
+} // namespace
+
 G4S_API g4s_status g4s_spmv(g4s_csr_t A, const double *x_dev, double *y_dev, double alpha, double beta, void *stream)
 {
     G4S_REQUIRE(A, "NULL handle");
@@ -711,8 +730,10 @@ G4S_API g4s_status g4s_spmv(g4s_csr_t A, const double *x_dev, double *y_dev, dou
         const int rows2 = two ? (A->rows & ~1) : 0;
         if (rows2) {
             const int nblocks = (rows2 / 2 + WG - 1) / WG, per_xcd = (nblocks + g4s::kXcds - 1) / g4s::kXcds;
-            const DiaFar far = A->dia_far;
+            DiaFar far = dia_walk(A->dia_far);
             const long long planes = far.stride ? ((long long)rows2 + far.stride - 1) / far.stride : 0;
+            far.planes = (int)std::max<long long>(planes, 1);
+            far.zshift = far.zshift ? (int)(planes / g4s::kXcds) : 0;
             const dim3 grid(far.stride ? (unsigned)(planes * far.blocks_per_slice * g4s::kXcds) : (unsigned)(per_xcd * g4s::kXcds)), block(WG);
 #define G4S_DIA2_LAUNCH(ND)                                                                                                                                           \
     do {                                                                                                                                                          \
@@ -727,10 +748,12 @@ G4S_API g4s_status g4s_spmv(g4s_csr_t A, const double *x_dev, double *y_dev, dou
         if (tail0 < A->rows) {
             const int n_tail = A->rows - tail0;
             const int nblocks = (n_tail + WG - 1) / WG, per_xcd = (nblocks + g4s::kXcds - 1) / g4s::kXcds;
-            DiaFar far = A->dia_far;
+            DiaFar far = dia_walk(A->dia_far);
             if (tail0 != 0) far.stride = 0;                          // the odd last row behind the two-row kernel
             if (far.stride) far.blocks_per_slice = (far.slice + WG - 1) / WG;
             const long long planes = far.stride ? ((long long)A->rows + far.stride - 1) / far.stride : 0;
+            far.planes = (int)std::max<long long>(planes, 1);
+            far.zshift = far.zshift ? (int)(planes / g4s::kXcds) : 0;
             const dim3 grid(far.stride ? (unsigned)(planes * far.blocks_per_slice * g4s::kXcds) : (unsigned)(per_xcd * g4s::kXcds)), block(WG);
 #define G4S_DIA_LAUNCH(ND)                                                                                                                                            \
     do {                                                                                                                                                          \

@@ -1,9 +1,9 @@
 #!/bin/bash
-# FETCH_SIZE and L2 hit counters of the diagonal kernel on the 431^3 operator with the plane-sliced and the contiguous XCD walk (one box, one call).
+# FETCH_SIZE and L2 hit counters of the diagonal kernel on the 431^3 operator with the plane-sliced (G4S_SPMV_DIA_WALK=l) and the contiguous (default) XCD walk (one box, one call).
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 for mode in sliced contig; do
-  if [ $mode = contig ]; then export G4S_SPMV_DIA_CONTIGUOUS=1; else unset G4S_SPMV_DIA_CONTIGUOUS; fi
+  if [ $mode = contig ]; then export G4S_SPMV_DIA_WALK=c; else export G4S_SPMV_DIA_WALK=l; fi
   O=$ROOT/gpurun_out/pmc2_$mode
   mkdir -p $O
   for grp in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
