@@ -700,14 +700,26 @@ G4S_API g4s_status g4s_csr_device_arrays(g4s_csr_t A, const int32_t **rowptr, co
 }
 
 namespace {
-// Which rows an XCD walks on the diagonal path (read per launch, so that tools/ab_lap7_walks.py can compare the walks on ONE handle and one pair of vectors —
+// Which rows an XCD walks on the diagonal path (switchable per launch — dia_switches — so that tools/ab_lap7_walks.py can compare the walks on ONE handle and one pair of vectors —
 // the same walk varies by ±8 % from process to process with the placement of its pages): contiguous eighths (default), or — G4S_SPMV_DIA_WALK=l — its eighth of
 // every plane of a 3-D stencil, plane after plane (15 % fewer bytes across the fabric, PMC; not faster: DESIGN §4.1), =s the same with the XCDs' starting planes
 // staggered. The plan holds the geometry (DiaFar) whenever the matrix has far planes.
+// The two A/B switches of the diagonal path are environment variables. A launch of a small matrix costs a few µs, so they are read ONCE per process — unless
+// G4S_SPMV_LIVE_ENV is set (before the first product), which makes every launch read them again: what the in-process A/B tools do.
+struct DiaSwitches { char walk; bool one_row; };
+DiaSwitches dia_switches()
+{
+    auto read = []() {
+        const char *wk = getenv("G4S_SPMV_DIA_WALK");
+        return DiaSwitches{wk ? wk[0] : 'c', getenv("G4S_SPMV_DIA_ONE_ROW") != nullptr};
+    };
+    static const bool live = getenv("G4S_SPMV_LIVE_ENV") != nullptr;
+    static const DiaSwitches once = read();
+    return live ? read() : once;
+}
 DiaFar dia_walk(DiaFar geometry)
 {
-    const char *wk = getenv("G4S_SPMV_DIA_WALK");
-    const char mode = wk ? wk[0] : 'c';
+    const char mode = dia_switches().walk;
     if (mode != 'l' && mode != 's') geometry.stride = 0;
     geometry.zshift = mode == 's' ? 1 : 0;
     return geometry;
@@ -726,7 +738,7 @@ G4S_API g4s_status g4s_spmv(g4s_csr_t A, const double *x_dev, double *y_dev, dou
     if (A->bcsr) return g4s::bcsr_spmv(A->bcsr, x_dev, y_dev, alpha, beta, s);
     if (A->d_dia) {
         // two rows per lane where it applies (≤ 16 diagonals, y 16-byte aligned, not disabled): the even part of the rows; an odd last row by the one-row kernel
-        const bool two = A->dia_nd <= 16 && (reinterpret_cast<uintptr_t>(y_dev) & 15u) == 0 && A->rows >= 2 && !getenv("G4S_SPMV_DIA_ONE_ROW");
+        const bool two = A->dia_nd <= 16 && (reinterpret_cast<uintptr_t>(y_dev) & 15u) == 0 && A->rows >= 2 && !dia_switches().one_row;
         const int rows2 = two ? (A->rows & ~1) : 0;
         if (rows2) {
             const int nblocks = (rows2 / 2 + WG - 1) / WG, per_xcd = (nblocks + g4s::kXcds - 1) / g4s::kXcds;

@@ -4,6 +4,7 @@ pair of vectors — for the 431^3 operator and the 10 M banded matrix. (Across p
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+os.environ["G4S_SPMV_LIVE_ENV"] = "1"                             # the library then reads the A/B switches at every launch
 from g4s_amd import host
 
 for name, A in (("lap7 431^3", host.laplacian_csr(7, 431, 431, 431)), ("banded 10M hb5", host.banded_csr(10_000_000, 5, 20240521))):

@@ -5,6 +5,7 @@ placement), so A/Bs across processes say little."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+os.environ["G4S_SPMV_LIVE_ENV"] = "1"                             # the library then reads the A/B switches at every launch
 from g4s_amd import host
 
 n = 431
