@@ -29,6 +29,9 @@
 #ifndef G4S_SPGEMM_UPR
 #define G4S_SPGEMM_UPR 4
 #endif
+#ifndef G4S_KO
+#define G4S_KO 0   // timing-only knock-outs of the big-row numeric kernel (wrong results; tools/ab_variants.sh): 1 no halvings, 2 no LDS atomics, 4 no bucket index, 8 no stores, 16 no accumulate step
+#endif
 #include "prims.hpp"
 #include <algorithm>
 #include <chrono>
@@ -511,7 +514,7 @@ struct BigCfg {
     static constexpr int kWindowWords = 1 << (kWindowBits - 5);      // = 32·T
     static constexpr int kChunk = 8 * T;                             // output entries per value pass
     static constexpr int kChunkBits = kWindowBits - 7;
-    static constexpr int kStage = 4 * T;                             // list items (non-empty words) staged in LDS per emit tile; fits the union with the flat lists
+    static constexpr int kStage = 5 * T;                             // list items (non-empty 4-word groups) staged in LDS per emit tile; with the T first positions behind it: the union with the flat lists (24·T bytes)
     static constexpr int kPerCu = 1024 / T;                          // workgroups per CU that fit in LDS (136 / 72 / 40 KiB each)
 };
 constexpr int kFlatUnitsPerRound = G4S_SPGEMM_UPR;   // 64-entry units of B rows a wave loads per round (independent loads in flight per lane)
@@ -525,9 +528,11 @@ __host__ __device__ __forceinline__ int split_bits(int N)
     const int lg = N > 1 ? 32 - __builtin_clz((unsigned)(N - 1)) : 0;   // ceil(log2 N)
     return lg - 4 < 16 ? 16 : (lg - 4 > 20 ? 20 : lg - 4);
 }
-// Word w of a window lives at LDS slot w ^ ((w >> 6) & 31): the emit step gives each thread 32 consecutive words, and unswizzled
-// the 64 lanes of a wave would read 2 banks (a 32-way conflict); swizzled they read 64.
-__device__ __forceinline__ int bm_slot(int w) { return w ^ ((w >> 6) & 31); }
+// Word w of a window lives at LDS slot w ^ (((w >> 6) & 7) << 2): the emit step gives each thread 32 consecutive words and reads them as eight
+// 16-byte groups; unswizzled, the lanes of a ds_read_b128 group would all sit on two 16-byte slots of the 256-byte bank row. The XOR moves whole
+// 4-word groups (bits 2–4 only), so a group stays one aligned 16-byte read, and within each of the instruction's four 16-lane groups
+// (MI355X_MICROARCH.md §LDS) the sixteen lanes land on sixteen different slots.
+__device__ __forceinline__ int bm_slot(int w) { return w ^ (((w >> 6) & 7) << 2); }
 constexpr int kWindowMaxN = 4 << 20;                  // widest B for which the window kernels take the mid-size rows too
 inline int window_max_n() { const char *e = getenv("G4S_SPGEMM_WINDOW_MAX_N"); return e ? atoi(e) : kWindowMaxN; }   // tests force the table kernels with 0
 // grid of the persistent big-row kernels: one workgroup per CU (their LDS allows no more), fewer when the class is small
@@ -610,15 +615,14 @@ struct BigSide {
     static constexpr int kCtrlInts = 32, kScanInts = 64, kTotalSlot = 24;   // ctrl[0 … 16): wave totals of the unit scan; ctrl[24]: the row's running count
     static constexpr int kUnitBatch = 2 * T;                                 // units mapped per batch (u16 entry index each)
     static constexpr size_t kFlatBytes = sizeof(int4) * T + sizeof(int) * (T + 4) + sizeof(unsigned short) * kUnitBatch;
-    static constexpr size_t kStageBytes = sizeof(int) * BigCfg<T>::kStage;
-    static constexpr size_t kStageBytes2 = kStageBytes + sizeof(int) * T;   // + the emit step's per-thread first positions
-    static constexpr size_t kBytes = sizeof(int) * (kCtrlInts + kScanInts) + (kFlatBytes > kStageBytes2 ? kFlatBytes : kStageBytes2);
-    int *ctrl, *scan, *stage, *base, *P;
+    static constexpr size_t kStageBytes = sizeof(int) * (BigCfg<T>::kStage + T);   // + the emit step's per-thread first positions
+    static constexpr size_t kBytes = sizeof(int) * (kCtrlInts + kScanInts) + (kFlatBytes > kStageBytes ? kFlatBytes : kStageBytes);
+    int *ctrl, *scan, *stage, *P;
     int4 *E;            // per A-entry: its B row [x, y) and the bits of its value
     unsigned short *M;  // per unit of the batch: its A-entry
     __device__ __forceinline__ explicit BigSide(int *base_)
     {
-        ctrl = base_; scan = base_ + kCtrlInts; stage = scan + kScanInts; base = stage + BigCfg<T>::kStage;
+        ctrl = base_; scan = base_ + kCtrlInts; stage = scan + kScanInts;
         E = reinterpret_cast<int4 *>(stage); P = reinterpret_cast<int *>(E + T); M = reinterpret_cast<unsigned short *>(P + T + 4);
     }
 };
@@ -730,97 +734,95 @@ __device__ __forceinline__ void flat_products(int a0, int a1, const int *__restr
 }
 
 // Emits the set bits of one LDS bitmap window (words swizzled by bm_slot) in ascending column order to out[0 … total) and returns
-// total (the same value in every thread). Thread t owns the 32 consecutive words [32t, 32t + 32): a block scan of the per-thread
-// (set bits, non-empty words) places its columns and its words. The bits themselves are then written word by word from a list of
-// the non-empty words, one word per thread: in a power-law row the first few hundred columns are all present, and a thread emitting
-// its own 32 words would write a thousand ids while the rest write a handful (measured: 38 % of the numeric kernel).
-// s_scan: 34 ints of LDS scratch, stage: kBigStage ints, first_pos: T ints. Contains barriers: call from uniform control flow.
-template <int T, bool KEEP_WORDS>
-__device__ __forceinline__ int emit_window_columns(const unsigned *bm, int w0, int *__restrict__ out, int *s_scan, int *stage, int *first_pos, int t)
+// total (the same value in every thread). Thread t owns the 32 consecutive words [32t, 32t + 32), read as eight 16-byte groups (128 columns each); a
+// block scan of the per-thread (set bits, non-empty groups) places its columns and its groups. The bits themselves are written group by group from a
+// list of the non-empty GROUPS, one item per thread: in a power-law row the first few hundred columns are all present, and a thread emitting its own
+// 1 024 columns would write a thousand ids while the rest write a handful (measured in round 1: 38 % of the numeric kernel; round 4 tried it again with
+// an LDS stage and a wave-cooperative path for crowded threads: 2–3× slower than the list, the per-thread loops diverge on every word).
+// Round 4: list items are 4-word groups instead of words — the list build is 8 steps per thread instead of 32 (it was 25 % of the symbolic window
+// kernels), an item's columns are at most 128 consecutive ids, and the words come in as 16-byte LDS reads.
+// s_scan: 32 ints of LDS scratch; stage: BigCfg<T>::kStage ints (list items), followed by T ints (per-thread first positions).
+// Contains barriers: call from uniform control flow; the caller puts a barrier between this call and the next write to the bitmap.
+template <int T>
+__device__ __forceinline__ int emit_window_columns(const unsigned *bm, int w0, int *__restrict__ out, int *s_scan, int *stage, int t)
 {
-    // KEEP_WORDS: the thread's 32 words stay in registers between the count and the list step (32 VGPRs the numeric kernel cannot spare)
-    constexpr int kBigThreads = T, kBigStage = BigCfg<T>::kStage;
     static_assert(BigCfg<T>::kWindowWords / T == 32, "emit layout");
+    constexpr int S = BigCfg<T>::kStage;
+    int *first_pos = stage + S;
     const int lane = t & 63, wave = t >> 6;
+    const int kq = (t >> 1) & 7;                                    // bm_slot's XOR for this thread's block, in 4-word groups ((32t + i) >> 6 == t >> 1)
     BIG_PROF_DECL_SYM;
-    unsigned nonempty = 0, words[KEEP_WORDS ? 32 : 1];
-    int cnt = 0;
-    if constexpr (KEEP_WORDS) {
+    unsigned gc_lo = 0, gc_hi = 0;                                  // set bits of groups 0–3 / 4–7, one byte each (a group holds at most 128)
+    int cnt = 0, ng = 0;
+    {
+        const uint4 *blk = reinterpret_cast<const uint4 *>(bm + t * 32);
+        uint4 g[8];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) words[i] = bm[bm_slot(t * 32 + i)];
+        for (int q = 0; q < 8; ++q) g[q] = blk[q ^ kq];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            cnt += __popc(words[i]);
-            nonempty |= (words[i] != 0u ? 1u : 0u) << i;
-        }
-    } else {
-#pragma unroll 8
-        for (int i = 0; i < 32; ++i) {
-            const unsigned w = bm[bm_slot(t * 32 + i)];
-            cnt += __popc(w);
-            nonempty |= (w != 0u ? 1u : 0u) << i;
+        for (int q = 0; q < 8; ++q) {
+            const int c = __popc(g[q].x) + __popc(g[q].y) + __popc(g[q].z) + __popc(g[q].w);
+            cnt += c;
+            ng += c != 0;
+            if (q < 4) gc_lo |= (unsigned)c << (8 * q); else gc_hi |= (unsigned)c << (8 * (q - 4));
         }
     }
-    const int nw = __popc(nonempty);
-    const bool dense = __any(nw > 6);                              // wave-uniform: most windows of most rows leave a thread 0–2 words
-    if (KEEP_WORDS) BIG_PROF(8);
-    const int incl_c = (int)wave_inclusive_sum((unsigned)cnt), incl_w = (int)wave_inclusive_sum((unsigned)nw);
-    if (lane == 63) { s_scan[wave] = incl_c; s_scan[16 + wave] = incl_w; }
+    BIG_PROF(8);
+    const int incl_c = (int)wave_inclusive_sum((unsigned)cnt), incl_g = (int)wave_inclusive_sum((unsigned)ng);
+    if (lane == 63) { s_scan[wave] = incl_c; s_scan[16 + wave] = incl_g; }
     __syncthreads();
-    if (KEEP_WORDS) BIG_PROF(9);
-    int p = incl_c - cnt, wq = incl_w - nw, total = 0, total_w = 0;   // first column / first word of this thread within the window
+    BIG_PROF(9);
+    int p = incl_c - cnt, gq = incl_g - ng, total = 0, total_g = 0; // first column / first list item of this thread within the window
 #pragma unroll
-    for (int u = 0; u < kBigThreads / 64; ++u) {
-        const int vc = s_scan[u], vw = s_scan[16 + u];
-        if (u < wave) { p += vc; wq += vw; }
+    for (int u = 0; u < T / 64; ++u) {
+        const int vc = s_scan[u], vg = s_scan[16 + u];
+        if (u < wave) { p += vc; gq += vg; }
         total += vc;
-        total_w += vw;
+        total_g += vg;
     }
-    first_pos[t] = p;                                              // a list item is (word << 10 | offset from its owner's first column)
-    for (int tile0 = 0; tile0 < total_w; tile0 += kBigStage) {
-        const int tile1 = tile0 + kBigStage;
-        if (wq < tile1 && wq + nw > tile0) {
-            int q = 0, j = wq;
-            if (KEEP_WORDS && dense) {                              // 32 predicated steps out of registers …
+    first_pos[t] = p;                                              // a list item is (group << 10 | offset from its owner's first column)
+    for (int tile0 = 0; tile0 < total_g; tile0 += S) {              // uniform; one tile unless more than S groups hold columns
+        const int tile1 = tile0 + S;
+        if (gq < tile1 && gq + ng > tile0) {
+            int q = 0, j = gq;
 #pragma unroll
-                for (int i = 0; i < 32; ++i) {
-                    if (words[i]) {
-                        if (j >= tile0 && j < tile1) stage[j - tile0] = ((t * 32 + i) << 10) | q;
-                        q += __popc(words[i]);                     // < 1024 before the thread's last word
-                        ++j;
-                    }
-                }
-            } else {                                                // … or one step per non-empty word (re-read from LDS)
-                unsigned m = nonempty;
-                while (m) {
-                    const int i = __ffs(m) - 1;
-                    m &= m - 1;
-                    if (j >= tile0 && j < tile1) stage[j - tile0] = ((t * 32 + i) << 10) | q;
-                    q += __popc(bm[bm_slot(t * 32 + i)]);
+            for (int i = 0; i < 8; ++i) {
+                const int c = (int)(((i < 4 ? gc_lo : gc_hi) >> (8 * (i & 3))) & 0xffu);
+                if (c) {
+                    if (j >= tile0 && j < tile1) stage[j - tile0] = ((t * 8 + i) << 10) | q;
+                    q += c;                                        // < 1024 before the thread's last group
                     ++j;
                 }
             }
         }
         __syncthreads();
-        if (KEEP_WORDS) BIG_PROF(10);
-        const int n = min(kBigStage, total_w - tile0);
-        for (int e = t; e < n; e += kBigThreads) {
+        BIG_PROF(10);
+        const int n = min(S, total_g - tile0);
+        for (int e = t; e < n; e += T) {
             const unsigned item = (unsigned)stage[e];
-            const int w = (int)(item >> 10);
-            unsigned bits = bm[bm_slot(w)];
-            int pos = first_pos[w >> 5] + (int)(item & 0x3ffu);
-            const int col0 = w0 + (w << 5);
-            while (bits) {
-                const int bit = __ffs(bits) - 1;
-                bits &= bits - 1;
+            const int gid = (int)(item >> 10), tt = gid >> 3;       // owner thread and its group
+            const uint4 g = reinterpret_cast<const uint4 *>(bm + tt * 32)[(gid & 7) ^ ((tt >> 1) & 7)];
+            int pos = first_pos[tt] + (int)(item & 0x3ffu);
+            const int col0 = w0 + (gid << 7);
+            unsigned long long b = ((unsigned long long)g.y << 32) | g.x;
+            while (b) {
+                const int bit = __ffsll((long long)b) - 1;
+                b &= b - 1;
                 out[pos++] = col0 + bit;
+            }
+            b = ((unsigned long long)g.w << 32) | g.z;
+            while (b) {
+                const int bit = __ffsll((long long)b) - 1;
+                b &= b - 1;
+                out[pos++] = col0 + 64 + bit;
             }
         }
         __syncthreads();
-        if (KEEP_WORDS) BIG_PROF(11);
+        BIG_PROF(11);
     }
-    __syncthreads();
-    if (KEEP_WORDS) { BIG_PROF(12); BIG_PROF_FLUSH; }
+    __syncthreads();                                               // (first_pos of a window without groups: nobody may still be reading it when the next call writes it)
+    BIG_PROF(12);
+    BIG_PROF_FLUSH;
     return total;
 }
 
@@ -828,12 +830,14 @@ __device__ __forceinline__ int emit_window_columns(const unsigned *bm, int w0, i
 // same LDS bitmap windows (no hash table that can overflow, no HBM bitmap, no global atomics). One workgroup per row.
 // pre_off / pre_cols (one-shot call only): rows with pre_off[row] >= 0 also write their sorted distinct columns to
 // pre_cols[pre_off[row] …], so that the numeric phase does not have to mark and emit them a second time.
+// out_rpt (the numeric phase's emit pass, round 4): the rows that carry NO columns (pre_off NULL or pre_off[row] < 0) write theirs to
+// pre_cols[out_rpt[row] …] — i.e. into ccol at the row's own offset — and the rows that do carry them are skipped; row_nz may be NULL.
 template <int T>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void spgemm_symbolic_window_kernel(
     const int *__restrict__ rows, int nrows, int *__restrict__ next_row /* not NULL: rows handed out one at a time (list sorted longest first) */,
     int N, int K, const int *__restrict__ wsplit, const int *__restrict__ arpt, const int *__restrict__ acol,
     const int *__restrict__ brpt, const int *__restrict__ bcol, const long long *__restrict__ row_flop, int *__restrict__ row_nz,
-    const long long *__restrict__ pre_off, int *__restrict__ pre_cols)
+    const long long *__restrict__ pre_off, int *__restrict__ pre_cols, const int *__restrict__ out_rpt, int nz_lo, int nz_hi)
 {
     constexpr int kBigThreads = T, kBigWindowBits = BigCfg<T>::kWindowBits, kBigWindowWords = BigCfg<T>::kWindowWords;
     extern __shared__ int lds_i[];                                 // dynamic only (Guideline 17): the layout of the numeric big-row kernel
@@ -853,7 +857,12 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     if (ridx >= nrows) break;
     const int row = rows[ridx];
     const int a0 = arpt[row], a1 = arpt[row + 1];
-    const long long po = pre_off ? pre_off[row] : -1;              // uniform
+    long long po = pre_off ? pre_off[row] : -1;                    // uniform
+    if (out_rpt) {                                                 // emit pass of the numeric phase: only the rows of this launch's size range without carried columns
+        const int onz = out_rpt[row + 1] - out_rpt[row];
+        if (po >= 0 || onz <= nz_lo || onz > nz_hi) continue;      // (nobody has touched LDS or a barrier for this row yet)
+        po = out_rpt[row];
+    }
     if (t == 0) s_total = 0;
     BIG_PROF_DECL_SYM;
     for (int w0 = 0; w0 < N; w0 += (1 << kBigWindowBits)) {
@@ -871,7 +880,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
             });
         BIG_PROF(1);
         if (po >= 0) {
-            const int total = emit_window_columns<T, true>(bm, w0, pre_cols + po + s_total, sd.scan, sd.stage, sd.base, t);
+            const int total = emit_window_columns<T>(bm, w0, pre_cols + po + s_total, sd.scan, sd.stage, t);
             if (t == 0) s_total += total;
             BIG_PROF(3);
         } else {
@@ -883,7 +892,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         }
         __syncthreads();
     }
-    if (t == 0) row_nz[row] = s_total;
+    if (t == 0 && row_nz) row_nz[row] = s_total;
     __syncthreads();
     BIG_PROF(6);
     BIG_PROF_FLUSH;
@@ -899,19 +908,19 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
 // the entry pass reads its bounds by entry index (no acol → wsplit dependence). need[i] = entries · (chunks − 1) of the i-th row of the launch's list (0 for
 // rows of one chunk); ct_off = its exclusive scan, indexed by list position like the kernel's own walk.
 __global__ void chunk_split_need_kernel(int n, const int *__restrict__ rows, const int *__restrict__ arpt, const int *__restrict__ crpt,
-                                        const long long *__restrict__ pre_off, int chunk, int nz_lo, int nz_hi, long long *__restrict__ need)
+                                        int chunk, int nz_lo, int nz_hi, long long *__restrict__ need)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int row = rows[i], nz = crpt[row + 1] - crpt[row];
-    need[i] = (nz > nz_lo && nz <= nz_hi && nz > chunk && pre_off[row] >= 0) ? (long long)(arpt[row + 1] - arpt[row]) * ((nz + chunk - 1) / chunk - 1) : 0;
+    need[i] = (nz > nz_lo && nz <= nz_hi && nz > chunk) ? (long long)(arpt[row + 1] - arpt[row]) * ((nz + chunk - 1) / chunk - 1) : 0;
 }
 // One thread per (row, entry, boundary) item, the items numbered through ct_off (a hub row alone holds millions of them: one workgroup per row took 2.6 ms
 // per launch for work of a few hundred µs).
 __global__ __launch_bounds__(256) void chunk_splits_kernel(long long total, int n, const int *__restrict__ rows, int K, int N, const int *__restrict__ wsplit,
                                                            const int *__restrict__ arpt, const int *__restrict__ acol, const int *__restrict__ brpt,
                                                            const int *__restrict__ bcol /* window ids */, const int *__restrict__ crpt,
-                                                           const long long *__restrict__ pre_off, const int *__restrict__ pre_cols, int chunk,
+                                                           const long long *__restrict__ pre_off, const int *__restrict__ pre_cols, const int *__restrict__ ccol /* window ids of the rows without carried columns */, int chunk,
                                                            const long long *__restrict__ ct_off /* n + 1 */, int *__restrict__ ct)
 {
     const long long i0 = (long long)blockIdx.x * blockDim.x, i = i0 + threadIdx.x;
@@ -925,10 +934,10 @@ __global__ __launch_bounds__(256) void chunk_splits_kernel(long long total, int 
     if (i >= total) return;
     while (ct_off[rl + 1] <= i) ++rl;
     const int row = rows[rl], nz = crpt[row + 1] - crpt[row];
-    const long long po = pre_off[row], idx = i - ct_off[rl];
+    const long long po = pre_off ? pre_off[row] : -1, idx = i - ct_off[rl];
     const int a0 = arpt[row], nb = (nz + chunk - 1) / chunk - 1;
     const int e = (int)(idx / nb), b = (int)(idx - (long long)e * nb) + 1;
-    const int c = acol[a0 + e], cb = pre_cols[po + (long long)chunk * b];
+    const int c = acol[a0 + e], cb = po >= 0 ? pre_cols[po + (long long)chunk * b] : ccol[crpt[row] + (long long)chunk * b];
     const int sb = split_bits(N), W = (N + (1 << sb) - 1) >> sb, wf = cb >> sb;
     int lo = (wsplit && wf > 0) ? wsplit[(size_t)(wf - 1) * K + c] : brpt[c];
     int hi = (wsplit && wf < W - 1) ? wsplit[(size_t)wf * K + c] : brpt[c + 1];
@@ -954,7 +963,6 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     constexpr int kBigThreads = T, kBigWindowBits = BigCfg<T>::kWindowBits, kBigWindowWords = BigCfg<T>::kWindowWords, kBigChunk = BigCfg<T>::kChunk;
     extern __shared__ int lds_i[];
     const BigSide<T> sd(lds_i + kBigWindowWords);
-    int &s_base = sd.ctrl[BigSide<T>::kTotalSlot];
     const int t = threadIdx.x;
     constexpr int kPerThread = kBigChunk / kBigThreads;             // 8 slots per thread
     int cc[kPerThread], nridx = 0;
@@ -980,47 +988,28 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         __syncthreads();
     }
     RowMeta cur = load_meta(ridx), nxt = cur;
+    bool have_first = false;                                       // this row's first chunk of columns was requested during the previous row's last chunk
     for (; ridx < nrows; ridx = nridx, cur = nxt) {                // persistent: see spgemm_symbolic_window_kernel
     if (next_row) { if (t == 0) sd.ctrl[29] = atomicAdd(next_row, 1); }   // read below, behind a barrier
     else { nridx = ridx + gridDim.x; nxt = load_meta(nridx); }
     const int row = cur.row, a0 = cur.a0, a1 = cur.a1, off = cur.off, nz = cur.nz;
     if (nz <= nz_lo || nz > nz_hi) {                               // uniform: the whole workgroup skips the row
         if (next_row) { __syncthreads(); nridx = __builtin_amdgcn_readfirstlane(sd.ctrl[29]); __syncthreads(); nxt = load_meta(nridx); }
+        have_first = false;
         continue;
     }
 
     BIG_PROF_DECL;
-    // ---- phase 1: sorted distinct columns — unless the symbolic phase of the one-shot call already left them in pre_cols
+    // The row's sorted distinct columns (window ids) are in place when this kernel starts: carried from the symbolic phase of the one-shot call in
+    // pre_cols[po …] (po >= 0), or written into ccol at the row's own offset by the emit pass in front of this launch (po < 0; round 4 — the mark-and-emit
+    // phase used to be part of this kernel and cost it registers on the path every product takes).
     const long long po = cur.po;                                   // uniform
-    unsigned *bm = reinterpret_cast<unsigned *>(lds_i);
-    if (t == 0) s_base = 0;
 #ifdef G4S_PROFILE_BIG
-    if (po + a0 + a1 + off + nz == -12345) s_base = 1;             // (forces the row's metadata to have arrived)
+    if (po + a0 + a1 + off + nz == -12345) sd.ctrl[30] = 1;        // (forces the row's metadata to have arrived)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     BIG_PROF(3);
 #endif
-    for (int w0 = 0; w0 < N && po < 0; w0 += (1 << kBigWindowBits)) {
-        for (int i = t; i < kBigWindowWords / 4; i += kBigThreads) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
-        __syncthreads();
-        BIG_PROF(0);
-        const int w1 = min(N, w0 + (1 << kBigWindowBits));
-        const int *wlo, *whi;
-        window_bounds(brpt, wsplit, K, N, w0, w1 - 1, wlo, whi);
-        flat_products<T, false, kFlatUnitsPerRound>(a0, a1, acol, nullptr, wlo, whi, bcol, nullptr, sd, t,
-            [&](const int (&col)[kFlatUnitsPerRound], const double (&)[kFlatUnitsPerRound], const double (&)[kFlatUnitsPerRound], const bool (&ok)[kFlatUnitsPerRound]) {
-#pragma unroll
-                for (int q = 0; q < kFlatUnitsPerRound; ++q)
-                    if (ok[q] && col[q] >= w0 && col[q] < w1) atomicOr(&bm[bm_slot((col[q] - w0) >> 5)], 1u << ((col[q] - w0) & 31));
-            });
-        BIG_PROF(1);
-        const int total = emit_window_columns<T, false>(bm, w0, ccol + off + s_base, sd.scan, sd.stage, sd.base, t);
-        BIG_PROF(3);
-        __syncthreads();
-        if (t == 0) s_base += total;
-        __syncthreads();
-    }
-    __threadfence_block();
-    __syncthreads();
+    __syncthreads();                                               // the next-row ticket (ctrl[29]) is visible; the previous row's last chunk is out of LDS
     BIG_PROF(0);
     if (next_row) { nridx = __builtin_amdgcn_readfirstlane(sd.ctrl[29]); nxt = load_meta(nridx); }   // (nobody writes the slot again before this row's last barrier)
 
@@ -1034,7 +1023,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     static_assert(4 * kBigChunk <= kBigWindowWords && kBigChunk <= 65536, "phase 2 reuses the bitmap region; slots are packed in 16 bits");
     constexpr int kU = kFlatUnitsPerRound;
     int kfirst = 0, klast = 0, shift = 0;
-    const bool exact = ct && po >= 0 && nz > kBigChunk;            // uniform: this row's chunks have exact splits — every product visited lies in the chunk
+    const bool exact = ct && nz > kBigChunk;                       // uniform: this row's chunks have exact splits — every product visited lies in the chunk
     const int nbnd = exact ? (nz + kBigChunk - 1) / kBigChunk - 1 : 0;
     const int *ctr = exact ? ct + ct_off[ridx] : nullptr;         // (by position in this launch's row list)
     // One round of a lane's products: their slots are found in lock-step (the dependent LDS reads of the kU searches interleave) for as many
@@ -1048,6 +1037,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
             in[q] = ok[q] && (exact || (col[q] >= kfirst && col[q] <= klast));
             any_in |= in[q];
         }
+        if (G4S_KO & 16) {
+#pragma unroll
+            for (int q = 0; q < kU; ++q) { asm volatile("" :: "v"(col[q])); asm volatile("" :: "v"(bv[q])); }
+            return;
+        }
         if (!__any(any_in)) return;
 #pragma unroll
         for (int q = 0; q < kU; ++q) {
@@ -1055,17 +1049,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
             const unsigned w = IDX[(key[q] - kfirst) >> shift];    // the column is present, so its bucket is not empty
             lo[q] = (int)(w >> 16); hi[q] = (int)(w & 0xffffu);
         }
-#ifdef G4S_PROFILE_BIG
-        prof_acc[9] += 1;                                          // rounds that search
-#endif
-        for (;;) {
+        for (; !(G4S_KO & 1);) {
             bool more = false;
 #pragma unroll
             for (int q = 0; q < kU; ++q) more |= lo[q] < hi[q];
             if (!__any(more)) break;
-#ifdef G4S_PROFILE_BIG
-            prof_acc[15] += 1;                                     // halvings
-#endif
             int mid[kU], km[kU];
 #pragma unroll
             for (int q = 0; q < kU; ++q) { mid[q] = (lo[q] + hi[q]) >> 1; km[q] = KC[mid[q]]; }   // the kU reads in flight together
@@ -1078,7 +1066,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         }
 #pragma unroll
         for (int q = 0; q < kU; ++q)
-            if (in[q]) atomicAdd(&V[lo[q]], av[q] * bv[q]);
+            if (in[q] && !(G4S_KO & 2)) atomicAdd(&V[lo[q]], av[q] * bv[q]);
     };
     // The chunk's sorted columns are issued a chunk ahead (they are consumed at the top of the next chunk, a whole accumulation pass later).
     auto fetch_chunk = [&](int q0) { fetch_from(po >= 0 ? pre_cols + po + q0 : ccol + off + q0, min(kBigChunk, nz - q0)); };
@@ -1113,18 +1101,30 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
             }
         }
     };
-    fetch_chunk(0);
+    if (!have_first) {                                             // uniform: the first row of this workgroup, or a skipped row in between
+        fetch_chunk(0);
 #pragma unroll
-    for (int u = 0; u < kPerThread; ++u) asm volatile("" :: "v"(cc[u]));   // settled on the loop's entry path too (see the store step): the first open needs them at once anyway
+        for (int u = 0; u < kPerThread; ++u) asm volatile("" :: "v"(cc[u]));   // settled on this path too (see the store step): the first open needs them at once anyway
+    }
+    have_first = true;
     for (int q0 = 0; q0 < nz; q0 += kBigChunk) {
         const int qn = min(kBigChunk, nz - q0);
         open_chunk(qn);
-        fetch_chunk(q0 + kBigChunk < nz ? q0 + kBigChunk : q0);    // unconditional (the last chunk re-reads itself): a load under a branch makes
-                                                                   // hipcc wait at the join for every load that might be in flight
+#ifdef G4S_PROFILE_BIG
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (q0 == 0) BIG_PROF(9); else BIG_PROF(1);               // the chunk's columns have arrived and are in LDS: first chunk of a row / later chunks
+#endif
+        {   // the next chunk's columns — in the row's last chunk: the first chunk of the workgroup's NEXT row (its metadata arrived at this row's start). One
+            // unconditional fetch from a selected pointer: a load under a branch makes hipcc wait at the join for every load that might be in flight.
+            const bool last = q0 + kBigChunk >= nz;                 // uniform
+            const int *src = last ? (nxt.po >= 0 ? pre_cols + nxt.po : ccol + nxt.off)
+                                  : (po >= 0 ? pre_cols + po + q0 + kBigChunk : ccol + off + q0 + kBigChunk);
+            fetch_from(src, last ? max(1, min(kBigChunk, nxt.nz)) : min(kBigChunk, nz - q0 - kBigChunk));
+        }
         __syncthreads();
         chunk_span(qn);
         BIG_PROF(6);
-        build_index(qn);
+        if (!(G4S_KO & 4)) build_index(qn);
         __syncthreads();
         BIG_PROF(7);
         const int *clo, *chi;
@@ -1156,13 +1156,13 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
 #pragma unroll
             for (int u = 0; u < kPerThread; ++u) {
                 const int i = t + u * kBigThreads;
-                if (i < qn) cval[off + q0 + i] = val[u];
+                if (i < qn && !(G4S_KO & 8)) cval[off + q0 + i] = val[u];
             }
             if (col_of || po >= 0) {                               // (a numeric-only call without a column map has them in place already)
 #pragma unroll
                 for (int u = 0; u < kPerThread; ++u) {
                     const int i = t + u * kBigThreads;
-                    if (i < qn) ccol[off + q0 + i] = orig[u];
+                    if (i < qn && !(G4S_KO & 8)) ccol[off + q0 + i] = orig[u];
                 }
             }
         }
@@ -1585,6 +1585,7 @@ struct PreSorted {
     const long long *d_off = nullptr;
     int *d_cols = nullptr;       // int cols[total], borrowed from the cache below
     bool holds_cache = false;
+    bool complete = false;       // every row the numeric window kernels will take carries its columns (no hub rows, no overflowed optimistic tables)
     ~PreSorted();
 };
 
@@ -1772,7 +1773,7 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
         auto k = spgemm_symbolic_window_kernel<T>;
         const size_t lds = big_lds_bytes<T>();
         G4S_TRY(allow_lds(k, lds));
-        if (n) hipLaunchKernelGGL(k, dim3(big_grid(n, BigCfg<T>::kPerCu)), dim3(T), lds, s, rows, n, next_row, N2, K, wsplit, arpt, acol, brpt, wcol, row_flop.as<long long>(), nz, poff, pcols);
+        if (n) hipLaunchKernelGGL(k, dim3(big_grid(n, BigCfg<T>::kPerCu)), dim3(T), lds, s, rows, n, next_row, N2, K, wsplit, arpt, acol, brpt, wcol, row_flop.as<long long>(), nz, poff, pcols, (const int *)nullptr, 0, 0);
         return G4S_OK;
     };
     SortedRows sorted[3];                                          // live until the stream is synchronised below
@@ -1811,6 +1812,7 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     G4S_HIP_TRY(hipStreamSynchronize(s));
     if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s symbolic: %d optimistic tables overflowed, %d window-class rows\n", n_ovf, rc.count[CLS_M2]);
     G4S_TRY(window(1024, ovf_rows.as<int>(), n_ovf, nullptr, nullptr));   // rows of the optimistic table class are not in the scratch
+    if (pre) pre->complete = pre_off != nullptr && n_ovf == 0 && rc.count[CLS_HUB] == 0 && x_med && x_large;
     G4S_TRY(window(t_win, rc.list(CLS_M2), rc.count[CLS_M2], pre_off, pre_cols, true));
     G4S_HIP_TRY(hipGetLastError());
     // hub rows (flop > 2 M): many workgroups per row on a bitmap in HBM
@@ -1902,14 +1904,14 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
     std::vector<std::unique_ptr<DevBuf>> ct_keep;
     auto chunk_splits = [&](int threads, const int *rows, int n, int nz_lo, int nz_hi, const long long **ct_off, const int **ct) -> int {
         *ct_off = nullptr; *ct = nullptr;
-        if (!pre || !pre_off || !wsplit || n == 0 || getenv("G4S_SPGEMM_NO_EXACT_SPLITS")) return G4S_OK;
+        if (!wsplit || n == 0 || getenv("G4S_SPGEMM_NO_EXACT_SPLITS")) return G4S_OK;
         if (threads != 1024 && !getenv("G4S_SPGEMM_EXACT_SPLITS_ALL")) return G4S_OK;   // the 256-thread launches hold rows of at most two 2 048-entry chunks: measured no gain (1.22 ms either way), 0.45 ms of splits
         const int chunk = 8 * threads;                             // BigCfg<T>::kChunk
         auto need = std::make_unique<DevBuf>(), off = std::make_unique<DevBuf>(), tab = std::make_unique<DevBuf>();
         G4S_TRY(need->alloc(sizeof(long long) * ((size_t)n + 1)));
         G4S_TRY(off->alloc(sizeof(long long) * ((size_t)n + 1)));
         G4S_HIP_TRY(hipMemsetAsync(need->as<long long>() + n, 0, sizeof(long long), s));
-        hipLaunchKernelGGL(chunk_split_need_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, rows, arpt, crpt, pre_off, chunk, nz_lo, nz_hi, need->as<long long>());
+        hipLaunchKernelGGL(chunk_split_need_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, rows, arpt, crpt, chunk, nz_lo, nz_hi, need->as<long long>());
         G4S_TRY(g4s::prims::exclusive_scan(need->as<long long>(), off->as<long long>(), (long long)n + 1, s));
         long long total = 0;
         G4S_HIP_TRY(hipMemcpyAsync(&total, off->as<long long>() + n, sizeof(long long), hipMemcpyDeviceToHost, s));
@@ -1918,20 +1920,35 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         // a table that cannot be allocated, run with the window pieces as before
         if (total <= 0 || total > (1ll << 28)) return G4S_OK;
         if (tab->alloc(sizeof(int) * (size_t)total) != G4S_OK) { (void)hipGetLastError(); return G4S_OK; }
-        hipLaunchKernelGGL(chunk_splits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, n, rows, K, N2, wsplit, arpt, acol, brpt, wcol, crpt, pre_off, pre_cols, chunk,
+        hipLaunchKernelGGL(chunk_splits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, n, rows, K, N2, wsplit, arpt, acol, brpt, wcol, crpt, pre_off, pre_cols, ccol, chunk,
                            off->as<long long>(), tab->as<int>());
         G4S_HIP_TRY(hipGetLastError());
         *ct_off = off->as<long long>(); *ct = tab->as<int>();
         ct_keep.push_back(std::move(need)); ct_keep.push_back(std::move(off)); ct_keep.push_back(std::move(tab));
         return G4S_OK;
     };
+    // The window kernels need every row's sorted distinct columns (window ids) before they start. The one-shot call carries them over from its symbolic
+    // phase; whatever is missing — every row in the two-call form, hub rows and overflowed optimistic tables in the one-shot form — is marked and emitted
+    // into ccol at the row's own offset by the symbolic window kernel in its emit-only mode, in front of the launch that needs it (round 4: this used to be
+    // phase 1 inside the numeric kernel itself).
+    const bool carried_complete = pre && pre->complete;
+    auto emit_pass = [&](auto shape, const int *rows, int n, int nz_lo, int nz_hi) -> int {
+        constexpr int T = decltype(shape)::value;
+        auto k = spgemm_symbolic_window_kernel<T>;
+        const size_t lds = big_lds_bytes<T>();
+        G4S_TRY(allow_lds(k, lds));
+        hipLaunchKernelGGL(k, dim3(big_grid(n, BigCfg<T>::kPerCu)), dim3(T), lds, s, rows, n, (int *)nullptr, N2, K, wsplit, arpt, acol, brpt, wcol, (const long long *)nullptr, (int *)nullptr,
+                           pre_off, ccol, crpt, nz_lo, nz_hi);
+        return G4S_OK;
+    };
     auto big_t = [&](auto shape, const int *rows, int n, int nz_lo, int nz_hi, int *next_row) -> int {
         constexpr int T = decltype(shape)::value;
         auto k = spgemm_numeric_big_kernel<T>;
-        const size_t lds = big_lds_bytes<T>();   // the bitmap (phase 2 reuses it) + scan scratch + long-B list + store staging
+        const size_t lds = big_lds_bytes<T>();   // value chunk (fp64 sums, columns, bucket index) + scan scratch + the flat lists
         G4S_TRY(allow_lds(k, lds));
         const long long *ct_off = nullptr;
         const int *ct = nullptr;
+        if (n && !carried_complete) G4S_TRY(emit_pass(shape, rows, n, nz_lo, nz_hi));
         if (n) G4S_TRY(chunk_splits(T, rows, n, nz_lo, nz_hi, &ct_off, &ct));
         if (n) hipLaunchKernelGGL(k, dim3(big_grid(n, BigCfg<T>::kPerCu)), dim3(T), lds, s, rows, n, nz_lo, nz_hi, next_row, N2, K, wsplit, arpt, acol, aval, brpt, wcol, winv, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols, ct_off, ct);
         return G4S_OK;

@@ -17,9 +17,10 @@ lib.g4s_debug_big_prof.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 lib.g4s_debug_big_prof(buf, 1)
 host.HashSpGEMM(A, A)
 lib.g4s_debug_big_prof(buf, 0)
-names = ["row start: barrier", "p1 walk", "round: lookup + issue", "row start: metadata loads", "round: load wait", "round: accumulate", "p2 load K/zero", "p2 bucket index", "p2 walk", "p2 long list", "p2 store", "flat entry pass", "flat scan", "flat map", "flat rounds"]
+names = ["row start: barrier", "p2 open: columns arrive + LDS writes (later chunks)", "round: lookup + issue", "row start: metadata loads", "round: load wait", "round: accumulate", "p2 load K/zero", "p2 bucket index", "p2 walk", "p2 long list", "p2 store", "flat entry pass", "flat scan", "flat map", "flat rounds"]
 tot = sum(buf[:11])
-names = names[:15] + ["search steps (count, not ticks)"]
-names[9] = "rounds that search (count)"
+names = names[:15] + ["-"]
+names[9] = "p2 open: columns arrive + LDS writes (first chunk of a row)"
+names[6] = "p2 open: prefetch issue + barrier + span"
 for n, v in zip(names, buf):
-    print(f"{n:18s} {v:16d} ticks {100.0 * v / max(tot, 1):6.2f} %")
+    print(f"{n:60s} {v:16d} ticks {100.0 * v / max(tot, 1):6.2f} %")
