@@ -22,10 +22,14 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 int scratch_alloc(void **p, size_t bytes, hipStream_t s);
 void scratch_free(void *p, hipStream_t s);
 int scratch_shutdown();
+// per-call arena over the big-block cache (runtime.cpp): between arena_enter and the matching arena_leave of a thread, scratch_alloc carves from cached chunks
+// and scratch_free does nothing; the outermost leave returns the chunks (idle: the call's stream has been synchronised)
+void arena_enter();
+void arena_leave(hipStream_t s, bool idle);
 void spgemm_release_cache();   // spgemm.hip
 // caching allocator for large device blocks (runtime.cpp); big_free returns false for a pointer it does not own
 int big_alloc(void **p, size_t bytes);
-bool big_free(void *p);
+bool big_free(void *p, bool idle = false);   // idle: every stream that used the block has been synchronised by the caller
 void big_release_all();
 void release_cached_device_memory();   // big_release_all + the SpGEMM column scratch (what g4s_trim does)
 hipError_t device_malloc(void **p, size_t bytes);   // hipMalloc that drops the library's caches and retries once on out-of-memory

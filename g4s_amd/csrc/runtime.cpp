@@ -30,8 +30,50 @@ hipMemPool_t g_pools[kMaxDevices] = {};
 std::mutex g_pool_mutex;
 } // namespace
 
+// Per-call arena (round 4). One SpGEMM call makes ≈ 150 small transient allocations (scan tile sums, sort counters, row lists, per-row tables); through the
+// stream-ordered pool their hipFreeAsync calls alone cost 3–4.5 ms per call on this stack (one 16 MB free: 3.2 ms — profiles/r04_spgemm_host_phases.txt).
+// Inside an ArenaScope, scratch_alloc hands out consecutive pieces of a few large chunks taken from the big-block cache and scratch_free is a no-op; when the
+// outermost scope of the thread ends (the call's stream synchronised by then) the chunks go back to the cache, so from the second call on no driver
+// allocation or free happens at all. Nothing is reused inside a call: the transients of the largest product add up to a few hundred MB.
+namespace {
+struct ArenaChunk { char *p; size_t bytes, used; };
+struct Arena { std::vector<ArenaChunk> chunks; int depth = 0; };
+thread_local Arena t_arena;
+constexpr size_t kArenaChunk = (size_t)256 << 20, kArenaAlign = 256;
+} // namespace
+
+void arena_enter() { ++t_arena.depth; }
+void arena_leave(hipStream_t s, bool idle)
+{
+    if (--t_arena.depth > 0) return;
+    if (t_arena.chunks.empty()) return;
+    if (!idle) (void)hipStreamSynchronize(s);                      // an error path left early: nothing may still read the chunks when they are handed out again
+    for (auto &c : t_arena.chunks) (void)big_free(c.p, true);
+    t_arena.chunks.clear();
+}
+static int arena_alloc(void **p, size_t bytes)
+{
+    bytes = (bytes + kArenaAlign - 1) / kArenaAlign * kArenaAlign;
+    if (bytes == 0) bytes = kArenaAlign;
+    for (auto &c : t_arena.chunks)
+        if (c.bytes - c.used >= bytes) { *p = c.p + c.used; c.used += bytes; return G4S_OK; }
+    void *q = nullptr;
+    const size_t want = bytes > kArenaChunk ? bytes : kArenaChunk;
+    G4S_TRY(big_alloc(&q, want));
+    t_arena.chunks.push_back(ArenaChunk{static_cast<char *>(q), want, bytes});
+    *p = q;
+    return G4S_OK;
+}
+static bool arena_owns(const void *p)
+{
+    for (const auto &c : t_arena.chunks)
+        if (p >= c.p && p < c.p + c.bytes) return true;
+    return false;
+}
+
 int scratch_alloc(void **p, size_t bytes, hipStream_t s)
 {
+    if (t_arena.depth > 0) return arena_alloc(p, bytes);
     int dev = 0;
     G4S_HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= kMaxDevices) return set_error(G4S_ERR_INVALID, "device %d outside the scratch pool table", dev);
@@ -56,7 +98,8 @@ int scratch_alloc(void **p, size_t bytes, hipStream_t s)
 
 void scratch_free(void *p, hipStream_t s)
 {
-    if (p) (void)hipFreeAsync(p, s);
+    if (!p || arena_owns(p)) return;
+    (void)hipFreeAsync(p, s);
 }
 
 // Large device blocks (product outputs, per-row bitmaps: tens of MB to tens of GB). On this stack a fresh allocation of that size —
@@ -124,7 +167,7 @@ int big_alloc(void **p, size_t bytes)
     return G4S_OK;
 }
 
-bool big_free(void *p)
+bool big_free(void *p, bool idle)
 {
     if (!p) return true;
     BigBlock blk{};
@@ -136,12 +179,16 @@ bool big_free(void *p)
         g_big_live.erase(it);
     }
     // nothing in flight may still touch the block when it is handed out again: synchronise the device that OWNS it
-    const int cur = current_device();
-    if (cur != blk.device) (void)hipSetDevice(blk.device);
-    (void)hipDeviceSynchronize();
-    if (cur != blk.device) (void)hipSetDevice(cur);
+    // (idle: the caller has already synchronised the one stream the block was used on — a device-wide synchronisation costs ≈ 0.2 ms per block on
+    // this stack even when nothing runs, and a SpGEMM call releases a dozen blocks)
+    if (!idle) {
+        const int cur = current_device();
+        if (cur != blk.device) (void)hipSetDevice(blk.device);
+        (void)hipDeviceSynchronize();
+        if (cur != blk.device) (void)hipSetDevice(cur);
+    }
     std::lock_guard<std::mutex> lock(g_big_mutex);
-    if (g_big_cache.size() >= 8 || g_big_cached_bytes + blk.bytes > big_cache_limit()) { (void)hipFree(p); return true; }
+    if (g_big_cache.size() >= 32 || g_big_cached_bytes + blk.bytes > big_cache_limit()) { (void)hipFree(p); return true; }
     g_big_cache.push_back(blk);
     g_big_cached_bytes += blk.bytes;
     return true;

@@ -37,6 +37,7 @@
 #include <chrono>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <vector>
 
 namespace {
@@ -49,14 +50,17 @@ constexpr int kEmpty = -1;
 // scratch, hub bitmaps) from its caching allocator (runtime.cpp) — plain hipMalloc of gigabytes took anything between 1 ms and 4 s
 // from one call to the next (measured on the one-call form: 95 ms to 2300 ms for the same product).
 thread_local hipStream_t t_stream = nullptr;   // the stream of the API call in progress on this thread: pool allocations and frees are ordered on it
+thread_local bool t_idle = false;              // the call's stream has been synchronised and nothing was launched since: its big blocks go back to the cache without a device-wide wait
 struct DevBuf {
     void *p = nullptr;
     hipStream_t s = nullptr;
     bool big = false;
+    size_t n = 0;
     ~DevBuf() { release(); }
     int alloc(size_t bytes, bool for_caller = false)              // for_caller: the pointer is handed out and comes back through g4s_dev_free
     {
         release();
+        n = bytes;
         big = for_caller || bytes >= ((size_t)64 << 20);
         if (big) return g4s::big_alloc(&p, bytes);
         s = t_stream;
@@ -65,10 +69,44 @@ struct DevBuf {
     void release()
     {
         if (!p) return;
-        if (big) (void)g4s::big_free(p); else g4s::scratch_free(p, s);
+        static const bool dbg = getenv("G4S_DEBUG_FREE") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (big) (void)g4s::big_free(p, t_idle); else g4s::scratch_free(p, s);
+        if (dbg) fprintf(stderr, "g4s free %s %zu bytes: %.3f ms\n", big ? "big" : "pool", n, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         p = nullptr;
     }
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// Transients of one API call come from the per-call arena (runtime.cpp). Declared before every DevBuf of the call, so it ends after them.
+struct ArenaScope {
+    ArenaScope() { g4s::arena_enter(); }
+    ~ArenaScope() { g4s::arena_leave(t_stream, t_idle); }
+};
+
+// Host-side phase times of one call under G4S_DEBUG (declared first in a function: its destructor runs after every buffer of the call has been released).
+struct DbgPhases {
+    using clk = std::chrono::steady_clock;
+    const char *what;
+    bool on;
+    clk::time_point t0, last;
+    std::string line;
+    explicit DbgPhases(const char *w) : what(w), on(getenv("G4S_DEBUG") != nullptr), t0(clk::now()), last(t0) {}
+    void mark(const char *name)
+    {
+        if (!on) return;
+        const auto now = clk::now();
+        char buf[96];
+        snprintf(buf, sizeof buf, " %s %.2f", name, std::chrono::duration<double, std::milli>(now - last).count());
+        line += buf;
+        last = now;
+    }
+    ~DbgPhases()
+    {
+        if (!on) return;
+        mark("release");
+        fprintf(stderr, "g4s %s host phases (ms):%s | total %.2f\n", what, line.c_str(), std::chrono::duration<double, std::milli>(clk::now() - t0).count());
+    }
 };
 
 __device__ __forceinline__ int lds_peek(const int *p) { return *reinterpret_cast<const volatile int *>(p); }
@@ -948,7 +986,54 @@ __global__ __launch_bounds__(256) void chunk_splits_kernel(long long total, int 
     ct[i] = lo;
 }
 
-template <int T>
+// Unit lists (round 4). The walk of a value chunk used to start with an entry pass (every A-entry's bounds from HBM into LDS), a block scan of the
+// entries' unit counts and a binary search per unit, three barriers and a dependent load chain per chunk, before the first product could be requested —
+// with nothing to overlap it: the kernel's LDS allows one workgroup per CU. All of that depends only on the row structure and the chunk splits, both known
+// before the kernel starts. So a pre-pass writes, per (row, chunk), the list of its UNITS — up to 64 consecutive entries of one B row that fall into the
+// chunk, with the A-value they are multiplied by — and the kernel reads its units with scalar loads, a round ahead of everything else:
+//   item (list position i, chunk q, A-entry e), ordered by (i, q, e): piece [split(e, q), split(e, q + 1)) of B row acol[e]  (split(e, 0) = row start,
+//   split(e, chunks) = row end: every entry of a B row used by row i lands in exactly one of the row's chunks);
+//   unit_count_kernel: units of the item = ceil(piece / 64); an exclusive scan gives the item's first unit; unit_expand_kernel writes the descriptors.
+struct __attribute__((aligned(16))) UnitDesc { int bpos, len, av_lo, av_hi; };   // 16 bytes: one s_load_dwordx4
+__global__ void unit_items_kernel(int n, const int *__restrict__ rows, const int *__restrict__ arpt, const int *__restrict__ crpt, int chunk, int nz_lo, int nz_hi,
+                                  long long *__restrict__ items)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int row = rows[i], nz = crpt[row + 1] - crpt[row];
+    items[i] = (nz > nz_lo && nz <= nz_hi) ? (long long)(arpt[row + 1] - arpt[row]) * ((nz + chunk - 1) / chunk) : 0;
+}
+template <bool EXPAND>
+__global__ __launch_bounds__(256) void unit_kernel(long long total, int n, const int *__restrict__ rows, const long long *__restrict__ item_off /* n + 1 */,
+                                                   const int *__restrict__ arpt, const int *__restrict__ acol, const double *__restrict__ aval,
+                                                   const int *__restrict__ brpt, const int *__restrict__ crpt, int chunk,
+                                                   const long long *__restrict__ ct_off, const int *__restrict__ ct,
+                                                   int *__restrict__ ucount /* !EXPAND: out */, const int *__restrict__ uoff /* EXPAND: in */, UnitDesc *__restrict__ U)
+{
+    const long long i0 = (long long)blockIdx.x * blockDim.x, i = i0 + threadIdx.x;
+    int rl = 0, rh = n;                                             // the list position that holds the workgroup's first item (uniform), then a short walk forward
+    while (rl < rh) {
+        const int mid = (rl + rh) >> 1;
+        if (item_off[mid + 1] > i0) rh = mid; else rl = mid + 1;
+    }
+    if (i >= total) return;
+    while (item_off[rl + 1] <= i) ++rl;
+    const int row = rows[rl], nz = crpt[row + 1] - crpt[row];
+    const int a0 = arpt[row], na = arpt[row + 1] - a0, nb = (nz + chunk - 1) / chunk - 1;
+    const long long idx = i - item_off[rl];
+    const int q = (int)(idx / na), e = (int)(idx - (long long)q * na);
+    const int c = acol[a0 + e];
+    const int *ctr = nb > 0 ? ct + ct_off[rl] + (long long)e * nb : nullptr;
+    const int lo = q == 0 ? brpt[c] : ctr[q - 1], hi = q == nb ? brpt[c + 1] : ctr[q];
+    if constexpr (!EXPAND) ucount[i] = hi > lo ? (hi - lo + 63) >> 6 : 0;
+    else {
+        const long long bits = __double_as_longlong(aval[a0 + e]);
+        UnitDesc *dst = U + uoff[i];
+        for (int k = lo; k < hi; k += 64) *dst++ = UnitDesc{k, min(64, hi - k), (int)(bits & 0xFFFFFFFFll), (int)(bits >> 32)};
+    }
+}
+
+template <int T, bool UNITS>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void spgemm_numeric_big_kernel(
     const int *__restrict__ rows, int nrows, int nz_lo, int nz_hi /* rows with nz outside (nz_lo, nz_hi] are left to the other shape */,
     int *__restrict__ next_row /* not NULL: rows are handed out one at a time through this counter (a list sorted longest first) */, int N, int K, const int *__restrict__ wsplit, const int *__restrict__ arpt, const int *__restrict__ acol, const double *__restrict__ aval,
@@ -956,7 +1041,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     const double *__restrict__ bval, const long long *__restrict__ row_flop,
     const int *__restrict__ crpt, int *__restrict__ ccol, double *__restrict__ cval,
     const long long *__restrict__ pre_off, const int *__restrict__ pre_cols,
-    const long long *__restrict__ ct_off /* exact chunk splits (chunk_splits_kernel), or NULL */, const int *__restrict__ ct)
+    const long long *__restrict__ ct_off /* exact chunk splits (chunk_splits_kernel), or NULL */, const int *__restrict__ ct,
+    const long long *__restrict__ item_off /* UNITS: first item of the list's i-th row (unit_kernel) */, const int *__restrict__ uoff /* first unit of an item */,
+    const UnitDesc *__restrict__ U)
 {
     // No static __shared__ in this kernel: it would sit in front of the dynamic region and push the fp64 table of phase 2 off its
     // 8-byte alignment (cdna_hip_programming.md Guideline 17). Everything is carved from the dynamic region instead.
@@ -973,11 +1060,14 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     // A row's metadata (its id, its ranges in A and C, where its carried columns start) sit behind two dependent loads: ticket → rows[] → arpt / crpt / pre_off.
     // They are uniform, so they are read with scalar loads (readfirstlane makes the ticket an SGPR), and the NEXT row's are requested as soon as its ticket is
     // known — before the value chunks of the current row — instead of at the top of its turn (110 K rows × two round trips were ≈ 10 % of the kernel).
-    struct RowMeta { int row, a0, a1, off, nz; long long po; };
+    struct RowMeta { int row, a0, a1, off, nz; long long po, ioff; int u0, u1; };
     auto load_meta = [&](int idx) {
-        const int r = rows[min(idx, nrows - 1)];                   // (a ticket past the end reads the last row: never used)
+        const int ci = min(idx, nrows - 1);                        // (a ticket past the end reads the last row: never used)
+        const int r = rows[ci];
         RowMeta m;
         m.row = r; m.a0 = arpt[r]; m.a1 = arpt[r + 1]; m.off = crpt[r]; m.nz = crpt[r + 1] - m.off; m.po = pre_off ? pre_off[r] : -1;
+        m.ioff = 0; m.u0 = 0; m.u1 = 0;
+        if constexpr (UNITS) { m.ioff = item_off[ci]; m.u0 = uoff[m.ioff]; m.u1 = uoff[m.ioff + (m.a1 - m.a0)]; }   // the units of the row's first chunk
         return m;
     };
     int ridx = blockIdx.x;
@@ -1023,9 +1113,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     static_assert(4 * kBigChunk <= kBigWindowWords && kBigChunk <= 65536, "phase 2 reuses the bitmap region; slots are packed in 16 bits");
     constexpr int kU = kFlatUnitsPerRound;
     int kfirst = 0, klast = 0, shift = 0;
-    const bool exact = ct && nz > kBigChunk;                       // uniform: this row's chunks have exact splits — every product visited lies in the chunk
+    const bool exact = UNITS || (ct && nz > kBigChunk);            // uniform: this row's chunks have exact splits — every product visited lies in the chunk
     const int nbnd = exact ? (nz + kBigChunk - 1) / kBigChunk - 1 : 0;
-    const int *ctr = exact ? ct + ct_off[ridx] : nullptr;         // (by position in this launch's row list)
+    const int *ctr = (!UNITS && exact) ? ct + ct_off[ridx] : nullptr;   // (by position in this launch's row list)
     // One round of a lane's products: their slots are found in lock-step (the dependent LDS reads of the kU searches interleave) for as many
     // halvings as the wave's deepest bucket needs — a unit is 64 consecutive entries of a sorted B row, so a wave's lanes sit in neighbouring
     // buckets — and the atomics come last. A round whose units all lie outside the chunk's column range is skipped by the whole wave.
@@ -1107,8 +1197,34 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         for (int u = 0; u < kPerThread; ++u) asm volatile("" :: "v"(cc[u]));   // settled on this path too (see the store step): the first open needs them at once anyway
     }
     have_first = true;
+    // UNITS: the chunk's products come from its unit list (unit_kernel): wave w takes units w·kU … w·kU + kU − 1 of every round, the descriptors read with scalar
+    // loads. Round 0 is requested before the chunk opens — its B-row loads fly under the LDS set-up, the two barriers and the bucket index.
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    int cu0 = cur.u0, cu1 = cur.u1, cu2 = 0, nu = 0;               // this chunk's units [cu0, cu1); cu2: end of the next chunk's
+    const int na = a1 - a0;
+    int rc[kU];
+    double rv[kU], rav[kU];
+    bool rok[kU];
+    auto request_round = [&](int g) {
+#pragma unroll
+        for (int q = 0; q < kU; ++q) {
+            const UnitDesc d = U[cu0 + min(g + q, nu - 1)];        // uniform: one s_load_dwordx4
+            rok[q] = g + q < nu && lane < d.len;
+            const int kk = d.bpos + min(lane, d.len - 1);
+            rc[q] = bcol[kk];
+            rv[q] = bval[kk];
+            rav[q] = __longlong_as_double(((long long)d.av_hi << 32) | (unsigned)d.av_lo);
+        }
+    };
     for (int q0 = 0; q0 < nz; q0 += kBigChunk) {
         const int qn = min(kBigChunk, nz - q0);
+        const int qi = q0 / kBigChunk;
+        if constexpr (UNITS) {
+            nu = cu1 - cu0;
+            request_round(wave * kU);
+            const int nch = (nz + kBigChunk - 1) / kBigChunk;
+            cu2 = uoff[cur.ioff + (long long)min(qi + 2, nch) * na];   // (consumed a chunk later)
+        }
         open_chunk(qn);
 #ifdef G4S_PROFILE_BIG
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1127,9 +1243,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         if (!(G4S_KO & 4)) build_index(qn);
         __syncthreads();
         BIG_PROF(7);
-        const int *clo, *chi;
-        window_bounds(brpt, wsplit, K, N, kfirst, klast, clo, chi);   // the part of each B row inside the windows this chunk spans
-        const int qi = q0 / kBigChunk;
+        const int *clo = brpt, *chi = brpt + 1;
+        if constexpr (!UNITS) window_bounds(brpt, wsplit, K, N, kfirst, klast, clo, chi);   // the part of each B row inside the windows this chunk spans
         // the chunk's columns as B's column ids (window ids → ids): a gather, started in front of the walk's last barrier so that it arrives under the barrier's skew
         int orig[kPerThread];
         auto gather_ids = [&]() {
@@ -1141,8 +1256,19 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
                 for (int u = 0; u < kPerThread; ++u) orig[u] = KC[min(t + u * kBigThreads, qn - 1)];
             }
         };
-        flat_products<T, true, kU>(a0, a1, acol, aval, clo, chi, bcol, bval, sd, t, accumulate,
-                                   (exact && qi > 0) ? ctr + (qi - 1) : nullptr, (exact && qi < nbnd) ? ctr + qi : nullptr, nbnd, gather_ids);
+        if constexpr (UNITS) {
+            accumulate(rc, rv, rav, rok);                          // round 0: requested at the top of the chunk
+            for (int g = (wave + T / 64) * kU; g < nu; g += (T / 64) * kU) {   // (uniform per wave; most chunks hold at most one round per wave)
+                request_round(g);
+                accumulate(rc, rv, rav, rok);
+            }
+            gather_ids();
+            __syncthreads();
+            cu0 = cu1; cu1 = cu2;
+        } else {
+            flat_products<T, true, kU>(a0, a1, acol, aval, clo, chi, bcol, bval, sd, t, accumulate,
+                                       (exact && qi > 0) ? ctr + (qi - 1) : nullptr, (exact && qi < nbnd) ? ctr + qi : nullptr, nbnd, gather_ids);
+        }
         BIG_PROF(8);
         {   // the chunk's values and column ids (gathered above).
             // hipcc's wait-count book: a register whose load is consumed only under a per-lane branch (the stores below) stays "pending" on the path that skips the
@@ -1690,8 +1816,11 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     G4S_REQUIRE(arpt && brpt && crpt && cnnz, "NULL argument");
     hipStream_t s = g4s::as_stream(stream);
     t_stream = s;
+    t_idle = false;
     *cnnz = 0;
     if (M == 0) { G4S_HIP_TRY(hipMemsetAsync(crpt, 0, sizeof(int), s)); return G4S_OK; }
+    DbgPhases dbg("symbolic");
+    ArenaScope arena;
     int annz = 0, bnnz = 0;
     G4S_TRY(read_last(arpt, M, &annz, s));
     G4S_TRY(read_last(brpt, K, &bnnz, s));
@@ -1699,14 +1828,17 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     G4S_TRY(check_ids(bcol, bnnz, N, "a column id of B", s));
 
     DevBuf row_flop, row_nz, ovf_rows, ovf_count;
+    dbg.mark("checks");
     G4S_TRY(row_flop.alloc(sizeof(long long) * (size_t)M));
     G4S_TRY(row_nz.alloc(sizeof(int) * ((size_t)M + 1)));
     G4S_HIP_TRY(hipMemsetAsync(row_nz.p, 0, sizeof(int) * ((size_t)M + 1), s));
     int64_t flop = 0;
     G4S_TRY(compute_row_flop(M, arpt, acol, brpt, row_flop.as<long long>(), &flop, s));
 
+    dbg.mark("row_flop");
     RowClasses rc;
     G4S_TRY(classify_rows(M, row_flop.as<long long>(), kSymLimits, N, rc, s));
+    dbg.mark("classes");
     if (getenv("G4S_DEBUG"))
         fprintf(stderr, "g4s symbolic classes: empty %d tiny %d small %d medium %d large %d hub %d (flop %lld)\n", rc.count[CLS_EMPTY], rc.count[CLS_TINY],
                 rc.count[CLS_SMALL], rc.count[CLS_MEDIUM], rc.count[CLS_LARGE], rc.count[CLS_HUB], (long long)flop);
@@ -1720,6 +1852,7 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     const int *wsplit = nullptr;
     G4S_TRY(build_window_splits(K, N2, brpt, wcol, pre ? pre->wsplit_buf : wsplit_local, &wsplit, s));
     if (pre) { pre->wsplit = wsplit; pre->has_wsplit = true; }
+    dbg.mark("colmap+splits");
     G4S_TRY(ovf_rows.alloc(sizeof(int) * (size_t)std::max(1, rc.count[CLS_LARGE])));
     G4S_TRY(ovf_count.alloc(sizeof(int)));
     G4S_HIP_TRY(hipMemsetAsync(ovf_count.p, 0, sizeof(int), s));
@@ -1768,6 +1901,7 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
             G4S_HIP_TRY(hipStreamSynchronize(s));
         }
     }
+    dbg.mark("tables+presort");
     auto window_t = [&](auto shape, const int *rows, int n, const long long *poff, int *pcols, int *next_row) -> int {
         constexpr int T = decltype(shape)::value;
         auto k = spgemm_symbolic_window_kernel<T>;
@@ -1820,6 +1954,7 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     G4S_TRY(fetch_rows_and_ranges(rc.list(CLS_HUB), rc.count[CLS_HUB], arpt, hub, ranges, s));
     G4S_TRY(run_hub_rows(false, hub, ranges, N, arpt, acol, nullptr, brpt, bcol, nullptr, nz, nullptr, nullptr, nullptr, s));
 
+    dbg.mark("windows+hub(+sync)");
     // scan(bin.row_nz, crpt, nrow+1); *nnz = crpt[nrow]   (hash_mult.h:506-507)
     const int nblocks = (M + kScanChunk - 1) / kScanChunk;
     DevBuf block_sums;
@@ -1837,6 +1972,8 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     hipLaunchKernelGGL(scan_write_kernel, dim3(nblocks), dim3(256), 0, s, M, nz, block_sums.as<long long>(), crpt);
     G4S_HIP_TRY(hipGetLastError());
     G4S_HIP_TRY(hipStreamSynchronize(s));
+    t_idle = true;
+    dbg.mark("scan");
     return G4S_OK;
 }
 } // namespace
@@ -1861,7 +1998,10 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
     G4S_REQUIRE(arpt && brpt && crpt, "NULL argument");
     hipStream_t s = g4s::as_stream(stream);
     t_stream = s;
+    t_idle = false;
     if (M == 0) return G4S_OK;
+    DbgPhases dbg("numeric");
+    ArenaScope arena;
     // lanes per A-entry are sized from the row's average B-row length; the exact nz of the output row (known here) stands in for
     // the flop count of the symbolic phase (they differ by the row's compression ratio), which saves a pass over A
     DevBuf row_size;
@@ -1874,6 +2014,7 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         fprintf(stderr, "g4s numeric classes: empty %d <=32 %d <=512 %d <=1024 %d <=2048 %d <=4096 %d <=32768 %d hub %d\n", rc.count[CLS_EMPTY], rc.count[CLS_TINY],
                 rc.count[CLS_SMALL], rc.count[CLS_MEDIUM], rc.count[CLS_LARGE], rc.count[CLS_M2], rc.count[CLS_M3], rc.count[CLS_HUB]);
 
+    dbg.mark("classes");
     if (int n = rc.count[CLS_TINY]) {
         auto k = spgemm_numeric_lds_kernel<256, 64, 64>;
         hipLaunchKernelGGL(k, dim3((n + 3) / 4), dim3(256), 4 * 64 * 12, s, rc.list(CLS_TINY), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
@@ -1902,10 +2043,11 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
     // exact chunk splits (chunk_splits_kernel) for the rows of one launch that hold more than one value chunk: one-shot call only (the sorted columns must
     // exist before the numeric kernel runs); the buffers live until the end of this call
     std::vector<std::unique_ptr<DevBuf>> ct_keep;
-    auto chunk_splits = [&](int threads, const int *rows, int n, int nz_lo, int nz_hi, const long long **ct_off, const int **ct) -> int {
-        *ct_off = nullptr; *ct = nullptr;
-        if (!wsplit || n == 0 || getenv("G4S_SPGEMM_NO_EXACT_SPLITS")) return G4S_OK;
-        if (threads != 1024 && !getenv("G4S_SPGEMM_EXACT_SPLITS_ALL")) return G4S_OK;   // the 256-thread launches hold rows of at most two 2 048-entry chunks: measured no gain (1.22 ms either way), 0.45 ms of splits
+    const bool use_units = !getenv("G4S_SPGEMM_NO_UNITS") && !getenv("G4S_SPGEMM_NO_EXACT_SPLITS");
+    auto chunk_splits = [&](int threads, const int *rows, int n, int nz_lo, int nz_hi, const long long **ct_off, const int **ct, bool *complete) -> int {
+        *ct_off = nullptr; *ct = nullptr; *complete = false;       // complete: every row of more than one chunk has its splits (or there is no such row)
+        if (n == 0 || getenv("G4S_SPGEMM_NO_EXACT_SPLITS")) return G4S_OK;
+        if (!use_units && (!wsplit || (threads != 1024 && !getenv("G4S_SPGEMM_EXACT_SPLITS_ALL")))) return G4S_OK;   // without unit lists the 256-thread launches (rows of at most two chunks) gain nothing from the splits
         const int chunk = 8 * threads;                             // BigCfg<T>::kChunk
         auto need = std::make_unique<DevBuf>(), off = std::make_unique<DevBuf>(), tab = std::make_unique<DevBuf>();
         G4S_TRY(need->alloc(sizeof(long long) * ((size_t)n + 1)));
@@ -1918,13 +2060,46 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         G4S_HIP_TRY(hipStreamSynchronize(s));
         // an optimisation, never a reason to fail: entries × chunks can outgrow any sensible table (rows of 10^5 entries and 10^6 outputs) — those products, and
         // a table that cannot be allocated, run with the window pieces as before
-        if (total <= 0 || total > (1ll << 28)) return G4S_OK;
+        if (total == 0) { *complete = true; *ct_off = off->as<long long>(); ct_keep.push_back(std::move(need)); ct_keep.push_back(std::move(off)); return G4S_OK; }
+        if (total < 0 || total > (1ll << 28)) return G4S_OK;
         if (tab->alloc(sizeof(int) * (size_t)total) != G4S_OK) { (void)hipGetLastError(); return G4S_OK; }
         hipLaunchKernelGGL(chunk_splits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, n, rows, K, N2, wsplit, arpt, acol, brpt, wcol, crpt, pre_off, pre_cols, ccol, chunk,
                            off->as<long long>(), tab->as<int>());
         G4S_HIP_TRY(hipGetLastError());
-        *ct_off = off->as<long long>(); *ct = tab->as<int>();
+        *ct_off = off->as<long long>(); *ct = tab->as<int>(); *complete = true;
         ct_keep.push_back(std::move(need)); ct_keep.push_back(std::move(off)); ct_keep.push_back(std::move(tab));
+        return G4S_OK;
+    };
+    // Unit lists of one launch (unit_kernel): items per row → scan → units per item → scan → descriptors. Never a reason to fail: without them (no splits, a table
+    // past its cap, no memory) the kernel walks its rows with the entry pass as before.
+    struct UnitLists { const long long *item_off = nullptr; const int *uoff = nullptr; const UnitDesc *U = nullptr; };
+    auto unit_lists = [&](int threads, const int *rows, int n, int nz_lo, int nz_hi, const long long *ct_off, const int *ct, UnitLists *out) -> int {
+        *out = UnitLists{};
+        const int chunk = 8 * threads;
+        auto items = std::make_unique<DevBuf>(), ioff = std::make_unique<DevBuf>(), ucnt = std::make_unique<DevBuf>(), uoff = std::make_unique<DevBuf>(), ud = std::make_unique<DevBuf>();
+        G4S_TRY(items->alloc(sizeof(long long) * ((size_t)n + 1)));
+        G4S_TRY(ioff->alloc(sizeof(long long) * ((size_t)n + 1)));
+        G4S_HIP_TRY(hipMemsetAsync(items->as<long long>() + n, 0, sizeof(long long), s));
+        hipLaunchKernelGGL(unit_items_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, rows, arpt, crpt, chunk, nz_lo, nz_hi, items->as<long long>());
+        G4S_TRY(g4s::prims::exclusive_scan(items->as<long long>(), ioff->as<long long>(), (long long)n + 1, s));
+        long long total = 0;
+        G4S_HIP_TRY(hipMemcpyAsync(&total, ioff->as<long long>() + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+        G4S_HIP_TRY(hipStreamSynchronize(s));
+        if (total <= 0 || total > (1ll << 28)) return G4S_OK;
+        if (ucnt->alloc(sizeof(int) * ((size_t)total + 1)) != G4S_OK || uoff->alloc(sizeof(int) * ((size_t)total + 1)) != G4S_OK) { (void)hipGetLastError(); return G4S_OK; }
+        G4S_HIP_TRY(hipMemsetAsync(ucnt->as<int>() + total, 0, sizeof(int), s));
+        const unsigned grid = (unsigned)((total + 255) / 256);
+        hipLaunchKernelGGL(unit_kernel<false>, dim3(grid), dim3(256), 0, s, total, n, rows, ioff->as<long long>(), arpt, acol, aval, brpt, crpt, chunk, ct_off, ct, ucnt->as<int>(), (const int *)nullptr, (UnitDesc *)nullptr);
+        G4S_TRY(g4s::prims::exclusive_scan(ucnt->as<int>(), uoff->as<int>(), total + 1, s));
+        int total_units = 0;
+        G4S_HIP_TRY(hipMemcpyAsync(&total_units, uoff->as<int>() + total, sizeof(int), hipMemcpyDeviceToHost, s));
+        G4S_HIP_TRY(hipStreamSynchronize(s));
+        if (total_units <= 0 || total_units > (1 << 27)) return G4S_OK;          // (a sum past 2^31 shows up as a negative total)
+        if (ud->alloc(sizeof(UnitDesc) * (size_t)total_units) != G4S_OK) { (void)hipGetLastError(); return G4S_OK; }
+        hipLaunchKernelGGL(unit_kernel<true>, dim3(grid), dim3(256), 0, s, total, n, rows, ioff->as<long long>(), arpt, acol, aval, brpt, crpt, chunk, ct_off, ct, (int *)nullptr, uoff->as<int>(), ud->as<UnitDesc>());
+        G4S_HIP_TRY(hipGetLastError());
+        out->item_off = ioff->as<long long>(); out->uoff = uoff->as<int>(); out->U = ud->as<UnitDesc>();
+        ct_keep.push_back(std::move(items)); ct_keep.push_back(std::move(ioff)); ct_keep.push_back(std::move(ucnt)); ct_keep.push_back(std::move(uoff)); ct_keep.push_back(std::move(ud));
         return G4S_OK;
     };
     // The window kernels need every row's sorted distinct columns (window ids) before they start. The one-shot call carries them over from its symbolic
@@ -1943,14 +2118,27 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
     };
     auto big_t = [&](auto shape, const int *rows, int n, int nz_lo, int nz_hi, int *next_row) -> int {
         constexpr int T = decltype(shape)::value;
-        auto k = spgemm_numeric_big_kernel<T>;
+        if (!n) return G4S_OK;
         const size_t lds = big_lds_bytes<T>();   // value chunk (fp64 sums, columns, bucket index) + scan scratch + the flat lists
-        G4S_TRY(allow_lds(k, lds));
         const long long *ct_off = nullptr;
         const int *ct = nullptr;
-        if (n && !carried_complete) G4S_TRY(emit_pass(shape, rows, n, nz_lo, nz_hi));
-        if (n) G4S_TRY(chunk_splits(T, rows, n, nz_lo, nz_hi, &ct_off, &ct));
-        if (n) hipLaunchKernelGGL(k, dim3(big_grid(n, BigCfg<T>::kPerCu)), dim3(T), lds, s, rows, n, nz_lo, nz_hi, next_row, N2, K, wsplit, arpt, acol, aval, brpt, wcol, winv, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols, ct_off, ct);
+        bool splits_complete = false;
+        UnitLists ul;
+        if (!carried_complete) G4S_TRY(emit_pass(shape, rows, n, nz_lo, nz_hi));
+        G4S_TRY(chunk_splits(T, rows, n, nz_lo, nz_hi, &ct_off, &ct, &splits_complete));
+        if (use_units && splits_complete) G4S_TRY(unit_lists(T, rows, n, nz_lo, nz_hi, ct_off, ct, &ul));
+        const dim3 grid(big_grid(n, BigCfg<T>::kPerCu));
+        if (ul.U) {
+            auto k = spgemm_numeric_big_kernel<T, true>;
+            G4S_TRY(allow_lds(k, lds));
+            hipLaunchKernelGGL(k, grid, dim3(T), lds, s, rows, n, nz_lo, nz_hi, next_row, N2, K, wsplit, arpt, acol, aval, brpt, wcol, winv, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols, ct_off, ct,
+                               ul.item_off, ul.uoff, ul.U);
+        } else {
+            auto k = spgemm_numeric_big_kernel<T, false>;
+            G4S_TRY(allow_lds(k, lds));
+            hipLaunchKernelGGL(k, grid, dim3(T), lds, s, rows, n, nz_lo, nz_hi, next_row, N2, K, wsplit, arpt, acol, aval, brpt, wcol, winv, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols, ct_off, ct,
+                               (const long long *)nullptr, (const int *)nullptr, (const UnitDesc *)nullptr);
+        }
         return G4S_OK;
     };
     auto big = [&](int threads, const int *rows, int n, int nz_lo = 0, int nz_hi = INT_MAX, int *next_row = nullptr) -> int {
@@ -1963,6 +2151,12 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
     const int m3_cut = getenv("G4S_SPGEMM_M3_CUT") ? atoi(getenv("G4S_SPGEMM_M3_CUT")) : kNumM3Cut;
     const char *e_med = getenv("G4S_SPGEMM_T_NUM_MED");
     const int t_med = e_med ? (atoi(e_med) ? shape_of("G4S_SPGEMM_T_NUM_MED", 1024) : 0) : kShapeNumMedium;   // 0: the table kernel
+    dbg.mark("table-kernels+maps");
+    const bool one_mid_launch = t_med && xn_large && xn_m2 && t_med == t_large && t_large == t_m2 && !getenv("G4S_SPGEMM_SPLIT_MID");
+    if (one_mid_launch) {
+        // the three mid-size classes (512 < nz <= 4 096) share a shape and their lists are adjacent: one launch, one set of unit lists, one tail instead of three
+        G4S_TRY(big(t_med, rc.list(CLS_MEDIUM), rc.count[CLS_MEDIUM] + rc.count[CLS_LARGE] + rc.count[CLS_M2]));
+    } else {
     if (t_med && xn_large) { G4S_TRY(big(t_med, rc.list(CLS_MEDIUM), rc.count[CLS_MEDIUM])); }
     else if (int n = rc.count[CLS_MEDIUM]) {
         auto k = spgemm_numeric_lds_kernel<256, 256, 2048>;
@@ -1980,6 +2174,8 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         G4S_TRY(allow_lds(k, num_lds_bytes(8192)));
         hipLaunchKernelGGL(k, dim3(n), dim3(1024), num_lds_bytes(8192), s, rc.list(CLS_M2), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
     }
+    }
+    dbg.mark("mid-launch");
     if (int n = rc.count[CLS_M3]) {
         // the class spans 4 K … 128 K entries: its short rows go to the many-workgroups shape, the long ones keep 1 024 threads
         if (t_m3 != 1024 && m3_cut > 0) { G4S_TRY(big(t_m3, rc.list(CLS_M3), n, 0, m3_cut)); G4S_TRY(big(1024, rc.list(CLS_M3), n, m3_cut, INT_MAX)); }
@@ -1993,10 +2189,13 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         }
     }
     G4S_HIP_TRY(hipGetLastError());
+    dbg.mark("big-launch(+sync)");
     std::vector<int> hub, ranges;
     G4S_TRY(fetch_rows_and_ranges(rc.list(CLS_HUB), rc.count[CLS_HUB], arpt, hub, ranges, s));
     G4S_TRY(run_hub_rows(true, hub, ranges, N, arpt, acol, aval, brpt, bcol, bval, nullptr, crpt, ccol, cval, s));
     G4S_HIP_TRY(hipStreamSynchronize(s));
+    t_idle = true;                                                 // (cleared by the next call on this thread)
+    dbg.mark("hub+sync");
     return G4S_OK;
 }
 } // namespace
@@ -2016,6 +2215,7 @@ G4S_API g4s_status g4s_spgemm_flop(int32_t M, const int32_t *arpt, const int32_t
     *flop = 0;
     if (M == 0) return G4S_OK;
     t_stream = nullptr;
+    t_idle = false;
     DevBuf rf;
     if (flags & G4S_DEVICE_POINTERS) {
         long long *d_rf = reinterpret_cast<long long *>(row_flop);
@@ -2053,8 +2253,10 @@ G4S_API g4s_status g4s_spgemm_csr_i32_f64(const int32_t *arpt, const int32_t *ac
     *crpt_out = nullptr; *ccol_out = nullptr; *cval_out = nullptr; *cnnz_out = 0;
     g4s_timings t{};
     const auto t_total = clk::now();
+    ArenaScope arena;                                              // spans both phases: the carried state of the symbolic phase lives in it
     const bool dev = (flags & G4S_DEVICE_POINTERS) != 0;
     t_stream = nullptr;                                            // the one-call form runs on the default stream
+    t_idle = false;
 
     // ---- create: inputs to the device (mkl_sparse_d_create_csr ×2 in the reference's timed path, mkl_mult.h:50-52)
     auto t0 = clk::now();
