@@ -779,10 +779,11 @@ __device__ __forceinline__ void flat_products(int a0, int a1, const int *__restr
 // an LDS stage and a wave-cooperative path for crowded threads: 2–3× slower than the list, the per-thread loops diverge on every word).
 // Round 4: list items are 4-word groups instead of words — the list build is 8 steps per thread instead of 32 (it was 25 % of the symbolic window
 // kernels), an item's columns are at most 128 consecutive ids, and the words come in as 16-byte LDS reads.
+// Every group that holds a bit is written back as zero when its item is read: the bitmap is clean again when the call returns.
 // s_scan: 32 ints of LDS scratch; stage: BigCfg<T>::kStage ints (list items), followed by T ints (per-thread first positions).
 // Contains barriers: call from uniform control flow; the caller puts a barrier between this call and the next write to the bitmap.
 template <int T>
-__device__ __forceinline__ int emit_window_columns(const unsigned *bm, int w0, int *__restrict__ out, int *s_scan, int *stage, int t)
+__device__ __forceinline__ int emit_window_columns(unsigned *bm, int w0, int *__restrict__ out, int *s_scan, int *stage, int t)
 {
     static_assert(BigCfg<T>::kWindowWords / T == 32, "emit layout");
     constexpr int S = BigCfg<T>::kStage;
@@ -839,7 +840,9 @@ __device__ __forceinline__ int emit_window_columns(const unsigned *bm, int w0, i
         for (int e = t; e < n; e += T) {
             const unsigned item = (unsigned)stage[e];
             const int gid = (int)(item >> 10), tt = gid >> 3;       // owner thread and its group
-            const uint4 g = reinterpret_cast<const uint4 *>(bm + tt * 32)[(gid & 7) ^ ((tt >> 1) & 7)];
+            uint4 *gp = reinterpret_cast<uint4 *>(bm + tt * 32) + ((gid & 7) ^ ((tt >> 1) & 7));
+            const uint4 g = *gp;
+            *gp = make_uint4(0u, 0u, 0u, 0u);                        // the window leaves the bitmap clean: the next one does not zero 32·T words first (12 % of the symbolic window kernels)
             int pos = first_pos[tt] + (int)(item & 0x3ffu);
             const int col0 = w0 + (gid << 7);
             unsigned long long b = ((unsigned long long)g.y << 32) | g.x;
@@ -934,6 +937,144 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     __syncthreads();
     BIG_PROF(6);
     BIG_PROF_FLUSH;
+    }
+}
+
+
+// ---- the symbolic window kernel on unit lists (round 4; the kernel above stays for the numeric phase's emit pass and as the fall-back).
+// Same idea as the numeric kernel's unit lists (unit_kernel below): the (row, window) walk used to open with an entry pass, a block scan and a unit map —
+// three barriers and a dependent load chain before the first column could be requested, once per window. A pre-pass (sym_unit_kernel) writes the units of every
+// (list position i, window w, A-entry e), ordered (i, w, e): the piece of B row acol[e] inside window w, cut into runs of at most 64 entries. The kernel reads
+// them with scalar loads, round 0 in front of the bitmap's zeroing, and takes its rows' metadata one row ahead.
+struct __attribute__((aligned(8))) SymUnit { int bpos, len; };
+__global__ void sym_items_kernel(int n, const int *__restrict__ rows, const int *__restrict__ arpt, int nwin, long long *__restrict__ items)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) items[i] = i < n ? (long long)(arpt[rows[i] + 1] - arpt[rows[i]]) * nwin : 0;
+}
+template <bool EXPAND>
+__global__ __launch_bounds__(256) void sym_unit_kernel(long long bound /* threads launched: an upper bound of the item count */, int n, const int *__restrict__ rows,
+                                                       const long long *__restrict__ item_off /* n + 1 */, const int *__restrict__ arpt, const int *__restrict__ acol,
+                                                       const int *__restrict__ brpt, int K, int N, const int *__restrict__ wsplit, int window_bits,
+                                                       int *__restrict__ ucount /* !EXPAND: out, bound + 1 entries */, const int *__restrict__ uoff, SymUnit *__restrict__ U)
+{
+    const long long i0 = (long long)blockIdx.x * blockDim.x, i = i0 + threadIdx.x, total = item_off[n];
+    if (i > bound) return;
+    if (i >= total) { if constexpr (!EXPAND) ucount[i] = 0; return; }   // (the scan runs over bound + 1 entries)
+    int rl = 0, rh = n;                                             // the list position that holds the workgroup's first item (uniform), then a short walk forward
+    while (rl < rh) {
+        const int mid = (rl + rh) >> 1;
+        if (item_off[mid + 1] > i0) rh = mid; else rl = mid + 1;
+    }
+    while (item_off[rl + 1] <= i) ++rl;
+    const int row = rows[rl], a0 = arpt[row], na = arpt[row + 1] - a0;
+    const long long idx = i - item_off[rl];
+    const int w = (int)(idx / na), e = (int)(idx - (long long)w * na);
+    const int c = acol[a0 + e];
+    int lo = brpt[c], hi = brpt[c + 1];
+    if (wsplit) {                                                  // the piece of the row inside window w (window_bounds)
+        const int sb = split_bits(N), W = (N + (1 << sb) - 1) >> sb;
+        const int cf = w << window_bits, cl = min(N, (w + 1) << window_bits) - 1, wf = cf >> sb, wl = cl >> sb;
+        if (wf > 0) lo = wsplit[(size_t)(wf - 1) * K + c];
+        if (wl < W - 1) hi = wsplit[(size_t)wl * K + c];
+    }
+    if constexpr (!EXPAND) ucount[i] = hi > lo ? (hi - lo + 63) >> 6 : 0;
+    else {
+        SymUnit *dst = U + uoff[i];
+        for (int k = lo; k < hi; k += 64) *dst++ = SymUnit{k, min(64, hi - k)};
+    }
+}
+
+template <int T>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void spgemm_symbolic_units_kernel(
+    const int *__restrict__ rows, int nrows, int *__restrict__ next_row /* not NULL: rows handed out one at a time (list sorted longest first) */,
+    int N, const int *__restrict__ arpt, const int *__restrict__ bcol, int *__restrict__ row_nz,
+    const long long *__restrict__ pre_off, int *__restrict__ pre_cols,
+    const long long *__restrict__ item_off, const int *__restrict__ uoff, const SymUnit *__restrict__ U)
+{
+    constexpr int kBigWindowBits = BigCfg<T>::kWindowBits, kBigWindowWords = BigCfg<T>::kWindowWords, kU = kFlatUnitsPerRound, kWaves = T / 64;
+    extern __shared__ int lds_i[];
+    unsigned *bm = reinterpret_cast<unsigned *>(lds_i);
+    const BigSide<T> sd(lds_i + kBigWindowWords);
+    int &s_total = sd.ctrl[BigSide<T>::kTotalSlot];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    struct RowMeta { int row, na, u0, u1; long long po, ioff; };
+    const long long total_items = item_off[nrows];
+    auto load_meta = [&](int idx) {                                 // uniform index: scalar loads
+        const int ci = min(idx, nrows - 1);                        // (a ticket past the end reads the last row: never used)
+        const int r = rows[ci];
+        RowMeta m;
+        m.row = r; m.na = arpt[r + 1] - arpt[r]; m.po = pre_off ? pre_off[r] : -1; m.ioff = item_off[ci];
+        m.u0 = uoff[m.ioff]; m.u1 = uoff[min(m.ioff + m.na, total_items)];
+        return m;
+    };
+    int ridx = blockIdx.x, nridx = 0;
+    if (next_row) {                                                // uniform
+        if (t == 0) sd.ctrl[28] = atomicAdd(next_row, 1);
+        __syncthreads();
+        ridx = __builtin_amdgcn_readfirstlane(sd.ctrl[28]);
+        __syncthreads();
+    }
+    RowMeta cur = load_meta(ridx), nxt = cur;
+    const int nwin = (N + (1 << kBigWindowBits) - 1) >> kBigWindowBits;
+    for (int i = t; i < kBigWindowWords / 4; i += T) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);   // once: every window leaves the bitmap clean
+    __syncthreads();
+    for (; ridx < nrows; ridx = nridx, cur = nxt) {
+        if (next_row) { if (t == 0) sd.ctrl[29] = atomicAdd(next_row, 1); }   // read below, behind the first barrier of the row
+        else { nridx = ridx + gridDim.x; nxt = load_meta(nridx); }
+        const long long po = cur.po;                               // uniform
+        const int na = cur.na;
+        if (t == 0) s_total = 0;
+        int cu0 = cur.u0, cu1 = cur.u1, cu2 = 0;
+        BIG_PROF_DECL_SYM;
+        for (int wi = 0; wi < nwin; ++wi) {
+            const int w0 = wi << kBigWindowBits, w1 = min(N, w0 + (1 << kBigWindowBits));
+            const int nu = cu1 - cu0;
+            int c[kU];
+            bool ok[kU];
+            auto request_round = [&](int g) {
+#pragma unroll
+                for (int q = 0; q < kU; ++q) {
+                    const SymUnit d = U[cu0 + min(g + q, max(nu, 1) - 1)];   // uniform: one s_load_dwordx2 (a window without units reads a neighbour's or the pad entry: not used)
+                    const int len = nu > 0 ? d.len : 1, bpos = nu > 0 ? d.bpos : 0;
+                    ok[q] = g + q < nu && lane < len;
+                    c[q] = bcol[bpos + min(lane, len - 1)];
+                }
+            };
+            auto mark_round = [&]() {
+#pragma unroll
+                for (int q = 0; q < kU; ++q)
+                    if (ok[q] && c[q] >= w0 && c[q] < w1) atomicOr(&bm[bm_slot((c[q] - w0) >> 5)], 1u << ((c[q] - w0) & 31));
+            };
+            request_round(wave * kU);
+            cu2 = uoff[min(cur.ioff + (long long)min(wi + 2, nwin) * na, total_items)];   // (consumed a window later)
+            BIG_PROF(0);
+            mark_round();                                          // (the bitmap is clean: zeroed at the kernel's start, left clean by every window since)
+            for (int g = (wave + kWaves) * kU; g < nu; g += kWaves * kU) {
+                request_round(g);
+                mark_round();
+            }
+            __syncthreads();
+            BIG_PROF(1);
+            if (wi == 0 && next_row) { nridx = __builtin_amdgcn_readfirstlane(sd.ctrl[29]); nxt = load_meta(nridx); }   // (nobody writes the slot again before this row's last barrier)
+            if (po >= 0) {
+                const int total = emit_window_columns<T>(bm, w0, pre_cols + po + s_total, sd.scan, sd.stage, t);
+                if (t == 0) s_total += total;
+                BIG_PROF(3);
+            } else {
+                int cnt = 0;
+                for (int i = t; i < kBigWindowWords; i += T) { cnt += __popc(bm[i]); bm[i] = 0u; }   // count and clean
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+                if (lane == 0 && cnt) atomicAdd(&s_total, cnt);
+            }
+            __syncthreads();
+            cu0 = cu1; cu1 = cu2;
+        }
+        if (t == 0) row_nz[cur.row] = s_total;
+        __syncthreads();
+        BIG_PROF(6);
+        BIG_PROF_FLUSH;
     }
 }
 
@@ -1061,13 +1202,15 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     // They are uniform, so they are read with scalar loads (readfirstlane makes the ticket an SGPR), and the NEXT row's are requested as soon as its ticket is
     // known — before the value chunks of the current row — instead of at the top of its turn (110 K rows × two round trips were ≈ 10 % of the kernel).
     struct RowMeta { int row, a0, a1, off, nz; long long po, ioff; int u0, u1; };
+    long long total_items = 0;
+    if constexpr (UNITS) total_items = item_off[nrows];
     auto load_meta = [&](int idx) {
         const int ci = min(idx, nrows - 1);                        // (a ticket past the end reads the last row: never used)
         const int r = rows[ci];
         RowMeta m;
         m.row = r; m.a0 = arpt[r]; m.a1 = arpt[r + 1]; m.off = crpt[r]; m.nz = crpt[r + 1] - m.off; m.po = pre_off ? pre_off[r] : -1;
         m.ioff = 0; m.u0 = 0; m.u1 = 0;
-        if constexpr (UNITS) { m.ioff = item_off[ci]; m.u0 = uoff[m.ioff]; m.u1 = uoff[m.ioff + (m.a1 - m.a0)]; }   // the units of the row's first chunk
+        if constexpr (UNITS) { m.ioff = item_off[ci]; m.u0 = uoff[m.ioff]; m.u1 = uoff[min(m.ioff + (m.a1 - m.a0), total_items)]; }   // the units of the row's first chunk (a row outside the launch's size range has no items)
         return m;
     };
     int ridx = blockIdx.x;
@@ -1102,6 +1245,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     __syncthreads();                                               // the next-row ticket (ctrl[29]) is visible; the previous row's last chunk is out of LDS
     BIG_PROF(0);
     if (next_row) { nridx = __builtin_amdgcn_readfirstlane(sd.ctrl[29]); nxt = load_meta(nridx); }   // (nobody writes the slot again before this row's last barrier)
+    // (round 4 tried the three dependent levels of load_meta behind three different barriers of the row's first chunk: 14.83 ms against 14.66 — the scalar
+    // loads share their counter with LDS, and spreading them only spreads the waits)
 
     // ---- phase 2: values, one chunk of the sorted columns at a time
     // A product finds its slot through a bucket index over the chunk's column span: bucket b = (col - first) >> shift holds
@@ -1110,6 +1255,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     double *V = reinterpret_cast<double *>(lds_i);                 // kBigChunk doubles
     int *KC = lds_i + 2 * kBigChunk;                                // kBigChunk ints
     unsigned *IDX = reinterpret_cast<unsigned *>(lds_i + 3 * kBigChunk);   // kBigChunk buckets: 4·kBigChunk ints = the bitmap's 128 KiB
+    unsigned short *IDX16 = reinterpret_cast<unsigned short *>(IDX);       // (low half: last slot, high half: first slot)
     static_assert(4 * kBigChunk <= kBigWindowWords && kBigChunk <= 65536, "phase 2 reuses the bitmap region; slots are packed in 16 bits");
     constexpr int kU = kFlatUnitsPerRound;
     int kfirst = 0, klast = 0, shift = 0;
@@ -1156,15 +1302,14 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         }
 #pragma unroll
         for (int q = 0; q < kU; ++q)
-            if (in[q] && !(G4S_KO & 2)) atomicAdd(&V[lo[q]], av[q] * bv[q]);
+            if (in[q] && !(G4S_KO & 2)) atomicAdd(&V[lo[q] & (kBigChunk - 1)], av[q] * bv[q]);   // (the mask: a stale bucket can only be read with a wrong crpt from the caller — stay inside the chunk)
     };
     // The chunk's sorted columns are issued a chunk ahead (they are consumed at the top of the next chunk, a whole accumulation pass later).
     auto fetch_chunk = [&](int q0) { fetch_from(po >= 0 ? pre_cols + po + q0 : ccol + off + q0, min(kBigChunk, nz - q0)); };
-    auto open_chunk = [&](int qn) {                                // cc → LDS, empty buckets
+    auto open_chunk = [&](int qn) {                                // cc → LDS (the bucket index is not cleared: only buckets that hold a column of this chunk are ever looked up, and those are rewritten)
 #pragma unroll
         for (int u = 0; u < kPerThread; ++u) {
             const int i = t + u * kBigThreads;
-            IDX[i] = 0u;
             if (i < qn) { KC[i] = cc[u]; V[i] = 0.0; }
         }
     };
@@ -1185,9 +1330,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         for (int u = 0; u < kPerThread; ++u) {
             const int i = t + u * kBigThreads;
             if (i < qn) {
-                const int bb = (b[u] - kfirst) >> shift;
-                if (i == 0 || ((bp[u] - kfirst) >> shift) != bb) atomicOr(&IDX[bb], (unsigned)i << 16);
-                if (i == qn - 1 || ((bn[u] - kfirst) >> shift) != bb) atomicOr(&IDX[bb], (unsigned)i);
+                const int bb = (b[u] - kfirst) >> shift;               // the columns are sorted: a bucket's first and last slot sit where the bucket id changes — two 16-bit stores, no atomics
+                if (i == 0 || ((bp[u] - kfirst) >> shift) != bb) IDX16[2 * bb + 1] = (unsigned short)i;
+                if (i == qn - 1 || ((bn[u] - kfirst) >> shift) != bb) IDX16[2 * bb] = (unsigned short)i;
             }
         }
     };
@@ -1223,20 +1368,22 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
             nu = cu1 - cu0;
             request_round(wave * kU);
             const int nch = (nz + kBigChunk - 1) / kBigChunk;
-            cu2 = uoff[cur.ioff + (long long)min(qi + 2, nch) * na];   // (consumed a chunk later)
+            cu2 = uoff[min(cur.ioff + (long long)min(qi + 2, nch) * na, total_items)];   // (consumed a chunk later)
         }
         open_chunk(qn);
 #ifdef G4S_PROFILE_BIG
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (q0 == 0) BIG_PROF(9); else BIG_PROF(1);               // the chunk's columns have arrived and are in LDS: first chunk of a row / later chunks
 #endif
-        {   // the next chunk's columns — in the row's last chunk: the first chunk of the workgroup's NEXT row (its metadata arrived at this row's start). One
-            // unconditional fetch from a selected pointer: a load under a branch makes hipcc wait at the join for every load that might be in flight.
+        auto fetch_next = [&]() {
+            // the next chunk's columns — in the row's last chunk: the first chunk of the workgroup's NEXT row. One unconditional fetch from a selected pointer: a
+            // load under a branch makes hipcc wait at the join for every load that might be in flight.
             const bool last = q0 + kBigChunk >= nz;                 // uniform
             const int *src = last ? (nxt.po >= 0 ? pre_cols + nxt.po : ccol + nxt.off)
                                   : (po >= 0 ? pre_cols + po + q0 + kBigChunk : ccol + off + q0 + kBigChunk);
             fetch_from(src, last ? max(1, min(kBigChunk, nxt.nz)) : min(kBigChunk, nz - q0 - kBigChunk));
-        }
+        };
+        fetch_next();
         __syncthreads();
         chunk_span(qn);
         BIG_PROF(6);
@@ -1902,12 +2049,43 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
         }
     }
     dbg.mark("tables+presort");
+    std::vector<std::unique_ptr<DevBuf>> unit_keep;                // unit lists of the window launches: live until the stream is synchronised below
+    const bool use_units = !getenv("G4S_SPGEMM_NO_UNITS");
     auto window_t = [&](auto shape, const int *rows, int n, const long long *poff, int *pcols, int *next_row) -> int {
         constexpr int T = decltype(shape)::value;
-        auto k = spgemm_symbolic_window_kernel<T>;
+        if (!n) return G4S_OK;
         const size_t lds = big_lds_bytes<T>();
+        const dim3 grid(big_grid(n, BigCfg<T>::kPerCu));
+        // unit lists (sym_unit_kernel), sized by bounds the host already has — items <= nnz(A) · windows, units <= flop / 64 + items — so that no count has to
+        // come back from the device in front of the launch
+        const int nwin = (N2 + (1 << BigCfg<T>::kWindowBits) - 1) >> BigCfg<T>::kWindowBits;
+        const long long ibound = (long long)annz * nwin, ubound = flop / 64 + ibound;
+        if (use_units && ibound > 0 && ibound <= (1ll << 28) && ubound <= (1ll << 28)) {
+            auto items = std::make_unique<DevBuf>(), ioff = std::make_unique<DevBuf>(), ucnt = std::make_unique<DevBuf>(), uoff = std::make_unique<DevBuf>(), ud = std::make_unique<DevBuf>();
+            bool ok = items->alloc(sizeof(long long) * ((size_t)n + 1)) == G4S_OK && ioff->alloc(sizeof(long long) * ((size_t)n + 1)) == G4S_OK &&
+                      ucnt->alloc(sizeof(int) * ((size_t)ibound + 1)) == G4S_OK && uoff->alloc(sizeof(int) * ((size_t)ibound + 1)) == G4S_OK &&
+                      ud->alloc(sizeof(SymUnit) * ((size_t)ubound + 1)) == G4S_OK;
+            if (!ok) (void)hipGetLastError();
+            if (ok) {
+                hipLaunchKernelGGL(sym_items_kernel, dim3((n + 256) / 256), dim3(256), 0, s, n, rows, arpt, nwin, items->as<long long>());
+                G4S_TRY(g4s::prims::exclusive_scan(items->as<long long>(), ioff->as<long long>(), (long long)n + 1, s));
+                const unsigned ugrid = (unsigned)((ibound + 256) / 256);
+                hipLaunchKernelGGL(sym_unit_kernel<false>, dim3(ugrid), dim3(256), 0, s, ibound, n, rows, ioff->as<long long>(), arpt, acol, brpt, K, N2, wsplit, BigCfg<T>::kWindowBits,
+                                   ucnt->as<int>(), (const int *)nullptr, (SymUnit *)nullptr);
+                G4S_TRY(g4s::prims::exclusive_scan(ucnt->as<int>(), uoff->as<int>(), ibound + 1, s));
+                hipLaunchKernelGGL(sym_unit_kernel<true>, dim3(ugrid), dim3(256), 0, s, ibound, n, rows, ioff->as<long long>(), arpt, acol, brpt, K, N2, wsplit, BigCfg<T>::kWindowBits,
+                                   (int *)nullptr, uoff->as<int>(), ud->as<SymUnit>());
+                auto k = spgemm_symbolic_units_kernel<T>;
+                G4S_TRY(allow_lds(k, lds));
+                hipLaunchKernelGGL(k, grid, dim3(T), lds, s, rows, n, next_row, N2, arpt, wcol, nz, poff, pcols, ioff->as<long long>(), uoff->as<int>(), ud->as<SymUnit>());
+                G4S_HIP_TRY(hipGetLastError());
+                unit_keep.push_back(std::move(items)); unit_keep.push_back(std::move(ioff)); unit_keep.push_back(std::move(ucnt)); unit_keep.push_back(std::move(uoff)); unit_keep.push_back(std::move(ud));
+                return G4S_OK;
+            }
+        }
+        auto k = spgemm_symbolic_window_kernel<T>;
         G4S_TRY(allow_lds(k, lds));
-        if (n) hipLaunchKernelGGL(k, dim3(big_grid(n, BigCfg<T>::kPerCu)), dim3(T), lds, s, rows, n, next_row, N2, K, wsplit, arpt, acol, brpt, wcol, row_flop.as<long long>(), nz, poff, pcols, (const int *)nullptr, 0, 0);
+        hipLaunchKernelGGL(k, grid, dim3(T), lds, s, rows, n, next_row, N2, K, wsplit, arpt, acol, brpt, wcol, row_flop.as<long long>(), nz, poff, pcols, (const int *)nullptr, 0, 0);
         return G4S_OK;
     };
     SortedRows sorted[3];                                          // live until the stream is synchronised below
@@ -1931,7 +2109,9 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
         G4S_TRY(allow_lds(k, sym_lds_bytes(1, 16384)));
         hipLaunchKernelGGL(k, dim3(n), dim3(256), sym_lds_bytes(1, 16384), s, rc.list(CLS_MEDIUM), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr);
     }
-    if (x_large) { G4S_TRY(window(t_large, rc.list(CLS_LARGE), rc.count[CLS_LARGE], pre_off, pre_cols, true)); }
+    const bool one_long_launch = x_large && t_large == t_win && !getenv("G4S_SPGEMM_SPLIT_LONG");   // LARGE and M2 share a shape and their lists are adjacent: one launch
+    if (one_long_launch) { G4S_TRY(window(t_large, rc.list(CLS_LARGE), rc.count[CLS_LARGE] + rc.count[CLS_M2], pre_off, pre_cols, true)); }
+    else if (x_large) { G4S_TRY(window(t_large, rc.list(CLS_LARGE), rc.count[CLS_LARGE], pre_off, pre_cols, true)); }
     else if (int n = rc.count[CLS_LARGE]) {
         auto k = spgemm_symbolic_lds_kernel<1024, 1024, 32768, true>;
         G4S_TRY(allow_lds(k, sym_lds_bytes(1, 32768)));
@@ -1942,12 +2122,14 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
 
     // rows too wide for a key table in LDS: the rows whose optimistic table filled up, and the window class → LDS bitmap windows
     int n_ovf = 0;
-    G4S_HIP_TRY(hipMemcpyAsync(&n_ovf, ovf_count.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    G4S_HIP_TRY(hipStreamSynchronize(s));
-    if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s symbolic: %d optimistic tables overflowed, %d window-class rows\n", n_ovf, rc.count[CLS_M2]);
-    G4S_TRY(window(1024, ovf_rows.as<int>(), n_ovf, nullptr, nullptr));   // rows of the optimistic table class are not in the scratch
+    if (!x_large) {                                                // (only the optimistic table kernel can overflow)
+        G4S_HIP_TRY(hipMemcpyAsync(&n_ovf, ovf_count.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        G4S_HIP_TRY(hipStreamSynchronize(s));
+        if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s symbolic: %d optimistic tables overflowed, %d window-class rows\n", n_ovf, rc.count[CLS_M2]);
+        G4S_TRY(window(1024, ovf_rows.as<int>(), n_ovf, nullptr, nullptr));   // rows of the optimistic table class are not in the scratch
+    }
     if (pre) pre->complete = pre_off != nullptr && n_ovf == 0 && rc.count[CLS_HUB] == 0 && x_med && x_large;
-    G4S_TRY(window(t_win, rc.list(CLS_M2), rc.count[CLS_M2], pre_off, pre_cols, true));
+    if (!one_long_launch) G4S_TRY(window(t_win, rc.list(CLS_M2), rc.count[CLS_M2], pre_off, pre_cols, true));
     G4S_HIP_TRY(hipGetLastError());
     // hub rows (flop > 2 M): many workgroups per row on a bitmap in HBM
     std::vector<int> hub, ranges;
