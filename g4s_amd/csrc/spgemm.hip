@@ -364,17 +364,19 @@ template <int WGSIZE, int THREADS, int TABLE, bool OPTIMISTIC>
 __global__ __launch_bounds__(WGSIZE) void spgemm_symbolic_lds_kernel(
     const int *__restrict__ rows, int nrows, const int *__restrict__ arpt, const int *__restrict__ acol,
     const int *__restrict__ brpt, const int *__restrict__ bcol, const long long *__restrict__ row_flop, int *__restrict__ row_nz,
-    int *__restrict__ overflow_rows, int *__restrict__ overflow_count)
+    int *__restrict__ overflow_rows, int *__restrict__ overflow_count, const int *__restrict__ nrows_dev = nullptr /* not NULL: the row count lives on the device and the grid strides */)
 {
     extern __shared__ int lds_i[];
     constexpr int RPB = WGSIZE / THREADS;           // rows per workgroup
+    if (nrows_dev) nrows = *nrows_dev;
+    for (int blk = blockIdx.x; blk * RPB < nrows; blk += gridDim.x) {
     constexpr int MAX_PROBES = OPTIMISTIC ? 512 : TABLE;   // optimistic tables give up when a probe sequence gets long, i.e. before they are full
     // Dynamic LDS only (a static array in front would break the 16-byte alignment of the int4 list, Guideline 17):
     // [tables: RPB·TABLE ints][long-B list: (kLongCap+1) int4, RPB == 1 only][s_cnt: RPB ints][s_ovf: RPB ints]
     int *s_cnt = lds_i + RPB * TABLE + (RPB == 1 ? 4 * (kLongCap + 1) : 0);
     int *s_ovf = s_cnt + RPB;
     const int sub = threadIdx.x / THREADS, t = threadIdx.x % THREADS;
-    const int ridx = blockIdx.x * RPB + sub;
+    const int ridx = blk * RPB + sub;
     const int row = ridx < nrows ? rows[ridx] : -1;
     int *T = lds_i + sub * TABLE;
     int4 *longs = reinterpret_cast<int4 *>(lds_i + RPB * TABLE);   // RPB == 1 kernels only (TABLE·4 bytes is a multiple of 16)
@@ -424,18 +426,22 @@ __global__ __launch_bounds__(WGSIZE) void spgemm_symbolic_lds_kernel(
         if (OPTIMISTIC && s_ovf[sub]) overflow_rows[atomicAdd(overflow_count, 1)] = row;   // no abort ⇒ every key was inserted ⇒ the count is exact
         else row_nz[row] = total;
     }
+    __syncthreads();                                               // the tables are re-initialised by the next round
+    }
 }
 
 template <int WGSIZE, int THREADS, int TABLE>
 __global__ __launch_bounds__(WGSIZE) void spgemm_numeric_lds_kernel(
     const int *__restrict__ rows, int nrows, const int *__restrict__ arpt, const int *__restrict__ acol, const double *__restrict__ aval,
     const int *__restrict__ brpt, const int *__restrict__ bcol, const double *__restrict__ bval, const long long *__restrict__ row_flop,
-    const int *__restrict__ crpt, int *__restrict__ ccol, double *__restrict__ cval)
+    const int *__restrict__ crpt, int *__restrict__ ccol, double *__restrict__ cval, const int *__restrict__ nrows_dev = nullptr /* see the symbolic kernel */)
 {
     extern __shared__ int lds_i[];
     constexpr int RPB = WGSIZE / THREADS;
+    if (nrows_dev) nrows = *nrows_dev;
+    for (int blk = blockIdx.x; blk * RPB < nrows; blk += gridDim.x) {
     const int sub = threadIdx.x / THREADS, t = threadIdx.x % THREADS;
-    const int ridx = blockIdx.x * RPB + sub;
+    const int ridx = blk * RPB + sub;
     const int row = ridx < nrows ? rows[ridx] : -1;
     // layout: all fp64 value tables first (8-byte aligned), then the key tables
     double *V = reinterpret_cast<double *>(lds_i) + sub * TABLE;
@@ -529,6 +535,8 @@ __global__ __launch_bounds__(WGSIZE) void spgemm_numeric_lds_kernel(
         }
         for (int s2 = t; s2 < nz; s2 += THREADS) { ccol[off + s2] = K[s2]; cval[off + s2] = V[s2]; }
     }
+    __syncthreads();                                               // the tables are re-initialised by the next round
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ big rows, all in LDS
@@ -601,6 +609,120 @@ __device__ __forceinline__ unsigned wave_inclusive_sum(unsigned x)
     x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 → rows 1 and 3
     x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 → rows 2 and 3
     return x;
+}
+
+// ------------------------------------------------------------------------------------------------ short rows: one wavefront merges the row (round 4)
+// Rows of at most kSmallCap products (47 % of the non-empty rows of R-MAT-21, 1.3 % of its products) used to take a 256-thread workgroup each: a 1 K-slot hash
+// table, then — numeric — a compaction and a bitonic sort between 45 barriers (2.0 ms for 31 M products; symbolic 0.6 ms). Such a row is a handful of A-entries
+// (2.2 on average) pointing at SORTED B rows, so one wavefront merges them instead, no block barrier anywhere:
+//   1. the row's products go to LDS run by run (a run = one B row; coalesced loads), values multiplied;
+//   2. every product finds its place in the merged order by rank: its index in its own run + the number of smaller columns in every other run (binary
+//      searches in LDS; equal columns keep the order of their runs);
+//   3. equal neighbours are one output column: the first of them adds the others up — in run order, i.e. in the reference's (j outer, k inner) order
+//      (hash_mult.h:583-593), so these rows come out BIT-IDENTICAL to the oracle — and a ballot places the row's columns.
+// Duplicate columns inside one B row are merged like any others. A row that does not fit (more than 64 A-entries, or more products than the cap — the numeric
+// classes are cut by output length, not by products) is appended to a list that the table kernels take afterwards.
+constexpr int kSmallCap = 512;
+template <bool NUMERIC>
+constexpr int small_wave_ints() { return kSmallCap + (NUMERIC ? 2 * kSmallCap : 0) + kSmallCap / 2; }   // columns | products (fp64) | source index per rank (u16)
+template <bool NUMERIC>
+__global__ __launch_bounds__(256) void spgemm_small_wave_kernel(
+    const int *__restrict__ rows, int nrows, const int *__restrict__ arpt, const int *__restrict__ acol, const double *__restrict__ aval,
+    const int *__restrict__ brpt, const int *__restrict__ bcol, const double *__restrict__ bval,
+    int *__restrict__ row_nz /* symbolic: out */, const int *__restrict__ crpt, int *__restrict__ ccol, double *__restrict__ cval,
+    int *__restrict__ ovf_rows, int *__restrict__ ovf_count)
+{
+    extern __shared__ int lds_i[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int *Cin = lds_i + wave * small_wave_ints<NUMERIC>();
+    double *Vin = reinterpret_cast<double *>(Cin + kSmallCap);      // (byte offset a multiple of 8: every region is)
+    unsigned short *Src = reinterpret_cast<unsigned short *>(Cin + kSmallCap + (NUMERIC ? 2 * kSmallCap : 0));
+    const int ridx = blockIdx.x * 4 + wave;
+    if (ridx >= nrows) return;                                     // (no block barrier in this kernel: waves come and go on their own)
+    const int row = rows[ridx];
+    const int a0 = arpt[row], na = arpt[row + 1] - a0;
+    int b0 = 0, len = 0;
+    double av = 0.0;
+    if (lane < na) {
+        const int c = acol[a0 + lane];
+        b0 = brpt[c];
+        len = brpt[c + 1] - b0;
+        if (NUMERIC) av = aval[a0 + lane];
+    }
+    const int incl = (int)wave_inclusive_sum((unsigned)len), P = incl - len;
+    const int flop = __builtin_amdgcn_readlane(incl, 63);
+    if (na > 64 || flop > kSmallCap) {                             // uniform
+        if (lane == 0) ovf_rows[atomicAdd(ovf_count, 1)] = row;
+        return;
+    }
+    auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    auto run = [&](int e, int &rb0, int &rlen, int &rP, double &rav) {   // uniform e: the run's data out of its lane
+        rb0 = __builtin_amdgcn_readlane(b0, e); rlen = __builtin_amdgcn_readlane(len, e); rP = __builtin_amdgcn_readlane(P, e);
+        if (NUMERIC) {
+            const long long bits = __double_as_longlong(av);
+            const int lo = __builtin_amdgcn_readlane((int)(bits & 0xFFFFFFFFll), e), hi = __builtin_amdgcn_readlane((int)(bits >> 32), e);
+            rav = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+        }
+    };
+    // 1. products → LDS, run by run
+    for (int e = 0; e < na; ++e) {
+        int rb0, rlen, rP;
+        double rav = 0.0;
+        run(e, rb0, rlen, rP, rav);
+        for (int k = lane; k < rlen; k += 64) {
+            Cin[rP + k] = bcol[rb0 + k];
+            if (NUMERIC) Vin[rP + k] = rav * bval[rb0 + k];         // multop, hash_mult.h:583
+        }
+    }
+    wave_sync();
+    // 2. rank of every product in the merged order
+    for (int e = 0; e < na; ++e) {
+        int rb0, rlen, rP;
+        double rav;
+        run(e, rb0, rlen, rP, rav);
+        for (int k = lane; k < rlen; k += 64) {
+            const int col = Cin[rP + k];
+            int rank = k;
+            for (int e2 = 0; e2 < na; ++e2) {
+                const int l2 = __builtin_amdgcn_readlane(len, e2), P2 = __builtin_amdgcn_readlane(P, e2);
+                if (e2 == e || l2 == 0) continue;                  // uniform
+                int lo = 0, hi = l2;                               // entries of run e2 in front of this one: smaller columns, and equal ones of an earlier run
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1, v = Cin[P2 + mid];
+                    const bool before = e2 < e ? v <= col : v < col;
+                    lo = before ? mid + 1 : lo;
+                    hi = before ? hi : mid;
+                }
+                rank += lo;
+            }
+            Src[rank] = (unsigned short)(rP + k);
+        }
+    }
+    wave_sync();
+    // 3. equal neighbours → one column; place the columns
+    const int off = NUMERIC ? crpt[row] : 0;
+    int base = 0;
+    for (int i0 = 0; i0 < flop; i0 += 64) {
+        const int i = i0 + lane;
+        const bool valid = i < flop;
+        const int sidx = valid ? Src[i] : 0, col = Cin[sidx];
+        const int prev = (valid && i > 0) ? Cin[Src[i - 1]] : -1;
+        const bool head = valid && (i == 0 || col != prev);
+        const unsigned long long mask = __ballot(head);
+        if (NUMERIC && head) {
+            double sum = Vin[sidx];
+            for (int m = i + 1; m < flop; ++m) {                   // addop in run order, hash_mult.h:588-593
+                const int s2 = Src[m];
+                if (Cin[s2] != col) break;
+                sum += Vin[s2];
+            }
+            const int o = off + base + __popcll(mask & ((1ull << lane) - 1ull));
+            ccol[o] = col;
+            cval[o] = sum;
+        }
+        base += __popcll(mask);
+    }
+    if (!NUMERIC && lane == 0) row_nz[row] = base;
 }
 
 // Window splits. B's rows are sorted by column, so the entries of row c that fall into bitmap window w are one contiguous piece:
@@ -2005,13 +2127,29 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     G4S_HIP_TRY(hipMemsetAsync(ovf_count.p, 0, sizeof(int), s));
     int *nz = row_nz.as<int>();
 
+    // rows of at most 512 products (the tiny and the small class: their lists are adjacent): one wavefront merges a row (spgemm_small_wave_kernel); what does not
+    // fit it (more than 64 A-entries) lands on a list that the table kernel takes, its count read on the device
+    DevBuf small_ovf, small_ovf_n;
+    const bool use_wave = !getenv("G4S_SPGEMM_NO_WAVE_ROWS");
+    if (int n = rc.count[CLS_TINY] + rc.count[CLS_SMALL]; n && use_wave) {
+        G4S_TRY(small_ovf.alloc(sizeof(int) * (size_t)n));
+        G4S_TRY(small_ovf_n.alloc(sizeof(int)));
+        G4S_HIP_TRY(hipMemsetAsync(small_ovf_n.p, 0, sizeof(int), s));
+        auto k = spgemm_small_wave_kernel<false>;
+        hipLaunchKernelGGL(k, dim3((n + 3) / 4), dim3(256), sizeof(int) * 4 * small_wave_ints<false>(), s, rc.list(CLS_TINY), n, arpt, acol, (const double *)nullptr, brpt, bcol,
+                           (const double *)nullptr, nz, (const int *)nullptr, (int *)nullptr, (double *)nullptr, small_ovf.as<int>(), small_ovf_n.as<int>());
+        auto k2 = spgemm_symbolic_lds_kernel<256, 256, 1024, false>;
+        hipLaunchKernelGGL(k2, dim3(std::min(n, 256)), dim3(256), sym_lds_bytes(1, 1024), s, small_ovf.as<int>(), 0, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr,
+                           (const int *)small_ovf_n.as<int>());
+    } else {
     if (int n = rc.count[CLS_TINY]) {
         auto k = spgemm_symbolic_lds_kernel<256, 64, 64, false>;
-        hipLaunchKernelGGL(k, dim3((n + 3) / 4), dim3(256), sym_lds_bytes(4, 64), s, rc.list(CLS_TINY), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr);
+        hipLaunchKernelGGL(k, dim3((n + 3) / 4), dim3(256), sym_lds_bytes(4, 64), s, rc.list(CLS_TINY), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr, (const int *)nullptr);
     }
     if (int n = rc.count[CLS_SMALL]) {
         auto k = spgemm_symbolic_lds_kernel<256, 256, 1024, false>;
-        hipLaunchKernelGGL(k, dim3(n), dim3(256), sym_lds_bytes(1, 1024), s, rc.list(CLS_SMALL), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr);
+        hipLaunchKernelGGL(k, dim3(n), dim3(256), sym_lds_bytes(1, 1024), s, rc.list(CLS_SMALL), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr, (const int *)nullptr);
+    }
     }
     // Up to kWindowMaxN columns (4 bitmap windows) the window kernel beats the key tables for every row past 512 products (it has no
     // probe chains and cannot overflow); with more windows each row would re-walk its products once per window, so tables take over.
@@ -2107,7 +2245,7 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     else if (int n = rc.count[CLS_MEDIUM]) {
         auto k = spgemm_symbolic_lds_kernel<256, 256, 16384, false>;
         G4S_TRY(allow_lds(k, sym_lds_bytes(1, 16384)));
-        hipLaunchKernelGGL(k, dim3(n), dim3(256), sym_lds_bytes(1, 16384), s, rc.list(CLS_MEDIUM), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr);
+        hipLaunchKernelGGL(k, dim3(n), dim3(256), sym_lds_bytes(1, 16384), s, rc.list(CLS_MEDIUM), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr, (const int *)nullptr);
     }
     const bool one_long_launch = x_large && t_large == t_win && !getenv("G4S_SPGEMM_SPLIT_LONG");   // LARGE and M2 share a shape and their lists are adjacent: one launch
     if (one_long_launch) { G4S_TRY(window(t_large, rc.list(CLS_LARGE), rc.count[CLS_LARGE] + rc.count[CLS_M2], pre_off, pre_cols, true)); }
@@ -2116,7 +2254,7 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
         auto k = spgemm_symbolic_lds_kernel<1024, 1024, 32768, true>;
         G4S_TRY(allow_lds(k, sym_lds_bytes(1, 32768)));
         hipLaunchKernelGGL(k, dim3(n), dim3(1024), sym_lds_bytes(1, 32768), s, rc.list(CLS_LARGE), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, ovf_rows.as<int>(),
-                           ovf_count.as<int>());
+                           ovf_count.as<int>(), (const int *)nullptr);
     }
     G4S_HIP_TRY(hipGetLastError());
 
@@ -2197,13 +2335,28 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
                 rc.count[CLS_SMALL], rc.count[CLS_MEDIUM], rc.count[CLS_LARGE], rc.count[CLS_M2], rc.count[CLS_M3], rc.count[CLS_HUB]);
 
     dbg.mark("classes");
+    // rows of at most 512 outputs: one wavefront merges a row (spgemm_small_wave_kernel); a row of more than 512 PRODUCTS (the classes are cut by output length) or
+    // more than 64 A-entries lands on a list that the table kernel takes, its count read on the device
+    DevBuf small_ovf, small_ovf_n;
+    if (int n = rc.count[CLS_TINY] + rc.count[CLS_SMALL]; n && !getenv("G4S_SPGEMM_NO_WAVE_ROWS")) {
+        G4S_TRY(small_ovf.alloc(sizeof(int) * (size_t)n));
+        G4S_TRY(small_ovf_n.alloc(sizeof(int)));
+        G4S_HIP_TRY(hipMemsetAsync(small_ovf_n.p, 0, sizeof(int), s));
+        auto k = spgemm_small_wave_kernel<true>;
+        hipLaunchKernelGGL(k, dim3((n + 3) / 4), dim3(256), sizeof(int) * 4 * small_wave_ints<true>(), s, rc.list(CLS_TINY), n, arpt, acol, aval, brpt, bcol, bval, (int *)nullptr, crpt, ccol, cval,
+                           small_ovf.as<int>(), small_ovf_n.as<int>());
+        auto k2 = spgemm_numeric_lds_kernel<256, 256, 1024>;
+        hipLaunchKernelGGL(k2, dim3(std::min(n, 256)), dim3(256), num_lds_bytes(1024), s, small_ovf.as<int>(), 0, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval,
+                           (const int *)small_ovf_n.as<int>());
+    } else {
     if (int n = rc.count[CLS_TINY]) {
         auto k = spgemm_numeric_lds_kernel<256, 64, 64>;
-        hipLaunchKernelGGL(k, dim3((n + 3) / 4), dim3(256), 4 * 64 * 12, s, rc.list(CLS_TINY), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
+        hipLaunchKernelGGL(k, dim3((n + 3) / 4), dim3(256), 4 * 64 * 12, s, rc.list(CLS_TINY), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval, (const int *)nullptr);
     }
     if (int n = rc.count[CLS_SMALL]) {
         auto k = spgemm_numeric_lds_kernel<256, 256, 1024>;
-        hipLaunchKernelGGL(k, dim3(n), dim3(256), num_lds_bytes(1024), s, rc.list(CLS_SMALL), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
+        hipLaunchKernelGGL(k, dim3(n), dim3(256), num_lds_bytes(1024), s, rc.list(CLS_SMALL), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval, (const int *)nullptr);
+    }
     }
     ColumnMap local_map;                                           // see spgemm_symbolic_impl; the one-shot call hands its map over
     if (!pre) {
@@ -2342,19 +2495,19 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
     if (t_med && xn_large) { G4S_TRY(big(t_med, rc.list(CLS_MEDIUM), rc.count[CLS_MEDIUM])); }
     else if (int n = rc.count[CLS_MEDIUM]) {
         auto k = spgemm_numeric_lds_kernel<256, 256, 2048>;
-        hipLaunchKernelGGL(k, dim3(n), dim3(256), num_lds_bytes(2048), s, rc.list(CLS_MEDIUM), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
+        hipLaunchKernelGGL(k, dim3(n), dim3(256), num_lds_bytes(2048), s, rc.list(CLS_MEDIUM), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval, (const int *)nullptr);
     }
     if (xn_large) { G4S_TRY(big(t_large, rc.list(CLS_LARGE), rc.count[CLS_LARGE])); }
     else if (int n = rc.count[CLS_LARGE]) {
         auto k = spgemm_numeric_lds_kernel<512, 512, 4096>;
         G4S_TRY(allow_lds(k, num_lds_bytes(4096)));
-        hipLaunchKernelGGL(k, dim3(n), dim3(512), num_lds_bytes(4096), s, rc.list(CLS_LARGE), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
+        hipLaunchKernelGGL(k, dim3(n), dim3(512), num_lds_bytes(4096), s, rc.list(CLS_LARGE), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval, (const int *)nullptr);
     }
     if (xn_m2) { G4S_TRY(big(t_m2, rc.list(CLS_M2), rc.count[CLS_M2])); }
     else if (int n = rc.count[CLS_M2]) {
         auto k = spgemm_numeric_lds_kernel<1024, 1024, 8192>;
         G4S_TRY(allow_lds(k, num_lds_bytes(8192)));
-        hipLaunchKernelGGL(k, dim3(n), dim3(1024), num_lds_bytes(8192), s, rc.list(CLS_M2), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval);
+        hipLaunchKernelGGL(k, dim3(n), dim3(1024), num_lds_bytes(8192), s, rc.list(CLS_M2), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval, (const int *)nullptr);
     }
     }
     dbg.mark("mid-launch");
