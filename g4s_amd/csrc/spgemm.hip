@@ -2518,6 +2518,9 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         else {
             // The class spans 4 K … 1 M outputs per row (a 250-fold range of work): longest rows first, handed out one at a time.
             SortedRows sr;
+            // (round 4 tried a clustered order instead — the rows past 64 K outputs longest first, the rest by their first column id, i.e. by the long B row most of
+            // their products come from, so that consecutive tickets find it in L2: 14.62 against 14.74 ms for the kernel, nothing for the call. B-row misses are
+            // not what this kernel waits for.)
             G4S_TRY(sr.build(n, rc.list(CLS_M3), nullptr, crpt, N, s));   // a row has at most N outputs
             G4S_TRY(big(m3_cut <= 0 ? t_m3 : 1024, sr.rows.as<int>(), n, 0, INT_MAX, sr.counter.as<int>()));   // (G4S_SPGEMM_M3_CUT=0 + G4S_SPGEMM_T_NUM_M3: the whole class in another shape)
             G4S_HIP_TRY(hipStreamSynchronize(s));                 // the sorted list and the counter die with this block
