@@ -1,11 +1,18 @@
 // g4s/graph.hpp — the vertex-centric graph programming interface of deepmd/source/op/graph.h:5-32, over the C-ABI.
 //   struct Graph { numNodes, degree, edgeWeight, states, temp }      graph.h:5-11
 //   GraphProcess(graph, result, gather, apply)                       graph.h:21-32
-// The reference runs the callbacks on 8 OpenMP threads; a GPU cannot call host code, so GraphProcess takes the descriptor of
-// the pattern the callbacks implement (one of the three that exist in the reference, include/g4s.h) and runs that pattern's
-// kernel. The callbacks stay in the signature so call sites keep their shape; they are not invoked.
+// Two spellings:
+//   * GraphProcess(graph, result, gather, apply) — the reference's own, global, four arguments (graph.h:21): a call site such as
+//     deepmd/source/op/opt_matmul.cc:51 compiles against this header unchanged. std::function callbacks are host code the device cannot run and
+//     carry no identity a pattern could be registered under, so this form gives them the interface's own semantics: the reference's driver loop
+//     (for every vertex: gather for each neighbour slot, then apply) on the host, through g4s_spmm_dense's path for unregistered pairs — one thread
+//     in ascending vertex order by default, 8 threads (the reference's hard-coded count, graph.h:23) with vertices handed out one at a time when the
+//     caller has declared its gathers race-free, or refusal: g4s_set_host_callback_policy (include/g4s.h).
+//   * g4s::GraphProcess(graph, result, gather, apply, pattern[, seconds]) — the device form: the descriptor says which of the three patterns the
+//     callbacks implement and that pattern's kernel runs; the callbacks stay in the signature so the call keeps its shape, they are not invoked.
 #pragma once
 #include <functional>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include "../g4s.h"
@@ -24,6 +31,17 @@ namespace g4s {
 namespace detail {
 inline void key_gather(int, int, const double **, const double *, double *) {}
 inline void key_apply(int, const double **, const double *, double *) {}
+// The C-ABI's callbacks are plain function pointers without a user-data argument: the std::function pair of the call in progress sits behind one
+// process-wide slot (calls from several threads take turns; the library's worker threads read the same slot).
+struct HostCall {
+    struct Graph *graph;
+    const std::function<void(int, int, struct Graph *, double *)> *gather;
+    const std::function<void(int, struct Graph *, double *)> *apply;
+};
+inline HostCall *&host_call() { static HostCall *p = nullptr; return p; }
+inline std::mutex &host_call_mutex() { static std::mutex m; return m; }
+inline void tramp_gather(int vi, int nb, const double **, const double *, double *result) { HostCall *c = host_call(); (*c->gather)(vi, nb, c->graph, result); }
+inline void tramp_apply(int vi, const double **, const double *, double *result) { HostCall *c = host_call(); if (*c->apply) (*c->apply)(vi, c->graph, result); }
 } // namespace detail
 
 inline void GraphProcess(struct Graph *graph, double *result,
@@ -40,3 +58,16 @@ inline void GraphProcess(struct Graph *graph, double *result,
     if (st != G4S_OK) throw std::runtime_error(std::string("GraphProcess: ") + g4s_last_error());
 }
 } // namespace g4s
+
+// The reference's spelling (deepmd/source/op/graph.h:21-32), global like there.
+inline void GraphProcess(struct Graph *graph, double *result, std::function<void(int, int, struct Graph *, double *)> gather,
+                         std::function<void(int, struct Graph *, double *)> apply)
+{
+    std::lock_guard<std::mutex> turn(g4s::detail::host_call_mutex());
+    g4s::detail::HostCall call{graph, &gather, &apply};
+    g4s::detail::host_call() = &call;
+    const g4s_status st = g4s_spmm_dense((uint32_t)getNumNodes(graph), (uint32_t)graph->degree, graph->edgeWeight, graph->states, graph->temp, result,
+                                         &g4s::detail::tramp_gather, &g4s::detail::tramp_apply, nullptr, 8 /* graph.h:23 */);
+    g4s::detail::host_call() = nullptr;
+    if (st != G4S_OK) throw std::runtime_error(std::string("GraphProcess: ") + g4s_last_error());
+}

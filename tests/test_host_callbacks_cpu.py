@@ -154,3 +154,27 @@ def test_refusal_stays_reachable(g4s):
     finally:
         g4s.g4s_set_host_callback_policy(capi.HOST_CALLBACKS_SERIAL)
     assert g4s.g4s_set_host_callback_policy(7) == capi.ERR_INVALID
+
+
+def test_four_argument_graphprocess_is_the_reference_spelling(tmp_path, ref):
+    """include/g4s/graph.hpp's global GraphProcess(graph, result, gather, apply) — the signature of deepmd/source/op/graph.h:21, std::function callbacks, no
+    descriptor — in a C++ program that builds the OptMatmul graph the way deepmd/source/op/opt_matmul.cc:43-61 does: against the reference's own GraphProcess
+    (oracle/_ref) bit for bit, serial and with the race-free declaration; the refusal policy surfaces as an exception."""
+    import subprocess
+    lib = os.path.join(ROOT, "g4s_amd", "lib")
+    exe = str(tmp_path / "graph_process_host")
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "graph_process_host.cpp"),
+                           "-L" + lib, "-lg4s_hip", "-Wl,-rpath," + lib, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-pthread", "-o", exe])
+    rng = np.random.default_rng(23)
+    M, N, K = 257, 19, 7
+    xx, w = rng.uniform(-1, 1, (M, N)), rng.uniform(-1, 1, (N, K))
+    want = np.zeros(M * K)
+    ref.ref_graph_process_dense(M, N, K, xx.ravel(), w.ravel(), want)
+    payload = f"{M} {N} {K}\n".encode() + xx.tobytes() + w.tobytes()
+    for mode in ("serial", "parallel"):
+        out = subprocess.run([exe, mode], input=payload, capture_output=True, timeout=120)
+        assert out.returncode == 0, out.stderr.decode()
+        got = np.frombuffer(out.stdout, dtype=np.float64)
+        assert np.array_equal(got, want), mode
+    out = subprocess.run([exe, "refuse"], input=payload, capture_output=True, timeout=120)
+    assert out.returncode == 3 and b"refused" in out.stderr
