@@ -13,6 +13,7 @@
 // D2H round trip per iteration (62 → see DESIGN.md §4.4 µs per Cookbook2 iteration).
 #include "common.hpp"
 #include "cg_async.hpp"
+namespace g4s { int64_t dist_smallest_slab(g4s_spmv_dist_t h); }   // dist.hip
 #include <algorithm>
 #include <cmath>
 #include <functional>
@@ -562,7 +563,11 @@ G4S_API g4s_status g4s_conj_grad_dist_tr(g4s_spmv_dist_t A, const g4s_transport 
                                          int32_t n_zero, const double *F_dev, double *d0_dev, double acc, int32_t steps, int32_t *cycles, double *residual,
                                          void *stream)
 {
-    G4S_REQUIRE(A && tr && tr->allreduce_sum_f64 && BI_dev && F_dev && d0_dev, "NULL argument");
+    G4S_REQUIRE(A && tr && tr->allreduce_sum_f64, "NULL argument");
+    // every rank sees the same partition: an empty slab is refused by ALL ranks here, in front of the first collective (a rank that returned alone would leave
+    // the others waiting in it)
+    G4S_REQUIRE(g4s::dist_smallest_slab(A) > 0, "every rank of the partition must own at least one row");
+    G4S_REQUIRE(BI_dev && F_dev && d0_dev, "NULL argument");
     G4S_REQUIRE(n_local > 0 && n_zero >= 0 && (n_zero == 0 || zero_resid_dev), "bad size");
     g4s_cg_ws_t ws = nullptr;
     G4S_TRY(g4s_cg_ws_create(&ws, n_local));

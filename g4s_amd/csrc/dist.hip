@@ -46,6 +46,7 @@ struct Rccl {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;   // optional
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                            // optional
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -74,6 +75,7 @@ int rccl_load()
     G4S_RCCL_SYM(AllGather, "ncclAllGather")
 #undef G4S_RCCL_SYM
     r.CommGetAsyncError = reinterpret_cast<decltype(r.CommGetAsyncError)>(dlsym(h, "ncclCommGetAsyncError"));
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(h, "ncclCommAbort"));
     g_rccl = r;
     return G4S_OK;
 }
@@ -88,6 +90,13 @@ int rccl_load()
 __global__ void dist_pack_kernel(long long n, const int32_t *__restrict__ idx, const double *__restrict__ x, double *__restrict__ send)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) send[i] = x[idx[i]];
+}
+
+// test hook: keeps a stream busy for a bounded number of 100 MHz ticks, then leaves
+__global__ void dist_stall_kernel(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
 }
 
 // y[rows[i]] += t[i]: the remote-column part of the few rows that have one
@@ -113,8 +122,8 @@ struct g4s_spmv_dist_s {
     int64_t nnz_own = 0, nnz_rem = 0;
     g4s_csr_t A_own = nullptr, A_rem = nullptr;
     int32_t n_ref = 0;
-    std::vector<int64_t> recv_cut;              // world+1: segment [recv_cut[k], recv_cut[k+1]) of x_rem belongs to owner k
-    std::vector<int64_t> give_cut;              // world+1: segment of the send buffer that goes to peer k
+    std::vector<int64_t> recv_cut;              // nseg+1 (= world+1 outside loopback): segment [recv_cut[k], recv_cut[k+1]) of x_rem belongs to owner k
+    std::vector<int64_t> give_cut;              // nseg+1: segment of the send buffer that goes to peer k
     std::vector<char> give_set;
     int32_t *d_want = nullptr;                  // n_ref indices, local to their owner's slab (what this rank asks for), in x_rem order
     int32_t *d_give = nullptr;                  // indices into x_local, concatenated per peer
@@ -128,6 +137,8 @@ struct g4s_spmv_dist_s {
     hipEvent_t ev_packed = nullptr, ev_done = nullptr;
     ncclComm_t comm = nullptr;
     bool exchange_posted = false;
+    bool poisoned = false;                      // a set-up exchange timed out or RCCL reported an asynchronous error: the communicator has been aborted, operations on the
+                                                // side stream may never complete. Nothing of this handle is synchronised or freed on the device any more (see dist_poison)
 };
 
 namespace {
@@ -135,6 +146,7 @@ namespace {
 void dist_release(g4s_spmv_dist_s *h)
 {
     if (!h) return;
+    if (h->poisoned) { delete h; return; }      // hipFree / hipStreamDestroy synchronise with work that may never finish: the device memory is left to the process's exit
     if (h->A_own) g4s_csr_destroy(h->A_own);
     if (h->A_rem) g4s_csr_destroy(h->A_rem);
     (void)hipFree(h->d_want); (void)hipFree(h->d_give); (void)hipFree(h->d_send); (void)hipFree(h->d_xrem); (void)hipFree(h->d_rem_rows); (void)hipFree(h->d_rem_y);
@@ -375,7 +387,7 @@ G4S_API g4s_status g4s_spmv_dist_create_rect(g4s_spmv_dist_t *out, int32_t rank,
         if (st != G4S_OK) return fail(st);
         // remote-column part: only the rows that have one, when they are under a quarter of the slab (never in the merged form, whose one product writes all of y)
         std::vector<int32_t> rem_rows;
-        if (!h->merged && h->nnz_rem > 0 && !getenv("G4S_DIST_NO_ROW_COMPACTION")) {
+        if (!h->merged && h->nnz_rem > 0) {
             for (int32_t i = 0; i < m; ++i)
                 if (S.rrp[(size_t)i + 1] > S.rrp[i]) rem_rows.push_back(i);
             if ((int64_t)rem_rows.size() * 4 >= m) rem_rows.clear();
@@ -428,7 +440,7 @@ G4S_API g4s_status g4s_spmv_dist_create(g4s_spmv_dist_t *out, int32_t rank, int3
 
 G4S_API g4s_status g4s_spmv_dist_destroy(g4s_spmv_dist_t h)
 {
-    if (h) (void)hipDeviceSynchronize();
+    if (h && !h->poisoned) (void)hipDeviceSynchronize();
     dist_release(h);
     return G4S_OK;
 }
@@ -445,8 +457,9 @@ G4S_API g4s_status g4s_spmv_dist_get_info(g4s_spmv_dist_t h, g4s_spmv_dist_info 
         info->recv_bytes = 8 * (h->recv_cut[h->nseg] - (h->merged ? h->recv_cut[(size_t)h->rank + 1] - h->recv_cut[h->rank] : 0));
         info->send_bytes = 8 * h->give_cut[h->nseg];
     }
-    info->reserved = (h->merged ? 1 : 0) | (h->allgather ? 2 : 0);
+    info->reserved = (h->merged ? 1 : 0) | (h->allgather ? 2 : 0) | (h->poisoned ? 4 : 0);
     g4s_csr_info ci;
+    if (h->poisoned) { info->own_path = info->rem_path = 0; info->connected = 0; return G4S_OK; }
     G4S_TRY(g4s_csr_get_info(h->A_own, &ci)); info->own_path = ci.spmv_path;
     G4S_TRY(g4s_csr_get_info(h->A_rem, &ci)); info->rem_path = ci.spmv_path;
     int ready = 1;
@@ -515,7 +528,8 @@ int wait_stream(hipStream_t stream, ncclComm_t comm, const char *what)
                 return g4s::set_error(G4S_ERR_HIP, "%s: RCCL reports %s", what, g_rccl.GetErrorString(ar));
         }
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
-            return g4s::set_error(G4S_ERR_HIP, "%s: no completion within %.0f s (a peer that never entered the exchange?)", what, limit);
+            return g4s::set_error(G4S_ERR_HIP, "%s: no completion within %.3g s (a peer that never entered the exchange?); the communicator has been aborted, the handle is "
+                                               "unusable: report and exit the process", what, limit);
         std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
 }
@@ -539,6 +553,20 @@ struct DevFree {
     ~DevFree() { if (p) (void)hipFree(p); }
 };
 
+// A set-up exchange did not complete (deadline, or an asynchronous RCCL error): the grouped send / receive is still queued on the side stream and hipFree,
+// hipStreamDestroy and hipDeviceSynchronize all wait for it — the time-out would only move the hang. So: abort the communicator (ncclCommAbort makes RCCL's
+// kernels leave), mark the handle, and from here on free and synchronise nothing that belongs to it (g4s_spmv_dist_destroy then only drops the host side).
+// The communicator is gone after this; the process is expected to report the error and EXIT — a supervisor starts a fresh process (never a re-exec of one
+// that has touched the GPU).
+int dist_poison(g4s_spmv_dist_s *h, DevFree &in_flight, int st)
+{
+    h->poisoned = true;
+    in_flight.p = nullptr;                                         // deliberately leaked: the stuck operation may still read or write it
+    if (h->comm && g_rccl.CommAbort) (void)g_rccl.CommAbort(h->comm);
+    h->comm = nullptr;
+    return st;
+}
+
 } // namespace
 
 G4S_API g4s_status g4s_spmv_dist_connect_rccl(g4s_spmv_dist_t h, void *comm)
@@ -558,6 +586,12 @@ G4S_API g4s_status g4s_spmv_dist_connect_rccl(g4s_spmv_dist_t h, void *comm)
     G4S_HIP_TRY(g4s::device_malloc(&cnt.p, sizeof(long long) * 2 * (size_t)W));
     long long *d_cnt = static_cast<long long *>(cnt.p);
     G4S_HIP_TRY(hipMemcpy(d_cnt, want_n.data(), sizeof(long long) * (size_t)W, hipMemcpyHostToDevice));
+    if (h->loopback && getenv("G4S_DIST_TEST_STALL")) {
+        // test hook (tests/test_dist_capi_gpu.py): the side stream is held up for a BOUNDED time (seconds; the kernel leaves on its own) in front of the exchange —
+        // what a peer that enters the exchange late, or never, looks like from here
+        const double sec = std::min(10.0, std::max(0.1, atof(getenv("G4S_DIST_TEST_STALL"))));
+        hipLaunchKernelGGL(dist_stall_kernel, dim3(1), dim3(1), 0, h->cstream, (long long)(sec * 1e8));
+    }
     G4S_TRY(rccl_group([&]() {
         for (int k = 0; k < W; ++k) {
             if (k == h->rank && !h->loopback) continue;
@@ -567,7 +601,7 @@ G4S_API g4s_status g4s_spmv_dist_connect_rccl(g4s_spmv_dist_t h, void *comm)
         }
         return ncclSuccess;
     }, "exchange of the want counts"));
-    G4S_TRY(wait_stream(h->cstream, h->comm, "exchange of the want counts"));
+    if (int st = wait_stream(h->cstream, h->comm, "exchange of the want counts"); st != G4S_OK) return dist_poison(h, cnt, st);
     G4S_HIP_TRY(hipMemcpy(give_n.data(), d_cnt + W, sizeof(long long) * (size_t)W, hipMemcpyDeviceToHost));
     if (!h->loopback) give_n[h->rank] = 0;
     const int64_t slab = h->off[(size_t)h->rank + 1] - h->off[h->rank];
@@ -588,7 +622,7 @@ G4S_API g4s_status g4s_spmv_dist_connect_rccl(g4s_spmv_dist_t h, void *comm)
         }
         return ncclSuccess;
     }, "exchange of the want lists"));
-    G4S_TRY(wait_stream(h->cstream, h->comm, "exchange of the want lists"));
+    if (int st = wait_stream(h->cstream, h->comm, "exchange of the want lists"); st != G4S_OK) return dist_poison(h, cnt, st);   // (d_give, d_want stay with the poisoned handle)
     h->give_cut = cut;
     std::fill(h->give_set.begin(), h->give_set.end(), 1);
     return G4S_OK;
@@ -621,6 +655,7 @@ G4S_API g4s_status g4s_spmv_dist_begin(g4s_spmv_dist_t h, const double *x_local_
     for (int k = 0; k < h->nseg; ++k)
         if (!(h->give_set[k] || (k == h->rank && !h->loopback)))
             return g4s::set_error(G4S_ERR_INVALID, "g4s_spmv_dist_begin: the give list of peer %d is not set (g4s_spmv_dist_connect_rccl or g4s_spmv_dist_set_give)", k);
+    G4S_REQUIRE(!h->poisoned, "the handle was poisoned by a failed set-up exchange (g4s_spmv_dist_connect_rccl): destroy it and exit the process");
     hipStream_t s = g4s::as_stream(stream);
     h->exchange_posted = false;
     if (h->allgather) {
@@ -634,7 +669,7 @@ G4S_API g4s_status g4s_spmv_dist_begin(g4s_spmv_dist_t h, const double *x_local_
             G4S_HIP_TRY(hipEventRecord(h->ev_done, h->cstream));
             h->exchange_posted = true;
         }
-        if (h->merged) return G4S_OK;
+        if (h->merged || h->local_rows == 0) return G4S_OK;        // (a rank without rows has posted its part of the exchange and is done: y may be NULL)
         return g4s_spmv(h->A_own, x_local_dev, y_local_dev, 1.0, 0.0, stream);
     }
     G4S_TRY(g4s_spmv_dist_buffers(h, nullptr, nullptr, nullptr, nullptr));
@@ -672,6 +707,7 @@ G4S_API g4s_status g4s_spmv_dist_begin(g4s_spmv_dist_t h, const double *x_local_
         return G4S_OK;
     }
     // the part of the product that needs nothing from anybody runs while the entries travel
+    if (h->local_rows == 0) return G4S_OK;                         // (posted its sends, owns no rows: y may be NULL)
     return g4s_spmv(h->A_own, x_local_dev, y_local_dev, 1.0, 0.0, stream);
 }
 
@@ -692,6 +728,17 @@ G4S_API g4s_status g4s_spmv_dist_finish(g4s_spmv_dist_t h, double *y_local_dev, 
     }
     return g4s_spmv(h->A_rem, h->d_xrem, y_local_dev, 1.0, 1.0, stream);
 }
+
+namespace g4s {
+// the smallest slab of the partition (the same on every rank): the solvers on a partitioned operator need at least one row everywhere, and can refuse a
+// partition that has an empty rank on ALL ranks alike, before their first collective
+int64_t dist_smallest_slab(g4s_spmv_dist_t h)
+{
+    int64_t m = INT64_MAX;
+    for (size_t k = 0; k + 1 < h->off.size(); ++k) m = std::min(m, h->off[k + 1] - h->off[k]);
+    return h->off.size() < 2 ? 0 : m;
+}
+} // namespace g4s
 
 G4S_API g4s_status g4s_spmv_dist_apply(g4s_spmv_dist_t h, const double *x_local_dev, double *y_local_dev, void *stream)
 {

@@ -661,7 +661,7 @@ int dense_rows_times_matrix_launch(int32_t M, int32_t N, int32_t K, const double
     const int G = (N + 7) / 8, GT = G;
     const size_t lds2 = sizeof(double) * 8 * (size_t)G * 16 * KT;
     if (N >= 2 && N % 2 == 0 && N <= 128 && K <= 128 && M >= 4096 && (KT == 2 || KT == 4 || KT == 7 || KT == 8) && (G == 4 || G == 7 || G == 13 || (G == 16 && KT <= 4)) /* (7–8 tiles × 16 groups would spill) */ && lds2 <= 140 * 1024 &&
-        (reinterpret_cast<uintptr_t>(xx_dev) & 15u) == 0 && !getenv("G4S_DENSE_RESIDENT_V1")) {
+        (reinterpret_cast<uintptr_t>(xx_dev) & 15u) == 0) {
         hipStream_t s = g4s::as_stream(stream);
         const int strips = (M + 15) / 16, grid = std::min(256, (strips + 7) / 8);
         double *dump = nullptr;

@@ -55,12 +55,10 @@ struct DevBuf {
     void *p = nullptr;
     hipStream_t s = nullptr;
     bool big = false;
-    size_t n = 0;
     ~DevBuf() { release(); }
     int alloc(size_t bytes, bool for_caller = false)              // for_caller: the pointer is handed out and comes back through g4s_dev_free
     {
         release();
-        n = bytes;
         big = for_caller || bytes >= ((size_t)64 << 20);
         if (big) return g4s::big_alloc(&p, bytes);
         s = t_stream;
@@ -69,10 +67,7 @@ struct DevBuf {
     void release()
     {
         if (!p) return;
-        static const bool dbg = getenv("G4S_DEBUG_FREE") != nullptr;
-        const auto t0 = std::chrono::steady_clock::now();
         if (big) (void)g4s::big_free(p, t_idle); else g4s::scratch_free(p, s);
-        if (dbg) fprintf(stderr, "g4s free %s %zu bytes: %.3f ms\n", big ? "big" : "pool", n, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         p = nullptr;
     }
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
@@ -176,6 +171,34 @@ __global__ void check_range_kernel(const int *__restrict__ ids, long long n, int
         bad |= (c < 0) | (c >= bound);
     }
     if (bad) atomicOr(flag, 1);
+}
+
+// B's rows must be sorted by column (the merge and window kernels cut them at column boundaries; repeated columns are fine). Counted in two passes that
+// cost nothing next to the product: every position whose column is smaller than its predecessor's (check_descents_kernel, fused with the range check), and
+// how many of those are the first entry of a row that follows a non-empty row (row_start_descents_kernel) — the only place a descent may be. Sorted iff equal.
+__global__ void check_descents_kernel(const int *__restrict__ ids, long long n, int bound, int *__restrict__ flag, unsigned long long *__restrict__ descents)
+{
+    int bad = 0;
+    unsigned long long d = 0;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
+        const int c = ids[k];
+        bad |= (c < 0) | (c >= bound);
+        if (k > 0 && c < ids[k - 1]) ++d;
+    }
+    if (bad) atomicOr(flag, 1);
+    d = (unsigned long long)wave_sum_ll((long long)d);
+    if ((threadIdx.x & 63) == 0 && d) atomicAdd(descents, d);
+}
+__global__ void row_start_descents_kernel(int K, const int *__restrict__ rpt, const int *__restrict__ ids, unsigned long long *__restrict__ legal)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long d = 0;
+    if (r > 0 && r < K) {
+        const int k = rpt[r];
+        if (k > rpt[r - 1] && k < rpt[K] && ids[k] < ids[k - 1]) d = 1;   // the first row that starts at k behind a non-empty row
+    }
+    d = (unsigned long long)wave_sum_ll((long long)d);
+    if ((threadIdx.x & 63) == 0 && d) atomicAdd(legal, d);
 }
 
 // ------------------------------------------------------------------------------------------------ row classes
@@ -593,8 +616,7 @@ inline int big_grid(int nrows, int wgs_per_cu = 1)
         cus_of[d] = (hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
     }
     const int cus = cus_of[d];
-    const char *e = getenv("G4S_SPGEMM_BIG_GRID");
-    const int g = (e ? atoi(e) : cus) * wgs_per_cu;
+    const int g = cus * wgs_per_cu;
     return nrows < g ? nrows : g;
 }
 
@@ -1880,6 +1902,25 @@ int check_ids(const int *ids, long long n, int bound, const char *what, hipStrea
     return G4S_OK;
 }
 
+// range check of B's column ids and the sorted-rows contract, one synchronisation
+int check_b(const int *brpt, const int *bcol, int K, long long bnnz, int N, hipStream_t s)
+{
+    if (bnnz <= 0) return G4S_OK;
+    DevBuf buf;
+    G4S_TRY(buf.alloc(sizeof(unsigned long long) * 3));
+    G4S_HIP_TRY(hipMemsetAsync(buf.p, 0, sizeof(unsigned long long) * 3, s));
+    unsigned long long *d = buf.as<unsigned long long>();
+    const int grid = (int)std::min<long long>((bnnz + 255) / 256, 4096);
+    hipLaunchKernelGGL(check_descents_kernel, dim3(grid), dim3(256), 0, s, bcol, bnnz, N, reinterpret_cast<int *>(d), d + 1);
+    hipLaunchKernelGGL(row_start_descents_kernel, dim3((K + 255) / 256), dim3(256), 0, s, K, brpt, bcol, d + 2);
+    unsigned long long h[3] = {0, 0, 0};
+    G4S_HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s));
+    G4S_HIP_TRY(hipStreamSynchronize(s));
+    if (h[0] & 0xffffffffull) return g4s::set_error(G4S_ERR_INVALID, "SpGEMM: a column id of B outside its valid range [0,%d)", N);
+    if (h[1] != h[2]) return g4s::set_error(G4S_ERR_INVALID, "SpGEMM: the rows of B must be sorted by column (%llu descending neighbours inside rows)", h[1] - h[2]);
+    return G4S_OK;
+}
+
 int read_last(const int *d_rpt, int n, int *out, hipStream_t s)
 {
     G4S_HIP_TRY(hipMemcpyAsync(out, d_rpt + n, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -2067,7 +2108,7 @@ int build_window_splits(int K, int N, const int *brpt, const int *bcol, DevBuf &
 {
     *out = nullptr;
     const int sb = split_bits(N), W = (N + (1 << sb) - 1) >> sb;
-    if (W < 2 || W > 16 || K <= 0 || getenv("G4S_SPGEMM_NO_SPLITS")) return G4S_OK;
+    if (W < 2 || W > 16 || K <= 0) return G4S_OK;
     const long long total = (long long)K * (W - 1);
     G4S_TRY(buf.alloc(sizeof(int) * (size_t)total));
     hipLaunchKernelGGL(window_splits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, K, W, sb, brpt, bcol, buf.as<int>());
@@ -2094,7 +2135,7 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     G4S_TRY(read_last(arpt, M, &annz, s));
     G4S_TRY(read_last(brpt, K, &bnnz, s));
     G4S_TRY(check_ids(acol, annz, K, "a column id of A", s));
-    G4S_TRY(check_ids(bcol, bnnz, N, "a column id of B", s));
+    G4S_TRY(check_b(brpt, bcol, K, bnnz, N, s));
 
     DevBuf row_flop, row_nz, ovf_rows, ovf_count;
     dbg.mark("checks");
@@ -2156,14 +2197,14 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     const bool x_med = N2 <= window_max_n(), x_large = x_med;
     const long long *pre_off = nullptr;
     int *pre_cols = nullptr;
-    if (pre && !getenv("G4S_SPGEMM_NO_PRESORT")) {
+    if (pre) {
         // which classes the window kernel counts in this call: M2 always, MEDIUM / LARGE while B is narrow enough
         const unsigned class_mask = (1u << CLS_M2) | (x_med ? (1u << CLS_MEDIUM) : 0u) | (x_large ? (1u << CLS_LARGE) : 0u);
         DevBuf need;
         G4S_TRY(need.alloc(sizeof(long long) * ((size_t)M + 1)));
         G4S_TRY(pre->off.alloc(sizeof(long long) * ((size_t)M + 1)));
         G4S_HIP_TRY(hipMemsetAsync(need.p, 0, sizeof(long long) * ((size_t)M + 1), s));
-        const long long min_flop = getenv("G4S_SPGEMM_PRESORT_MIN") ? atoll(getenv("G4S_SPGEMM_PRESORT_MIN")) : kPresortMinFlop;
+        const long long min_flop = kPresortMinFlop;
         hipLaunchKernelGGL(presorted_need_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, rc.cls.as<int>(), class_mask, row_flop.as<long long>(), N2, min_flop, need.as<long long>());
         G4S_TRY(g4s::prims::exclusive_scan(need.as<long long>(), pre->off.as<long long>(), (long long)M + 1, s));
         long long total_cols = 0;
@@ -2247,7 +2288,7 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
         G4S_TRY(allow_lds(k, sym_lds_bytes(1, 16384)));
         hipLaunchKernelGGL(k, dim3(n), dim3(256), sym_lds_bytes(1, 16384), s, rc.list(CLS_MEDIUM), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr, (const int *)nullptr);
     }
-    const bool one_long_launch = x_large && t_large == t_win && !getenv("G4S_SPGEMM_SPLIT_LONG");   // LARGE and M2 share a shape and their lists are adjacent: one launch
+    const bool one_long_launch = x_large && t_large == t_win;   // LARGE and M2 share a shape and their lists are adjacent: one launch
     if (one_long_launch) { G4S_TRY(window(t_large, rc.list(CLS_LARGE), rc.count[CLS_LARGE] + rc.count[CLS_M2], pre_off, pre_cols, true)); }
     else if (x_large) { G4S_TRY(window(t_large, rc.list(CLS_LARGE), rc.count[CLS_LARGE], pre_off, pre_cols, true)); }
     else if (int n = rc.count[CLS_LARGE]) {
@@ -2487,7 +2528,7 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
     const char *e_med = getenv("G4S_SPGEMM_T_NUM_MED");
     const int t_med = e_med ? (atoi(e_med) ? shape_of("G4S_SPGEMM_T_NUM_MED", 1024) : 0) : kShapeNumMedium;   // 0: the table kernel
     dbg.mark("table-kernels+maps");
-    const bool one_mid_launch = t_med && xn_large && xn_m2 && t_med == t_large && t_large == t_m2 && !getenv("G4S_SPGEMM_SPLIT_MID");
+    const bool one_mid_launch = t_med && xn_large && xn_m2 && t_med == t_large && t_large == t_m2;
     if (one_mid_launch) {
         // the three mid-size classes (512 < nz <= 4 096) share a shape and their lists are adjacent: one launch, one set of unit lists, one tail instead of three
         G4S_TRY(big(t_med, rc.list(CLS_MEDIUM), rc.count[CLS_MEDIUM] + rc.count[CLS_LARGE] + rc.count[CLS_M2]));

@@ -173,36 +173,24 @@ __global__ void spmv_long_fixup_kernel(const LongRow *__restrict__ lrows, int n_
 // indices — a 2-flop-per-entry product gains nothing from the matrix cores).
 constexpr int kMaxDiags = 32;
 struct DiaOffsets { int off[kMaxDiags]; };
-// A 3-D stencil in natural ordering has two diagonals one PLANE away (±431² for the 431³ Laplacian): x[row + plane] is needed again a plane later as the
-// centre and two planes later as x[row − plane]. With every XCD walking a contiguous eighth of the rows that reuse distance is three planes of x (4.5 MB) plus
-// the streams in between — more than an XCD's 4 MiB L2, so x crosses the fabric three times (PMC: 6.7 GB fetched for 5.4 GB of own reads). In the plane-sliced
-// walk XCD j takes the j-th eighth of EVERY plane, plane after plane: the three slices it needs are 0.56 MB and stay in its L2 (PMC: 5.65 GB fetched). Measured on
-// one handle in one process the sliced walk is NOT faster (1–2 % slower on three boxes; staggered starting planes 5–8 % slower): the kernel is not bound by
-// the fabric bytes. It is therefore opt-in (dia_walk below); the geometry is computed at plan time when the largest offset is far (≥ 16 K rows) and symmetric
-// and the rows hold ≥ 8 planes.
-struct DiaFar { int stride, slice, blocks_per_slice, planes, zshift; };   // stride 0: the contiguous walk; zshift: XCD j starts j·zshift planes further on (wrapping)
+// Which rows an XCD walks. Blocks of one XCD walk a contiguous eighth of the rows, so that the shifted reads of x of neighbouring row blocks go through one L2.
+// A 3-D stencil has two diagonals one PLANE away (±431² for the 431³ Laplacian) and x[row + plane] is needed again one and two planes later; with contiguous
+// eighths that reuse distance is three planes of x plus the streams in between, more than a 4 MiB L2, so x crosses the fabric three times (PMC: 6.72 GB fetched
+// for 5.44 GB of own reads). Round 3 built a plane-sliced walk (XCD j takes the j-th eighth of EVERY plane, plane after plane: 5.65 GB fetched, L2 hit 0.36
+// instead of 0.20) and a variant with staggered starting planes; on one handle in one process they ran 1 % and 5–8 % SLOWER on four boxes (DESIGN §4.1:
+// profiles/r03_ab_lap7_walks.txt) — the kernel is not bound by the bytes that cross the fabric — and were removed in round 4. Likewise the switch back to one
+// row per lane (two rows per lane: −4 % / −10 %, profiles/r03, tools history).
 
 template <int ND, bool NT>
 __global__ __launch_bounds__(WG) void spmv_dia_kernel(int rows, int cols, int nd, DiaOffsets offs, long long ld, const double *__restrict__ dia,
                                                        const unsigned *__restrict__ mask, const double *__restrict__ x, double *__restrict__ y,
-                                                       double alpha, double beta, int blocks_per_xcd, int row0 /* first row of this launch */, DiaFar far)
+                                                       double alpha, double beta, int blocks_per_xcd, int row0 /* first row of this launch */)
 {
-    // blocks of one XCD walk a contiguous range of rows: neighbouring row blocks read neighbouring parts of x through the same L2 —
-    // or, with far planes, the XCD's eighth of every plane (DiaFar; one row per lane: blocks_per_slice counts WG rows)
+    // blocks of one XCD walk a contiguous range of rows: neighbouring row blocks read neighbouring parts of x through the same L2
     const int b = (int)blockIdx.x;
-    int row;
-    if (far.stride) {
-        const int j = b % g4s::kXcds, l = b / g4s::kXcds, z0 = l / far.blocks_per_slice, w = l - z0 * far.blocks_per_slice;
-        const int z = (z0 + j * far.zshift) % far.planes;
-        const long long base = (long long)z * far.stride;
-        const long long r = base + min(j * far.slice, far.stride) + w * WG + (int)threadIdx.x;
-        if (r >= base + min((j + 1) * far.slice, far.stride) || r >= rows) return;
-        row = (int)r;
-    } else {
-        const int lb = (b % g4s::kXcds) * blocks_per_xcd + b / g4s::kXcds;
-        row = row0 + lb * WG + (int)threadIdx.x;
-        if (row >= rows) return;
-    }
+    const int lb = (b % g4s::kXcds) * blocks_per_xcd + b / g4s::kXcds;
+    const int row = row0 + lb * WG + (int)threadIdx.x;
+    if (row >= rows) return;
     const unsigned m = mask[row];
     double v[ND], xv[ND];
 #pragma unroll
@@ -227,24 +215,12 @@ typedef unsigned dia_uint2 __attribute__((ext_vector_type(2)));
 template <int ND, bool NT>
 __global__ __launch_bounds__(WG) void spmv_dia2_kernel(int rows2 /* even part of the row count */, int cols, int nd, DiaOffsets offs, long long ld, const double *__restrict__ dia,
                                                         const unsigned *__restrict__ mask, const double *__restrict__ x, double *__restrict__ y,
-                                                        double alpha, double beta, int blocks_per_xcd, DiaFar far)
+                                                        double alpha, double beta, int blocks_per_xcd)
 {
     const int b = (int)blockIdx.x;
-    int row;
-    if (far.stride) {
-        // plane-sliced walk (see DiaFar): XCD j takes the j-th eighth of every plane, plane after plane
-        const int j = b % g4s::kXcds, l = b / g4s::kXcds, z0 = l / far.blocks_per_slice, w = l - z0 * far.blocks_per_slice;
-        const int z = (z0 + j * far.zshift) % far.planes;          // staggered start: the eight XCDs are never on the same plane
-        const long long base = (long long)z * far.stride;
-        const long long lo = (base + min(j * far.slice, far.stride) + 1) & ~1ll, hi = (base + min((j + 1) * far.slice, far.stride) + 1) & ~1ll;   // even: 16-byte accesses
-        const long long r = lo + 2 * (w * WG + (int)threadIdx.x);
-        if (r >= hi || r >= rows2) return;
-        row = (int)r;
-    } else {
-        const int lb = (b % g4s::kXcds) * blocks_per_xcd + b / g4s::kXcds;
-        row = 2 * (lb * WG + (int)threadIdx.x);
-        if (row >= rows2) return;
-    }
+    const int lb = (b % g4s::kXcds) * blocks_per_xcd + b / g4s::kXcds;
+    const int row = 2 * (lb * WG + (int)threadIdx.x);
+    if (row >= rows2) return;
     const dia_uint2 m = *reinterpret_cast<const dia_uint2 *>(mask + row);
     dia_double2 v[ND];
     double x0[ND], x1[ND];
@@ -330,7 +306,6 @@ struct g4s_csr_s {
     int dia_nd = 0;
     long long dia_ld = 0;
     DiaOffsets dia_offs{};
-    DiaFar dia_far{0, 0, 0, 1, 0};
     g4s::PbPlan *pb = nullptr;      // propagation-blocked path (spmv_pb.hip) for matrices without gather locality
     g4s::BcsrPlan *bcsr = nullptr;  // block-row form of an assembled FE matrix (spmv_bcsr.hip)
 };
@@ -526,7 +501,7 @@ void release(g4s_csr_s *A)
 int try_build_dia(g4s_csr_s *A)
 {
     const int32_t rows = A->rows;
-    if (rows < 1024 || A->nnz < 4096 || getenv("G4S_SPMV_NO_DIA")) return G4S_OK;
+    if (rows < 1024 || A->nnz < 4096) return G4S_OK;
     std::vector<int> offs;
     const int S = 2048;
     std::vector<int32_t> cbuf;
@@ -567,18 +542,6 @@ int try_build_dia(g4s_csr_s *A)
     (void)hipFree(d_fail);
     if (e != hipSuccess || h_fail) { (void)hipFree(dia); (void)hipFree(mask); return e == hipSuccess ? G4S_OK : g4s::set_error(G4S_ERR_HIP, "diagonal fill failed: %s", hipGetErrorString(e)); }
     A->d_dia = dia; A->d_dia_mask = mask; A->dia_nd = nd; A->dia_ld = ld; A->dia_offs = D;
-    // plane-sliced walk (DiaFar): the outermost diagonals are ±stride with stride ≥ 16 K rows, every other offset is well inside a slice, ≥ 8 planes
-    A->dia_far = DiaFar{0, 0, 0, 1, 0};
-    if (nd >= 3) {
-        const long long stride = D.off[nd - 1];
-        const long long inner = std::max<long long>(std::abs((long long)D.off[1]), std::abs((long long)D.off[nd - 2]));
-        const long long slice = (stride + g4s::kXcds - 1) / g4s::kXcds;
-        if (stride >= 16384 && D.off[0] == -stride && 8 * inner <= slice && (long long)rows >= 8 * stride) {
-            A->dia_far.stride = (int)stride;
-            A->dia_far.slice = (int)slice;
-            A->dia_far.blocks_per_slice = (int)((slice + 2 + 2 * WG - 1) / (2 * WG));
-        }
-    }
     A->plan_bytes += (int64_t)(sizeof(double) * (size_t)(ld * nd) + sizeof(unsigned) * (size_t)rows);
     return G4S_OK;
 }
@@ -699,33 +662,6 @@ G4S_API g4s_status g4s_csr_device_arrays(g4s_csr_t A, const int32_t **rowptr, co
     return G4S_OK;
 }
 
-namespace {
-// Which rows an XCD walks on the diagonal path (switchable per launch — dia_switches — so that tools/ab_lap7_walks.py can compare the walks on ONE handle and one pair of vectors —
-// the same walk varies by ±8 % from process to process with the placement of its pages): contiguous eighths (default), or — G4S_SPMV_DIA_WALK=l — its eighth of
-// every plane of a 3-D stencil, plane after plane (15 % fewer bytes across the fabric, PMC; not faster: DESIGN §4.1), =s the same with the XCDs' starting planes
-// staggered. The plan holds the geometry (DiaFar) whenever the matrix has far planes.
-// The two A/B switches of the diagonal path are environment variables. A launch of a small matrix costs a few µs, so they are read ONCE per process — unless
-// G4S_SPMV_LIVE_ENV is set (before the first product), which makes every launch read them again: what the in-process A/B tools do.
-struct DiaSwitches { char walk; bool one_row; };
-DiaSwitches dia_switches()
-{
-    auto read = []() {
-        const char *wk = getenv("G4S_SPMV_DIA_WALK");
-        return DiaSwitches{wk ? wk[0] : 'c', getenv("G4S_SPMV_DIA_ONE_ROW") != nullptr};
-    };
-    static const bool live = getenv("G4S_SPMV_LIVE_ENV") != nullptr;
-    static const DiaSwitches once = read();
-    return live ? read() : once;
-}
-DiaFar dia_walk(DiaFar geometry)
-{
-    const char mode = dia_switches().walk;
-    if (mode != 'l' && mode != 's') geometry.stride = 0;
-    geometry.zshift = mode == 's' ? 1 : 0;
-    return geometry;
-}
-} // namespace
-
 G4S_API g4s_status g4s_spmv(g4s_csr_t A, const double *x_dev, double *y_dev, double alpha, double beta, void *stream)
 {
     G4S_REQUIRE(A, "NULL handle");
@@ -737,20 +673,16 @@ G4S_API g4s_status g4s_spmv(g4s_csr_t A, const double *x_dev, double *y_dev, dou
     if (A->pb) return g4s::pb_spmv(A->pb, x_dev, y_dev, alpha, beta, s);
     if (A->bcsr) return g4s::bcsr_spmv(A->bcsr, x_dev, y_dev, alpha, beta, s);
     if (A->d_dia) {
-        // two rows per lane where it applies (≤ 16 diagonals, y 16-byte aligned, not disabled): the even part of the rows; an odd last row by the one-row kernel
-        const bool two = A->dia_nd <= 16 && (reinterpret_cast<uintptr_t>(y_dev) & 15u) == 0 && A->rows >= 2 && !dia_switches().one_row;
+        // two rows per lane where it applies (≤ 16 diagonals, y 16-byte aligned): the even part of the rows; an odd last row by the one-row kernel
+        const bool two = A->dia_nd <= 16 && (reinterpret_cast<uintptr_t>(y_dev) & 15u) == 0 && A->rows >= 2;
         const int rows2 = two ? (A->rows & ~1) : 0;
         if (rows2) {
             const int nblocks = (rows2 / 2 + WG - 1) / WG, per_xcd = (nblocks + g4s::kXcds - 1) / g4s::kXcds;
-            DiaFar far = dia_walk(A->dia_far);
-            const long long planes = far.stride ? ((long long)rows2 + far.stride - 1) / far.stride : 0;
-            far.planes = (int)std::max<long long>(planes, 1);
-            far.zshift = far.zshift ? (int)(planes / g4s::kXcds) : 0;
-            const dim3 grid(far.stride ? (unsigned)(planes * far.blocks_per_slice * g4s::kXcds) : (unsigned)(per_xcd * g4s::kXcds)), block(WG);
+            const dim3 grid((unsigned)(per_xcd * g4s::kXcds)), block(WG);
 #define G4S_DIA2_LAUNCH(ND)                                                                                                                                           \
     do {                                                                                                                                                          \
-        if (A->use_nt) hipLaunchKernelGGL((spmv_dia2_kernel<ND, true>), grid, block, 0, s, rows2, A->cols, A->dia_nd, A->dia_offs, A->dia_ld, A->d_dia, A->d_dia_mask, x_dev, y_dev, alpha, beta, per_xcd, far);  \
-        else hipLaunchKernelGGL((spmv_dia2_kernel<ND, false>), grid, block, 0, s, rows2, A->cols, A->dia_nd, A->dia_offs, A->dia_ld, A->d_dia, A->d_dia_mask, x_dev, y_dev, alpha, beta, per_xcd, far);           \
+        if (A->use_nt) hipLaunchKernelGGL((spmv_dia2_kernel<ND, true>), grid, block, 0, s, rows2, A->cols, A->dia_nd, A->dia_offs, A->dia_ld, A->d_dia, A->d_dia_mask, x_dev, y_dev, alpha, beta, per_xcd);  \
+        else hipLaunchKernelGGL((spmv_dia2_kernel<ND, false>), grid, block, 0, s, rows2, A->cols, A->dia_nd, A->dia_offs, A->dia_ld, A->d_dia, A->d_dia_mask, x_dev, y_dev, alpha, beta, per_xcd);           \
     } while (0)
             if (A->dia_nd <= 8) G4S_DIA2_LAUNCH(8);
             else G4S_DIA2_LAUNCH(16);
@@ -760,17 +692,11 @@ G4S_API g4s_status g4s_spmv(g4s_csr_t A, const double *x_dev, double *y_dev, dou
         if (tail0 < A->rows) {
             const int n_tail = A->rows - tail0;
             const int nblocks = (n_tail + WG - 1) / WG, per_xcd = (nblocks + g4s::kXcds - 1) / g4s::kXcds;
-            DiaFar far = dia_walk(A->dia_far);
-            if (tail0 != 0) far.stride = 0;                          // the odd last row behind the two-row kernel
-            if (far.stride) far.blocks_per_slice = (far.slice + WG - 1) / WG;
-            const long long planes = far.stride ? ((long long)A->rows + far.stride - 1) / far.stride : 0;
-            far.planes = (int)std::max<long long>(planes, 1);
-            far.zshift = far.zshift ? (int)(planes / g4s::kXcds) : 0;
-            const dim3 grid(far.stride ? (unsigned)(planes * far.blocks_per_slice * g4s::kXcds) : (unsigned)(per_xcd * g4s::kXcds)), block(WG);
+            const dim3 grid((unsigned)(per_xcd * g4s::kXcds)), block(WG);
 #define G4S_DIA_LAUNCH(ND)                                                                                                                                            \
     do {                                                                                                                                                          \
-        if (A->use_nt) hipLaunchKernelGGL((spmv_dia_kernel<ND, true>), grid, block, 0, s, A->rows, A->cols, A->dia_nd, A->dia_offs, A->dia_ld, A->d_dia, A->d_dia_mask, x_dev, y_dev, alpha, beta, per_xcd, tail0, far);  \
-        else hipLaunchKernelGGL((spmv_dia_kernel<ND, false>), grid, block, 0, s, A->rows, A->cols, A->dia_nd, A->dia_offs, A->dia_ld, A->d_dia, A->d_dia_mask, x_dev, y_dev, alpha, beta, per_xcd, tail0, far);           \
+        if (A->use_nt) hipLaunchKernelGGL((spmv_dia_kernel<ND, true>), grid, block, 0, s, A->rows, A->cols, A->dia_nd, A->dia_offs, A->dia_ld, A->d_dia, A->d_dia_mask, x_dev, y_dev, alpha, beta, per_xcd, tail0);  \
+        else hipLaunchKernelGGL((spmv_dia_kernel<ND, false>), grid, block, 0, s, A->rows, A->cols, A->dia_nd, A->dia_offs, A->dia_ld, A->d_dia, A->d_dia_mask, x_dev, y_dev, alpha, beta, per_xcd, tail0);           \
     } while (0)
             if (A->dia_nd <= 8) G4S_DIA_LAUNCH(8);
             else if (A->dia_nd <= 16) G4S_DIA_LAUNCH(16);

@@ -140,7 +140,7 @@ struct BcsrPlan {
 int bcsr_try_build(BcsrPlan **out, int rows, int cols, long long nnz, const int32_t *d_rowptr, const int32_t *d_colids, const double *d_values, bool use_nt)
 {
     *out = nullptr;
-    if (getenv("G4S_SPMV_NO_BCSR") || rows < 64 || nnz <= 0) return G4S_OK;
+    if (rows < 64 || nnz <= 0) return G4S_OK;
     for (int b : {3, 2, 4}) {
         const int bb = b * b;
         if (rows % b || cols % b || nnz % bb || nnz < 2ll * b * rows) continue;   // at least two blocks per block-row on average: otherwise the CSR kernel is as good

@@ -197,9 +197,21 @@ class DistSpMV:
         self.allgather = exchange == "allgather"                   # ONE ncclAllGather of the padded slabs instead of packed point-to-point messages
         flags = capi.DEVICE_POINTERS | spmv_flags | (capi.DIST_LOOPBACK if loopback else 0) | (capi.DIST_ALLGATHER if self.allgather else 0)
         self.comm = None
+        self._views = None
         self.rccl = dist.is_initialized() and dist.get_backend(group) == "nccl" if (world > 1) else bool(loopback)
-        # Set-up is a sequence of phases, the later ones collective. After each one the ranks agree (one all-reduce of a flag) whether it
-        # succeeded EVERYWHERE; if not, every rank raises at the same point — none is left waiting inside a collective the others never enter.
+        # Set-up is a sequence of phases, the later ones collective. BEFORE a collective phase the ranks agree that all of them are about to enter it, and
+        # after each phase whether it succeeded everywhere (one all-reduce of a flag each); if not, every rank raises at the same point — none is left
+        # waiting inside a collective the others never enter. Whatever a failed set-up had already built (the native handle with its two device copies of
+        # the slab, the communicator) is released before the exception leaves the constructor: the caller never gets an object it could close().
+        try:
+            self._setup(offs, rank, world, rowptr, colids, values, n_cols, flags, col_offsets)
+        except BaseException:
+            self.close()
+            raise
+        DistSpMV._by_handle[self.h.value] = self                  # (only a fully wired handle is reachable from the transport callback)
+
+    def _setup(self, offs, rank, world, rowptr, colids, values, n_cols, flags, col_offsets):
+        capi, host, group = self._capi, self._host, self.group
         if col_offsets is None:
             self._phase("create", lambda: capi.check(self.lib.g4s_spmv_dist_create(
                 C.byref(self.h), rank, world, offs, int(n_cols), host._ptr(rowptr), host._ptr(colids), host._ptr(values), flags)))
@@ -208,7 +220,6 @@ class DistSpMV:
             coffs = (C.c_int64 * (world + 1))(*[int(v) for v in col_offsets])
             self._phase("create", lambda: capi.check(self.lib.g4s_spmv_dist_create_rect(
                 C.byref(self.h), rank, world, offs, coffs, host._ptr(rowptr), host._ptr(colids), host._ptr(values), flags)))
-        DistSpMV._by_handle[self.h.value] = self
         if self.rccl:
             idbuf = torch.zeros(128, dtype=torch.uint8)
             if rank == 0:
@@ -222,26 +233,44 @@ class DistSpMV:
                 idbuf = t.cpu()
             raw = (C.c_char * 128).from_buffer_copy(bytes(idbuf.numpy().tobytes()))
             self.comm = C.c_void_p()
-            self._phase("communicator", lambda: capi.check(self.lib.g4s_comm_create(C.byref(self.comm), world, rank, raw)))
-            self._phase("connect", lambda: capi.check(self.lib.g4s_spmv_dist_connect_rccl(self.h, self.comm)))
+            comm = C.c_void_p()
+            self._phase("communicator", lambda: capi.check(self.lib.g4s_comm_create(C.byref(comm), world, rank, raw)), collective=True)
+            self.comm = comm
+            self._phase("connect", lambda: capi.check(self.lib.g4s_spmv_dist_connect_rccl(self.h, self.comm)), collective=True)
         elif world > 1 and not self.allgather:
-            self._phase("wire", self._wire_by_torch)
-        self._views = None
+            self._phase("wire", self._wire_by_torch, collective=True)
 
-    def _phase(self, name, fn):
-        err = None
-        try:
-            fn()
-            if os.environ.get("G4S_DIST_FAIL") == f"{name}:{self.rank}":      # test hook: this phase "fails" on this rank — after its collectives,
-                raise RuntimeError("G4S_DIST_FAIL")                           # so that the ranks still meet in the agreement all-reduce below
-        except Exception as e:                                               # noqa: BLE001 — re-raised below, on every rank
-            err = e
+    def _agree(self, ok):
+        """min over the ranks of a flag (True only if True everywhere); a no-op for one rank."""
         if self.world > 1 and dist.is_initialized():
             on_gpu = dist.get_backend(self.group) == "nccl"
-            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu")
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
-            if int(ok.item()) == 0 and err is None:
-                err = RuntimeError(f"g4s_spmv_dist set-up: phase '{name}' failed on another rank")
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            return int(t.item()) == 1
+        return bool(ok)
+
+    def _phase(self, name, fn, collective=False):
+        """One set-up phase. G4S_DIST_FAIL (test hook) = "<phase>:<rank>" makes the phase fail on that rank after it ran (its collectives done), and
+        "pre:<phase>:<rank>" BEFORE it runs — the real failure mode: a rank that raises in front of a collective its peers are about to enter."""
+        err = None
+        hook = os.environ.get("G4S_DIST_FAIL")
+        fires_before, fires_after = hook == f"pre:{name}:{self.rank}", hook == f"{name}:{self.rank}"
+        if fires_before or fires_after:
+            os.environ.pop("G4S_DIST_FAIL")                        # one shot: the set-up a caller falls back to is not hit again
+        if collective:
+            # readiness: nobody enters the phase's collectives unless everybody is about to
+            if not self._agree(not fires_before):
+                raise RuntimeError("G4S_DIST_FAIL (before the phase)" if fires_before else f"g4s_spmv_dist set-up: another rank could not enter phase '{name}'")
+        try:
+            if not collective and fires_before:
+                raise RuntimeError("G4S_DIST_FAIL (before the phase)")
+            fn()
+            if fires_after:
+                raise RuntimeError("G4S_DIST_FAIL")
+        except Exception as e:                                               # noqa: BLE001 — re-raised below, on every rank
+            err = e
+        if not self._agree(err is None) and err is None:
+            err = RuntimeError(f"g4s_spmv_dist set-up: phase '{name}' failed on another rank")
         if err is not None:
             raise err
 
@@ -360,10 +389,14 @@ class DistSpMV:
         return d0, cycles.value, res.value
 
     def close(self):
-        if self.h:
+        poisoned = False
+        if getattr(self, "h", None):
+            i = self._capi.DistInfo()
+            poisoned = self.lib.g4s_spmv_dist_get_info(self.h, C.byref(i)) == 0 and bool(i.reserved & 4)
             DistSpMV._by_handle.pop(self.h.value, None)
             self.lib.g4s_spmv_dist_destroy(self.h)
             self.h = None
-        if self.comm is not None:
-            self.lib.g4s_comm_destroy(self.comm)
+        if getattr(self, "comm", None) is not None:
+            if self.comm and not poisoned:                         # (a poisoned handle has aborted its communicator already: nothing left to destroy)
+                self.lib.g4s_comm_destroy(self.comm)
             self.comm = None

@@ -154,7 +154,7 @@ typedef struct g4s_dist_split {
     int32_t *own_rowptr, *own_colids; double *own_values;
     int32_t *rem_rowptr, *rem_colids; double *rem_values;
     int32_t *want;            /* packed mode: n_ref entries */
-    int64_t *recv_cut;        /* world+1 entries */
+    int64_t *recv_cut;        /* segments + 1 entries (segments = world; in loopback mode the rehearsed peer count) */
 } g4s_dist_split;
 g4s_status g4s_dist_split_rows(int32_t rank, int32_t world, const int64_t *row_offsets, int64_t n_cols,
                                const int32_t *rowptr, const int32_t *colids, const double *values, unsigned flags, g4s_dist_split *out);
@@ -167,7 +167,8 @@ typedef struct g4s_spmv_dist_info {
     int64_t send_bytes, recv_bytes;             /* per product */
     int32_t own_path, rem_path;                 /* g4s_csr_info.spmv_path of the two parts */
     int32_t connected, reserved;                /* connected: every peer's give list is known; reserved: bit 0 = merged form (own columns are few and live in
-                                                 * the remote x with the remote ones: one product per step instead of two), bit 1 = all-gather exchange */
+                                                 * the remote x with the remote ones: one product per step instead of two), bit 1 = all-gather exchange,
+                                                 * bit 2 = poisoned by a failed set-up exchange (see g4s_spmv_dist_apply) */
 } g4s_spmv_dist_info;
 /* flags: G4S_HOST_POINTERS / G4S_DEVICE_POINTERS for the three matrix arrays, the G4S_SPMV_* path flags, G4S_DIST_LOOPBACK, G4S_DIST_ALLGATHER.
  * row_offsets: world+1 entries, host memory; row_offsets[world] == n_cols. Collective only in the sense that every rank creates its own. */
@@ -186,8 +187,13 @@ g4s_status g4s_spmv_dist_connect_rccl(g4s_spmv_dist_t h, void *comm);
  * slab, device memory); the caller carries every list to its owner and hands it over with _set_give (flags: host or device pointer). */
 g4s_status g4s_spmv_dist_want(g4s_spmv_dist_t h, int32_t peer, int64_t *count, const int32_t **idx_dev);
 g4s_status g4s_spmv_dist_set_give(g4s_spmv_dist_t h, int32_t peer, int64_t count, const int32_t *idx, unsigned flags);
-/* y_local = (A·x)[own rows]. x_local_dev / y_local_dev: this rank's slabs, device memory. Asynchronous on `stream`; RCCL traffic runs on
- * a stream of the handle. Needs g4s_spmv_dist_connect_rccl when world > 1. */
+/* y_local = (A·x)[own rows]. x_local_dev / y_local_dev: this rank's slabs, device memory (y may be NULL on a rank that owns no rows, x on a
+ * rank that owns no x entries — a rectangular operator; such a rank still posts its part of the exchange). Asynchronous on `stream`; RCCL
+ * traffic runs on a stream of the handle. Needs g4s_spmv_dist_connect_rccl when world > 1.
+ * Failure of the set-up exchange: g4s_spmv_dist_connect_rccl waits with a deadline (G4S_DIST_TIMEOUT_S, default 120 s) and watches RCCL's
+ * asynchronous error state. When either fires — a peer never entered the exchange — the communicator is ABORTED (ncclCommAbort) and the handle
+ * is poisoned: later calls on it fail, g4s_spmv_dist_destroy drops only its host side (the device memory of the stuck operation is left to the
+ * process's exit, nothing is synchronised). The caller reports the error and exits non-zero; a supervisor starts a fresh process. */
 g4s_status g4s_spmv_dist_apply(g4s_spmv_dist_t h, const double *x_local_dev, double *y_local_dev, void *stream);
 /* The same in two halves for callers with their own transport: _begin packs the send buffer and starts y = A_own·x_local; the caller moves
  * send_dev[send_cut[k]..send_cut[k+1]) to peer k and receives peer k's entries into recv_dev[recv_cut[k]..recv_cut[k+1]) (both ordered after
@@ -216,7 +222,11 @@ typedef struct g4s_timings {
 g4s_status g4s_spgemm_flop(int32_t M, const int32_t *arpt, const int32_t *acol, const int32_t *brpt,
                            int64_t *flop, int64_t *row_flop, unsigned flags);
 
-/* Raw-pointer SpGEMM with the call shape of mkl(...) (mm/inc/mkl_mult.h:40-43): inputs borrowed,
+/* Input contract of the three SpGEMM entry points: zero-based CSR, the rows of B sorted by column (what CSR::construct produces, mm/inc/CSR.h:640-651;
+ * repeated columns inside a row are allowed and are added up) — the merge and window kernels cut B's rows at column boundaries. A's rows may be in any
+ * order. Column ids are range-checked (G4S_ERR_INVALID); a B with descending columns inside a row is refused (G4S_ERR_INVALID) by g4s_spgemm_symbolic and
+ * the one-call form.
+ * Raw-pointer SpGEMM with the call shape of mkl(...) (mm/inc/mkl_mult.h:40-43): inputs borrowed,
  * outputs allocated by the callee — with g4s_malloc for host pointers (free with g4s_free), with
  * g4s_dev_alloc for G4S_DEVICE_POINTERS (free with g4s_dev_free). A is M×K, B is K×N, C is M×N.
  * cnnz is int64; G4S_ERR_OVERFLOW is returned (and nothing allocated) if it exceeds INT32_MAX,

@@ -4,9 +4,6 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# the diagonal SpMV path reads its A/B switches (G4S_SPMV_DIA_WALK, G4S_SPMV_DIA_ONE_ROW) once per process unless this is set before its first product;
-# tests/test_spmv_gpu.py flips them between products
-os.environ.setdefault("G4S_SPMV_LIVE_ENV", "1")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

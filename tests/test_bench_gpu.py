@@ -77,10 +77,12 @@ def test_bench_two_ranks_rehearsal(workload, exchange):
     assert "2 rank(s)" in d["config"]["partition"] and ("packed ncclSend" if exchange == "dist" else "ncclAllGather") in d["config"]["exchange"]
 
 
-def test_bench_two_ranks_fall_back_together():
-    """One rank's wiring of the packed exchange fails: every rank takes the library's all-gather exchange instead (agreed through one all-reduce;
-    it needs no wiring), none hangs."""
-    env = dict(os.environ, G4S_BENCH_SAME_DEVICE="1", G4S_DIST_FAIL="wire:1")
+@pytest.mark.parametrize("fail", ["wire:1", "pre:wire:1", "create:1"])
+def test_bench_two_ranks_fall_back_together(fail):
+    """One rank's set-up of the packed exchange fails — after the wiring's collectives, BEFORE them (the peer is about to enter a point-to-point round the
+    failing rank never posts: the readiness agreement in front of every collective phase keeps it out), or already in the local create: every rank takes the
+    library's all-gather exchange instead (it needs no wiring), none hangs."""
+    env = dict(os.environ, G4S_BENCH_SAME_DEVICE="1", G4S_DIST_FAIL=fail)
     r = _launch_two_ranks(["--steps", "3", "--warmup", "1", "--small", "--backend", "gloo", "--no-cpu-baseline"], env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     d = _last_json(r.stdout)

@@ -158,3 +158,66 @@ def test_dist_rect_rank_without_rows():
     capi.check(lib.g4s_spmv_dist_apply(h, C.c_void_p(x.data_ptr()), None, None))
     torch.cuda.synchronize()
     capi.check(lib.g4s_spmv_dist_destroy(h))
+
+
+_STALL_SCRIPT = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+import numpy as np, torch
+from g4s_amd import dist as gdist, capi
+from tests.helpers import power_law_csr
+n = 20000
+rp, ci, va = power_law_csr(n, n, 41, 3000)
+free0 = torch.cuda.mem_get_info()[0]
+os.environ["G4S_DIST_TEST_STALL"] = "4"          # the side stream is held up for 4 s in front of the set-up exchange: a peer that enters late or never
+os.environ["G4S_DIST_TIMEOUT_S"] = "0.5"
+t0 = time.time()
+try:
+    gdist.DistSpMV([0, n], 0, 1, torch.from_numpy(rp).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(va).cuda(), n, loopback=True)
+    print("NO ERROR"); sys.exit(3)
+except capi.G4SError as e:
+    dt = time.time() - t0
+    print("ERROR:", e)
+    print("SECONDS", round(dt, 2))
+# the constructor has destroyed the poisoned handle on its way out: that must not have waited for the stuck exchange either
+print("DONE", round(time.time() - t0, 2))
+sys.stdout.flush()
+os._exit(0)                                        # (the aborted communicator's process is not expected to live on: exit without the runtime's teardown)
+"""
+
+
+def test_dist_connect_time_out_poisons_the_handle_and_returns(tmp_path):
+    """the deadline of the set-up waits used to return while the grouped ncclSend / ncclRecv was still pending — the error path then blocked in hipFree
+    and hipDeviceSynchronize behind the same stuck operation. Now the communicator is aborted, the handle poisoned, nothing of it is freed or synchronised: with
+    a 0.5 s deadline and an exchange that is held up for 4 s (loopback rehearsal), the constructor raises after the deadline, not after the hold-up."""
+    import subprocess
+    import sys
+    script = tmp_path / "stall.py"
+    script.write_text(_STALL_SCRIPT.format(root=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "no completion within" in r.stdout and "aborted" in r.stdout
+    secs = float([l for l in r.stdout.splitlines() if l.startswith("DONE")][0].split()[1])
+    assert secs < 3.0, r.stdout                                  # (the hold-up alone is 4 s: nothing waited for it)
+
+
+def test_dist_setup_failure_releases_the_native_handle(monkeypatch):
+    """a set-up phase that fails after 'create' used to leave the native handle (two device copies of the slab, plans, index lists) allocated with no
+    object to close(). The constructor now releases what it built before the exception leaves it: free device memory returns to where it was."""
+    from g4s_amd import dist as gdist
+    n = 400000
+    rp, ci, va = power_law_csr(n, n, 43, 200)
+    d = [torch.from_numpy(a).cuda() for a in (rp, ci, va)]
+    torch.cuda.synchronize()
+    before_handles = len(gdist.DistSpMV._by_handle)
+    free0 = torch.cuda.mem_get_info()[0]
+    for hook in ("create:0", "pre:create:0"):
+        monkeypatch.setenv("G4S_DIST_FAIL", hook)
+        with pytest.raises(RuntimeError, match="G4S_DIST_FAIL"):
+            gdist.DistSpMV([0, n], 0, 1, *d, n)
+        torch.cuda.synchronize()
+        assert len(gdist.DistSpMV._by_handle) == before_handles
+        assert torch.cuda.mem_get_info()[0] >= free0 - (8 << 20), "the failed set-up left device memory behind"
+    D = gdist.DistSpMV([0, n], 0, 1, *d, n)                    # (the hook is one-shot: the next set-up succeeds)
+    assert D.h
+    D.close()

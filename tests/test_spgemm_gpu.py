@@ -179,6 +179,61 @@ def test_spgemm_value_chunk_splits(oracle, monkeypatch, splits):
     _three_window_case(oracle, False)
 
 
+@pytest.mark.parametrize("walk", ["units", "entry_pass"])
+@pytest.mark.parametrize("short_rows", ["wave", "tables"])
+@pytest.mark.parametrize("two_phase", [False, True])
+def test_spgemm_walk_forms(oracle, monkeypatch, walk, short_rows, two_phase):
+    """Round 4: the window kernels walk their products from precomputed unit lists (default) or with the per-chunk entry pass they fall back to when a unit
+    table would outgrow its cap (G4S_SPGEMM_NO_UNITS); rows of at most 512 products are merged by one wavefront (default) or go through the hash-table
+    kernels that also take what the wavefront kernel hands back (G4S_SPGEMM_NO_WAVE_ROWS). Every combination, both call forms, every row class."""
+    if walk == "entry_pass":
+        monkeypatch.setenv("G4S_SPGEMM_NO_UNITS", "1")
+    if short_rows == "tables":
+        monkeypatch.setenv("G4S_SPGEMM_NO_WAVE_ROWS", "1")
+    rp, ci, va = power_law_csr(6000, 6000, 23, 1500)
+    _check(oracle, (rp, ci, va), (rp, ci, va), 6000, 6000, 6000, two_phase=two_phase)
+    _three_window_case(oracle, two_phase)
+
+
+def test_spgemm_short_rows_by_one_wavefront(oracle):
+    """spgemm_small_wave_kernel on the cases its merge has to get right: a row whose runs share columns (sums in run order), duplicate columns INSIDE a B row
+    (an unmerged CSR, CSR.h:485-669 keeps duplicates), empty B rows among the entries, a row of exactly 512 products, a row of 70 entries (more than the 64 lanes:
+    handed to the table kernel), a row of 600 products whose output is shorter than 512 (numeric classes are cut by output length: handed back too). The sums of
+    these rows are added in the reference's (j outer, k inner) order: bit for bit equal to the oracle's, not only within the tolerance."""
+    from g4s_amd import host
+    rng = np.random.default_rng(77)
+    K, N = 400, 5000
+    blen = rng.integers(1, 9, K)
+    blen[:10] = 0                                                  # B rows 0-9 empty
+    blen[10] = 512; blen[11] = 300; blen[12] = 300; blen[13:16] = 200
+    brp = np.concatenate([[0], np.cumsum(blen)]).astype(np.int32)
+    bci = np.concatenate([np.sort(rng.choice(N, l, replace=False)) if l else np.zeros(0, np.int64) for l in blen]).astype(np.int32)
+    # duplicates inside B row 20 (a repeated column, adjacent after sorting)
+    bci[brp[20]:brp[21]] = np.sort(np.resize(bci[brp[20]:brp[21]][:max(1, blen[20] // 2)], blen[20]))
+    bci[brp[12]:brp[13]] = bci[brp[11]:brp[12]]                    # rows 11 and 12 hold the same columns: every product of row "11+12" is a duplicate
+    bva = rng.integers(-8, 9, brp[-1]).astype(np.float64) + rng.uniform(-1, 1, brp[-1])
+    rows = [np.array([10]),                                        # exactly 512 products
+            np.array([11, 12]),                                    # 600 products, 300 outputs
+            np.array([0, 3, 20, 25]),                              # empty B rows among the entries, duplicates inside a run
+            np.sort(rng.choice(np.arange(16, K), 70, replace=False)),   # 70 entries
+            np.array([13, 14, 15]),                                # 600 products, overlapping columns by chance only
+            np.array([5]),                                         # only an empty B row
+            np.arange(20, 60)]                                     # 40 short runs
+    arp = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    aci = np.concatenate(rows).astype(np.int32)
+    ava = rng.uniform(-2, 2, arp[-1])
+    M = len(rows)
+    for two_phase in (False, True):
+        c = _check(oracle, (arp, aci, ava), (brp, bci, bva), M, K, N, two_phase=two_phase)
+        crpt, ccol, cval = c.to_host()
+        orpt, ocol, oval = oracle.spgemm((arp, aci, ava), (brp, bci, bva), N, sort_output=True)
+        flop = np.array([sum(blen[c_] for c_ in r) for r in rows])
+        for i in range(M):
+            if flop[i] <= 512 and len(rows[i]) <= 64:
+                assert np.array_equal(cval[crpt[i]:crpt[i + 1]], oval[orpt[i]:orpt[i + 1]]), f"row {i} is not bit-identical"
+        assert crpt[2] - crpt[1] == 300 and crpt[6] == crpt[5]
+
+
 @pytest.mark.parametrize("two_phase", [False, True])
 def test_spgemm_row_of_300k_outputs(oracle, column_map, two_phase):
     """Output rows of ≈ 150 K and ≈ 142 K entries (19 value chunks; past the 131 072 a list item of the emit step once packed) next to
@@ -324,3 +379,24 @@ def test_spgemm_randomised_seams():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_spgemm.py"), "--cases", "25", "--seed", "5"], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "all ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_spgemm_refuses_unsorted_rows_of_b():
+    """The input contract (include/g4s.h): the rows of B sorted by column — the merge and window kernels cut them at column boundaries. A descent inside a row is
+    G4S_ERR_INVALID from the symbolic phase and the one-call form; a descent ACROSS a row boundary is what sorted rows look like, repeated columns are fine."""
+    from g4s_amd import capi, host
+    rng = np.random.default_rng(3)
+    rp, ci, va = random_csr(300, 300, 0.05, 9)
+    a = host.CSR.from_host(rp, ci, va, 300, 300)
+    host.HashSpGEMM(a, a)                                          # sorted: fine
+    bad = ci.copy()
+    r = int(np.argmax(np.diff(rp) >= 2))
+    bad[rp[r]], bad[rp[r] + 1] = bad[rp[r] + 1], bad[rp[r]]        # one swapped pair inside a row
+    b = host.CSR.from_host(rp, bad, va, 300, 300)
+    with pytest.raises(capi.G4SError, match="sorted by column"):
+        host.HashSpGEMM(a, b)
+    with pytest.raises(capi.G4SError, match="sorted by column"):
+        host.HashSpGEMM(a, b, two_phase=True)
+    dup = ci.copy()
+    dup[rp[r] + 1] = dup[rp[r]]                                    # a repeated column: allowed
+    host.HashSpGEMM(a, host.CSR.from_host(rp, dup, va, 300, 300))
