@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("G4S_LIB") or os.path.join(_HERE, "lib", "libg4s_hip.so")   # G4S_LIB: the host-sanitized build (tools/run_sanitized_cpu_tests.sh)
 
 OK, ERR_INVALID, ERR_NOMEM, ERR_HIP, ERR_OVERFLOW, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
-HOST_POINTERS, DEVICE_POINTERS, SORT_OUTPUT, SPMV_NO_NT, SPMV_BLOCKED, SPMV_STREAM, DIST_LOOPBACK, DIST_ALLGATHER = 0, 1, 2, 4, 8, 16, 32, 64
+HOST_POINTERS, DEVICE_POINTERS, SORT_OUTPUT, SPMV_NO_NT, SPMV_BLOCKED, SPMV_STREAM, DIST_LOOPBACK, DIST_ALLGATHER, SPMV_UPDATABLE = 0, 1, 2, 4, 8, 16, 32, 64, 128
 PATTERN_ELEMENT_BLOCK_MATVEC, PATTERN_DENSE_ROW_TIMES_MATRIX, PATTERN_SYM_QUADRATIC_FORM = 1, 2, 3
 DENSE_DGEMM, DENSE_DSYMM, DENSE_DTRMM, DENSE_DGEMV, DENSE_DSYMV, DENSE_DTRMV, DENSE_DSPMV = 1, 2, 3, 4, 5, 6, 7
 
@@ -94,6 +94,8 @@ SIGNATURES = {
     "g4s_memcpy_d2h": (C.c_int, [vp, vp, C.c_size_t]),
     "g4s_csr_create": (C.c_int, [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int64, vp, vp, vp, C.c_uint]),
     "g4s_csr_destroy": (C.c_int, [vp]),
+    "g4s_csr_update_values": (C.c_int, [vp, vp, C.c_uint, vp]),
+    "g4s_spmv_dist_update_values": (C.c_int, [vp, vp, C.c_uint, vp]),
     "g4s_csr_get_info": (C.c_int, [vp, C.POINTER(CsrInfo)]),
     "g4s_csr_device_arrays": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
     "g4s_spmv": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, vp]),

@@ -125,6 +125,8 @@ struct g4s_spmv_dist_s {
     std::vector<int64_t> recv_cut;              // nseg+1 (= world+1 outside loopback): segment [recv_cut[k], recv_cut[k+1]) of x_rem belongs to owner k
     std::vector<int64_t> give_cut;              // nseg+1: segment of the send buffer that goes to peer k
     std::vector<char> give_set;
+    int32_t *d_src_own = nullptr, *d_src_rem = nullptr;   // G4S_SPMV_UPDATABLE: where in the local CSR arrays the entries of the two parts came from
+    double *d_stage = nullptr;                  // … and one staging array for their new values (max(nnz_own, nnz_rem) doubles)
     int32_t *d_want = nullptr;                  // n_ref indices, local to their owner's slab (what this rank asks for), in x_rem order
     int32_t *d_give = nullptr;                  // indices into x_local, concatenated per peer
     double *d_send = nullptr, *d_xrem = nullptr;
@@ -149,6 +151,7 @@ void dist_release(g4s_spmv_dist_s *h)
     if (h->poisoned) { delete h; return; }      // hipFree / hipStreamDestroy synchronise with work that may never finish: the device memory is left to the process's exit
     if (h->A_own) g4s_csr_destroy(h->A_own);
     if (h->A_rem) g4s_csr_destroy(h->A_rem);
+    (void)hipFree(h->d_src_own); (void)hipFree(h->d_src_rem); (void)hipFree(h->d_stage);
     (void)hipFree(h->d_want); (void)hipFree(h->d_give); (void)hipFree(h->d_send); (void)hipFree(h->d_xrem); (void)hipFree(h->d_rem_rows); (void)hipFree(h->d_rem_y);
     if (h->ev_packed) (void)hipEventDestroy(h->ev_packed);
     if (h->ev_done) (void)hipEventDestroy(h->ev_done);
@@ -168,6 +171,7 @@ struct Split {
     int64_t pad = 0;
     int32_t n_ref = 0;                                              // length of the remote x (packed: referenced columns; all-gather: world·pad)
     std::vector<int32_t> orp, oci, rrp, rci, want;
+    std::vector<int32_t> osrc, rsrc;                                // position in the local CSR arrays of every entry of the two parts (g4s_spmv_dist_update_values)
     std::vector<double> ova, rva;
     std::vector<int64_t> recv_cut;
 };
@@ -232,12 +236,12 @@ int split_rows(int rank, int world, const std::vector<int64_t> &off, int64_t n_c
     for (int32_t i = 0; i < m; ++i) {
         for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
             const int32_t c = ci[k];
-            if (c >= own_lo && c < own_hi) { S.oci.push_back((int32_t)(c - r0)); S.ova.push_back(va[k]); }
+            if (c >= own_lo && c < own_hi) { S.oci.push_back((int32_t)(c - r0)); S.ova.push_back(va[k]); S.osrc.push_back(k); }
             else {
                 int32_t rc;
                 if (allgather) { const int o = loopback ? 0 : owner_of(off, c); rc = (int32_t)(S.pad * o + (c - off[o])); }
                 else rc = (int32_t)(std::lower_bound(ref.begin(), ref.end(), c) - ref.begin());
-                S.rci.push_back(rc); S.rva.push_back(va[k]);
+                S.rci.push_back(rc); S.rva.push_back(va[k]); S.rsrc.push_back(k);
             }
         }
         S.orp[(size_t)i + 1] = (int32_t)S.oci.size(); S.rrp[(size_t)i + 1] = (int32_t)S.rci.size();
@@ -382,7 +386,17 @@ G4S_API g4s_status g4s_spmv_dist_create_rect(g4s_spmv_dist_t *out, int32_t rank,
         h->merged = S.merged; h->allgather = S.allgather; h->pad = S.pad; h->n_ref = S.n_ref; h->nseg = S.nseg;
         h->nnz_own = (int64_t)S.oci.size(); h->nnz_rem = (int64_t)S.rci.size();
         h->recv_cut = S.recv_cut;
-        const unsigned path_flags = flags & (G4S_SPMV_NO_NT | G4S_SPMV_BLOCKED | G4S_SPMV_STREAM);
+        const unsigned path_flags = flags & (G4S_SPMV_NO_NT | G4S_SPMV_BLOCKED | G4S_SPMV_STREAM | G4S_SPMV_UPDATABLE);
+        if (flags & G4S_SPMV_UPDATABLE) {
+            const size_t stage = std::max<size_t>(std::max(S.osrc.size(), S.rsrc.size()), 1);
+            if (g4s::device_malloc((void **)&h->d_src_own, sizeof(int32_t) * std::max<size_t>(S.osrc.size(), 1)) != hipSuccess ||
+                g4s::device_malloc((void **)&h->d_src_rem, sizeof(int32_t) * std::max<size_t>(S.rsrc.size(), 1)) != hipSuccess ||
+                g4s::device_malloc((void **)&h->d_stage, sizeof(double) * stage) != hipSuccess)
+                return fail(g4s::set_error(G4S_ERR_NOMEM, "device allocation failed"));
+            if ((!S.osrc.empty() && hipMemcpy(h->d_src_own, S.osrc.data(), sizeof(int32_t) * S.osrc.size(), hipMemcpyHostToDevice) != hipSuccess) ||
+                (!S.rsrc.empty() && hipMemcpy(h->d_src_rem, S.rsrc.data(), sizeof(int32_t) * S.rsrc.size(), hipMemcpyHostToDevice) != hipSuccess))
+                return fail(g4s::set_error(G4S_ERR_HIP, "H2D copy failed"));
+        }
         st = g4s_csr_create(&h->A_own, m, (int32_t)(r1 - r0), h->nnz_own, S.orp.data(), S.oci.data(), S.ova.data(), G4S_HOST_POINTERS | path_flags);
         if (st != G4S_OK) return fail(st);
         // remote-column part: only the rows that have one, when they are under a quarter of the slab (never in the merged form, whose one product writes all of y)
@@ -436,6 +450,26 @@ G4S_API g4s_status g4s_spmv_dist_create(g4s_spmv_dist_t *out, int32_t rank, int3
     *out = nullptr;
     G4S_TRY(check_partition(rank, world, row_offsets, n_cols));    // square: x is partitioned like the rows
     return g4s_spmv_dist_create_rect(out, rank, world, row_offsets, row_offsets, rowptr, colids, values, flags);
+}
+
+// New values for this rank's rows (the order of the arrays the handle was created from): each of the two parts gathers its entries through its source map
+// and hands them to its own CSR handle (g4s_csr_update_values). No communication: every rank updates its slab.
+G4S_API g4s_status g4s_spmv_dist_update_values(g4s_spmv_dist_t h, const double *values_local, unsigned flags, void *stream)
+{
+    G4S_REQUIRE(h && !h->poisoned, "bad handle");
+    G4S_REQUIRE(h->d_src_own, "the handle was created without G4S_SPMV_UPDATABLE");
+    G4S_REQUIRE(values_local || h->nnz_own + h->nnz_rem == 0, "values is NULL");
+    G4S_REQUIRE(flags & G4S_DEVICE_POINTERS, "g4s_spmv_dist_update_values takes a device array");
+    hipStream_t s = g4s::as_stream(stream);
+    for (int part = 0; part < 2; ++part) {
+        const int64_t n = part ? h->nnz_rem : h->nnz_own;
+        if (!n) continue;
+        const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
+        hipLaunchKernelGGL(dist_pack_kernel, dim3(grid), dim3(256), 0, s, (long long)n, part ? h->d_src_rem : h->d_src_own, values_local, h->d_stage);
+        G4S_HIP_TRY(hipGetLastError());
+        G4S_TRY(g4s_csr_update_values(part ? h->A_rem : h->A_own, h->d_stage, G4S_DEVICE_POINTERS, stream));   // (the parts own their arrays: copied in, in stream order)
+    }
+    return G4S_OK;
 }
 
 G4S_API g4s_status g4s_spmv_dist_destroy(g4s_spmv_dist_t h)

@@ -306,6 +306,7 @@ struct g4s_csr_s {
     int dia_nd = 0;
     long long dia_ld = 0;
     DiaOffsets dia_offs{};
+    unsigned flags = 0;             // of g4s_csr_create
     g4s::PbPlan *pb = nullptr;      // propagation-blocked path (spmv_pb.hip) for matrices without gather locality
     g4s::BcsrPlan *bcsr = nullptr;  // block-row form of an assembled FE matrix (spmv_bcsr.hip)
 };
@@ -564,6 +565,7 @@ G4S_API g4s_status g4s_csr_create(g4s_csr_t *out, int32_t rows, int32_t cols, in
     g4s_csr_s *A = new (std::nothrow) g4s_csr_s();
     if (!A) return g4s::set_error(G4S_ERR_NOMEM, "host allocation failed");
     A->rows = rows; A->cols = cols; A->nnz = nnz;
+    A->flags = flags;
     A->use_nt = !(flags & G4S_SPMV_NO_NT);
 
     std::vector<int32_t> h_rowptr_copy;
@@ -616,7 +618,7 @@ G4S_API g4s_status g4s_csr_create(g4s_csr_t *out, int32_t rows, int32_t cols, in
     // Path choice: the row-streaming kernel unless the x gathers have no locality (or the caller forces one).
     const bool want_pb = (flags & G4S_SPMV_BLOCKED) || (!(flags & G4S_SPMV_STREAM) && g4s::pb_should_use(rows, cols, nnz, A->d_colids));
     if (want_pb && nnz > 0) {
-        st = g4s::pb_build(&A->pb, rows, cols, nnz, A->d_rowptr, A->d_colids, A->d_values);
+        st = g4s::pb_build(&A->pb, rows, cols, nnz, A->d_rowptr, A->d_colids, A->d_values, (flags & G4S_SPMV_UPDATABLE) != 0);
         A->plan_bytes += g4s::pb_bytes(A->pb);
         if (st != G4S_OK && (flags & G4S_SPMV_BLOCKED)) return fail(st);   // auto mode falls back to the streaming path
     }
@@ -632,6 +634,60 @@ G4S_API g4s_status g4s_csr_create(g4s_csr_t *out, int32_t rows, int32_t cols, in
         A->plan_bytes += g4s::bcsr_bytes(A->bcsr);
     }
     *out = A;
+    return G4S_OK;
+}
+
+namespace {
+// new values into the diagonals (the pattern is the plan's: every entry's offset is in the set, dia_fill_kernel checked it at create)
+__global__ void dia_refill_kernel(int rows, int nd, DiaOffsets offs, long long ld, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colids,
+                                  const double *__restrict__ values, double *__restrict__ dia)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    for (int k = rowptr[row]; k < rowptr[row + 1]; ++k) {
+        const int o = colids[k] - row;
+        int lo = 0, hi = nd;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (offs.off[mid] < o) lo = mid + 1; else hi = mid; }
+        if (lo < nd) dia[(long long)lo * ld + row] = values[k];
+    }
+}
+} // namespace
+
+// New values, same pattern (citcoms/lib/Drive_solvers.c:88,134 → construct_stiffness_B_matrix, Construct_arrays.c:740: the stiffness matrix is rebuilt
+// before every Stokes solve and inside the viscosity iteration). The CSR array is replaced (owned copy: copied into; borrowed: the handle borrows the new
+// array), then whatever the plan keeps of the values in another order is refreshed on `stream`: the regrouped producer stream of the blocked path (one
+// gather pass through its value map), the diagonals, the block-major copy; the row-streaming kernel reads the CSR array itself.
+G4S_API g4s_status g4s_csr_update_values(g4s_csr_t A, const double *values, unsigned flags, void *stream)
+{
+    G4S_REQUIRE(A, "NULL handle");
+    if (A->nnz == 0) return G4S_OK;
+    hipStream_t s = g4s::as_stream(stream);
+    const bool dev = (flags & G4S_DEVICE_POINTERS) != 0;
+    if (values && values != A->d_values) {
+        if (A->owns) {
+            G4S_HIP_TRY(hipMemcpyAsync(const_cast<double *>(A->d_values), values, sizeof(double) * (size_t)A->nnz, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+        } else {
+            G4S_REQUIRE(dev, "the handle borrows device arrays: new values must be a device array too (it is borrowed from here on)");
+            A->d_values = values;
+        }
+    }
+    if (A->pb) {
+        if (g4s::pb_has_value_map(A->pb)) return g4s::pb_update_values(A->pb, A->d_values, s);
+        // created without G4S_SPMV_UPDATABLE: the regrouping is done again (the cost of a create, on the NULL stream like a create)
+        G4S_HIP_TRY(hipStreamSynchronize(s));
+        A->plan_bytes -= g4s::pb_bytes(A->pb);
+        g4s::pb_destroy(A->pb);
+        A->pb = nullptr;
+        G4S_TRY(g4s::pb_build(&A->pb, A->rows, A->cols, A->nnz, A->d_rowptr, A->d_colids, A->d_values, false));
+        A->plan_bytes += g4s::pb_bytes(A->pb);
+        return G4S_OK;
+    }
+    if (A->d_dia) {
+        hipLaunchKernelGGL(dia_refill_kernel, dim3((A->rows + 255) / 256), dim3(256), 0, s, A->rows, A->dia_nd, A->dia_offs, A->dia_ld, A->d_rowptr, A->d_colids, A->d_values, A->d_dia);
+        G4S_HIP_TRY(hipGetLastError());
+        return G4S_OK;
+    }
+    if (A->bcsr) return g4s::bcsr_update_values(A->bcsr, A->d_colids, A->d_values, s);
     return G4S_OK;
 }
 

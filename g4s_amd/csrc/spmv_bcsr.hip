@@ -183,6 +183,14 @@ int bcsr_try_build(BcsrPlan **out, int rows, int cols, long long nnz, const int3
     return G4S_OK;
 }
 
+// new values into the block-major copy (the pattern is the plan's: the block-column ids are rewritten with what they already hold)
+int bcsr_update_values(BcsrPlan *P, const int32_t *d_colids, const double *d_values, hipStream_t s)
+{
+    hipLaunchKernelGGL(bcsr_fill_kernel, dim3((P->rows + 255) / 256), dim3(256), 0, s, P->rows, P->b, P->d_rowptr, d_colids, d_values, P->bval.as<double>(), P->bcol.as<int32_t>());
+    G4S_HIP_TRY(hipGetLastError());
+    return G4S_OK;
+}
+
 void bcsr_destroy(BcsrPlan *P) { delete P; }
 long long bcsr_bytes(const BcsrPlan *P) { return P ? P->bytes : 0; }
 int bcsr_block(const BcsrPlan *P) { return P ? P->b : 0; }

@@ -141,7 +141,7 @@ __global__ void pb_cell_starts_kernel(long long nnz, const unsigned *__restrict_
 __global__ void pb_fill_producer_kernel(long long nnz, const int *__restrict__ colids, const unsigned *__restrict__ colmap, const double *__restrict__ values, const int *__restrict__ rowid,
                                         const unsigned *__restrict__ perm, const unsigned *__restrict__ sorted_keys, int band_key_bits, int RB,
                                         const int *__restrict__ shift, unsigned short *__restrict__ p_lcol, double *__restrict__ p_val,
-                                        int *__restrict__ t_row, int *__restrict__ t_cell)
+                                        int *__restrict__ t_row, int *__restrict__ t_cell, int *__restrict__ p_src /* may be NULL: the CSR index behind every slot (g4s_csr_update_values) */)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (long long)gridDim.x * blockDim.x) {
         const unsigned k = perm[i], key = sorted_keys[i];
@@ -149,8 +149,19 @@ __global__ void pb_fill_producer_kernel(long long nnz, const int *__restrict__ c
         const long long pos = i + shift[q];
         p_lcol[pos] = (unsigned short)(colmap[colids[k]] & (kBand - 1));
         p_val[pos] = values[k];
+        if (p_src) p_src[pos] = (int)k;
         t_row[pos] = rowid[k];
         t_cell[pos] = q;
+    }
+}
+
+// New values into the stored order (g4s_csr_update_values): slot j holds CSR entry p_src[j] (pads: −1, their value stays 0). The gathers are nearly
+// sequential — a cell keeps the CSR order of its entries — so this is one pass over the producer stream.
+__global__ void pb_update_values_kernel(long long slots, const int *__restrict__ p_src, const double *__restrict__ values, double *__restrict__ p_val)
+{
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < slots; j += (long long)gridDim.x * blockDim.x) {
+        const int k = p_src[j];
+        if (k >= 0) p_val[j] = values[k];
     }
 }
 
@@ -409,12 +420,14 @@ struct PbPlan {
     int rows = 0, cols = 0, CB = 0, RB = 0;
     long long nnz = 0, micro_runs = 0;
     DevBuf p_lcol, p_val, masks, mbase, c_lrow, prod, delta, pitems, citems, split_bands, hot_cols, hot_x;
+    DevBuf p_src;                                                   // G4S_SPMV_UPDATABLE: CSR index of every producer slot
+    long long slots = 0;
     int n_pitems = 0, n_citems = 0, n_split = 0, H = 0;
     size_t lds_producer = 0, lds_consumer = 0;
     long long bytes = 0;
 };
 
-int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowptr, const int *d_colids, const double *d_values)
+int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowptr, const int *d_colids, const double *d_values, bool keep_value_map)
 {
     *out = nullptr;
     if (nnz <= 0 || rows <= 0 || cols <= 0) return set_error(G4S_ERR_INVALID, "pb_build: empty matrix");
@@ -524,8 +537,14 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     G4S_HIP_TRY(hipMemset(P->p_val.p, 0, P->p_val.bytes));
     G4S_HIP_TRY(hipMemset(t_row.p, 0xFF, t_row.bytes));           // −1 = pad
     G4S_HIP_TRY(hipMemset(t_cell.p, 0, t_cell.bytes));
+    P->slots = totP;
+    if (keep_value_map) {
+        G4S_TRY(P->p_src.alloc(sizeof(int) * (size_t)(totP + 64)));
+        G4S_HIP_TRY(hipMemset(P->p_src.p, 0xFF, P->p_src.bytes));   // −1 = pad
+    }
     hipLaunchKernelGGL(pb_fill_producer_kernel, dim3(grid_for(nnz)), dim3(256), 0, nullptr, nnz, d_colids, colmap.as<unsigned>(), d_values, rowid.as<int>(), perm.as<unsigned>(),
-                       key_s.as<unsigned>(), bits, RB, d_shP.as<int>(), P->p_lcol.as<unsigned short>(), P->p_val.as<double>(), t_row.as<int>(), t_cell.as<int>());
+                       key_s.as<unsigned>(), bits, RB, d_shP.as<int>(), P->p_lcol.as<unsigned short>(), P->p_val.as<double>(), t_row.as<int>(), t_cell.as<int>(),
+                       keep_value_map ? P->p_src.as<int>() : (int *)nullptr);
     G4S_HIP_TRY(hipGetLastError());
     G4S_HIP_TRY(hipDeviceSynchronize());
     key_s.release(); perm.release(); rowid.release(); startP.release(); colmap.release();
@@ -609,7 +628,7 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     G4S_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pb_producer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_producer));
     G4S_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pb_consumer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_consumer));
     G4S_HIP_TRY(hipDeviceSynchronize());
-    P->bytes = (long long)(P->p_lcol.bytes + P->p_val.bytes + P->masks.bytes + P->mbase.bytes + P->c_lrow.bytes + P->prod.bytes + P->delta.bytes +
+    P->bytes = (long long)(P->p_src.bytes + P->p_lcol.bytes + P->p_val.bytes + P->masks.bytes + P->mbase.bytes + P->c_lrow.bytes + P->prod.bytes + P->delta.bytes +
                            P->pitems.bytes + P->citems.bytes + P->split_bands.bytes + P->hot_cols.bytes + P->hot_x.bytes);
     if (getenv("G4S_DEBUG"))
         fprintf(stderr, "g4s blocked SpMV plan: %d x %d bands (%d hot), nnz %lld, padded %lld, micro-runs %lld (%.3f per nonzero), %d producer / %d consumer items, %d split bands, %.2f GB\n",
@@ -621,6 +640,16 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
 void pb_destroy(PbPlan *P) { delete P; }
 
 long long pb_bytes(const PbPlan *P) { return P ? P->bytes : 0; }
+bool pb_has_value_map(const PbPlan *P) { return P && P->p_src.p != nullptr; }
+
+// new values (CSR order, device) into the plan's regrouped copy; needs the value map (G4S_SPMV_UPDATABLE at create)
+int pb_update_values(PbPlan *P, const double *d_values, hipStream_t s)
+{
+    if (!P->p_src.p) return set_error(G4S_ERR_UNSUPPORTED, "the blocked plan was built without its value map");
+    hipLaunchKernelGGL(pb_update_values_kernel, dim3(grid_for(P->slots)), dim3(256), 0, s, P->slots, P->p_src.as<int>(), d_values, P->p_val.as<double>());
+    G4S_HIP_TRY(hipGetLastError());
+    return G4S_OK;
+}
 
 int pb_spmv(PbPlan *P, const double *x, double *y, double alpha, double beta, hipStream_t s)
 {

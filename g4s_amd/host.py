@@ -78,6 +78,14 @@ class CSR:
         capi.check(capi.load().g4s_spmv(self.handle, _ptr(x), _ptr(y), float(alpha), float(beta), _stream()))
         return y
 
+    def update_values(self, values):
+        """New values for the same pattern (g4s_csr_update_values), in place: `values` (device tensor, nnz doubles) replaces self.values — the handle borrows
+        the tensor's memory from here on — and the plan's own copy is refreshed on the current torch stream."""
+        assert values.dtype == torch.float64 and values.is_cuda and values.numel() == self.nnz
+        self.values = values
+        if self._handle is not None:
+            capi.check(capi.load().g4s_csr_update_values(self._handle, _ptr(values), capi.DEVICE_POINTERS, _stream()))
+
     def close(self):
         if self._handle is not None:
             capi.load().g4s_csr_destroy(self._handle)

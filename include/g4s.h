@@ -45,6 +45,9 @@ typedef int g4s_status;
 #define G4S_SPMV_STREAM     16u /* SpMV: force the row-streaming CSR kernel (default: chosen per matrix — blocked for matrices without gather locality,
                                  * the index-free diagonal form for stencil / banded matrices, the CSR kernel otherwise) */
 
+#define G4S_SPMV_UPDATABLE 128u /* SpMV: the values of this matrix will be replaced (g4s_csr_update_values): a plan that keeps them in another order also keeps the
+                                 * map back to the CSR order (blocked path: 4 bytes per entry), so that an update is one pass instead of a new plan */
+
 /* ------------------------------------------------------------------ runtime */
 const char *g4s_version(void);
 const char *g4s_last_error(void);                 /* thread-local, never NULL                              */
@@ -94,8 +97,8 @@ typedef struct g4s_csr_info {
  * With G4S_HOST_POINTERS the three arrays are copied to the device (the handle owns the copies);
  * with G4S_DEVICE_POINTERS they are borrowed and must outlive the handle. Replaces the container role of
  * CSR<int,double> (mm/inc/CSR.h:22-113) for device residency.
- * The handle is a SNAPSHOT of the matrix: the execution plan (and, on the blocked path, a regrouped copy of the values) is
- * built here; changing the arrays afterwards requires a new handle.
+ * The handle is a SNAPSHOT of the matrix: the execution plan (and, on three of the four paths, a copy of the values in the plan's own order) is
+ * built here; the PATTERN is fixed for the handle's life, new VALUES go in through g4s_csr_update_values.
  * Concurrency: a handle supports ONE product in flight at a time — g4s_spmv uses per-handle workspaces (the partial sums of split long
  * rows on the streaming path, the product buffer and the gathered hot columns on the blocked path), so two g4s_spmv calls on the same
  * handle must be ordered (same stream, or an event between them); different handles are independent.
@@ -104,6 +107,14 @@ typedef struct g4s_csr_info {
  * non-blocking stream synchronises it first. */
 g4s_status g4s_csr_create(g4s_csr_t *out, int32_t rows, int32_t cols, int64_t nnz,
                           const int32_t *rowptr, const int32_t *colids, const double *values, unsigned flags);
+/* New values for the same pattern — what a time-stepping caller does to its operator (CitcomS rebuilds the stiffness matrix before every Stokes solve and
+ * inside the viscosity iteration: citcoms/lib/Drive_solvers.c:88,134 → construct_stiffness_B_matrix, Construct_arrays.c:740). values: nnz entries in the
+ * order of the arrays the handle was created from (flags: G4S_HOST_POINTERS or G4S_DEVICE_POINTERS), or NULL when a BORROWED device array has been rewritten
+ * in place. A handle that owns its arrays copies them in; a handle that borrows device arrays borrows the new array from here on (device pointer required).
+ * The plan's own copy is refreshed on `stream` (asynchronous like g4s_spmv, ordered with the products on that stream): one gather pass on the blocked path
+ * (created with G4S_SPMV_UPDATABLE; without the flag the regrouping is repeated — the cost of a create), a refill of the diagonals / the block-major copy,
+ * nothing on the row-streaming path. Results afterwards are those of a handle freshly created from the new values, bit for bit. */
+g4s_status g4s_csr_update_values(g4s_csr_t A, const double *values, unsigned flags, void *stream);
 g4s_status g4s_csr_destroy(g4s_csr_t A);
 g4s_status g4s_csr_get_info(g4s_csr_t A, g4s_csr_info *info);
 /* Device pointers of the handle's arrays (borrowed). */
@@ -203,6 +214,9 @@ g4s_status g4s_spmv_dist_begin(g4s_spmv_dist_t h, const double *x_local_dev, dou
  * slot k = [k·pad, (k+1)·pad) comes from rank k. */
 g4s_status g4s_spmv_dist_buffers(g4s_spmv_dist_t h, double **send_dev, const int64_t **send_cut, double **recv_dev, const int64_t **recv_cut);
 g4s_status g4s_spmv_dist_finish(g4s_spmv_dist_t h, double *y_local_dev, void *stream);
+/* New values for this rank's rows, same pattern (see g4s_csr_update_values): values_local_dev in the order of the arrays given to _create, device memory;
+ * the handle must have been created with G4S_SPMV_UPDATABLE. Asynchronous on `stream`; no communication. */
+g4s_status g4s_spmv_dist_update_values(g4s_spmv_dist_t h, const double *values_local_dev, unsigned flags, void *stream);
 /* RCCL communicator for hosts that have none (rank 0 makes the 128-byte id, every rank gets it by its own means and calls _create), and
  * the sum all-reduce the dot products of a Krylov solver need (citcoms/lib/Global_operations.c:534-562). RCCL is dlopen'ed at first use. */
 g4s_status g4s_comm_unique_id(void *id128);
