@@ -638,18 +638,23 @@ G4S_API g4s_status g4s_csr_create(g4s_csr_t *out, int32_t rows, int32_t cols, in
 }
 
 namespace {
-// new values into the diagonals (the pattern is the plan's: every entry's offset is in the set, dia_fill_kernel checked it at create)
-__global__ void dia_refill_kernel(int rows, int nd, DiaOffsets offs, long long ld, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colids,
-                                  const double *__restrict__ values, double *__restrict__ dia)
+// new values into the diagonals. The pattern is the plan's: row r's entries are its present diagonals in ascending offset order (dia_fill_kernel checked
+// that at create), so entry j of the row belongs to the j-th set bit of its mask — no column ids, no search; one lane per row, the loads of a row's values in
+// flight together, the stores unit-stride per diagonal.
+template <int ND>
+__global__ __launch_bounds__(256) void dia_refill_kernel(int rows, int nd, long long ld, const int32_t *__restrict__ rowptr, const unsigned *__restrict__ mask,
+                                                         const double *__restrict__ values, double *__restrict__ dia)
 {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= rows) return;
-    for (int k = rowptr[row]; k < rowptr[row + 1]; ++k) {
-        const int o = colids[k] - row;
-        int lo = 0, hi = nd;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (offs.off[mid] < o) lo = mid + 1; else hi = mid; }
-        if (lo < nd) dia[(long long)lo * ld + row] = values[k];
-    }
+    const unsigned m = mask[row];
+    const int k0 = rowptr[row], last = max(rowptr[row + 1] - 1, k0);
+    double v[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) v[d] = values[min(k0 + (int)__popc(m & ((1u << d) - 1u)), last)];   // (absent diagonals read a neighbour: not stored)
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+        if (d < nd && ((m >> d) & 1u)) dia[(long long)d * ld + row] = v[d];
 }
 } // namespace
 
@@ -683,7 +688,10 @@ G4S_API g4s_status g4s_csr_update_values(g4s_csr_t A, const double *values, unsi
         return G4S_OK;
     }
     if (A->d_dia) {
-        hipLaunchKernelGGL(dia_refill_kernel, dim3((A->rows + 255) / 256), dim3(256), 0, s, A->rows, A->dia_nd, A->dia_offs, A->dia_ld, A->d_rowptr, A->d_colids, A->d_values, A->d_dia);
+        const dim3 grid((A->rows + 255) / 256), block(256);
+        if (A->dia_nd <= 8) hipLaunchKernelGGL(dia_refill_kernel<8>, grid, block, 0, s, A->rows, A->dia_nd, A->dia_ld, A->d_rowptr, A->d_dia_mask, A->d_values, A->d_dia);
+        else if (A->dia_nd <= 16) hipLaunchKernelGGL(dia_refill_kernel<16>, grid, block, 0, s, A->rows, A->dia_nd, A->dia_ld, A->d_rowptr, A->d_dia_mask, A->d_values, A->d_dia);
+        else hipLaunchKernelGGL(dia_refill_kernel<32>, grid, block, 0, s, A->rows, A->dia_nd, A->dia_ld, A->d_rowptr, A->d_dia_mask, A->d_values, A->d_dia);
         G4S_HIP_TRY(hipGetLastError());
         return G4S_OK;
     }

@@ -160,8 +160,8 @@ __global__ void pb_fill_producer_kernel(long long nnz, const int *__restrict__ c
 __global__ void pb_update_values_kernel(long long slots, const int *__restrict__ p_src, const double *__restrict__ values, double *__restrict__ p_val)
 {
     for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < slots; j += (long long)gridDim.x * blockDim.x) {
-        const int k = p_src[j];
-        if (k >= 0) p_val[j] = values[k];
+        const int k = __builtin_nontemporal_load(p_src + j);        // the two streams pass through; the cache is left to the gathered values
+        if (k >= 0) __builtin_nontemporal_store(values[k], p_val + j);
     }
 }
 

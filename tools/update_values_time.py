@@ -25,7 +25,7 @@ def timed(fn, reps):
 out = []
 n = 1_000_000 if a.small else 10_000_000
 cases = [("R-MAT configs[1]", lambda f: host.rmat_csr(n, 24, 10 * n, 20240521, spmv_flags=f | capi.SPMV_UPDATABLE)),
-         ("7-pt stencil 431x431x60", lambda f: host.laplacian_csr("lap7", 431, 431, 60 if not a.small else 8, spmv_flags=f)),
+         ("7-pt stencil 431x431x60", lambda f: host.laplacian_csr(7, 431, 431, 60 if not a.small else 8, spmv_flags=f)),
          ("banded 10M hb 5", lambda f: host.banded_csr(n, 5, 3, spmv_flags=f))]
 for name, make in cases:
     A = make(0)
