@@ -197,7 +197,10 @@ def config_secondary(kind, world, rank, steps, warmup, small, host, gdist, dist,
                           "kernel_own_bytes": own, "kernel_own_gbs": round(own * steps / el / 1e9, 1), "kernel_own_frac_of_8TBs": round(own * steps / el / 1e9 / 8000.0, 4)})
     return {**extra, "workload": WORKLOADS[kind] + (" [--small size]" if small else ""), "n_gpus": world, "rows": n, "nnz": nnz, "steps": steps, "ms_per_step": round(el / steps * 1e3, 5),
             "value": round(nnz * steps / el / 1e9, 3), "unit": "GEdges/s", "spmv_path": {0: "stream", 1: "blocked", 3: "diagonal (index-free)", 4: "block-row"}.get(path, str(path)),
-            "hbm_gbs_algorithmic_whole_job": round(alg * steps / el / 1e9, 1), "frac_of_n_gpus_x_8TBs": round(alg * steps / el / 1e9 / (8000.0 * world), 4)}
+            "hbm_gbs_algorithmic_whole_job": round(alg * steps / el / 1e9, 1),
+            # the fraction of n_gpus x 8 TB/s on the bytes the kernel MOVES: the CSR-algorithmic bytes on the CSR paths; on the index-free diagonal path those
+            # bytes are not moved (its own fraction is kernel_own_frac_of_8TBs above) and the figure is labelled for what it is: a CSR-equivalent rate
+            ("csr_equivalent_frac_of_n_gpus_x_8TBs" if path == 3 else "frac_of_n_gpus_x_8TBs"): round(alg * steps / el / 1e9 / (8000.0 * world), 4)}
 
 
 def config2_spgemm(small, host, capi, torch, runs=10, mkl_threads=14):
@@ -419,16 +422,25 @@ def main():
 
     # HBM bytes per launch come from PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, tools/prof_pmc.sh), which cannot run inside this process:
     # the number is read from the stored profile of the same workload and SpMV path, and the line says so (traffic_source).
+    # A stored number is only as good as the kernels it was taken on: the profile records the SHA-256 of the SpMV kernel sources (tools/kernel_hash.py:
+    # spmv.hip, spmv_pb.hip, spmv_bcsr.hip, prims.hpp, common.hpp) and a number whose hash differs from the sources of the loaded build is refused.
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             if tj.get("workload") == args.workload and tj.get("n_gpus") == world and not args.small and tj.get("spmv_path", info["spmv_path"]) == info["spmv_path"]:
-                traffic = tj.get("hbm_bytes_per_launch")
-                traffic_source = f"stored PMC profile profiles/{tj.get('source', 'traffic_latest.json')} (not measured by this run)"
-        except Exception:
-            traffic = None
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import kernel_hash
+                now = kernel_hash.spmv_kernel_hash()
+                if tj.get("kernel_sources_sha256") == now:
+                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = f"stored PMC profile profiles/{tj.get('source', 'traffic_latest.json')} of the same kernel sources (sha256 {now[:12]}…; not measured by this run)"
+                else:
+                    traffic_source = (f"REFUSED: profiles/traffic_latest.json was taken on kernel sources {str(tj.get('kernel_sources_sha256'))[:12]}…, this build is {now[:12]}… "
+                                      "— re-take it with tools/r04_profile.sh")
+        except Exception as e:                                      # noqa: BLE001
+            traffic, traffic_source = None, f"stored profile unreadable: {type(e).__name__}"
 
     result = {
         "metric": "fp64 SpMV GEdges/s",

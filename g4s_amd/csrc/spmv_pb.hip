@@ -597,8 +597,10 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     // profiles/README.md); a row slab of it (the per-rank matrix of the multi-GPU bench, an eighth of the nonzeros) would then have
     // ~90 heavy producer items and ~20–80 consumer items for 256 CUs, and measured 20–25 % faster at 32 K / 16 K.
     auto pow2_at_most = [](long long v) { long long p = 1; while (p * 2 <= v) p *= 2; return p; };
-    const long long auto_pc = std::min<long long>(kProducerChunk, std::max<long long>(32768, pow2_at_most(totP / 512)));
-    const long long auto_cc = std::min<long long>(kConsumerChunk, std::max<long long>(16384, pow2_at_most(P->micro_runs / 256)));
+    // (round 4, the 8-way slabs again, tools/dist_probe.py: 64 K / 32 K for 10–13 M entries measured 4 % faster than 32 K / 16 K — a producer item pays ≈ 6 µs
+    // for staging its band of x whatever its length — and 128 K / 64 K 20 % slower: too few items for 256 CUs)
+    const long long auto_pc = std::min<long long>(kProducerChunk, std::max<long long>(32768, pow2_at_most(totP / 128)));
+    const long long auto_cc = std::min<long long>(kConsumerChunk, std::max<long long>(16384, pow2_at_most(P->micro_runs / 128)));
     const int kPC = (std::max<long long>(kSpan * kPbThreads, getenv("G4S_PB_PCHUNK") ? atoll(getenv("G4S_PB_PCHUNK")) : auto_pc) / kWindow) * (kWindow / kSpan);   // spans per item, whole windows
     const int kCC = (int)std::max<long long>(4, (getenv("G4S_PB_CCHUNK") ? atoll(getenv("G4S_PB_CCHUNK")) : auto_cc) & ~3ll);
     std::vector<ProducerItem> pit;
