@@ -20,9 +20,9 @@ namespace g4s {
 namespace {
 
 #ifndef G4S_BCSR_TILE
-#define G4S_BCSR_TILE 2048
+#define G4S_BCSR_TILE 1024
 #endif
-// entries (16 KiB of products) per workgroup, as the CSR kernel's stream blocks; 4096 measured the same (7.2–7.4 µs on the Cookbook2 matrix)
+// entries (8 KiB of products) per workgroup: see the note behind the kernel for the sizes measured
 constexpr int kWG = 256, kTile = G4S_BCSR_TILE, kUnroll = kTile / kWG, kMaxBrows = 512;
 
 struct DevBuf {
@@ -127,6 +127,11 @@ __global__ __launch_bounds__(kWG) void spmv_bcsr_kernel(const Item *__restrict__
     }
 }
 
+// Round 4 measured a persistent, register-double-buffered form of this kernel (a few workgroups per CU walking the items with a stride, the loads of the next
+// item issued before the row sums of the current one — VERDICT r3 item 6) on the Cookbook2 matrix, one process per build: 8.8 µs with two workgroups per CU,
+// 7.7 with three, 7.0 with four, 12.7 with one, against 6.8 for this one-item-per-workgroup form — the product is bound by the latency of ONE dependent pair of
+// loads (block id → x) per workgroup and by nothing else, so the more workgroups are in flight at once the better, and a loop over items only serialises them.
+// What did help: 1 024-entry tiles (four block-rows per workgroup, twice the workgroups): 6.4 µs (1 280 and 1 536: the same; 768: 7.1; 4 096: 7.3).
 } // namespace
 
 struct BcsrPlan {
@@ -198,6 +203,7 @@ int bcsr_block(const BcsrPlan *P) { return P ? P->b : 0; }
 int bcsr_spmv(BcsrPlan *P, const double *x, double *y, double alpha, double beta, hipStream_t s)
 {
     if (!P->n_items) return G4S_OK;
+
 #define G4S_BCSR_LAUNCH(B)                                                                                                                              \
     do {                                                                                                                                               \
         if (P->use_nt) hipLaunchKernelGGL((spmv_bcsr_kernel<B, true>), dim3(P->n_items), dim3(kWG), 0, s, P->items.as<Item>(), P->d_rowptr, P->bcol.as<int32_t>(), P->bval.as<double>(), x, y, alpha, beta); \
