@@ -108,6 +108,7 @@ SIGNATURES = {
     "g4s_dist_split_free": (None, [C.POINTER(DistSplit)]),
     "g4s_spmv_dist_create": (C.c_int, [C.POINTER(vp), C.c_int32, C.c_int32, i64p, C.c_int64, vp, vp, vp, C.c_uint]),
     "g4s_spmv_dist_create_rect": (C.c_int, [C.POINTER(vp), C.c_int32, C.c_int32, i64p, i64p, vp, vp, vp, C.c_uint]),
+    "g4s_spmv_dist_create_columns": (C.c_int, [C.POINTER(vp), C.c_int32, C.c_int32, i64p, C.c_int32, vp, vp, vp, C.c_uint]),
     "g4s_spmv_dist_destroy": (C.c_int, [vp]),
     "g4s_spmv_dist_get_info": (C.c_int, [vp, C.POINTER(DistInfo)]),
     "g4s_spmv_dist_connect_rccl": (C.c_int, [vp, vp]),

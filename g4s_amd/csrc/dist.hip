@@ -139,6 +139,8 @@ struct g4s_spmv_dist_s {
     hipEvent_t ev_packed = nullptr, ev_done = nullptr;
     ncclComm_t comm = nullptr;
     bool exchange_posted = false;
+    bool columns = false;                       // column-partition variant (g4s_spmv_dist_create_columns): this rank holds A[:, its slab of x]; the product is a
+                                                // partial y of ALL rows, summed over the ranks by an all-reduce
     bool poisoned = false;                      // a set-up exchange timed out or RCCL reported an asynchronous error: the communicator has been aborted, operations on the
                                                 // side stream may never complete. Nothing of this handle is synchronised or freed on the device any more (see dist_poison)
 };
@@ -452,11 +454,73 @@ G4S_API g4s_status g4s_spmv_dist_create(g4s_spmv_dist_t *out, int32_t rank, int3
     return g4s_spmv_dist_create_rect(out, rank, world, row_offsets, row_offsets, rowptr, colids, values, flags);
 }
 
+// Column-partition variant (north_star: "all-reduce of partial products … only where the problem shards naturally"; SURVEY §8e: "implement only as a correctness
+// variant"): rank g holds the COLUMNS [col_offsets[g], col_offsets[g+1]) of A — every row, global column ids inside its slab — and the matching slab of x;
+// y = Σ_g A[:, g]·x_g: every rank forms a partial y of all n_rows entries and an all-reduce (ncclAllReduce on the handle's communicator, or the caller's own
+// between _begin and _finish) sums them, so every rank ends with the WHOLE y. For a square n × n operator that moves 2·(N−1)/N·n entries per rank and product
+// against the (N−1)/N·n of the all-gather of x in the row partition — and n instead of the few per cent of n the packed halo exchange moves —, and every rank
+// then holds (and has reduced) all of y: the row partition is the product's form, this one exists to be checked against it (closest reference pattern: the
+// rank-strided loop + MPI_Allreduce of cantera/src/thermo/RedlichKwongMFTP.cpp:1014-1015).
+G4S_API g4s_status g4s_spmv_dist_create_columns(g4s_spmv_dist_t *out, int32_t rank, int32_t world, const int64_t *col_offsets, int32_t n_rows,
+                                                const int32_t *rowptr, const int32_t *colids, const double *values, unsigned flags)
+{
+    G4S_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    G4S_REQUIRE(rowptr && col_offsets && world >= 1 && rank >= 0 && rank < world && n_rows >= 0, "bad argument");
+    for (int k = 0; k < world; ++k) G4S_REQUIRE(col_offsets[k] <= col_offsets[k + 1], "col_offsets must not decrease");
+    G4S_REQUIRE(col_offsets[0] == 0 && col_offsets[world] <= INT32_MAX, "bad col_offsets");
+    const int64_t c0 = col_offsets[rank], c1 = col_offsets[rank + 1];
+    auto h = new (std::nothrow) g4s_spmv_dist_s();
+    if (!h) return g4s::set_error(G4S_ERR_NOMEM, "host allocation failed");
+    auto fail = [&](int code) { dist_release(h); return code; };
+    try {
+        h->rank = rank; h->world = world; h->local_rows = n_rows; h->columns = true; h->nseg = world;
+        h->off.assign(col_offsets, col_offsets + world + 1);
+        const bool dp = (flags & G4S_DEVICE_POINTERS) != 0;
+        std::vector<int32_t> rp((size_t)n_rows + 1);
+        if (dp) { if (hipMemcpy(rp.data(), rowptr, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost) != hipSuccess) return fail(g4s::set_error(G4S_ERR_HIP, "D2H copy of rowptr failed")); }
+        else std::copy(rowptr, rowptr + n_rows + 1, rp.begin());
+        if (rp[0] != 0) return fail(g4s::set_error(G4S_ERR_INVALID, "rowptr[0] != 0"));
+        for (int32_t i = 0; i < n_rows; ++i)
+            if (rp[(size_t)i + 1] < rp[i]) return fail(g4s::set_error(G4S_ERR_INVALID, "rowptr decreases at row %d", i));
+        const int64_t nnz = rp[n_rows];
+        if (nnz && !(colids && values)) return fail(g4s::set_error(G4S_ERR_INVALID, "colids/values NULL with nnz > 0"));
+        std::vector<int32_t> ci((size_t)nnz);
+        std::vector<double> va((size_t)nnz);
+        if (nnz) {
+            if (dp) {
+                if (hipMemcpy(ci.data(), colids, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost) != hipSuccess ||
+                    hipMemcpy(va.data(), values, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost) != hipSuccess)
+                    return fail(g4s::set_error(G4S_ERR_HIP, "D2H copy of the matrix failed"));
+            } else { std::copy(colids, colids + nnz, ci.begin()); std::copy(values, values + nnz, va.begin()); }
+        }
+        for (int64_t k = 0; k < nnz; ++k) {
+            if (ci[(size_t)k] < c0 || ci[(size_t)k] >= c1) return fail(g4s::set_error(G4S_ERR_INVALID, "a column index is outside this rank's slab [%lld, %lld)", (long long)c0, (long long)c1));
+            ci[(size_t)k] -= (int32_t)c0;
+        }
+        h->nnz_own = nnz;
+        const unsigned path_flags = flags & (G4S_SPMV_NO_NT | G4S_SPMV_BLOCKED | G4S_SPMV_STREAM | G4S_SPMV_UPDATABLE);
+        int st = g4s_csr_create(&h->A_own, n_rows, (int32_t)std::max<int64_t>(c1 - c0, 1), nnz, rp.data(), ci.data(), va.data(), G4S_HOST_POINTERS | path_flags);
+        if (st != G4S_OK) return fail(st);
+        h->recv_cut.assign((size_t)world + 1, 0);
+        h->give_cut.assign((size_t)world + 1, 0);
+        h->give_set.assign((size_t)world, 1);                       // nothing to wire
+        if (hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming) != hipSuccess)
+            return fail(g4s::set_error(G4S_ERR_HIP, "stream / event creation failed"));
+    } catch (const std::bad_alloc &) {
+        return fail(g4s::set_error(G4S_ERR_NOMEM, "host allocation failed"));
+    }
+    *out = h;
+    return G4S_OK;
+}
+
 // New values for this rank's rows (the order of the arrays the handle was created from): each of the two parts gathers its entries through its source map
 // and hands them to its own CSR handle (g4s_csr_update_values). No communication: every rank updates its slab.
 G4S_API g4s_status g4s_spmv_dist_update_values(g4s_spmv_dist_t h, const double *values_local, unsigned flags, void *stream)
 {
     G4S_REQUIRE(h && !h->poisoned, "bad handle");
+    if (h->columns) return g4s_csr_update_values(h->A_own, values_local, flags, stream);   // one part, in the caller's order
     G4S_REQUIRE(h->d_src_own, "the handle was created without G4S_SPMV_UPDATABLE");
     G4S_REQUIRE(values_local || h->nnz_own + h->nnz_rem == 0, "values is NULL");
     G4S_REQUIRE(flags & G4S_DEVICE_POINTERS, "g4s_spmv_dist_update_values takes a device array");
@@ -491,7 +555,14 @@ G4S_API g4s_status g4s_spmv_dist_get_info(g4s_spmv_dist_t h, g4s_spmv_dist_info 
         info->recv_bytes = 8 * (h->recv_cut[h->nseg] - (h->merged ? h->recv_cut[(size_t)h->rank + 1] - h->recv_cut[h->rank] : 0));
         info->send_bytes = 8 * h->give_cut[h->nseg];
     }
-    info->reserved = (h->merged ? 1 : 0) | (h->allgather ? 2 : 0) | (h->poisoned ? 4 : 0);
+    info->reserved = (h->merged ? 1 : 0) | (h->allgather ? 2 : 0) | (h->poisoned ? 4 : 0) | (h->columns ? 8 : 0);
+    if (h->columns && !h->poisoned) {                              // every rank sends and receives its partial y in the all-reduce (ring: 2·(N−1)/N of it)
+        info->send_bytes = info->recv_bytes = h->world > 1 ? (int64_t)(16.0 * h->local_rows * (h->world - 1) / h->world) : 0;
+        g4s_csr_info ci2;
+        G4S_TRY(g4s_csr_get_info(h->A_own, &ci2));
+        info->own_path = ci2.spmv_path; info->rem_path = 0; info->connected = 1;
+        return G4S_OK;
+    }
     g4s_csr_info ci;
     if (h->poisoned) { info->own_path = info->rem_path = 0; info->connected = 0; return G4S_OK; }
     G4S_TRY(g4s_csr_get_info(h->A_own, &ci)); info->own_path = ci.spmv_path;
@@ -608,7 +679,7 @@ G4S_API g4s_status g4s_spmv_dist_connect_rccl(g4s_spmv_dist_t h, void *comm)
     G4S_REQUIRE(h && comm, "NULL argument");
     G4S_TRY(rccl_load());
     h->comm = reinterpret_cast<ncclComm_t>(comm);
-    if (h->allgather) return G4S_OK;                               // no lists to exchange: the collective itself is the wiring
+    if (h->allgather || h->columns) return G4S_OK;                 // no lists to exchange: the collective itself is the wiring
     // a send buffer sized from earlier give lists (g4s_spmv_dist_buffers, or a product that ran before the wiring) would be too small for the new ones
     if (h->d_send) { (void)hipFree(h->d_send); h->d_send = nullptr; }
     const int W = h->nseg;                                         // segments; segment k talks to rank k (loopback: every segment to rank 0)
@@ -665,6 +736,13 @@ G4S_API g4s_status g4s_spmv_dist_connect_rccl(g4s_spmv_dist_t h, void *comm)
 G4S_API g4s_status g4s_spmv_dist_buffers(g4s_spmv_dist_t h, double **send_dev, const int64_t **send_cut, double **recv_dev, const int64_t **recv_cut)
 {
     G4S_REQUIRE(h, "NULL handle");
+    if (h->columns) {                                              // nothing of x travels: the caller's transport all-reduces y itself between _begin and _finish
+        if (send_dev) *send_dev = nullptr;
+        if (recv_dev) *recv_dev = nullptr;
+        if (send_cut) *send_cut = h->give_cut.data();
+        if (recv_cut) *recv_cut = h->recv_cut.data();
+        return G4S_OK;
+    }
     if (h->allgather) {
         // send = this rank's slot of the gathered vector (pad entries, the same for every peer: send_cut = {0, …, 0, pad});
         // recv = the gathered vector, slot k = [k·pad, (k+1)·pad) from rank k
@@ -692,6 +770,10 @@ G4S_API g4s_status g4s_spmv_dist_begin(g4s_spmv_dist_t h, const double *x_local_
     G4S_REQUIRE(!h->poisoned, "the handle was poisoned by a failed set-up exchange (g4s_spmv_dist_connect_rccl): destroy it and exit the process");
     hipStream_t s = g4s::as_stream(stream);
     h->exchange_posted = false;
+    if (h->columns) {                                              // the partial y of all rows; its sum over the ranks follows (_finish, or the caller's transport)
+        if (h->local_rows == 0) return G4S_OK;
+        return g4s_spmv(h->A_own, x_local_dev, y_local_dev, 1.0, 0.0, stream);
+    }
     if (h->allgather) {
         // own slab into its slot of the gathered vector, then ONE in-place all-gather on the side stream while the own-column product runs
         const int64_t slab = h->off[(size_t)h->rank + 1] - h->off[h->rank];
@@ -749,6 +831,10 @@ G4S_API g4s_status g4s_spmv_dist_finish(g4s_spmv_dist_t h, double *y_local_dev, 
 {
     G4S_REQUIRE(h && (y_local_dev || h->local_rows == 0), "NULL argument");   // (a rank of a rectangular operator may own x entries but no rows)
     hipStream_t s = g4s::as_stream(stream);
+    if (h->columns) {
+        if (h->comm && h->world > 1 && h->local_rows) G4S_RCCL_TRY(g_rccl.AllReduce(y_local_dev, y_local_dev, (size_t)h->local_rows, ncclDouble, ncclSum, h->comm, s));
+        return G4S_OK;
+    }
     if (h->exchange_posted) G4S_HIP_TRY(hipStreamWaitEvent(s, h->ev_done, 0));
     h->exchange_posted = false;
     if (h->local_rows == 0) return G4S_OK;
@@ -777,6 +863,8 @@ int64_t dist_smallest_slab(g4s_spmv_dist_t h)
 G4S_API g4s_status g4s_spmv_dist_apply(g4s_spmv_dist_t h, const double *x_local_dev, double *y_local_dev, void *stream)
 {
     G4S_REQUIRE(h, "NULL handle");
+    if (h->columns && h->world > 1 && !h->comm)
+        return g4s::set_error(G4S_ERR_INVALID, "g4s_spmv_dist_apply on a column partition needs g4s_spmv_dist_connect_rccl; with another transport all-reduce y between _begin and _finish");
     if ((h->world > 1 || (h->loopback && !h->allgather)) && !h->comm && (h->n_ref || h->give_cut[h->nseg]))
         return g4s::set_error(G4S_ERR_INVALID, "g4s_spmv_dist_apply needs g4s_spmv_dist_connect_rccl; with another transport use _begin / _buffers / _finish");
     G4S_TRY(g4s_spmv_dist_begin(h, x_local_dev, y_local_dev, stream));

@@ -214,6 +214,13 @@ g4s_status g4s_spmv_dist_begin(g4s_spmv_dist_t h, const double *x_local_dev, dou
  * slot k = [k·pad, (k+1)·pad) comes from rank k. */
 g4s_status g4s_spmv_dist_buffers(g4s_spmv_dist_t h, double **send_dev, const int64_t **send_cut, double **recv_dev, const int64_t **recv_cut);
 g4s_status g4s_spmv_dist_finish(g4s_spmv_dist_t h, double *y_local_dev, void *stream);
+/* Column-partition variant — a CORRECTNESS variant (north_star's "all-reduce of partial products"): rank g holds the columns
+ * [col_offsets[g], col_offsets[g+1]) of A (all n_rows rows, global column ids inside the slab) and that slab of x; _begin forms the partial y of ALL rows
+ * (y_local_dev: n_rows entries), _finish / _apply sum it over the ranks with ncclAllReduce on the communicator of g4s_spmv_dist_connect_rccl — every rank ends
+ * with the whole y. With another transport the caller all-reduces y itself between _begin and _finish (_buffers has nothing to hand out). Twice the traffic of
+ * the all-gather exchange and every rank reduces all of y: the row partition is the product's form. get_info.reserved bit 3. */
+g4s_status g4s_spmv_dist_create_columns(g4s_spmv_dist_t *out, int32_t rank, int32_t world, const int64_t *col_offsets, int32_t n_rows,
+                                        const int32_t *rowptr, const int32_t *colids, const double *values, unsigned flags);
 /* New values for this rank's rows, same pattern (see g4s_csr_update_values): values_local_dev in the order of the arrays given to _create, device memory;
  * the handle must have been created with G4S_SPMV_UPDATABLE. Asynchronous on `stream`; no communication. */
 g4s_status g4s_spmv_dist_update_values(g4s_spmv_dist_t h, const double *values_local_dev, unsigned flags, void *stream);

@@ -223,3 +223,86 @@ def test_dist_setup_failure_releases_the_native_handle(monkeypatch):
     D = gdist.DistSpMV([0, n], 0, 1, *d, n)                    # (the hook is one-shot: the next set-up succeeds)
     assert D.h
     D.close()
+
+
+def _column_worker(rank, world, port, kind, out_dir):
+    """One rank of the column partition: the columns of its slab (every row), the partial y of all rows, the sum over the ranks by the process group."""
+    import ctypes as C
+    import scipy.sparse as sp
+    import torch.distributed as dist
+    init_gloo(rank, world, port)
+    torch.cuda.set_device(0)
+    from g4s_amd import capi
+    from tests import oracle_lib
+    lib = capi.load()
+    rp, ci, va, n = _matrix(kind, oracle_lib.load())
+    A = sp.csr_matrix((va, ci, rp), shape=(n, n))
+    cuts = [n * k // world for k in range(world + 1)]
+    S = A[:, cuts[rank]:cuts[rank + 1]].tocsr()
+    S.sort_indices()
+    lrp, lci, lva = S.indptr.astype(np.int32), (S.indices + cuts[rank]).astype(np.int32), S.data.astype(np.float64)
+    h = C.c_void_p()
+    offs = (C.c_int64 * (world + 1))(*cuts)
+    capi.check(lib.g4s_spmv_dist_create_columns(C.byref(h), rank, world, offs, n, lrp.ctypes.data, lci.ctypes.data if len(lci) else None, lva.ctypes.data if len(lva) else None, capi.HOST_POINTERS))
+    info = capi.DistInfo()
+    capi.check(lib.g4s_spmv_dist_get_info(h, C.byref(info)))
+    assert info.reserved & 8 and info.connected == 1 and info.local_rows == n
+    x = np.random.default_rng(3).uniform(-1, 1, n)
+    xl = torch.from_numpy(x[cuts[rank]:cuts[rank + 1]]).cuda()
+    y = torch.empty(n, dtype=torch.float64, device="cuda")
+    for _ in range(2):
+        capi.check(lib.g4s_spmv_dist_begin(h, C.c_void_p(xl.data_ptr()) if xl.numel() else None, y.data_ptr(), None))
+        torch.cuda.synchronize()
+        yc = y.cpu()                                               # the caller's transport: all-reduce of the partial products (gloo on the host)
+        dist.all_reduce(yc)
+        y.copy_(yc)
+        capi.check(lib.g4s_spmv_dist_finish(h, y.data_ptr(), None))
+    np.save(os.path.join(out_dir, f"y{rank}.npy"), y.cpu().numpy())
+    # wrong input: a column outside the slab is refused
+    if len(lci):
+        bad = lci.copy()
+        bad[0] = cuts[rank + 1] if rank + 1 < world else cuts[rank] - 1 if rank > 0 else n
+        h2 = C.c_void_p()
+        assert lib.g4s_spmv_dist_create_columns(C.byref(h2), rank, world, offs, n, lrp.ctypes.data, bad.ctypes.data, lva.ctypes.data, capi.HOST_POINTERS) == capi.ERR_INVALID
+    dist.barrier()
+    capi.check(lib.g4s_spmv_dist_destroy(h))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kind", [(1, "powerlaw"), (2, "powerlaw"), (3, "powerlaw"), (3, "lap7")])
+def test_dist_column_partition_matches_oracle(tmp_path, oracle, world, kind):
+    """north_star's "all-reduce of partial products" (a correctness variant): y = Σ_g A[:, g]·x_g over a column partition, every rank ending with the
+    whole y — equal to the oracle's product on every rank."""
+    mp.spawn(_column_worker, args=(world, os.path.join(str(tmp_path), "rendezvous"), kind, str(tmp_path)), nprocs=world, join=True)
+    rp, ci, va, n = _matrix(kind, oracle)
+    x = np.random.default_rng(3).uniform(-1, 1, n)
+    want = oracle.spmv(rp, ci, va, x)
+    _, asum = oracle.spmv_ld(rp, ci, va, x)
+    for r in range(world):
+        got = np.load(tmp_path / f"y{r}.npy")
+        assert np.all(np.abs(got - want) <= TOL * asum + 1e-300), r
+
+
+def test_dist_column_partition_rccl_all_reduce_single_rank(oracle):
+    """The library's own path for the column partition: g4s_comm_create + g4s_spmv_dist_connect_rccl + g4s_spmv_dist_apply (one rank: the all-reduce is skipped,
+    the wiring and the entry points are the multi-rank ones)."""
+    import ctypes as C
+    from g4s_amd import capi
+    lib = capi.load()
+    rp, ci, va, n = _matrix("powerlaw", oracle)
+    h, comm = C.c_void_p(), C.c_void_p()
+    offs = (C.c_int64 * 2)(0, n)
+    capi.check(lib.g4s_spmv_dist_create_columns(C.byref(h), 0, 1, offs, n, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, capi.HOST_POINTERS))
+    raw = (C.c_char * 128)()
+    capi.check(lib.g4s_comm_unique_id(raw))
+    capi.check(lib.g4s_comm_create(C.byref(comm), 1, 0, raw))
+    capi.check(lib.g4s_spmv_dist_connect_rccl(h, comm))
+    x = np.random.default_rng(3).uniform(-1, 1, n)
+    xd, y = torch.from_numpy(x).cuda(), torch.empty(n, dtype=torch.float64, device="cuda")
+    capi.check(lib.g4s_spmv_dist_apply(h, xd.data_ptr(), y.data_ptr(), None))
+    torch.cuda.synchronize()
+    want = oracle.spmv(rp, ci, va, x)
+    _, asum = oracle.spmv_ld(rp, ci, va, x)
+    assert np.all(np.abs(y.cpu().numpy() - want) <= TOL * asum + 1e-300)
+    capi.check(lib.g4s_spmv_dist_destroy(h))
+    capi.check(lib.g4s_comm_destroy(comm))
