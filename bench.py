@@ -423,7 +423,7 @@ def main():
     # HBM bytes per launch come from PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, tools/prof_pmc.sh), which cannot run inside this process:
     # the number is read from the stored profile of the same workload and SpMV path, and the line says so (traffic_source).
     # A stored number is only as good as the kernels it was taken on: the profile records the SHA-256 of the SpMV kernel sources (tools/kernel_hash.py:
-    # spmv.hip, spmv_pb.hip, spmv_bcsr.hip, prims.hpp, common.hpp) and a number whose hash differs from the sources of the loaded build is refused.
+    # spmv.hip, spmv_pb.hip, spmv_bcsr.hip and their headers, common.hpp) and a number whose hash differs from the sources of the loaded build is refused.
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):

@@ -162,6 +162,23 @@ __global__ __launch_bounds__(256) void row_flop_kernel(int M, const int *__restr
     }
 }
 
+// Round 4: the same numbers, entry-parallel — the kernel above spends 0.7 ms of a 34 ms product waiting (8 lanes per row, most rows hold three entries, 59 % none:
+// PMC waiting 0.90, issuing 0.07): every A-entry writes the length of its B row, an exclusive scan runs over the entries, and a row's flop is the difference of
+// the scan at its two ends. Balanced whatever the row lengths are.
+__global__ void entry_flop_kernel(long long annz, const int *__restrict__ acol, const int *__restrict__ brpt, long long *__restrict__ f)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > annz) return;
+    if (k == annz) { f[k] = 0; return; }                           // (the scan runs over annz + 1 entries: its last output is the total)
+    const int c = acol[k];
+    f[k] = brpt[c + 1] - brpt[c];
+}
+__global__ void row_flop_from_scan_kernel(int M, const int *__restrict__ arpt, const long long *__restrict__ P, long long *__restrict__ row_flop)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) row_flop[i] = P[arpt[i + 1]] - P[arpt[i]];
+}
+
 // Range check of A's column ids against B's row count (an out-of-range id would fault in brpt[c]).
 __global__ void check_range_kernel(const int *__restrict__ ids, long long n, int bound, int *flag)
 {
@@ -186,19 +203,26 @@ __global__ void check_descents_kernel(const int *__restrict__ ids, long long n, 
         if (k > 0 && c < ids[k - 1]) ++d;
     }
     if (bad) atomicOr(flag, 1);
-    d = (unsigned long long)wave_sum_ll((long long)d);
-    if ((threadIdx.x & 63) == 0 && d) atomicAdd(descents, d);
+    __shared__ unsigned long long s_d[4];                          // one atomic per WORKGROUP: nearly every wave of a sparse matrix sees a row boundary, and
+    d = (unsigned long long)wave_sum_ll((long long)d);             // 10^5 atomics on one counter cost more than the pass itself (0.2 ms)
+    if ((threadIdx.x & 63) == 0) s_d[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0 && s_d[0] + s_d[1] + s_d[2] + s_d[3]) atomicAdd(descents, s_d[0] + s_d[1] + s_d[2] + s_d[3]);
 }
-__global__ void row_start_descents_kernel(int K, const int *__restrict__ rpt, const int *__restrict__ ids, unsigned long long *__restrict__ legal)
+__global__ __launch_bounds__(256) void row_start_descents_kernel(int K, const int *__restrict__ rpt, const int *__restrict__ ids, unsigned long long *__restrict__ legal)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long d = 0;
-    if (r > 0 && r < K) {
+    const int nnz = rpt[K];
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < K; r += gridDim.x * blockDim.x) {
+        if (r == 0) continue;
         const int k = rpt[r];
-        if (k > rpt[r - 1] && k < rpt[K] && ids[k] < ids[k - 1]) d = 1;   // the first row that starts at k behind a non-empty row
+        if (k > rpt[r - 1] && k < nnz && ids[k] < ids[k - 1]) ++d;  // the first row that starts at k behind a non-empty row
     }
+    __shared__ unsigned long long s_d[4];
     d = (unsigned long long)wave_sum_ll((long long)d);
-    if ((threadIdx.x & 63) == 0 && d) atomicAdd(legal, d);
+    if ((threadIdx.x & 63) == 0) s_d[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0 && s_d[0] + s_d[1] + s_d[2] + s_d[3]) atomicAdd(legal, s_d[0] + s_d[1] + s_d[2] + s_d[3]);
 }
 
 // ------------------------------------------------------------------------------------------------ row classes
@@ -217,43 +241,81 @@ constexpr ClassLimits kSymLimits{{32, 512, 8192, 32768, 2097152, -1}, {0, 0, 0, 
 #endif
 constexpr ClassLimits kNumLimits{{32, 512, 1024, 2048, 4096, G4S_SPGEMM_BIG_LIMIT}, {0, 0, 0, 0, 0, 0}};   // M3: the all-LDS big-row kernel
 
-__global__ void classify_kernel(int M, const long long *__restrict__ size, ClassLimits lim, int cols_clip,
-                                int *__restrict__ cls, int *__restrict__ hist)
+// (Round 4: few workgroups, each on a contiguous range of rows, global atomics once per workgroup and class. The first form — one workgroup per 256 rows, its
+// class counts added to eight global counters — put 65 K atomics on eight addresses of one L2 channel: 97 µs per launch for a 24 MB pass, four launches per product.)
+constexpr int kClassBlocks = 512;
+__device__ __forceinline__ int class_of(long long u, const ClassLimits &lim, int cols_clip)
+{
+    if (u == 0) return CLS_EMPTY;
+    const long long uc = (cols_clip > 0 && u > cols_clip) ? cols_clip : u;   // BIN.h:164 clips the bound at cols
+    int c = CLS_HUB;
+#pragma unroll
+    for (int i = 5; i >= 0; --i)
+        if ((lim.raw[i] ? u : uc) <= lim.lim[i]) c = CLS_TINY + i;
+    return c;
+}
+__global__ __launch_bounds__(256) void classify_kernel(int M, const long long *__restrict__ size, ClassLimits lim, int cols_clip,
+                                                       int *__restrict__ cls, int *__restrict__ hist)
 {
     __shared__ int s_hist[CLS_COUNT];
     if (threadIdx.x < CLS_COUNT) s_hist[threadIdx.x] = 0;
     __syncthreads();
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < M) {
-        const long long u = size[i];
-        int c;
-        if (u == 0) c = CLS_EMPTY;
-        else {
-            const long long uc = (cols_clip > 0 && u > cols_clip) ? cols_clip : u; // BIN.h:164 clips the bound at cols
-            c = CLS_HUB;
-#pragma unroll
-            for (int i = 5; i >= 0; --i)
-                if ((lim.raw[i] ? u : uc) <= lim.lim[i]) c = CLS_TINY + i;
-        }
+    const int per = (M + (int)gridDim.x - 1) / (int)gridDim.x, r0 = blockIdx.x * per, r1 = min(M, r0 + per);
+    int cnt[CLS_COUNT] = {0};
+    for (int i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
+        const int c = class_of(size[i], lim, cols_clip);
         cls[i] = c;
-        atomicAdd(&s_hist[c], 1);
+#pragma unroll
+        for (int k = 0; k < CLS_COUNT; ++k) cnt[k] += c == k;
+    }
+#pragma unroll
+    for (int k = 0; k < CLS_COUNT; ++k) {
+        int v = cnt[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_hist[k], v);
     }
     __syncthreads();
     if (threadIdx.x < CLS_COUNT && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_hist[threadIdx.x]);
 }
 
-__global__ void scatter_rows_kernel(int M, const int *__restrict__ cls, int *__restrict__ cursor, int *__restrict__ lists)
+// the same ranges: count the range's rows per class, reserve the places with one atomic per class, then place the rows (wave ballots rank them)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(int M, const int *__restrict__ cls, int *__restrict__ cursor, int *__restrict__ lists)
 {
     __shared__ int s_cnt[CLS_COUNT], s_base[CLS_COUNT];
     if (threadIdx.x < CLS_COUNT) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int c = 0, local = 0;
-    if (i < M) { c = cls[i]; local = atomicAdd(&s_cnt[c], 1); }
+    const int per = (M + (int)gridDim.x - 1) / (int)gridDim.x, r0 = blockIdx.x * per, r1 = min(M, r0 + per), lane = threadIdx.x & 63;
+    int cnt[CLS_COUNT] = {0};
+    for (int i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
+        const int c = cls[i];
+#pragma unroll
+        for (int k = 0; k < CLS_COUNT; ++k) cnt[k] += c == k;
+    }
+#pragma unroll
+    for (int k = 0; k < CLS_COUNT; ++k) {
+        int v = cnt[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0 && v) atomicAdd(&s_cnt[k], v);
+    }
     __syncthreads();
-    if (threadIdx.x < CLS_COUNT && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], s_cnt[threadIdx.x]); // cursor[c] starts at the class offset
+    if (threadIdx.x < CLS_COUNT) { s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], s_cnt[threadIdx.x]) : 0; s_cnt[threadIdx.x] = 0; }   // cursor[c] starts at the class offset
     __syncthreads();
-    if (i < M) lists[s_base[c] + local] = i;
+    for (int i0 = r0; i0 < r1; i0 += blockDim.x) {                 // uniform trip count: the ballots below need every lane
+        const int i = i0 + threadIdx.x;
+        const int c = i < r1 ? cls[i] : -1;
+        int place = 0;
+#pragma unroll
+        for (int k = 0; k < CLS_COUNT; ++k) {
+            const unsigned long long m = __ballot(c == k);
+            int wbase = 0;
+            if (lane == 0 && m) wbase = atomicAdd(&s_cnt[k], __popcll(m));
+            wbase = __shfl(wbase, 0, 64);
+            if (c == k) place = s_base[k] + wbase + __popcll(m & ((1ull << lane) - 1ull));
+        }
+        if (i < r1) lists[place] = i;
+    }
 }
 
 __global__ void gather_ranges_kernel(const int *__restrict__ rows, int n, const int *__restrict__ arpt, int *__restrict__ out)
@@ -1318,6 +1380,84 @@ __global__ __launch_bounds__(256) void unit_kernel(long long total, int n, const
     }
 }
 
+// The same lists built by TASKS (round 4, second form): one thread per (row, A-entry) walks the row's chunk boundaries in order — every search starts where the
+// previous one ended, the entry's B-row bounds and value are loaded once for all its chunks — and writes both the splits and the unit counts; a second pass over
+// the same tasks writes the descriptors. Replaces chunk_splits_kernel + unit_kernel<false> + unit_kernel<true> (one thread per (entry, boundary) / per item, each
+// re-deriving its row and re-loading its bounds: 0.75 + 0.36 + 0.69 ms per product) on the default path, with one count read back instead of three.
+__global__ void unit_rows_kernel(int n, const int *__restrict__ rows, const int *__restrict__ arpt, const int *__restrict__ crpt, int chunk, int nz_lo, int nz_hi,
+                                 long long *__restrict__ tasks, long long *__restrict__ items)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    long long na = 0, nch = 0;
+    if (i < n) {
+        const int row = rows[i], nz = crpt[row + 1] - crpt[row];
+        if (nz > nz_lo && nz <= nz_hi) { na = arpt[row + 1] - arpt[row]; nch = (nz + chunk - 1) / chunk; }
+    }
+    tasks[i] = na;
+    items[i] = na * nch;
+}
+__global__ void diff_ll_kernel(int n, const long long *__restrict__ a, const long long *__restrict__ b, long long *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] - b[i];
+}
+template <bool EXPAND>
+__global__ __launch_bounds__(256) void unit_task_kernel(long long bound /* threads launched: an upper bound of the task count */, int n, const int *__restrict__ rows,
+                                                        const long long *__restrict__ task_off, const long long *__restrict__ item_off,
+                                                        const int *__restrict__ arpt, const int *__restrict__ acol, const double *__restrict__ aval,
+                                                        const int *__restrict__ brpt, const int *__restrict__ bcol /* window ids */, const int *__restrict__ crpt,
+                                                        const long long *__restrict__ pre_off, const int *__restrict__ pre_cols, const int *__restrict__ ccol, int chunk,
+                                                        int *__restrict__ ct /* splits: item_off[i] − task_off[i] + e·(chunks − 1) */, int *__restrict__ ucount,
+                                                        const int *__restrict__ uoff, UnitDesc *__restrict__ U, int have_ct /* !EXPAND: the splits are in ct already (chunk_splits_kernel) */)
+{
+    const long long t0 = (long long)blockIdx.x * blockDim.x, t = t0 + threadIdx.x, total = task_off[n];
+    if (t > bound) return;
+    if constexpr (!EXPAND) { if (t == 0) ucount[item_off[n]] = 0; }       // (the scan of the counts runs over items + 1 entries)
+    if (t >= total) return;
+    int rl = 0, rh = n;                                             // the list position that holds the workgroup's first task (uniform), then a short walk forward
+    while (rl < rh) {
+        const int mid = (rl + rh) >> 1;
+        if (task_off[mid + 1] > t0) rh = mid; else rl = mid + 1;
+    }
+    while (task_off[rl + 1] <= t) ++rl;
+    const int row = rows[rl], e = (int)(t - task_off[rl]);
+    const int a0 = arpt[row], na = arpt[row + 1] - a0, off = crpt[row], nz = crpt[row + 1] - off, nb = (nz + chunk - 1) / chunk - 1;
+    const int c = acol[a0 + e];
+    const int end = brpt[c + 1];
+    int prev = brpt[c];
+    const long long io = item_off[rl];
+    int *ctr = ct + (io - task_off[rl]) + (long long)e * nb;
+    if constexpr (!EXPAND) {
+        const long long po = pre_off ? pre_off[row] : -1;
+        const int *cols = po >= 0 ? pre_cols + po : ccol + off;    // the row's sorted distinct columns (window ids)
+        for (int b = 1; b <= nb; ++b) {
+            int lo = prev, hi = end;
+            if (have_ct) lo = ctr[b - 1];                           // (uniform) one thread per (entry, boundary) has searched already: 10^7 short independent searches beat 10^6 chains of them
+            else {
+                const int cb = cols[(long long)chunk * b];
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (bcol[mid] < cb) lo = mid + 1; else hi = mid;
+                }
+                ctr[b - 1] = lo;
+            }
+            ucount[io + (long long)(b - 1) * na + e] = (lo - prev + 63) >> 6;
+            prev = lo;
+        }
+        ucount[io + (long long)nb * na + e] = (end - prev + 63) >> 6;
+    } else {
+        const long long bits = __double_as_longlong(aval[a0 + e]);
+        const int lo32 = (int)(bits & 0xFFFFFFFFll), hi32 = (int)(bits >> 32);
+        for (int q = 0; q <= nb; ++q) {
+            const int s1 = q < nb ? ctr[q] : end;
+            UnitDesc *dst = U + uoff[io + (long long)q * na + e];
+            for (int k = prev; k < s1; k += 64) *dst++ = UnitDesc{k, min(64, s1 - k), lo32, hi32};
+            prev = s1;
+        }
+    }
+}
+
 template <int T, bool UNITS>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void spgemm_numeric_big_kernel(
     const int *__restrict__ rows, int nrows, int nz_lo, int nz_hi /* rows with nz outside (nz_lo, nz_hi] are left to the other shape */,
@@ -1791,7 +1931,7 @@ int classify_rows(int M, const long long *d_size, const ClassLimits &lim, int co
     G4S_TRY(rc.lists.alloc(sizeof(int) * (size_t)M));
     G4S_TRY(rc.hist.alloc(sizeof(int) * 2 * CLS_COUNT));
     G4S_HIP_TRY(hipMemsetAsync(rc.hist.p, 0, sizeof(int) * 2 * CLS_COUNT, s));
-    const int grid = (M + 255) / 256;
+    const int grid = std::min(kClassBlocks, (M + 255) / 256);
     hipLaunchKernelGGL(classify_kernel, dim3(grid), dim3(256), 0, s, M, d_size, lim, cols_clip, rc.cls.as<int>(), rc.hist.as<int>());
     G4S_HIP_TRY(hipMemcpyAsync(rc.count, rc.hist.p, sizeof(int) * CLS_COUNT, hipMemcpyDeviceToHost, s));
     G4S_HIP_TRY(hipStreamSynchronize(s));
@@ -1873,8 +2013,22 @@ int fetch_rows_and_ranges(const int *d_list, int n, const int *d_arpt, std::vect
     return G4S_OK;
 }
 
-int compute_row_flop(int M, const int *arpt, const int *acol, const int *brpt, long long *d_row_flop, int64_t *total, hipStream_t s)
+int compute_row_flop(int M, const int *arpt, const int *acol, const int *brpt, long long *d_row_flop, int64_t *total, hipStream_t s, long long annz = -1)
 {
+    if (M > 0 && annz > 0 && annz < (1ll << 31)) {                  // entry-parallel form (the caller knows nnz(A))
+        DevBuf f, P;
+        G4S_TRY(f.alloc(sizeof(long long) * ((size_t)annz + 1)));
+        G4S_TRY(P.alloc(sizeof(long long) * ((size_t)annz + 1)));
+        hipLaunchKernelGGL(entry_flop_kernel, dim3((unsigned)((annz + 256) / 256)), dim3(256), 0, s, annz, acol, brpt, f.as<long long>());
+        G4S_TRY(g4s::prims::exclusive_scan(f.as<long long>(), P.as<long long>(), annz + 1, s));
+        hipLaunchKernelGGL(row_flop_from_scan_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, arpt, P.as<long long>(), d_row_flop);
+        G4S_HIP_TRY(hipGetLastError());
+        long long h = 0;
+        G4S_HIP_TRY(hipMemcpyAsync(&h, P.as<long long>() + annz, sizeof(h), hipMemcpyDeviceToHost, s));
+        G4S_HIP_TRY(hipStreamSynchronize(s));
+        if (total) *total = (int64_t)h;
+        return G4S_OK;
+    }
     DevBuf tot;
     G4S_TRY(tot.alloc(sizeof(unsigned long long)));
     G4S_HIP_TRY(hipMemsetAsync(tot.p, 0, sizeof(unsigned long long), s));
@@ -1912,7 +2066,7 @@ int check_b(const int *brpt, const int *bcol, int K, long long bnnz, int N, hipS
     unsigned long long *d = buf.as<unsigned long long>();
     const int grid = (int)std::min<long long>((bnnz + 255) / 256, 4096);
     hipLaunchKernelGGL(check_descents_kernel, dim3(grid), dim3(256), 0, s, bcol, bnnz, N, reinterpret_cast<int *>(d), d + 1);
-    hipLaunchKernelGGL(row_start_descents_kernel, dim3((K + 255) / 256), dim3(256), 0, s, K, brpt, bcol, d + 2);
+    hipLaunchKernelGGL(row_start_descents_kernel, dim3(std::min((K + 255) / 256, 2048)), dim3(256), 0, s, K, brpt, bcol, d + 2);
     unsigned long long h[3] = {0, 0, 0};
     G4S_HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s));
     G4S_HIP_TRY(hipStreamSynchronize(s));
@@ -2022,6 +2176,7 @@ struct PreSorted {
     int *d_cols = nullptr;       // int cols[total], borrowed from the cache below
     bool holds_cache = false;
     bool complete = false;       // every row the numeric window kernels will take carries its columns (no hub rows, no overflowed optimistic tables)
+    long long flop = -1;         // the product's flop: bounds the unit lists of the numeric launches without a count read back
     ~PreSorted();
 };
 
@@ -2143,7 +2298,7 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     G4S_TRY(row_nz.alloc(sizeof(int) * ((size_t)M + 1)));
     G4S_HIP_TRY(hipMemsetAsync(row_nz.p, 0, sizeof(int) * ((size_t)M + 1), s));
     int64_t flop = 0;
-    G4S_TRY(compute_row_flop(M, arpt, acol, brpt, row_flop.as<long long>(), &flop, s));
+    G4S_TRY(compute_row_flop(M, arpt, acol, brpt, row_flop.as<long long>(), &flop, s, annz));
 
     dbg.mark("row_flop");
     RowClasses rc;
@@ -2307,7 +2462,7 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
         if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s symbolic: %d optimistic tables overflowed, %d window-class rows\n", n_ovf, rc.count[CLS_M2]);
         G4S_TRY(window(1024, ovf_rows.as<int>(), n_ovf, nullptr, nullptr));   // rows of the optimistic table class are not in the scratch
     }
-    if (pre) pre->complete = pre_off != nullptr && n_ovf == 0 && rc.count[CLS_HUB] == 0 && x_med && x_large;
+    if (pre) { pre->complete = pre_off != nullptr && n_ovf == 0 && rc.count[CLS_HUB] == 0 && x_med && x_large; pre->flop = flop; }
     if (!one_long_launch) G4S_TRY(window(t_win, rc.list(CLS_M2), rc.count[CLS_M2], pre_off, pre_cols, true));
     G4S_HIP_TRY(hipGetLastError());
     // hub rows (flop > 2 M): many workgroups per row on a bitmap in HBM
@@ -2478,6 +2633,54 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         ct_keep.push_back(std::move(items)); ct_keep.push_back(std::move(ioff)); ct_keep.push_back(std::move(ucnt)); ct_keep.push_back(std::move(uoff)); ct_keep.push_back(std::move(ud));
         return G4S_OK;
     };
+    // the same lists by (row, A-entry) tasks (unit_task_kernel): splits, counts and descriptors in two passes over the tasks, ONE count read back
+    const long long class_flop_bound = pre ? pre->flop : -1;       // units <= flop / 64 + items; the one-shot call knows the product's flop (−1: unknown → the count is read back)
+    auto unit_lists_by_tasks = [&](int threads, const int *rows, int n, int nz_lo, int nz_hi, UnitLists *out) -> int {
+        *out = UnitLists{};
+        const int chunk = 8 * threads;
+        auto tasks = std::make_unique<DevBuf>(), toff = std::make_unique<DevBuf>(), items = std::make_unique<DevBuf>(), ioff = std::make_unique<DevBuf>(), ctb = std::make_unique<DevBuf>(),
+             ucnt = std::make_unique<DevBuf>(), uoff = std::make_unique<DevBuf>(), ud = std::make_unique<DevBuf>();
+        G4S_TRY(tasks->alloc(sizeof(long long) * ((size_t)n + 1))); G4S_TRY(toff->alloc(sizeof(long long) * ((size_t)n + 1)));
+        G4S_TRY(items->alloc(sizeof(long long) * ((size_t)n + 1))); G4S_TRY(ioff->alloc(sizeof(long long) * ((size_t)n + 1)));
+        hipLaunchKernelGGL(unit_rows_kernel, dim3((n + 256) / 256), dim3(256), 0, s, n, rows, arpt, crpt, chunk, nz_lo, nz_hi, tasks->as<long long>(), items->as<long long>());
+        G4S_TRY(g4s::prims::exclusive_scan(tasks->as<long long>(), toff->as<long long>(), (long long)n + 1, s));
+        G4S_TRY(g4s::prims::exclusive_scan(items->as<long long>(), ioff->as<long long>(), (long long)n + 1, s));
+        long long totals[2] = {0, 0};
+        G4S_HIP_TRY(hipMemcpyAsync(&totals[0], toff->as<long long>() + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+        G4S_HIP_TRY(hipMemcpyAsync(&totals[1], ioff->as<long long>() + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+        G4S_HIP_TRY(hipStreamSynchronize(s));
+        const long long ntask = totals[0], nitem = totals[1];
+        if (ntask <= 0 || nitem <= 0 || nitem > (1ll << 28)) return G4S_OK;
+        if (ctb->alloc(sizeof(int) * (size_t)std::max<long long>(nitem - ntask, 1)) != G4S_OK || ucnt->alloc(sizeof(int) * ((size_t)nitem + 1)) != G4S_OK ||
+            uoff->alloc(sizeof(int) * ((size_t)nitem + 1)) != G4S_OK) { (void)hipGetLastError(); return G4S_OK; }
+        const unsigned grid = (unsigned)((ntask + 255) / 256);
+        // the splits: one thread per (entry, interior chunk boundary) — chunk_splits_kernel, its offsets = item_off − task_off (entries · (chunks − 1) per row)
+        const long long nct = nitem - ntask;
+        auto ctoff = std::make_unique<DevBuf>();
+        G4S_TRY(ctoff->alloc(sizeof(long long) * ((size_t)n + 1)));
+        hipLaunchKernelGGL(diff_ll_kernel, dim3((n + 256) / 256), dim3(256), 0, s, n + 1, ioff->as<long long>(), toff->as<long long>(), ctoff->as<long long>());
+        if (nct > 0)
+            hipLaunchKernelGGL(chunk_splits_kernel, dim3((unsigned)((nct + 255) / 256)), dim3(256), 0, s, nct, n, rows, K, N2, wsplit, arpt, acol, brpt, wcol, crpt, pre_off, pre_cols, ccol, chunk,
+                               ctoff->as<long long>(), ctb->as<int>());
+        hipLaunchKernelGGL(unit_task_kernel<false>, dim3(grid), dim3(256), 0, s, ntask, n, rows, toff->as<long long>(), ioff->as<long long>(), arpt, acol, aval, brpt, wcol, crpt,
+                           pre_off, pre_cols, ccol, chunk, ctb->as<int>(), ucnt->as<int>(), (const int *)nullptr, (UnitDesc *)nullptr, 1);
+        G4S_TRY(g4s::prims::exclusive_scan(ucnt->as<int>(), uoff->as<int>(), nitem + 1, s));
+        long long ubound = class_flop_bound >= 0 ? class_flop_bound / 64 + nitem : -1;
+        if (ubound < 0 || ubound > (1ll << 27)) {                   // no bound from the caller (or a loose one): read the count
+            int total_units = 0;
+            G4S_HIP_TRY(hipMemcpyAsync(&total_units, uoff->as<int>() + nitem, sizeof(int), hipMemcpyDeviceToHost, s));
+            G4S_HIP_TRY(hipStreamSynchronize(s));
+            if (total_units <= 0 || total_units > (1 << 27)) return G4S_OK;      // (a sum past 2^31 shows up as a negative total)
+            ubound = total_units;
+        }
+        if (ud->alloc(sizeof(UnitDesc) * (size_t)ubound) != G4S_OK) { (void)hipGetLastError(); return G4S_OK; }
+        hipLaunchKernelGGL(unit_task_kernel<true>, dim3(grid), dim3(256), 0, s, ntask, n, rows, toff->as<long long>(), ioff->as<long long>(), arpt, acol, aval, brpt, wcol, crpt,
+                           pre_off, pre_cols, ccol, chunk, ctb->as<int>(), (int *)nullptr, uoff->as<int>(), ud->as<UnitDesc>(), 1);
+        G4S_HIP_TRY(hipGetLastError());
+        out->item_off = ioff->as<long long>(); out->uoff = uoff->as<int>(); out->U = ud->as<UnitDesc>();
+        for (auto *b : {&tasks, &toff, &items, &ioff, &ctb, &ucnt, &uoff, &ud, &ctoff}) ct_keep.push_back(std::move(*b));
+        return G4S_OK;
+    };
     // The window kernels need every row's sorted distinct columns (window ids) before they start. The one-shot call carries them over from its symbolic
     // phase; whatever is missing — every row in the two-call form, hub rows and overflowed optimistic tables in the one-shot form — is marked and emitted
     // into ccol at the row's own offset by the symbolic window kernel in its emit-only mode, in front of the launch that needs it (round 4: this used to be
@@ -2501,8 +2704,11 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         bool splits_complete = false;
         UnitLists ul;
         if (!carried_complete) G4S_TRY(emit_pass(shape, rows, n, nz_lo, nz_hi));
-        G4S_TRY(chunk_splits(T, rows, n, nz_lo, nz_hi, &ct_off, &ct, &splits_complete));
-        if (use_units && splits_complete) G4S_TRY(unit_lists(T, rows, n, nz_lo, nz_hi, ct_off, ct, &ul));
+        if (use_units && !getenv("G4S_SPGEMM_UNITS_BY_ITEMS")) G4S_TRY(unit_lists_by_tasks(T, rows, n, nz_lo, nz_hi, &ul));
+        if (!ul.U) {                                               // the item-parallel pre-pass (tests keep it alive: G4S_SPGEMM_UNITS_BY_ITEMS), and the walk without unit lists
+            G4S_TRY(chunk_splits(T, rows, n, nz_lo, nz_hi, &ct_off, &ct, &splits_complete));
+            if (use_units && splits_complete) G4S_TRY(unit_lists(T, rows, n, nz_lo, nz_hi, ct_off, ct, &ul));
+        }
         const dim3 grid(big_grid(n, BigCfg<T>::kPerCu));
         if (ul.U) {
             auto k = spgemm_numeric_big_kernel<T, true>;

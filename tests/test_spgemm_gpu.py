@@ -179,7 +179,7 @@ def test_spgemm_value_chunk_splits(oracle, monkeypatch, splits):
     _three_window_case(oracle, False)
 
 
-@pytest.mark.parametrize("walk", ["units", "entry_pass"])
+@pytest.mark.parametrize("walk", ["units", "units_by_items", "entry_pass"])
 @pytest.mark.parametrize("short_rows", ["wave", "tables"])
 @pytest.mark.parametrize("two_phase", [False, True])
 def test_spgemm_walk_forms(oracle, monkeypatch, walk, short_rows, two_phase):
@@ -188,6 +188,8 @@ def test_spgemm_walk_forms(oracle, monkeypatch, walk, short_rows, two_phase):
     kernels that also take what the wavefront kernel hands back (G4S_SPGEMM_NO_WAVE_ROWS). Every combination, both call forms, every row class."""
     if walk == "entry_pass":
         monkeypatch.setenv("G4S_SPGEMM_NO_UNITS", "1")
+    if walk == "units_by_items":                                   # the item-parallel pre-pass behind the same lists (the fall-back of the task-parallel one)
+        monkeypatch.setenv("G4S_SPGEMM_UNITS_BY_ITEMS", "1")
     if short_rows == "tables":
         monkeypatch.setenv("G4S_SPGEMM_NO_WAVE_ROWS", "1")
     rp, ci, va = power_law_csr(6000, 6000, 23, 1500)

@@ -4,7 +4,7 @@ whose hash differs from the tree it runs from. Usage: python tools/kernel_hash.p
 import hashlib
 import os
 
-FILES = ("spmv.hip", "spmv_pb.hip", "spmv_bcsr.hip", "spmv_pb.hpp", "spmv_bcsr.hpp", "prims.hpp", "common.hpp")
+FILES = ("spmv.hip", "spmv_pb.hip", "spmv_bcsr.hip", "spmv_pb.hpp", "spmv_bcsr.hpp", "common.hpp")
 
 
 def spmv_kernel_hash(root=None):
