@@ -2103,19 +2103,32 @@ struct ColumnMap {
     int width(int N) const { return n2 ? n2 : N; }
     const int *inverse() const { return n2 ? inv.as<int>() : nullptr; }
 };
-__global__ void colmap_mark_kernel(long long nnz, int N, const int *__restrict__ bcol, unsigned *__restrict__ bm)
+// (Round 4: one BYTE per column, set with plain stores — every writer stores the same 1, so the race is benign — and packed into bitmap words by the count
+// kernel; the atomicOr per entry on a bitmap whose popular words every wave hits cost 0.3 ms per product.)
+__global__ void colmap_mark_kernel(long long nnz, int N, const int *__restrict__ bcol, unsigned char *__restrict__ seen)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nnz) return;
     const int c = bcol[k];
-    if (c < 0 || c >= N) return;                                   // the numeric-only call does not range-check B again: never write outside the bitmap
-    const unsigned bit = 1u << (c & 31);
-    if (!(bm[c >> 5] & bit)) atomicOr(&bm[c >> 5], bit);
+    if (c < 0 || c >= N) return;                                   // the numeric-only call does not range-check B again: never write outside the map
+    seen[c] = 1;
 }
-__global__ void colmap_popc_kernel(int W, const unsigned *__restrict__ bm, int *__restrict__ cnt)
+__global__ void colmap_popc_kernel(int W, int N, const unsigned char *__restrict__ seen, unsigned *__restrict__ bm, int *__restrict__ cnt)
 {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w <= W) cnt[w] = w < W ? __popc(bm[w]) : 0;                // W + 1 items: the scan's last element is the total
+    if (w > W) return;                                             // W + 1 items: the scan's last element is the total
+    unsigned word = 0;
+    if (w < W) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(seen + (size_t)w * 32);   // (the byte map is padded to a multiple of 32)
+        const uint4 a = p[0], b = p[1];
+        const unsigned v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) word |= ((v[q] >> (8 * j)) & 1u) << (4 * q + j);
+        bm[w] = word;
+    }
+    cnt[w] = __popc(word);
 }
 __global__ void colmap_inverse_kernel(int W, const unsigned *__restrict__ bm, const int *__restrict__ prefix, int *__restrict__ inv)
 {
@@ -2142,13 +2155,14 @@ int build_column_map(int N, long long bnnz, const int *bcol, ColumnMap &cm, hipS
     cm.n2 = 0;
     if (N < (1 << 16) || bnnz <= 0 || getenv("G4S_SPGEMM_NO_COLMAP")) return G4S_OK;   // a single small window either way
     const int W = (N + 31) >> 5;
-    DevBuf bm, cnt, prefix;
+    DevBuf bm, cnt, prefix, seen;
     G4S_TRY(bm.alloc(sizeof(unsigned) * (size_t)W));
+    G4S_TRY(seen.alloc((size_t)W * 32));
+    G4S_HIP_TRY(hipMemsetAsync(seen.p, 0, (size_t)W * 32, s));
     G4S_TRY(cnt.alloc(sizeof(int) * ((size_t)W + 1)));
     G4S_TRY(prefix.alloc(sizeof(int) * ((size_t)W + 1)));
-    G4S_HIP_TRY(hipMemsetAsync(bm.p, 0, sizeof(unsigned) * (size_t)W, s));
-    hipLaunchKernelGGL(colmap_mark_kernel, dim3((unsigned)((bnnz + 255) / 256)), dim3(256), 0, s, bnnz, N, bcol, bm.as<unsigned>());
-    hipLaunchKernelGGL(colmap_popc_kernel, dim3((W + 256) / 256), dim3(256), 0, s, W, bm.as<unsigned>(), cnt.as<int>());
+    hipLaunchKernelGGL(colmap_mark_kernel, dim3((unsigned)((bnnz + 255) / 256)), dim3(256), 0, s, bnnz, N, bcol, seen.as<unsigned char>());
+    hipLaunchKernelGGL(colmap_popc_kernel, dim3((W + 256) / 256), dim3(256), 0, s, W, N, seen.as<unsigned char>(), bm.as<unsigned>(), cnt.as<int>());
     G4S_TRY(g4s::prims::exclusive_scan(cnt.as<int>(), prefix.as<int>(), (long long)W + 1, s));
     int n2 = 0;
     G4S_HIP_TRY(hipMemcpyAsync(&n2, prefix.as<int>() + W, sizeof(int), hipMemcpyDeviceToHost, s));
