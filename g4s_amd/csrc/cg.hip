@@ -559,6 +559,95 @@ int dist_product(g4s_spmv_dist_t A, const g4s_transport *tr, const double *x, do
 }
 } // namespace g4s
 
+namespace g4s {
+// The partitioned solve as an object (the counterpart of CgRun above): start() enqueues the set-up, the first batch of iterations and the loop test
+// without a host wait; the caller may go on enqueuing work that uses d0 speculatively and read the state together with its own scalars
+// (stokes.hip: g4s_stokes_uzawa_cg_dist — one host wait per outer iteration). Every rank reads the same all-reduced sums, so every rank sees
+// the same (count, done, residual) and takes the same turn.
+struct DistCgAsync {
+    g4s_spmv_dist_t A = nullptr;
+    const g4s_transport *tr = nullptr;
+    g4s_cg_ws_t ws = nullptr;
+    const double *BI = nullptr;
+    const int32_t *zero_resid = nullptr;
+    double *d0 = nullptr, *part = nullptr, acc = 0.0;
+    int n_zero = 0, steps = 0, enqueued = 0;
+    void *stream = nullptr;
+    CgState h{};
+
+    // Iterations past the one that meets the test are no-ops in the CG kernels; their product and all-reduces still run, on data nothing
+    // reads again (the partial sums are rewritten by the next solve's first kernel).
+    int enqueue(int todo)
+    {
+        double *p = nullptr, *Ap = nullptr;
+        for (int it = 0; it < todo; ++it) {
+            G4S_TRY(g4s_cg_direction(ws, steps, acc, stream));
+            G4S_TRY(g4s_cg_buffers(ws, &p, &Ap, nullptr));
+            G4S_TRY(g4s::dist_product(A, tr, p, Ap, stream));
+            G4S_TRY(g4s_cg_reduce_pAp(ws, stream));
+            G4S_TRY(tr->allreduce_sum_f64(tr->ctx, part + kDotBlocks, kDotBlocks, stream));
+            G4S_TRY(g4s_cg_update(ws, BI, d0, stream));
+            G4S_TRY(tr->allreduce_sum_f64(tr->ctx, part, 3 * kDotBlocks, stream));          // [0, 256) r·z and [512, 768) r·r; the middle third is rewritten before its next use
+        }
+        enqueued += todo;
+        return g4s_cg_direction(ws, steps, acc, stream);                                    // the loop test behind the batch (a no-op once done)
+    }
+    int start(int batch, const double *F)
+    {
+        G4S_TRY(g4s_cg_begin(ws, F, BI, d0, zero_resid, n_zero, stream));
+        G4S_TRY(g4s_cg_buffers(ws, nullptr, nullptr, &part));
+        G4S_TRY(tr->allreduce_sum_f64(tr->ctx, part, 3 * kDotBlocks, stream));              // r·z and r·r of the start vector
+        return enqueue(std::max(1, std::min(batch, steps + 1)));
+    }
+    int read() { G4S_HIP_TRY(hipMemcpyAsync(&h, ws->st, sizeof(CgState), hipMemcpyDeviceToHost, g4s::as_stream(stream))); return G4S_OK; }
+    int complete()                                                                          // h: read after a synchronisation
+    {
+        int batch = std::min(32, std::max(2, enqueued * 2));
+        while (!h.done) {
+            G4S_TRY(enqueue(std::max(1, std::min(batch, steps - enqueued + 1))));
+            G4S_TRY(read());
+            G4S_HIP_TRY(hipStreamSynchronize(g4s::as_stream(stream)));
+            batch = std::min(32, batch * 2);
+        }
+        return G4S_OK;
+    }
+    int finish()                                                                            // conj_grad :409, no synchronisation
+    {
+        if (n_zero) hipLaunchKernelGGL(cg_strip_kernel, dim3((n_zero + kThreads - 1) / kThreads), dim3(kThreads), 0, g4s::as_stream(stream), n_zero, zero_resid, d0);
+        G4S_HIP_TRY(hipGetLastError());
+        return G4S_OK;
+    }
+};
+
+int dist_cg_async_start(DistCgAsync **out, g4s_cg_ws_t ws, g4s_spmv_dist_t A, const g4s_transport *tr, const double *BI, const int32_t *zero_resid, int32_t n_zero,
+                        const double *F, double *d0, double acc, int32_t steps, void *stream)
+{
+    *out = nullptr;
+    auto c = new (std::nothrow) DistCgAsync();
+    if (!c) return set_error(G4S_ERR_NOMEM, "host allocation failed");
+    c->A = A; c->tr = tr; c->ws = ws; c->BI = BI; c->zero_resid = zero_resid; c->n_zero = n_zero; c->d0 = d0; c->acc = acc; c->steps = steps; c->stream = stream;
+    int st = c->start(cg_first_batch(), F);
+    if (st == G4S_OK) st = c->finish();
+    if (st != G4S_OK) { delete c; return st; }
+    *out = c;
+    return G4S_OK;
+}
+int dist_cg_async_read(DistCgAsync *c) { return c->read(); }
+int dist_cg_async_settle(DistCgAsync *c, bool *speculation_held, int32_t *cycles, double *residual)
+{
+    *speculation_held = c->h.done != 0;
+    if (!c->h.done) {
+        G4S_TRY(c->complete());
+        G4S_TRY(c->finish());
+    }
+    cg_last_iterations() = c->h.count;
+    if (cycles) *cycles = c->h.count;
+    if (residual) *residual = c->h.residual;
+    return G4S_OK;
+}
+void dist_cg_async_free(DistCgAsync *c) { delete c; }
+} // namespace g4s
+
 G4S_API g4s_status g4s_conj_grad_dist_tr(g4s_spmv_dist_t A, const g4s_transport *tr, int32_t n_local, const double *BI_dev, const int32_t *zero_resid_dev,
                                          int32_t n_zero, const double *F_dev, double *d0_dev, double acc, int32_t steps, int32_t *cycles, double *residual,
                                          void *stream)
@@ -571,39 +660,17 @@ G4S_API g4s_status g4s_conj_grad_dist_tr(g4s_spmv_dist_t A, const g4s_transport 
     G4S_REQUIRE(n_local > 0 && n_zero >= 0 && (n_zero == 0 || zero_resid_dev), "bad size");
     g4s_cg_ws_t ws = nullptr;
     G4S_TRY(g4s_cg_ws_create(&ws, n_local));
+    // Iterations are enqueued in batches with ONE read of (count, done, residual) behind each batch — the first as long as the previous solve of
+    // this thread plus one (g4s::cg_first_batch, as the single-GPU solve): with an RCCL transport nothing inside a batch waits for the host.
     auto run = [&]() -> int {
-        G4S_TRY(g4s_cg_begin(ws, F_dev, BI_dev, d0_dev, zero_resid_dev, n_zero, stream));
-        double *p = nullptr, *Ap = nullptr, *part = nullptr;
-        G4S_TRY(g4s_cg_buffers(ws, &p, &Ap, &part));
-        G4S_TRY(tr->allreduce_sum_f64(tr->ctx, part, 3 * kDotBlocks, stream));              // r·z and r·r of the start vector
-        int32_t count = 0, done = 0;
-        double res = 0.0;
-        // Iterations are enqueued in batches with ONE read of (count, done, residual) behind each batch — the first as long as the previous solve of
-        // this thread plus one (g4s::cg_first_batch, as the single-GPU solve): with an RCCL transport nothing inside a batch waits for the host.
-        // Iterations past the one that meets the test are no-ops in the CG kernels; their product and all-reduces still run, on data nothing
-        // reads again (the partial sums are rewritten by the next solve's first kernel).
-        int batch = g4s::cg_first_batch(), enqueued = 0;
-        for (;;) {
-            const int todo = std::max(1, std::min(batch, steps - enqueued + 1));
-            for (int it = 0; it < todo; ++it) {
-                G4S_TRY(g4s_cg_direction(ws, steps, acc, stream));
-                G4S_TRY(g4s_cg_buffers(ws, &p, &Ap, nullptr));
-                G4S_TRY(g4s::dist_product(A, tr, p, Ap, stream));
-                G4S_TRY(g4s_cg_reduce_pAp(ws, stream));
-                G4S_TRY(tr->allreduce_sum_f64(tr->ctx, part + kDotBlocks, kDotBlocks, stream));
-                G4S_TRY(g4s_cg_update(ws, BI_dev, d0_dev, stream));
-                G4S_TRY(tr->allreduce_sum_f64(tr->ctx, part, 3 * kDotBlocks, stream));      // [0, 256) r·z and [512, 768) r·r; the middle third is rewritten before its next use
-            }
-            enqueued += todo;
-            G4S_TRY(g4s_cg_direction(ws, steps, acc, stream));                              // the loop test behind the batch (a no-op once done)
-            G4S_TRY(g4s_cg_state(ws, &count, &done, &res, stream));
-            if (done) break;
-            batch = std::min(32, batch * 2);
-        }
-        g4s::cg_last_iterations() = count;
-        G4S_TRY(g4s_cg_end(ws, d0_dev, zero_resid_dev, n_zero, stream));
-        if (cycles) *cycles = count;
-        if (residual) *residual = res;
+        g4s::DistCgAsync *c = nullptr;
+        G4S_TRY(g4s::dist_cg_async_start(&c, ws, A, tr, BI_dev, zero_resid_dev, n_zero, F_dev, d0_dev, acc, steps, stream));
+        struct Free { g4s::DistCgAsync *c; ~Free() { g4s::dist_cg_async_free(c); } } guard{c};
+        G4S_TRY(g4s::dist_cg_async_read(c));
+        G4S_HIP_TRY(hipStreamSynchronize(g4s::as_stream(stream)));
+        bool held = true;
+        G4S_TRY(g4s::dist_cg_async_settle(c, &held, cycles, residual));
+        G4S_HIP_TRY(hipStreamSynchronize(g4s::as_stream(stream)));
         return G4S_OK;
     };
     const int st = run();

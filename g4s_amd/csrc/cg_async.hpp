@@ -15,4 +15,13 @@ int cg_async_read(CgAsync *c);                      // enqueues the copy of the 
 // not, the solve is run to its end here (synchronising) and d0 stripped again; the caller must redo what it had enqueued behind the solve.
 int cg_async_settle(CgAsync *c, bool *speculation_held, int32_t *cycles, double *residual);
 void cg_async_free(CgAsync *c);
+
+// The same for a row-partitioned operator (g4s_conj_grad_dist_tr's loop): the product and the all-reduces of the dot products go through the
+// transport; `ws` (g4s_cg_ws_create) is the caller's, reused from solve to solve. Every rank reads the same all-reduced sums and takes the same turn.
+struct DistCgAsync;
+int dist_cg_async_start(DistCgAsync **out, g4s_cg_ws_t ws, g4s_spmv_dist_t A, const g4s_transport *tr, const double *BI, const int32_t *zero_resid, int32_t n_zero,
+                        const double *F, double *d0, double acc, int32_t steps, void *stream);
+int dist_cg_async_read(DistCgAsync *c);
+int dist_cg_async_settle(DistCgAsync *c, bool *speculation_held, int32_t *cycles, double *residual);
+void dist_cg_async_free(DistCgAsync *c);
 } // namespace g4s

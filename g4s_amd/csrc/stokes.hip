@@ -458,14 +458,16 @@ G4S_API g4s_status g4s_stokes_uzawa_cg_dist(g4s_spmv_dist_t K, g4s_spmv_dist_t D
     auto div_u = [&](const double *u_in, double *out) -> int { return g4s::dist_product(D, tr, u_in, out, stream); };                                   // assemble_div_u
     int64_t inner_total = 0;
     const double inner_acc = prm->imp * prm->inner_accuracy_scale * prm->v_res;
-    auto solve_del2_u = [&](const double *rhs, double *d0, int *valid) -> int {
-        int32_t cycles = 0;
-        double residual = 0.0;
-        G4S_TRY(g4s_conj_grad_dist_tr(K, tr, neq, BI, zero_resid, n_zero, rhs, d0, inner_acc, prm->v_steps_low, &cycles, &residual, stream));
-        inner_total += cycles;
-        *valid = residual < inner_acc ? 1 : 0;
-        return G4S_OK;
-    };
+    // one CG workspace for every velocity solve of the call
+    struct Ws { g4s_cg_ws_t w = nullptr; ~Ws() { (void)g4s_cg_ws_destroy(w); } } ws;
+    G4S_TRY(g4s_cg_ws_create(&ws.w, neq));
+    // V and P of the NEXT outer iteration are written beside the current ones (ping-pong), as in g4s_stokes_uzawa_cg: an iteration enqueued behind a
+    // velocity solve whose first batch turns out not to have met its test is enqueued again, from unchanged inputs
+    Scratch scr2; scr2.s = s;
+    G4S_TRY(g4s::scratch_alloc(&scr2.p, nq + np, s));
+    double *Vc = V, *Vn = reinterpret_cast<double *>(scr2.p), *Pc = P, *Pn = reinterpret_cast<double *>(static_cast<char *>(scr2.p) + nq);
+    const bool speculate = !(getenv("G4S_STOKES_SYNC") && atoi(getenv("G4S_STOKES_SYNC")) != 0);
+    struct CgFree { g4s::DistCgAsync *c; ~CgFree() { g4s::dist_cg_async_free(c); } };
 
     // ---- initial_vel_residual (:839-881): F = FF − grad(P) − K·V, stripped; K·u1 = F; V += u1
     int valid = 0;
@@ -475,8 +477,20 @@ G4S_API g4s_status g4s_stokes_uzawa_cg_dist(g4s_spmv_dist_t K, g4s_spmv_dist_t D
     strip(u1);
     each(neq, [=] __device__(int i) { F[i] = F[i] - u1[i]; });
     strip(F);
-    G4S_TRY(solve_del2_u(F, u1, &valid));
-    strip(u1);
+    {
+        // this solve's result feeds sums whose inputs it also writes in place (V += u1): waited for, not speculated on — once per call
+        g4s::DistCgAsync *cg = nullptr;
+        G4S_TRY(g4s::dist_cg_async_start(&cg, ws.w, K, tr, BI, zero_resid, n_zero, F, u1, inner_acc, prm->v_steps_low, stream));
+        CgFree guard{cg};
+        G4S_TRY(g4s::dist_cg_async_read(cg));
+        G4S_HIP_TRY(hipStreamSynchronize(s));
+        bool held = true;
+        int32_t cycles = 0;
+        double residual = 0.0;
+        G4S_TRY(g4s::dist_cg_async_settle(cg, &held, &cycles, &residual));
+        inner_total += cycles;
+        valid = residual < inner_acc ? 1 : 0;
+    }
     each(neq, [=] __device__(int i) { V[i] = V[i] + u1[i]; });
 
     G4S_TRY(div_u(V, r1));
@@ -506,22 +520,49 @@ G4S_API g4s_status g4s_stokes_uzawa_cg_dist(g4s_spmv_dist_t K, g4s_spmv_dist_t D
         const bool first = count == 0;
         each(nel, [=] __device__(int i) { s2[i] = first ? z1[i] : z1[i] + sc[DELTA] * s1[i]; });
         G4S_TRY(grad_p(s2, tmp));
-        G4S_TRY(solve_del2_u(tmp, u1, &valid));
-        strip(u1);
-        G4S_TRY(div_u(u1, Fp));
-        G4S_TRY(reduce(nel, [=] __device__(int i) { return Sum3{s2[i] * Fp[i], 0.0, 0.0}; }, [=] __device__() { sc[ALPHA] = sc[R1Z1] / raw[0]; }));
-        each(nel, [=] __device__(int i) { const double alpha = sc[ALPHA]; r2[i] = r1[i] - alpha * Fp[i]; P[i] += alpha * s2[i]; });
-        each(neq, [=] __device__(int i) { V[i] -= sc[ALPHA] * u1[i]; });
-        G4S_TRY(div_u(V, z1));
-        G4S_TRY(reduce(std::max(neq, nel), [=] __device__(int i) {
-            Sum3 o{0.0, 0.0, 0.0};
-            if (i < neq) { o.a = V[i] * V[i] * vmass[i]; o.b = u1[i] * u1[i] * vmass[i]; }
-            if (i < nel) o.c = P[i] * P[i] * area[i];
-            return o;
-        }, [=] __device__() { sc[VDOTV] = raw[0]; sc[U1DOTU1] = raw[1]; sc[PDOTP] = raw[2]; }));
-        G4S_TRY(reduce(nel, [=] __device__(int i) { return Sum3{s2[i] * s2[i] * area[i], z1[i] * z1[i] / area[i], 0.0}; },
-                       [=] __device__() { sc[S2S2] = raw[0]; sc[DIVN] = raw[1]; sc[R0Z0] = sc[R1Z1]; }));
-        G4S_TRY(fetch());
+        // K·u1 = grad(s2): the solve's first batch is only enqueued (products, exchanges and all-reduces included — with an RCCL transport none of them
+        // waits for the host); the rest of the outer iteration goes behind it at once and ONE synchronisation brings back the solve's state and the
+        // nine scalars. Until round 4 this loop waited three times per outer iteration (the solve's state, the solve's end, the scalars).
+        g4s::DistCgAsync *cg = nullptr;
+        G4S_TRY(g4s::dist_cg_async_start(&cg, ws.w, K, tr, BI, zero_resid, n_zero, tmp, u1, inner_acc, prm->v_steps_low, stream));
+        CgFree guard{cg};
+        int32_t cycles = 0;
+        double residual = 0.0;
+        bool held = true;
+        if (!speculate) {
+            G4S_TRY(g4s::dist_cg_async_read(cg));
+            G4S_HIP_TRY(hipStreamSynchronize(s));
+            G4S_TRY(g4s::dist_cg_async_settle(cg, &held, &cycles, &residual));
+        }
+        auto rest_of_iteration = [&]() -> int {
+            G4S_TRY(div_u(u1, Fp));
+            G4S_TRY(reduce(nel, [=] __device__(int i) { return Sum3{s2[i] * Fp[i], 0.0, 0.0}; }, [=] __device__() { sc[ALPHA] = sc[R1Z1] / raw[0]; }));
+            each(std::max(nel, neq), [=] __device__(int i) {
+                const double alpha = sc[ALPHA];
+                if (i < nel) { r2[i] = r1[i] - alpha * Fp[i]; Pn[i] = Pc[i] + alpha * s2[i]; }
+                if (i < neq) Vn[i] = Vc[i] - alpha * u1[i];
+            });
+            G4S_TRY(div_u(Vn, z1));
+            G4S_TRY(reduce(std::max(neq, nel), [=] __device__(int i) {
+                Sum3 o{0.0, 0.0, 0.0};
+                if (i < neq) { o.a = Vn[i] * Vn[i] * vmass[i]; o.b = u1[i] * u1[i] * vmass[i]; }
+                if (i < nel) o.c = Pn[i] * Pn[i] * area[i];
+                return o;
+            }, [=] __device__() { sc[VDOTV] = raw[0]; sc[U1DOTU1] = raw[1]; sc[PDOTP] = raw[2]; }));
+            G4S_TRY(reduce(nel, [=] __device__(int i) { return Sum3{s2[i] * s2[i] * area[i], z1[i] * z1[i] / area[i], 0.0}; },
+                           [=] __device__() { sc[S2S2] = raw[0]; sc[DIVN] = raw[1]; sc[R0Z0] = sc[R1Z1]; }));
+            return G4S_OK;
+        };
+        G4S_TRY(rest_of_iteration());
+        if (speculate) {
+            G4S_TRY(g4s::dist_cg_async_read(cg));
+            G4S_TRY(fetch());
+            G4S_TRY(g4s::dist_cg_async_settle(cg, &held, &cycles, &residual));
+            if (!held) G4S_TRY(rest_of_iteration());              // u1 is final only now: once more, from the same V, P, r1, s2 (all ranks alike)
+        }
+        inner_total += cycles;
+        valid = residual < inner_acc ? 1 : 0;
+        if (!speculate || !held) G4S_TRY(fetch());
         if (hsc[R1Z1] == 0.0) return g4s::set_error(G4S_ERR_INVALID, "g4s_stokes_uzawa_cg_dist: <r1, z1> = 0 at the head of iteration %d (the source asserts)", count);
         const double alpha = hsc[ALPHA];
         vdotv = hsc[VDOTV] / volume;
@@ -536,6 +577,12 @@ G4S_API g4s_status g4s_stokes_uzawa_cg_dist(g4s_spmv_dist_t K, g4s_spmv_dist_t D
         else converging = dvelocity < prm->imp ? converging + 1 : 0;
         std::swap(s1, s2);
         std::swap(r1, r2);
+        std::swap(Vc, Vn);
+        std::swap(Pc, Pn);
+    }
+    if (Vc != V) {                                                 // an odd number of iterations: the result sits in the scratch pair
+        G4S_HIP_TRY(hipMemcpyAsync(V, Vc, sizeof(double) * (size_t)neq, hipMemcpyDeviceToDevice, s));
+        G4S_HIP_TRY(hipMemcpyAsync(P, Pc, sizeof(double) * (size_t)nel, hipMemcpyDeviceToDevice, s));
     }
     G4S_HIP_TRY(hipGetLastError());
     G4S_HIP_TRY(hipStreamSynchronize(s));
