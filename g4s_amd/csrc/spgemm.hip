@@ -844,7 +844,12 @@ __device__ unsigned long long g_big_prof[32];                     // [0, 16): nu
 #define BIG_PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[16] = {}; constexpr int prof_base = 0
 #define BIG_PROF_DECL_SYM unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[16] = {}; constexpr int prof_base = 16
 #define BIG_PROF(slot) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof_acc[slot] += n_ - prof_t; prof_t = n_; } while (0)
-#define BIG_PROF_FLUSH do { if (threadIdx.x == 0 && (blockIdx.x & 15) == 0) {   /* one workgroup in 16 reports: the flush atomics of all of them would sit in front of the next loads */ _Pragma("unroll") for (int s_ = 0; s_ < 16; ++s_) if (prof_acc[s_]) atomicAdd(&g_big_prof[prof_base + s_], prof_acc[s_]); } _Pragma("unroll") for (int s_ = 0; s_ < 16; ++s_) prof_acc[s_] = 0; } while (0)
+#ifdef G4S_PROF_LAST_WAVE   /* the report of the LAST wavefront instead of the first: a section that is long in one and a barrier wait in the other is imbalance */
+#define BIG_PROF_TID (blockDim.x - 64)
+#else
+#define BIG_PROF_TID 0
+#endif
+#define BIG_PROF_FLUSH do { if (threadIdx.x == BIG_PROF_TID && (blockIdx.x & 15) == 0) {   /* one workgroup in 16 reports: the flush atomics of all of them would sit in front of the next loads */ _Pragma("unroll") for (int s_ = 0; s_ < 16; ++s_) if (prof_acc[s_]) atomicAdd(&g_big_prof[prof_base + s_], prof_acc[s_]); } _Pragma("unroll") for (int s_ = 0; s_ < 16; ++s_) prof_acc[s_] = 0; } while (0)
 #else
 #define BIG_PROF_DECL
 #define BIG_PROF_DECL_SYM
@@ -1064,6 +1069,7 @@ __device__ __forceinline__ int emit_window_columns(unsigned *bm, int w0, int *__
                 out[pos++] = col0 + 64 + bit;
             }
         }
+        BIG_PROF(13);
         __syncthreads();
         BIG_PROF(11);
     }
@@ -1472,7 +1478,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
 {
     // No static __shared__ in this kernel: it would sit in front of the dynamic region and push the fp64 table of phase 2 off its
     // 8-byte alignment (cdna_hip_programming.md Guideline 17). Everything is carved from the dynamic region instead.
-    constexpr int kBigThreads = T, kBigWindowBits = BigCfg<T>::kWindowBits, kBigWindowWords = BigCfg<T>::kWindowWords, kBigChunk = BigCfg<T>::kChunk;
+    constexpr int kBigThreads = T, kBigWindowWords = BigCfg<T>::kWindowWords, kBigChunk = BigCfg<T>::kChunk;
     extern __shared__ int lds_i[];
     const BigSide<T> sd(lds_i + kBigWindowWords);
     const int t = threadIdx.x;
@@ -1509,7 +1515,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     for (; ridx < nrows; ridx = nridx, cur = nxt) {                // persistent: see spgemm_symbolic_window_kernel
     if (next_row) { if (t == 0) sd.ctrl[29] = atomicAdd(next_row, 1); }   // read below, behind a barrier
     else { nridx = ridx + gridDim.x; nxt = load_meta(nridx); }
-    const int row = cur.row, a0 = cur.a0, a1 = cur.a1, off = cur.off, nz = cur.nz;
+    const int a0 = cur.a0, a1 = cur.a1, off = cur.off, nz = cur.nz;
     if (nz <= nz_lo || nz > nz_hi) {                               // uniform: the whole workgroup skips the row
         if (next_row) { __syncthreads(); nridx = __builtin_amdgcn_readfirstlane(sd.ctrl[29]); __syncthreads(); nxt = load_meta(nridx); }
         have_first = false;

@@ -18,7 +18,7 @@ lib.g4s_debug_big_prof(buf, 1)
 host.HashSpGEMM(A, A)                                            # the one-call form: the symbolic window kernels also emit the sorted columns
 lib.g4s_debug_big_prof(buf, 0)
 names = {16: "zero bitmap + barrier", 17: "flat products (mark)", 19: "emit (all)", 22: "row start / end",
-         24: "  emit: words + popcount", 25: "  emit: scan + barrier", 26: "  emit: list build + barrier", 27: "  emit: write columns + barrier", 28: "  emit: last barrier"}
+         24: "  emit: words + popcount", 25: "  emit: scan + barrier", 26: "  emit: list build + barrier", 29: "  emit: write columns (wave 0's own loops)", 27: "  emit: barrier behind the column writes", 28: "  emit: last barrier"}
 tot = sum(buf[k] for k in (16, 17, 19, 22))
 for k, nme in names.items():
     print(f"{nme:26s} {buf[k]:16d} ticks {100.0 * buf[k] / max(tot, 1):6.2f} %")
