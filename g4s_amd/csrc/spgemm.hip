@@ -1022,13 +1022,17 @@ __device__ __forceinline__ int emit_window_columns(unsigned *bm, int w0, int *__
     if (lane == 63) { s_scan[wave] = incl_c; s_scan[16 + wave] = incl_g; }
     __syncthreads();
     BIG_PROF(9);
-    int p = incl_c - cnt, gq = incl_g - ng, total = 0, total_g = 0; // first column / first list item of this thread within the window
-#pragma unroll
-    for (int u = 0; u < T / 64; ++u) {
-        const int vc = s_scan[u], vg = s_scan[16 + u];
-        if (u < wave) { p += vc; gq += vg; }
-        total += vc;
-        total_g += vg;
+    int p = incl_c - cnt, gq = incl_g - ng, total, total_g;          // first column / first list item of this thread within the window
+    {
+        // the wave totals: lanes 0 … T/64 − 1 read one each and a wave scan adds them (every thread reading all of them was 2·T/64 LDS reads per thread: the
+        // CU issues one LDS instruction at a time, and 16 waves × 32 of them stood in front of the list build)
+        constexpr int kW = T / 64;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const unsigned sc = (unsigned)wave_inclusive_sum(lane < kW ? (unsigned)s_scan[lane] : 0u);
+        const unsigned sg = (unsigned)wave_inclusive_sum(lane < kW ? (unsigned)s_scan[16 + lane] : 0u);
+        total = (int)__builtin_amdgcn_readlane(sc, kW - 1);
+        total_g = (int)__builtin_amdgcn_readlane(sg, kW - 1);
+        if (wv > 0) { p += (int)__builtin_amdgcn_readlane(sc, wv - 1); gq += (int)__builtin_amdgcn_readlane(sg, wv - 1); }
     }
     first_pos[t] = p;                                              // a list item is (group << 10 | offset from its owner's first column)
     for (int tile0 = 0; tile0 < total_g; tile0 += S) {              // uniform; one tile unless more than S groups hold columns
@@ -1048,26 +1052,44 @@ __device__ __forceinline__ int emit_window_columns(unsigned *bm, int w0, int *__
         __syncthreads();
         BIG_PROF(10);
         const int n = min(S, total_g - tile0);
-        for (int e = t; e < n; e += T) {
-            const unsigned item = (unsigned)stage[e];
-            const int gid = (int)(item >> 10), tt = gid >> 3;       // owner thread and its group
+        // Two of a thread's items go through the three dependent LDS reads together — item, its group's words, its owner's first position — then through the bit loops
+        // (1, 2 and all S / T at once measured within 2 % of each other). What the step costs is instruction issue: 150 M wave-iterations of the bit loops per product
+        // for 1.9 G columns (13 active lanes each; a group holds 3 columns on average, 57 % of the groups one) at ≈ 12 VALU instructions per iteration. Round 4 also
+        // tried a lane walking all its items as ONE queue of bits (fewer wave-iterations: max over lanes of a sum instead of a sum of maxima): each iteration then
+        // carries the queue's selects, 25–30 instructions — 8.2 / 5.6 ms against 6.2 / 4.1 for the two window shapes.
+        constexpr int kI = 2;
+        for (int e0 = 0; e0 < n; e0 += kI * T) {
+        unsigned item[kI];
+        uint4 g[kI];
+        int pos[kI];
+#pragma unroll
+        for (int k = 0; k < kI; ++k) item[k] = (unsigned)stage[min(e0 + t + k * T, max(n, 1) - 1)];
+#pragma unroll
+        for (int k = 0; k < kI; ++k) {
+            const int gid = (int)(item[k] >> 10), tt = gid >> 3;    // owner thread and its group
             uint4 *gp = reinterpret_cast<uint4 *>(bm + tt * 32) + ((gid & 7) ^ ((tt >> 1) & 7));
-            const uint4 g = *gp;
-            *gp = make_uint4(0u, 0u, 0u, 0u);                        // the window leaves the bitmap clean: the next one does not zero 32·T words first (12 % of the symbolic window kernels)
-            int pos = first_pos[tt] + (int)(item & 0x3ffu);
-            const int col0 = w0 + (gid << 7);
-            unsigned long long b = ((unsigned long long)g.y << 32) | g.x;
+            const bool mine = e0 + t + k * T < n;
+            g[k] = mine ? *gp : make_uint4(0u, 0u, 0u, 0u);
+            if (mine) *gp = make_uint4(0u, 0u, 0u, 0u);             // the window leaves the bitmap clean: the next one does not zero 32·T words first (12 % of the symbolic window kernels)
+            pos[k] = first_pos[tt] + (int)(item[k] & 0x3ffu);
+        }
+#pragma unroll
+        for (int k = 0; k < kI; ++k) {
+            const int col0 = w0 + (int)((item[k] >> 10) << 7);
+            int ps = pos[k];
+            unsigned long long b = ((unsigned long long)g[k].y << 32) | g[k].x;
             while (b) {
                 const int bit = __ffsll((long long)b) - 1;
                 b &= b - 1;
-                out[pos++] = col0 + bit;
+                out[ps++] = col0 + bit;
             }
-            b = ((unsigned long long)g.w << 32) | g.z;
+            b = ((unsigned long long)g[k].w << 32) | g[k].z;
             while (b) {
                 const int bit = __ffsll((long long)b) - 1;
                 b &= b - 1;
-                out[pos++] = col0 + 64 + bit;
+                out[ps++] = col0 + 64 + bit;
             }
+        }
         }
         BIG_PROF(13);
         __syncthreads();
