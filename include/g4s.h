@@ -469,7 +469,10 @@ g4s_status g4s_conj_grad_dist_tr(g4s_spmv_dist_t A, const g4s_transport *tr, int
  * On one rank the element-ordered sums of g4s_stokes_uzawa_cg become CSR row sums: same terms, same order within a part, the own-column
  * and remote-column parts added separately — results agree to rounding, iteration counts normally exactly.
  * vmass_dev[neq_local] = NMass of the node that owns the equation (the weight of global_v_norm2), area_dev[nel_local], volume = mesh volume,
- * zero_resid: LOCAL equation indices; BI / BPI: the two preconditioner diagonals, local slabs. V / P updated in place. */
+ * zero_resid: LOCAL equation indices; BI / BPI: the two preconditioner diagonals, local slabs. V / P updated in place.
+ * The host waits once per outer iteration: a velocity solve's first batch of iterations is enqueued with what follows it, and the rest of the iteration is
+ * enqueued again if that batch turns out not to have met the solve's test (all ranks read the same all-reduced sums and take the same turn);
+ * G4S_STOKES_SYNC=1 waits for every solve instead. */
 g4s_status g4s_stokes_uzawa_cg_dist(g4s_spmv_dist_t K, g4s_spmv_dist_t D, g4s_spmv_dist_t Dt, const g4s_transport *tr, int32_t neq_local, int32_t nel_local,
                                     const double *BI_dev, const double *BPI_dev, const double *vmass_dev, const double *area_dev, double volume,
                                     const int32_t *zero_resid_dev, int32_t n_zero, const double *F_dev, double *V_dev, double *P_dev,
