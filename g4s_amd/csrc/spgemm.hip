@@ -79,6 +79,10 @@ struct ArenaScope {
     ~ArenaScope() { g4s::arena_leave(t_stream, t_idle); }
 };
 
+// (Round 4 tried a second stream for the short-row kernels — one wavefront per row, bound by their chain of dependent loads — beside the pre-passes of the
+// window classes, which are latency-bound too: 33.5 ms against 32.6 for the call, three alternating runs each. The persistent window kernels behind the pre-passes
+// start on CUs the short rows still hold, and their longest-first tickets then run late on those. One stream.)
+
 // Host-side phase times of one call under G4S_DEBUG (declared first in a function: its destructor runs after every buffer of the call has been released).
 struct DbgPhases {
     using clk = std::chrono::steady_clock;
@@ -172,6 +176,17 @@ __global__ void entry_flop_kernel(long long annz, const int *__restrict__ acol, 
     if (k == annz) { f[k] = 0; return; }                           // (the scan runs over annz + 1 entries: its last output is the total)
     const int c = acol[k];
     f[k] = brpt[c + 1] - brpt[c];
+}
+// the same with the range check of A's column ids fused in (an id outside [0, K) counts no products and raises the flag: the caller reads flag and total together)
+__global__ void entry_flop_checked_kernel(long long annz, const int *__restrict__ acol, int K, const int *__restrict__ brpt, long long *__restrict__ f, unsigned long long *flag)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > annz) return;
+    if (k == annz) { f[k] = 0; return; }
+    const int c = acol[k];
+    const bool ok = c >= 0 && c < K;
+    f[k] = ok ? brpt[c + 1] - brpt[c] : 0;
+    if (!ok) atomicOr(flag, 1ull);
 }
 __global__ void row_flop_from_scan_kernel(int M, const int *__restrict__ arpt, const long long *__restrict__ P, long long *__restrict__ row_flop)
 {
@@ -2103,6 +2118,52 @@ int check_b(const int *brpt, const int *bcol, int K, long long bnnz, int N, hipS
     return G4S_OK;
 }
 
+// The opening of a one-shot or symbolic call in ONE host wait (it was three: A's ids, B's ids and order, the flop total): B's checks, the per-entry flop with
+// the check of A's ids fused in, its scan, the per-row flop; flags and total come back together.
+int checked_row_flop(int M, int K, int N, const int *arpt, const int *acol, long long annz, const int *brpt, const int *bcol, long long bnnz,
+                     long long *d_row_flop, int64_t *total, hipStream_t s)
+{
+    if (!(M > 0 && annz > 0 && annz < (1ll << 31))) {              // the row-parallel form keeps its own sequence
+        G4S_TRY(check_ids(acol, annz, K, "a column id of A", s));
+        G4S_TRY(check_b(brpt, bcol, K, bnnz, N, s));
+        return compute_row_flop(M, arpt, acol, brpt, d_row_flop, total, s, annz);
+    }
+    DevBuf buf, f, P;
+    G4S_TRY(buf.alloc(sizeof(unsigned long long) * 4));
+    G4S_HIP_TRY(hipMemsetAsync(buf.p, 0, sizeof(unsigned long long) * 4, s));
+    unsigned long long *d = buf.as<unsigned long long>();
+    if (bnnz > 0) {
+        const int grid = (int)std::min<long long>((bnnz + 255) / 256, 4096);
+        hipLaunchKernelGGL(check_descents_kernel, dim3(grid), dim3(256), 0, s, bcol, bnnz, N, reinterpret_cast<int *>(d), d + 1);
+        hipLaunchKernelGGL(row_start_descents_kernel, dim3(std::min((K + 255) / 256, 2048)), dim3(256), 0, s, K, brpt, bcol, d + 2);
+    }
+    G4S_TRY(f.alloc(sizeof(long long) * ((size_t)annz + 1)));
+    G4S_TRY(P.alloc(sizeof(long long) * ((size_t)annz + 1)));
+    hipLaunchKernelGGL(entry_flop_checked_kernel, dim3((unsigned)((annz + 256) / 256)), dim3(256), 0, s, annz, acol, K, brpt, f.as<long long>(), d + 3);
+    G4S_TRY(g4s::prims::exclusive_scan(f.as<long long>(), P.as<long long>(), annz + 1, s));
+    hipLaunchKernelGGL(row_flop_from_scan_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, arpt, P.as<long long>(), d_row_flop);
+    G4S_HIP_TRY(hipGetLastError());
+    unsigned long long h[4] = {0, 0, 0, 0};
+    long long tot = 0;
+    G4S_HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s));
+    G4S_HIP_TRY(hipMemcpyAsync(&tot, P.as<long long>() + annz, sizeof(tot), hipMemcpyDeviceToHost, s));
+    G4S_HIP_TRY(hipStreamSynchronize(s));
+    if (h[3]) return g4s::set_error(G4S_ERR_INVALID, "SpGEMM: a column id of A outside its valid range [0,%d)", K);
+    if (h[0] & 0xffffffffull) return g4s::set_error(G4S_ERR_INVALID, "SpGEMM: a column id of B outside its valid range [0,%d)", N);
+    if (h[1] != h[2]) return g4s::set_error(G4S_ERR_INVALID, "SpGEMM: the rows of B must be sorted by column (%llu descending neighbours inside rows)", h[1] - h[2]);
+    if (total) *total = (int64_t)tot;
+    return G4S_OK;
+}
+
+// the last entries of two row-pointer arrays (nnz(A), nnz(B)) in one host wait
+int read_last2(const int *a_rpt, int na, int *a_out, const int *b_rpt, int nb, int *b_out, hipStream_t s)
+{
+    G4S_HIP_TRY(hipMemcpyAsync(a_out, a_rpt + na, sizeof(int), hipMemcpyDeviceToHost, s));
+    G4S_HIP_TRY(hipMemcpyAsync(b_out, b_rpt + nb, sizeof(int), hipMemcpyDeviceToHost, s));
+    G4S_HIP_TRY(hipStreamSynchronize(s));
+    return G4S_OK;
+}
+
 int read_last(const int *d_rpt, int n, int *out, hipStream_t s)
 {
     G4S_HIP_TRY(hipMemcpyAsync(out, d_rpt + n, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -2201,8 +2262,7 @@ int build_column_map(int N, long long bnnz, const int *bcol, ColumnMap &cm, hipS
     hipLaunchKernelGGL(colmap_inverse_kernel, dim3((W + 255) / 256), dim3(256), 0, s, W, bm.as<unsigned>(), prefix.as<int>(), cm.inv.as<int>());
     hipLaunchKernelGGL(colmap_apply_kernel, dim3((unsigned)((bnnz + 255) / 256)), dim3(256), 0, s, bnnz, bcol, bm.as<unsigned>(), prefix.as<int>(),
                        cm.bcol2.as<int>());
-    G4S_HIP_TRY(hipGetLastError());
-    G4S_HIP_TRY(hipStreamSynchronize(s));                         // bm / prefix die here
+    G4S_HIP_TRY(hipGetLastError());                               // (bm / prefix / seen are released in stream order — or with the call's arena: no wait here)
     cm.n2 = n2;
     if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s column map: %d of %d columns of B hold entries\n", n2, N);
     return G4S_OK;
@@ -2329,18 +2389,14 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     DbgPhases dbg("symbolic");
     ArenaScope arena;
     int annz = 0, bnnz = 0;
-    G4S_TRY(read_last(arpt, M, &annz, s));
-    G4S_TRY(read_last(brpt, K, &bnnz, s));
-    G4S_TRY(check_ids(acol, annz, K, "a column id of A", s));
-    G4S_TRY(check_b(brpt, bcol, K, bnnz, N, s));
+    G4S_TRY(read_last2(arpt, M, &annz, brpt, K, &bnnz, s));
 
     DevBuf row_flop, row_nz, ovf_rows, ovf_count;
-    dbg.mark("checks");
     G4S_TRY(row_flop.alloc(sizeof(long long) * (size_t)M));
     G4S_TRY(row_nz.alloc(sizeof(int) * ((size_t)M + 1)));
     G4S_HIP_TRY(hipMemsetAsync(row_nz.p, 0, sizeof(int) * ((size_t)M + 1), s));
     int64_t flop = 0;
-    G4S_TRY(compute_row_flop(M, arpt, acol, brpt, row_flop.as<long long>(), &flop, s, annz));
+    G4S_TRY(checked_row_flop(M, K, N, arpt, acol, annz, brpt, bcol, bnnz, row_flop.as<long long>(), &flop, s));
 
     dbg.mark("row_flop");
     RowClasses rc;
@@ -2415,13 +2471,10 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
         if (cols) {
             pre->holds_cache = true;
             hipLaunchKernelGGL(presorted_mark_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, need.as<long long>(), pre->off.as<long long>());
-            G4S_HIP_TRY(hipGetLastError());
-            G4S_HIP_TRY(hipStreamSynchronize(s));                    // need / tmp die at the end of this block
+            G4S_HIP_TRY(hipGetLastError());                        // (need is released in stream order — or with the call's arena: no wait here)
             pre->d_off = pre_off = pre->off.as<long long>();
             pre->d_cols = pre_cols = cols;
             if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s symbolic: %.2f GB scratch for pre-sorted columns\n", total_cols * 4 / 1e9);
-        } else {
-            G4S_HIP_TRY(hipStreamSynchronize(s));
         }
     }
     dbg.mark("tables+presort");
@@ -2812,7 +2865,7 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
             // not what this kernel waits for.)
             G4S_TRY(sr.build(n, rc.list(CLS_M3), nullptr, crpt, N, s));   // a row has at most N outputs
             G4S_TRY(big(m3_cut <= 0 ? t_m3 : 1024, sr.rows.as<int>(), n, 0, INT_MAX, sr.counter.as<int>()));   // (G4S_SPGEMM_M3_CUT=0 + G4S_SPGEMM_T_NUM_M3: the whole class in another shape)
-            G4S_HIP_TRY(hipStreamSynchronize(s));                 // the sorted list and the counter die with this block
+            // (the sorted list and the counter are released in stream order — or with the call's arena: no wait here)
         }
     }
     G4S_HIP_TRY(hipGetLastError());
