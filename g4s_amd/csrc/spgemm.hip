@@ -1612,11 +1612,17 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
             const unsigned w = IDX[(key[q] - kfirst) >> shift];    // the column is present, so its bucket is not empty
             lo[q] = (int)(w >> 16); hi[q] = (int)(w & 0xffffu);
         }
+#ifdef G4S_PROFILE_BIG
+        prof_acc[11] += 1;                                          // rounds (of the reporting wavefront) and halving steps: how deep the buckets are
+#endif
         for (; !(G4S_KO & 1);) {
             bool more = false;
 #pragma unroll
             for (int q = 0; q < kU; ++q) more |= lo[q] < hi[q];
             if (!__any(more)) break;
+#ifdef G4S_PROFILE_BIG
+            prof_acc[12] += 1;
+#endif
             int mid[kU], km[kU];
 #pragma unroll
             for (int q = 0; q < kU; ++q) { mid[q] = (lo[q] + hi[q]) >> 1; km[q] = KC[mid[q]]; }   // the kU reads in flight together

@@ -17,7 +17,7 @@ lib.g4s_debug_big_prof.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 lib.g4s_debug_big_prof(buf, 1)
 host.HashSpGEMM(A, A)
 lib.g4s_debug_big_prof(buf, 0)
-names = ["row start: barrier", "p2 open: columns arrive + LDS writes (later chunks)", "round: lookup + issue", "row start: metadata loads", "round: load wait", "round: accumulate", "p2 load K/zero", "p2 bucket index", "p2 walk", "p2 long list", "p2 store", "flat entry pass", "flat scan", "flat map", "flat rounds"]
+names = ["row start: barrier", "p2 open: columns arrive + LDS writes (later chunks)", "round: lookup + issue", "row start: metadata loads", "round: load wait", "round: accumulate", "p2 load K/zero", "p2 bucket index", "p2 walk", "p2 long list", "p2 store", "(count) rounds of the reporting wavefront", "(count) halving steps in those rounds", "flat map", "flat rounds"]
 tot = sum(buf[:11])
 names = names[:15] + ["-"]
 names[9] = "p2 open: columns arrive + LDS writes (first chunk of a row)"
