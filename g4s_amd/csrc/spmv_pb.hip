@@ -267,7 +267,28 @@ __global__ __launch_bounds__(kPbThreads) void pb_producer_kernel(const ProducerI
         mk[u] = masks[p >> 2];
         mb[u] = mbase[p >> 2];
     }
+#ifdef G4S_PB_STAGE_LOOP   /* A/B only (tools/build_variant.sh): the staging loop as it was until round 4 */
     for (int i = threadIdx.x; i < kBand; i += kPbThreads) xs[i] = (c0 + i < xlimit) ? xsrc[c0 + i] : 0.0;
+#else
+    {
+        // The band of x: ALL of a thread's loads first, then the LDS writes. As a plain loop this compiled to 16 × (load, wait, write) — sixteen round trips in a
+        // row, ≈ 6 µs per work item with nothing to overlap them (one workgroup per CU), found in round 4 in the ISA. The index is clamped instead of predicated
+        // so that the loads carry no branch.
+        constexpr int kPerThread = kBand / kPbThreads;
+        static_assert(kBand % kPbThreads == 0, "band staging");
+        double xv[kPerThread];
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+            const int i = c0 + (int)threadIdx.x + k * kPbThreads;
+            xv[k] = xsrc[min(i, xlimit - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+            const int i = (int)threadIdx.x + k * kPbThreads;
+            xs[i] = (c0 + i < xlimit) ? xv[k] : 0.0;
+        }
+    }
+#endif
     __syncthreads();
     const int q = threadIdx.x & 3;                                 // position of this lane's pair inside its span
     for (; base - (int)threadIdx.x < p_end; base += STEP) {        // uniform trip count per workgroup: every lane takes part in the shuffles
@@ -282,6 +303,8 @@ __global__ __launch_bounds__(kPbThreads) void pb_producer_kernel(const ProducerI
                 mb_n[u] = mbase[p >> 2];
             }
         }
+        // (round 4 tried all of a tile's x reads from LDS up front and unconditional instead of one under each pad test: 0.3843 / 0.3797 / 0.3850 ms against
+        // 0.3812 / 0.3796 / 0.3810 as written here, alternating processes on one box — the waves of the other SIMDs cover those waits already)
 #pragma unroll
         for (int u = 0; u < kPairUnroll; ++u) {
             const int p = base + u * kPbThreads;
