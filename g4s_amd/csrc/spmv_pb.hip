@@ -426,13 +426,26 @@ __global__ __launch_bounds__(kPbThreads) void pb_consumer_kernel(const ConsumerI
     }
     __syncthreads();
     const int r0 = it.rband << kBandBits;
-    for (int i = threadIdx.x; i < kBand; i += kPbThreads) {
-        const int r = r0 + i;
-        if (r >= rows) break;
-        if (it.split) {
-            if (ys[i] != 0.0) atomicAdd(&y[r], alpha * ys[i]);     // y was pre-scaled by beta (pb_prepare_kernel)
-        } else {
-            y[r] = beta == 0.0 ? alpha * ys[i] : alpha * ys[i] + beta * y[r];
+    // All of a thread's sums out of LDS first, and — beta != 0 — all its old y values in flight together: as a loop with a break every row waited for its own
+    // LDS read, and for its own round trip to y when beta != 0 (sixteen in a row per work item). Neutral for the bench line (beta = 0: 0.3910 against 0.3919 ms).
+    constexpr int kRowsPerThread = kBand / kPbThreads;
+    double yv[kRowsPerThread], yo[kRowsPerThread];
+    const bool read_y = !it.split && beta != 0.0;                  // (uniform)
+#pragma unroll
+    for (int k = 0; k < kRowsPerThread; ++k) {
+        yv[k] = ys[(int)threadIdx.x + k * kPbThreads];
+        const int r = min(r0 + (int)threadIdx.x + k * kPbThreads, rows - 1);
+        yo[k] = read_y ? y[r] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < kRowsPerThread; ++k) {
+        const int r = r0 + (int)threadIdx.x + k * kPbThreads;
+        if (r < rows) {
+            if (it.split) {
+                if (yv[k] != 0.0) atomicAdd(&y[r], alpha * yv[k]);  // y was pre-scaled by beta (pb_prepare_kernel)
+            } else {
+                y[r] = beta == 0.0 ? alpha * yv[k] : alpha * yv[k] + beta * yo[k];
+            }
         }
     }
 }
