@@ -28,5 +28,6 @@ for f in files:
             if re.search(r"s_cbranch\w+ " + re.escape(lab) + r"\b", t): break
             j += 1
         if 0 < loads <= 3 and waits:
-            name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", kernel], capture_output=True, text=True).stdout.strip()
+            try: name = subprocess.run(["c++filt", kernel], capture_output=True, text=True).stdout.strip()
+            except OSError: name = kernel
             print(f"{f}: {name[:100]}  {lab}: {loads} load(s), {waits} × vmcnt(0), {j - i} lines")
