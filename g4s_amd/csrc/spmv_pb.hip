@@ -156,7 +156,8 @@ __global__ void pb_fill_producer_kernel(long long nnz, const int *__restrict__ c
 }
 
 // New values into the stored order (g4s_csr_update_values): slot j holds CSR entry p_src[j] (pads: −1, their value stays 0). The gathers are nearly
-// sequential — a cell keeps the CSR order of its entries — so this is one pass over the producer stream.
+// sequential — a cell keeps the CSR order of its entries — so this is one pass over the producer stream. (Round 4 tried four slots per thread, the index loads and
+// the gathers in flight together: 1.31 against 1.18–1.21 ms — the pass is bound by the lines its gathers touch, ≈ 6 GB for 1e8 entries, not by their latency.)
 __global__ void pb_update_values_kernel(long long slots, const int *__restrict__ p_src, const double *__restrict__ values, double *__restrict__ p_val)
 {
     for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < slots; j += (long long)gridDim.x * blockDim.x) {
