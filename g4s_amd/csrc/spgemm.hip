@@ -1195,6 +1195,40 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
 // three barriers and a dependent load chain before the first column could be requested, once per window. A pre-pass (sym_unit_kernel) writes the units of every
 // (list position i, window w, A-entry e), ordered (i, w, e): the piece of B row acol[e] inside window w, cut into runs of at most 64 entries. The kernel reads
 // them with scalar loads, round 0 in front of the bitmap's zeroing, and takes its rows' metadata one row ahead.
+// A row's metadata for the persistent window kernels, packed per LIST POSITION by a pre-pass (round 4): the kernels used to chase ticket → rows[] → arpt / crpt /
+// pre_off → item_off → uoff with scalar loads, four dependent round trips that every wavefront of the workgroup sat through once per row (≈ 1.2 µs × 430 rows per
+// workgroup in the long class, × 205 in the mid-size one); one 48-byte (numeric) / 32-byte (symbolic) scalar load now.
+struct __attribute__((aligned(16))) NumRowMeta { int row, a0, a1, off, nz, u0, u1, pad; long long po, ioff; };
+struct __attribute__((aligned(16))) SymRowMeta { int row, na, u0, u1; long long po, ioff; };
+__global__ void num_row_meta_kernel(int n, const int *__restrict__ rows, const int *__restrict__ arpt, const int *__restrict__ crpt, const long long *__restrict__ pre_off,
+                                    const long long *__restrict__ item_off /* NULL: no unit lists */, const int *__restrict__ uoff, NumRowMeta *__restrict__ meta)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = rows[i];
+    NumRowMeta m;
+    m.row = r; m.a0 = arpt[r]; m.a1 = arpt[r + 1]; m.off = crpt[r]; m.nz = crpt[r + 1] - m.off; m.pad = 0;
+    m.po = pre_off ? pre_off[r] : -1;
+    m.ioff = 0; m.u0 = 0; m.u1 = 0;
+    if (item_off) {
+        const long long total_items = item_off[n];
+        m.ioff = item_off[i]; m.u0 = uoff[m.ioff]; m.u1 = uoff[min(m.ioff + (m.a1 - m.a0), total_items)];   // the units of the row's first chunk (a row outside the launch's size range has no items)
+    }
+    meta[i] = m;
+}
+__global__ void sym_row_meta_kernel(int n, const int *__restrict__ rows, const int *__restrict__ arpt, const long long *__restrict__ pre_off,
+                                    const long long *__restrict__ item_off, const int *__restrict__ uoff, SymRowMeta *__restrict__ meta)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = rows[i];
+    const long long total_items = item_off[n];
+    SymRowMeta m;
+    m.row = r; m.na = arpt[r + 1] - arpt[r]; m.po = pre_off ? pre_off[r] : -1; m.ioff = item_off[i];
+    m.u0 = uoff[m.ioff]; m.u1 = uoff[min(m.ioff + m.na, total_items)];
+    meta[i] = m;
+}
+
 struct __attribute__((aligned(8))) SymUnit { int bpos, len; };
 __global__ void sym_items_kernel(int n, const int *__restrict__ rows, const int *__restrict__ arpt, int nwin, long long *__restrict__ items)
 {
@@ -1239,7 +1273,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     const int *__restrict__ rows, int nrows, int *__restrict__ next_row /* not NULL: rows handed out one at a time (list sorted longest first) */,
     int N, const int *__restrict__ arpt, const int *__restrict__ bcol, int *__restrict__ row_nz,
     const long long *__restrict__ pre_off, int *__restrict__ pre_cols,
-    const long long *__restrict__ item_off, const int *__restrict__ uoff, const SymUnit *__restrict__ U)
+    const long long *__restrict__ item_off, const int *__restrict__ uoff, const SymUnit *__restrict__ U, const SymRowMeta *__restrict__ meta /* per list position (sym_row_meta_kernel) */)
 {
     constexpr int kBigWindowBits = BigCfg<T>::kWindowBits, kBigWindowWords = BigCfg<T>::kWindowWords, kU = kFlatUnitsPerRound, kWaves = T / 64;
     extern __shared__ int lds_i[];
@@ -1249,12 +1283,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     struct RowMeta { int row, na, u0, u1; long long po, ioff; };
     const long long total_items = item_off[nrows];
-    auto load_meta = [&](int idx) {                                 // uniform index: scalar loads
+    auto load_meta = [&](int idx) {                                 // uniform index: one 32-byte scalar load
         const int ci = min(idx, nrows - 1);                        // (a ticket past the end reads the last row: never used)
-        const int r = rows[ci];
+        const SymRowMeta p = meta[ci];
         RowMeta m;
-        m.row = r; m.na = arpt[r + 1] - arpt[r]; m.po = pre_off ? pre_off[r] : -1; m.ioff = item_off[ci];
-        m.u0 = uoff[m.ioff]; m.u1 = uoff[min(m.ioff + m.na, total_items)];
+        m.row = p.row; m.na = p.na; m.po = p.po; m.ioff = p.ioff; m.u0 = p.u0; m.u1 = p.u1;
         return m;
     };
     int ridx = blockIdx.x, nridx = 0;
@@ -1282,10 +1315,12 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
             int c[kU];
             bool ok[kU];
             auto request_round = [&](int g) {
+                SymUnit d[kU];                                      // all of the round's descriptors first (see the numeric kernel's request_round)
+#pragma unroll
+                for (int q = 0; q < kU; ++q) d[q] = U[cu0 + min(g + q, max(nu, 1) - 1)];   // uniform: one s_load_dwordx2 each (a window without units reads a neighbour's or the pad entry: not used)
 #pragma unroll
                 for (int q = 0; q < kU; ++q) {
-                    const SymUnit d = U[cu0 + min(g + q, max(nu, 1) - 1)];   // uniform: one s_load_dwordx2 (a window without units reads a neighbour's or the pad entry: not used)
-                    const int len = nu > 0 ? d.len : 1, bpos = nu > 0 ? d.bpos : 0;
+                    const int len = nu > 0 ? d[q].len : 1, bpos = nu > 0 ? d[q].bpos : 0;
                     ok[q] = g + q < nu && lane < len;
                     c[q] = bcol[bpos + min(lane, len - 1)];
                 }
@@ -1541,7 +1576,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     const long long *__restrict__ pre_off, const int *__restrict__ pre_cols,
     const long long *__restrict__ ct_off /* exact chunk splits (chunk_splits_kernel), or NULL */, const int *__restrict__ ct,
     const long long *__restrict__ item_off /* UNITS: first item of the list's i-th row (unit_kernel) */, const int *__restrict__ uoff /* first unit of an item */,
-    const UnitDesc *__restrict__ U)
+    const UnitDesc *__restrict__ U, const NumRowMeta *__restrict__ meta /* per list position (num_row_meta_kernel) */)
 {
     // No static __shared__ in this kernel: it would sit in front of the dynamic region and push the fp64 table of phase 2 off its
     // 8-byte alignment (cdna_hip_programming.md Guideline 17). Everything is carved from the dynamic region instead.
@@ -1563,11 +1598,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     if constexpr (UNITS) total_items = item_off[nrows];
     auto load_meta = [&](int idx) {
         const int ci = min(idx, nrows - 1);                        // (a ticket past the end reads the last row: never used)
-        const int r = rows[ci];
+        const NumRowMeta p = meta[ci];                             // uniform index: scalar loads, ONE round trip
         RowMeta m;
-        m.row = r; m.a0 = arpt[r]; m.a1 = arpt[r + 1]; m.off = crpt[r]; m.nz = crpt[r + 1] - m.off; m.po = pre_off ? pre_off[r] : -1;
-        m.ioff = 0; m.u0 = 0; m.u1 = 0;
-        if constexpr (UNITS) { m.ioff = item_off[ci]; m.u0 = uoff[m.ioff]; m.u1 = uoff[min(m.ioff + (m.a1 - m.a0), total_items)]; }   // the units of the row's first chunk (a row outside the launch's size range has no items)
+        m.row = p.row; m.a0 = p.a0; m.a1 = p.a1; m.off = p.off; m.nz = p.nz; m.po = p.po; m.ioff = p.ioff; m.u0 = p.u0; m.u1 = p.u1;
         return m;
     };
     int ridx = blockIdx.x;
@@ -1714,14 +1747,18 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     double rv[kU], rav[kU];
     bool rok[kU];
     auto request_round = [&](int g) {
+        // the round's kU descriptors first (uniform: one s_load_dwordx4 each, all in flight), then its vector loads — descriptor by descriptor the compiler waited
+        // for each scalar load before it issued that unit's two vector loads: kU scalar round trips in a row in front of every round (ISA, round 4)
+        UnitDesc d[kU];
+#pragma unroll
+        for (int q = 0; q < kU; ++q) d[q] = U[cu0 + min(g + q, nu - 1)];
 #pragma unroll
         for (int q = 0; q < kU; ++q) {
-            const UnitDesc d = U[cu0 + min(g + q, nu - 1)];        // uniform: one s_load_dwordx4
-            rok[q] = g + q < nu && lane < d.len;
-            const int kk = d.bpos + min(lane, d.len - 1);
+            rok[q] = g + q < nu && lane < d[q].len;
+            const int kk = d[q].bpos + min(lane, d[q].len - 1);
             rc[q] = bcol[kk];
             rv[q] = bval[kk];
-            rav[q] = __longlong_as_double(((long long)d.av_hi << 32) | (unsigned)d.av_lo);
+            rav[q] = __longlong_as_double(((long long)d[q].av_hi << 32) | (unsigned)d[q].av_lo);
         }
     };
     for (int q0 = 0; q0 < nz; q0 += kBigChunk) {
@@ -2540,10 +2577,14 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
                 G4S_TRY(g4s::prims::exclusive_scan(ucnt->as<int>(), uoff->as<int>(), ibound + 1, s));
                 hipLaunchKernelGGL(sym_unit_kernel<true>, dim3(ugrid), dim3(256), 0, s, ibound, n, rows, ioff->as<long long>(), arpt, acol, brpt, K, N2, wsplit, BigCfg<T>::kWindowBits,
                                    (int *)nullptr, uoff->as<int>(), ud->as<SymUnit>());
+                auto rmeta = std::make_unique<DevBuf>();
+                G4S_TRY(rmeta->alloc(sizeof(SymRowMeta) * (size_t)n));
+                hipLaunchKernelGGL(sym_row_meta_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, rows, arpt, poff, ioff->as<long long>(), uoff->as<int>(), rmeta->as<SymRowMeta>());
                 auto k = spgemm_symbolic_units_kernel<T>;
                 G4S_TRY(allow_lds(k, lds));
-                hipLaunchKernelGGL(k, grid, dim3(T), lds, s, rows, n, next_row, N2, arpt, wcol, nz, poff, pcols, ioff->as<long long>(), uoff->as<int>(), ud->as<SymUnit>());
+                hipLaunchKernelGGL(k, grid, dim3(T), lds, s, rows, n, next_row, N2, arpt, wcol, nz, poff, pcols, ioff->as<long long>(), uoff->as<int>(), ud->as<SymUnit>(), rmeta->as<SymRowMeta>());
                 G4S_HIP_TRY(hipGetLastError());
+                unit_keep.push_back(std::move(rmeta));
                 unit_keep.push_back(std::move(items)); unit_keep.push_back(std::move(ioff)); unit_keep.push_back(std::move(ucnt)); unit_keep.push_back(std::move(uoff)); unit_keep.push_back(std::move(ud));
                 return G4S_OK;
             }
@@ -2841,17 +2882,21 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
             if (use_units && splits_complete) G4S_TRY(unit_lists(T, rows, n, nz_lo, nz_hi, ct_off, ct, &ul));
         }
         const dim3 grid(big_grid(n, BigCfg<T>::kPerCu));
+        auto rmeta = std::make_unique<DevBuf>();
+        G4S_TRY(rmeta->alloc(sizeof(NumRowMeta) * (size_t)n));
+        hipLaunchKernelGGL(num_row_meta_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, rows, arpt, crpt, pre_off, ul.U ? ul.item_off : (const long long *)nullptr, ul.uoff, rmeta->as<NumRowMeta>());
         if (ul.U) {
             auto k = spgemm_numeric_big_kernel<T, true>;
             G4S_TRY(allow_lds(k, lds));
             hipLaunchKernelGGL(k, grid, dim3(T), lds, s, rows, n, nz_lo, nz_hi, next_row, N2, K, wsplit, arpt, acol, aval, brpt, wcol, winv, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols, ct_off, ct,
-                               ul.item_off, ul.uoff, ul.U);
+                               ul.item_off, ul.uoff, ul.U, rmeta->as<NumRowMeta>());
         } else {
             auto k = spgemm_numeric_big_kernel<T, false>;
             G4S_TRY(allow_lds(k, lds));
             hipLaunchKernelGGL(k, grid, dim3(T), lds, s, rows, n, nz_lo, nz_hi, next_row, N2, K, wsplit, arpt, acol, aval, brpt, wcol, winv, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols, ct_off, ct,
-                               (const long long *)nullptr, (const int *)nullptr, (const UnitDesc *)nullptr);
+                               (const long long *)nullptr, (const int *)nullptr, (const UnitDesc *)nullptr, rmeta->as<NumRowMeta>());
         }
+        ct_keep.push_back(std::move(rmeta));
         return G4S_OK;
     };
     auto big = [&](int threads, const int *rows, int n, int nz_lo = 0, int nz_hi = INT_MAX, int *next_row = nullptr) -> int {
