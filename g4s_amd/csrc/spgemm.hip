@@ -27,7 +27,7 @@
 // the reference's (j outer, k inner): equal within the 1e-10 relative tolerance of the north star, not bit for bit.
 #include "common.hpp"
 #ifndef G4S_SPGEMM_UPR
-#define G4S_SPGEMM_UPR 4
+#define G4S_SPGEMM_UPR 6   /* 4 until the end of round 4; with a round's descriptors requested together 5 / 6 / 7 / 8 units ran 31.2 / 31.0 / 31.25 / 31.75 ms against 31.6 (2: 34.1) */
 #endif
 #ifndef G4S_KO
 #define G4S_KO 0   // timing-only knock-outs of the big-row numeric kernel (wrong results; tools/ab_variants.sh): 1 no halvings, 2 no LDS atomics, 4 no bucket index, 8 no stores, 16 no accumulate step
