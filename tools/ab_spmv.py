@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """A/B timing of SpMV variants in ONE process (rule 24 of the HIP guide: interleaved rounds, median and min).
-usage: python tools/ab_spmv.py [--workloads rmat,banded,lap7] [--rounds 5] [--iters 50]"""
+usage: python tools/ab_spmv.py [--workloads rmat,rmat12m,banded,lap7] [--rounds 5] [--iters 50]
+rmat12m: a 1.25 M × 1.25 M R-MAT of ≈ 12 M entries — the size of one rank's slab of configs[1] in the 8-way partition (what lifts a slab lifts
+every matrix of this size)."""
 import argparse
 import os
 import sys
@@ -18,7 +20,7 @@ ap.add_argument("--variants", default="0,4")
 args = ap.parse_args()
 
 for w in args.workloads.split(","):
-    A0 = bench.build_matrix(w, host, False)
+    A0 = host.rmat_csr(1_250_000, 21, 12_500_000, 20240523) if w == "rmat12m" else bench.build_matrix(w, host, False)
     x = host.synth_vector(7, A0.cols)
     variants = {}
     for v in args.variants.split(","):
