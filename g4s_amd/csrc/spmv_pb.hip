@@ -275,8 +275,8 @@ __global__ __launch_bounds__(kPbThreads) void pb_producer_kernel(const ProducerI
         // The band of x: ALL of a thread's loads first, then the LDS writes. As a plain loop this compiled to 16 × (load, wait, write) — sixteen round trips in a
         // row, ≈ 6 µs per work item with nothing to overlap them (one workgroup per CU), found in round 4 in the ISA. The index is clamped instead of predicated
         // so that the loads carry no branch. (Then tried: one persistent workgroup per CU walking the items with the NEXT item's descriptor and band of x loaded into
-        // registers under the current item's main loop — 0.416 against 0.400 ms on one box with a static stride over the items, 0.406–0.407 against 0.399–0.404 with a
-        // ticket counter in the hardware's own dispatch order: the per-item prologue is not an exposed cost.)
+        // registers under the current item's main loop — 0.416 against 0.400 ms on one box, 256 or 512 workgroups: the static order loses more balance than the hidden
+        // ≈ 3 µs per item buy.)
         constexpr int kPerThread = kBand / kPbThreads;
         static_assert(kBand % kPbThreads == 0, "band staging");
         double xv[kPerThread];
