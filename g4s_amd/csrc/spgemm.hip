@@ -2261,6 +2261,7 @@ constexpr long long kPresortMinFlop = 512;    // every row that reaches a window
 struct ColumnMap {
     DevBuf bcol2, inv;           // int[nnz(B)] compact id per entry; int[N2] original id per compact id
     int n2 = 0;                  // 0: not in use
+    bool keep = false;           // the map outlives the API call that builds it (g4s_spgemm_symbolic → g4s_spgemm_numeric): its arrays come from the block cache, not from the call's arena
     const int *cols(const int *bcol) const { return n2 ? bcol2.as<int>() : bcol; }
     int width(int N) const { return n2 ? n2 : N; }
     const int *inverse() const { return n2 ? inv.as<int>() : nullptr; }
@@ -2330,8 +2331,8 @@ int build_column_map(int N, long long bnnz, const int *bcol, ColumnMap &cm, hipS
     G4S_HIP_TRY(hipMemcpyAsync(&n2, prefix.as<int>() + W, sizeof(int), hipMemcpyDeviceToHost, s));
     G4S_HIP_TRY(hipStreamSynchronize(s));
     if (n2 <= 0 || (long long)n2 * 8 > (long long)N * 7) return G4S_OK;
-    G4S_TRY(cm.bcol2.alloc(sizeof(int) * (size_t)bnnz));
-    G4S_TRY(cm.inv.alloc(sizeof(int) * (size_t)n2));
+    G4S_TRY(cm.bcol2.alloc(sizeof(int) * (size_t)bnnz, cm.keep));
+    G4S_TRY(cm.inv.alloc(sizeof(int) * (size_t)n2, cm.keep));
     hipLaunchKernelGGL(colmap_inverse_kernel, dim3((W + 255) / 256), dim3(256), 0, s, W, bm.as<unsigned>(), prefix.as<int>(), cm.inv.as<int>());
     hipLaunchKernelGGL(colmap_apply_kernel, dim3((unsigned)((bnnz + 255) / 256)), dim3(256), 0, s, bnnz, bcol, bm.as<unsigned>(), prefix.as<int>(),
                        cm.bcol2.as<int>());
@@ -2352,6 +2353,7 @@ struct PreSorted {
     bool holds_cache = false;
     bool complete = false;       // every row the numeric window kernels will take carries its columns (no hub rows, no overflowed optimistic tables)
     long long flop = -1;         // the product's flop: bounds the unit lists of the numeric launches without a count read back
+    bool keep = false;           // carried from g4s_spgemm_symbolic to the g4s_spgemm_numeric call that follows it (see CarriedSymbolic): nothing of it may live in a call's arena
     ~PreSorted();
 };
 
@@ -2434,13 +2436,13 @@ __global__ void presorted_mark_kernel(int M, const long long *__restrict__ need,
 namespace {
 // wsplit for the window kernels (see window_splits_kernel); left empty (kernels then read whole rows) for a single window or when
 // the table would be large (more than 16 windows).
-int build_window_splits(int K, int N, const int *brpt, const int *bcol, DevBuf &buf, const int **out, hipStream_t s)
+int build_window_splits(int K, int N, const int *brpt, const int *bcol, DevBuf &buf, const int **out, hipStream_t s, bool keep = false)
 {
     *out = nullptr;
     const int sb = split_bits(N), W = (N + (1 << sb) - 1) >> sb;
     if (W < 2 || W > 16 || K <= 0) return G4S_OK;
     const long long total = (long long)K * (W - 1);
-    G4S_TRY(buf.alloc(sizeof(int) * (size_t)total));
+    G4S_TRY(buf.alloc(sizeof(int) * (size_t)total, keep));
     hipLaunchKernelGGL(window_splits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, K, W, sb, brpt, bcol, buf.as<int>());
     G4S_HIP_TRY(hipGetLastError());
     *out = buf.as<int>();
@@ -2486,7 +2488,7 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     const int N2 = cmap.width(N);
     DevBuf wsplit_local;
     const int *wsplit = nullptr;
-    G4S_TRY(build_window_splits(K, N2, brpt, wcol, pre ? pre->wsplit_buf : wsplit_local, &wsplit, s));
+    G4S_TRY(build_window_splits(K, N2, brpt, wcol, pre ? pre->wsplit_buf : wsplit_local, &wsplit, s, pre && pre->keep));
     if (pre) { pre->wsplit = wsplit; pre->has_wsplit = true; }
     dbg.mark("colmap+splits");
     G4S_TRY(ovf_rows.alloc(sizeof(int) * (size_t)std::max(1, rc.count[CLS_LARGE])));
@@ -2528,7 +2530,7 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
         const unsigned class_mask = (1u << CLS_M2) | (x_med ? (1u << CLS_MEDIUM) : 0u) | (x_large ? (1u << CLS_LARGE) : 0u);
         DevBuf need;
         G4S_TRY(need.alloc(sizeof(long long) * ((size_t)M + 1)));
-        G4S_TRY(pre->off.alloc(sizeof(long long) * ((size_t)M + 1)));
+        G4S_TRY(pre->off.alloc(sizeof(long long) * ((size_t)M + 1), pre->keep));
         G4S_HIP_TRY(hipMemsetAsync(need.p, 0, sizeof(long long) * ((size_t)M + 1), s));
         const long long min_flop = kPresortMinFlop;
         hipLaunchKernelGGL(presorted_need_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, rc.cls.as<int>(), class_mask, row_flop.as<long long>(), N2, min_flop, need.as<long long>());
@@ -2666,11 +2668,42 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
 }
 } // namespace
 
+// The two-call form carries what the one-call form carries between its phases (round 4): g4s_spgemm_symbolic leaves the sorted columns of the window classes, the
+// column map and the window splits behind, keyed by its arguments; the g4s_spgemm_numeric call that follows WITH THE SAME ARRAYS takes them over instead of
+// marking and emitting every row again (34 → 21 ms on configs[2]; the symbolic call pays the emit: 7 → 10 ms). One product at a time per process: the next
+// symbolic or one-call product, g4s_trim and g4s_shutdown drop whatever is still held (the column scratch is one cached block per process). The arrays must not
+// change between the two calls — the contract of the two-call form anyway: crpt describes THIS product. G4S_SPGEMM_NO_CARRY=1: as before.
+namespace {
+struct CarriedSymbolic {
+    std::mutex m;
+    std::unique_ptr<PreSorted> pre;
+    int M = 0, K = 0, N = 0;
+    const void *arpt = nullptr, *acol = nullptr, *brpt = nullptr, *bcol = nullptr, *crpt = nullptr;
+};
+CarriedSymbolic g_carried;
+void drop_carried()
+{
+    std::unique_ptr<PreSorted> old;
+    { std::lock_guard<std::mutex> lock(g_carried.m); old = std::move(g_carried.pre); }
+    // (destroyed outside the lock: its blocks go back to the cache behind a device synchronisation)
+}
+} // namespace
+
 G4S_API g4s_status g4s_spgemm_symbolic(int32_t M, int32_t K, int32_t N,
                                        const int32_t *arpt, const int32_t *acol, const int32_t *brpt, const int32_t *bcol,
                                        int32_t *crpt, int64_t *cnnz, void *stream)
 {
-    return spgemm_symbolic_impl(M, K, N, arpt, acol, brpt, bcol, crpt, cnnz, stream, nullptr);
+    drop_carried();
+    if (getenv("G4S_SPGEMM_NO_CARRY")) return spgemm_symbolic_impl(M, K, N, arpt, acol, brpt, bcol, crpt, cnnz, stream, nullptr);
+    auto pre = std::make_unique<PreSorted>();
+    pre->keep = true; pre->cmap.keep = true;
+    const int st = spgemm_symbolic_impl(M, K, N, arpt, acol, brpt, bcol, crpt, cnnz, stream, pre.get());
+    if (st != G4S_OK) return st;
+    std::lock_guard<std::mutex> lock(g_carried.m);
+    g_carried.pre = std::move(pre);
+    g_carried.M = M; g_carried.K = K; g_carried.N = N;
+    g_carried.arpt = arpt; g_carried.acol = acol; g_carried.brpt = brpt; g_carried.bcol = bcol; g_carried.crpt = crpt;
+    return G4S_OK;
 }
 
 namespace {
@@ -2966,7 +2999,14 @@ G4S_API g4s_status g4s_spgemm_numeric(int32_t M, int32_t K, int32_t N,
                                       const int32_t *brpt, const int32_t *bcol, const double *bval,
                                       const int32_t *crpt, int32_t *ccol, double *cval, unsigned flags, void *stream)
 {
-    return spgemm_numeric_impl(M, K, N, arpt, acol, aval, brpt, bcol, bval, crpt, ccol, cval, flags, stream, nullptr);
+    std::unique_ptr<PreSorted> pre;                                // the state the symbolic call of THIS product left behind, if any
+    {
+        std::lock_guard<std::mutex> lock(g_carried.m);
+        if (g_carried.pre && g_carried.M == M && g_carried.K == K && g_carried.N == N && g_carried.arpt == arpt && g_carried.acol == acol && g_carried.brpt == brpt &&
+            g_carried.bcol == bcol && g_carried.crpt == crpt)
+            pre = std::move(g_carried.pre);
+    }
+    return spgemm_numeric_impl(M, K, N, arpt, acol, aval, brpt, bcol, bval, crpt, ccol, cval, flags, stream, pre.get());
 }
 
 G4S_API g4s_status g4s_spgemm_flop(int32_t M, const int32_t *arpt, const int32_t *acol, const int32_t *brpt,
@@ -3013,6 +3053,7 @@ G4S_API g4s_status g4s_spgemm_csr_i32_f64(const int32_t *arpt, const int32_t *ac
     G4S_REQUIRE(M >= 0 && K >= 0 && N >= 0 && arpt && brpt, "bad argument");
     *crpt_out = nullptr; *ccol_out = nullptr; *cval_out = nullptr; *cnnz_out = 0;
     g4s_timings t{};
+    drop_carried();                                                // (a two-call product left unfinished holds the column scratch)
     const auto t_total = clk::now();
     ArenaScope arena;                                              // spans both phases: the carried state of the symbolic phase lives in it
     const bool dev = (flags & G4S_DEVICE_POINTERS) != 0;
@@ -3109,6 +3150,7 @@ extern "C" __attribute__((visibility("default"))) int g4s_debug_big_prof(unsigne
 namespace g4s {
 void spgemm_release_cache()
 {
+    drop_carried();
     std::lock_guard<std::mutex> lock(g_col_cache.m);
     if (g_col_cache.p && !g_col_cache.in_use) { (void)hipFree(g_col_cache.p); g_col_cache.p = nullptr; g_col_cache.bytes = 0; }
 }

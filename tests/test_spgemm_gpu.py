@@ -197,6 +197,63 @@ def test_spgemm_walk_forms(oracle, monkeypatch, walk, short_rows, two_phase):
     _three_window_case(oracle, two_phase)
 
 
+def test_spgemm_two_call_form_carries_its_columns(oracle, monkeypatch):
+    """g4s_spgemm_symbolic leaves the sorted columns, the column map and the window splits of ITS product for the g4s_spgemm_numeric call that follows with the same
+    arrays (round 4). Checked: the carried and the uncarried (G4S_SPGEMM_NO_CARRY) numeric calls give the same C; a symbolic call of another product in between
+    drops the state (the first product's numeric call then runs without it); a one-call product in between drops it too; a numeric call with other arrays
+    does not take it."""
+    import ctypes as C
+    from g4s_amd import capi, host
+    lib = capi.load()
+    rpX, ciX, vaX = power_law_csr(6000, 6000, 23, 1500)
+    rpY, ciY, vaY = power_law_csr(5000, 5000, 19, 1700)
+    X, Y = host.CSR.from_host(rpX, ciX, vaX, 6000, 6000), host.CSR.from_host(rpY, ciY, vaY, 5000, 5000)
+
+    def symbolic(a):
+        crpt = torch.empty(a.rows + 1, dtype=torch.int32, device="cuda")
+        cnnz = C.c_int64(0)
+        capi.check(lib.g4s_spgemm_symbolic(a.rows, a.cols, a.cols, host._ptr(a.rowptr), host._ptr(a.colids), host._ptr(a.rowptr), host._ptr(a.colids), host._ptr(crpt), C.byref(cnnz), None))
+        return crpt, cnnz.value
+
+    def numeric(a, crpt, cnnz):
+        ccol = torch.empty(cnnz, dtype=torch.int32, device="cuda")
+        cval = torch.empty(cnnz, dtype=torch.float64, device="cuda")
+        capi.check(lib.g4s_spgemm_numeric(a.rows, a.cols, a.cols, host._ptr(a.rowptr), host._ptr(a.colids), host._ptr(a.values), host._ptr(a.rowptr), host._ptr(a.colids),
+                                          host._ptr(a.values), host._ptr(crpt), host._ptr(ccol), host._ptr(cval), capi.DEVICE_POINTERS | capi.SORT_OUTPUT, None))
+        return ccol.cpu().numpy(), cval.cpu().numpy()
+
+    def expect(A, n):
+        orpt, ocol, oval = oracle.spgemm(A, A, n, sort_output=True)
+        _, _, scale = oracle.spgemm(_abs(A), _abs(A), n, sort_output=True)
+        return orpt, ocol, oval, scale
+
+    wantX, wantY = expect((rpX, ciX, vaX), 6000), expect((rpY, ciY, vaY), 5000)
+
+    def same(got, crpt, want):
+        assert np.array_equal(crpt.cpu().numpy(), want[0]) and np.array_equal(got[0], want[1])
+        assert np.all(np.abs(got[1] - want[2]) <= TOL * want[3] + 1e-300)
+
+    cX, nX = symbolic(X)
+    same(numeric(X, cX, nX), cX, wantX)                            # carried
+    monkeypatch.setenv("G4S_SPGEMM_NO_CARRY", "1")
+    cX2, nX2 = symbolic(X)
+    same(numeric(X, cX2, nX2), cX2, wantX)                         # not carried
+    monkeypatch.delenv("G4S_SPGEMM_NO_CARRY")
+    cX, nX = symbolic(X)
+    cY, nY = symbolic(Y)                                           # drops X's state
+    same(numeric(X, cX, nX), cX, wantX)                            # X without it (Y's stays: other arrays)
+    same(numeric(Y, cY, nY), cY, wantY)                            # Y carried
+    cX, nX = symbolic(X)
+    host.HashSpGEMM(Y, Y)                                          # a one-call product in between drops it
+    same(numeric(X, cX, nX), cX, wantX)
+    cX, nX = symbolic(X)
+    Xb = host.CSR.from_host(rpX, ciX, vaX, 6000, 6000)             # the same matrix in OTHER arrays: the key does not match
+    cXb, nXb = torch.empty_like(cX), nX
+    cXb.copy_(cX)
+    same(numeric(Xb, cXb, nXb), cXb, wantX)
+    capi.check(lib.g4s_trim())                                     # releases what the last symbolic call still holds
+
+
 def test_spgemm_short_rows_by_one_wavefront(oracle):
     """spgemm_small_wave_kernel on the cases its merge has to get right: a row whose runs share columns (sums in run order), duplicate columns INSIDE a B row
     (an unmerged CSR, CSR.h:485-669 keeps duplicates), empty B rows among the entries, a row of exactly 512 products, a row of 70 entries (more than the 64 lanes:
