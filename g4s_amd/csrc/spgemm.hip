@@ -2670,20 +2670,22 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
 
 // The two-call form carries what the one-call form carries between its phases (round 4): g4s_spgemm_symbolic leaves the sorted columns of the window classes, the
 // column map and the window splits behind, keyed by its arguments; the g4s_spgemm_numeric call that follows WITH THE SAME ARRAYS takes them over instead of
-// marking and emitting every row again (34 → 21 ms on configs[2]; the symbolic call pays the emit: 7 → 10 ms). One product at a time per process: the next
+// marking and emitting every row again (33 → 20 ms on configs[2]; the symbolic call pays the emit: 7 → 11.6 ms) — and so does every further numeric call on
+// that pattern (new values, same structure). One product at a time per process: the next
 // symbolic or one-call product, g4s_trim and g4s_shutdown drop whatever is still held (the column scratch is one cached block per process). The arrays must not
 // change between the two calls — the contract of the two-call form anyway: crpt describes THIS product. G4S_SPGEMM_NO_CARRY=1: as before.
 namespace {
 struct CarriedSymbolic {
     std::mutex m;
-    std::unique_ptr<PreSorted> pre;
+    std::shared_ptr<PreSorted> pre;                                // (shared: a numeric call in progress keeps it alive when another thread's product drops it)
     int M = 0, K = 0, N = 0;
     const void *arpt = nullptr, *acol = nullptr, *brpt = nullptr, *bcol = nullptr, *crpt = nullptr;
 };
-CarriedSymbolic g_carried;
+// (never destroyed: a product still carried when the process ends must not release device blocks from a static destructor, after the HIP runtime's own teardown)
+CarriedSymbolic &g_carried = *new CarriedSymbolic();
 void drop_carried()
 {
-    std::unique_ptr<PreSorted> old;
+    std::shared_ptr<PreSorted> old;
     { std::lock_guard<std::mutex> lock(g_carried.m); old = std::move(g_carried.pre); }
     // (destroyed outside the lock: its blocks go back to the cache behind a device synchronisation)
 }
@@ -2695,7 +2697,7 @@ G4S_API g4s_status g4s_spgemm_symbolic(int32_t M, int32_t K, int32_t N,
 {
     drop_carried();
     if (getenv("G4S_SPGEMM_NO_CARRY")) return spgemm_symbolic_impl(M, K, N, arpt, acol, brpt, bcol, crpt, cnnz, stream, nullptr);
-    auto pre = std::make_unique<PreSorted>();
+    auto pre = std::make_shared<PreSorted>();
     pre->keep = true; pre->cmap.keep = true;
     const int st = spgemm_symbolic_impl(M, K, N, arpt, acol, brpt, bcol, crpt, cnnz, stream, pre.get());
     if (st != G4S_OK) return st;
@@ -2999,12 +3001,12 @@ G4S_API g4s_status g4s_spgemm_numeric(int32_t M, int32_t K, int32_t N,
                                       const int32_t *brpt, const int32_t *bcol, const double *bval,
                                       const int32_t *crpt, int32_t *ccol, double *cval, unsigned flags, void *stream)
 {
-    std::unique_ptr<PreSorted> pre;                                // the state the symbolic call of THIS product left behind, if any
-    {
+    std::shared_ptr<PreSorted> pre;                                // the state the symbolic call of THIS product left behind, if any — it stays for further numeric
+    {                                                              // calls on the same pattern (new values of A or B, the time-stepping case) until something drops it
         std::lock_guard<std::mutex> lock(g_carried.m);
         if (g_carried.pre && g_carried.M == M && g_carried.K == K && g_carried.N == N && g_carried.arpt == arpt && g_carried.acol == acol && g_carried.brpt == brpt &&
             g_carried.bcol == bcol && g_carried.crpt == crpt)
-            pre = std::move(g_carried.pre);
+            pre = g_carried.pre;
     }
     return spgemm_numeric_impl(M, K, N, arpt, acol, aval, brpt, bcol, bval, crpt, ccol, cval, flags, stream, pre.get());
 }

@@ -262,7 +262,8 @@ g4s_status g4s_spgemm_csr_i32_f64(const int32_t *arpt, const int32_t *acol, cons
  * symbolic writes crpt_dev[M+1] (int32) and *cnnz; numeric fills ccol_dev/cval_dev (cnnz entries each).
  * The symbolic call keeps what it learned about the product (the sorted columns of the long rows, the column map of B, B's window splits) for the numeric
  * call that follows it with THE SAME arrays (same pointers, unchanged contents — crpt describes this product and no other): that call then does not traverse
- * the structure again (the pair costs what the one-call form costs). One product at a time per process: the next symbolic or one-call product, g4s_trim
+ * the structure again (the pair costs what the one-call form costs), nor do further numeric calls on the same arrays (new VALUES of A or B, same pattern: the
+ * time-stepping case). One product at a time per process: the next symbolic or one-call product, g4s_trim
  * and g4s_shutdown release whatever is still held; a numeric call with other arrays, or without a symbolic call before it, works as before. */
 g4s_status g4s_spgemm_symbolic(int32_t M, int32_t K, int32_t N,
                                const int32_t *arpt_dev, const int32_t *acol_dev,

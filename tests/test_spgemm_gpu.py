@@ -235,6 +235,10 @@ def test_spgemm_two_call_form_carries_its_columns(oracle, monkeypatch):
 
     cX, nX = symbolic(X)
     same(numeric(X, cX, nX), cX, wantX)                            # carried
+    X.values.mul_(2.0)                                             # new values, same pattern: the state serves further numeric calls
+    got = numeric(X, cX, nX)
+    assert np.array_equal(got[0], wantX[1]) and np.all(np.abs(got[1] - 4.0 * wantX[2]) <= 4.0 * TOL * wantX[3] + 1e-300)
+    X.values.mul_(0.5)
     monkeypatch.setenv("G4S_SPGEMM_NO_CARRY", "1")
     cX2, nX2 = symbolic(X)
     same(numeric(X, cX2, nX2), cX2, wantX)                         # not carried
