@@ -4,6 +4,7 @@
 // as binary doubles; "parallel" as argv[1] declares the gather race-free (it is: every (vertex, neighbour) writes its own slot).
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <vector>
 #include "g4s/graph.hpp"
 
@@ -15,6 +16,15 @@ int main(int argc, char **argv)
     if (fread(xx.data(), sizeof(double), xx.size(), stdin) != xx.size() || fread(w.data(), sizeof(double), w.size(), stdin) != w.size()) return 2;
     if (argc > 1 && !strcmp(argv[1], "parallel")) g4s_set_host_callback_policy(G4S_HOST_CALLBACKS_PARALLEL);
     if (argc > 1 && !strcmp(argv[1], "refuse")) g4s_set_host_callback_policy(G4S_HOST_CALLBACKS_REFUSE);
+    // "scoped_race_free": the declaration as a scope around the untouched call (g4s::ScopedRaceFree) instead of the process-wide policy;
+    // "scoped_pattern": g4s::ScopedPattern names the call's pattern — the same untouched call line then runs the fp64 MFMA kernel (needs a GPU)
+    const bool scoped_rf = argc > 1 && !strcmp(argv[1], "scoped_race_free"), scoped_pat = argc > 1 && !strcmp(argv[1], "scoped_pattern");
+    g4s_pattern_desc desc;
+    memset(&desc, 0, sizeof desc);
+    desc.kind = G4S_PATTERN_DENSE_ROW_TIMES_MATRIX;
+    desc.inner = N;
+    std::unique_ptr<g4s::ScopedRaceFree> rf(scoped_rf ? new g4s::ScopedRaceFree() : nullptr);
+    std::unique_ptr<g4s::ScopedPattern> pat(scoped_pat ? new g4s::ScopedPattern(desc) : nullptr);
     struct Graph graph;
     graph.states = w.data();
     graph.numNodes = M;

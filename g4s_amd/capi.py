@@ -135,6 +135,7 @@ SIGNATURES = {
     "g4s_register_pattern": (C.c_int, [FUN_GATHER, FUN_APPLY, C.POINTER(PatternDesc)]),
     "g4s_unregister_pattern": (C.c_int, [FUN_GATHER, FUN_APPLY]),
     "g4s_set_host_callback_policy": (C.c_int, [C.c_int32]),
+    "g4s_set_host_callback_policy_thread": (C.c_int, [C.c_int32, C.POINTER(C.c_int32)]),
     "spmm_dense": (None, [C.c_uint32, C.c_uint32, vp, vp, vp, vp, FUN_GATHER, FUN_APPLY, f64p, C.c_int]),
     "g4s_spmm_dense": (C.c_int, [C.c_uint32, C.c_uint32, vp, vp, vp, vp, FUN_GATHER, FUN_APPLY, f64p, C.c_int]),
     "g4s_elem_op_create": (C.c_int, [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp]),

@@ -357,6 +357,8 @@ namespace g4s {
 struct CgAsync {
     CgRun run;
     CgState h{};
+    bool read_pending = false;   // an asynchronous copy into h has been enqueued and nobody has settled since: the object must outlive it
+    hipStream_t s = nullptr;
 };
 
 int cg_async_start(CgAsync **out, g4s_elem_op_t op, g4s_csr_t A, int32_t neq, const double *BI, const int32_t *zero_resid, int32_t n_zero,
@@ -369,14 +371,16 @@ int cg_async_start(CgAsync **out, g4s_elem_op_t op, g4s_csr_t A, int32_t neq, co
     int st = c->run.start(cg_matvec_for(op, A), neq, BI, zero_resid, n_zero, F, d0, acc, steps, cg_first_batch(), s, bc_mask);
     if (st == G4S_OK) st = c->run.finish();
     if (st != G4S_OK) { delete c; return st; }
+    c->s = s;
     *out = c;
     return G4S_OK;
 }
 
-int cg_async_read(CgAsync *c) { return c->run.read_state_async(&c->h); }
+int cg_async_read(CgAsync *c) { c->read_pending = true; return c->run.read_state_async(&c->h); }
 
 int cg_async_settle(CgAsync *c, bool *speculation_held, int32_t *cycles, double *residual)
 {
+    c->read_pending = false;                                       // (the caller has synchronised: that is the contract of settle)
     *speculation_held = c->h.done != 0;
     if (!c->h.done) {
         G4S_TRY(c->run.complete(c->h));
@@ -388,7 +392,8 @@ int cg_async_settle(CgAsync *c, bool *speculation_held, int32_t *cycles, double 
     return G4S_OK;
 }
 
-void cg_async_free(CgAsync *c) { delete c; }
+// An error between read and settle (the caller's own work failed) frees the object while the copy into c->h may still be in flight: wait for it first.
+void cg_async_free(CgAsync *c) { if (c && c->read_pending) (void)hipStreamSynchronize(c->s); delete c; }
 } // namespace g4s
 
 
@@ -599,7 +604,8 @@ struct DistCgAsync {
         G4S_TRY(tr->allreduce_sum_f64(tr->ctx, part, 3 * kDotBlocks, stream));              // r·z and r·r of the start vector
         return enqueue(std::max(1, std::min(batch, steps + 1)));
     }
-    int read() { G4S_HIP_TRY(hipMemcpyAsync(&h, ws->st, sizeof(CgState), hipMemcpyDeviceToHost, g4s::as_stream(stream))); return G4S_OK; }
+    bool read_pending = false;                                                              // see CgAsync
+    int read() { read_pending = true; G4S_HIP_TRY(hipMemcpyAsync(&h, ws->st, sizeof(CgState), hipMemcpyDeviceToHost, g4s::as_stream(stream))); return G4S_OK; }
     int complete()                                                                          // h: read after a synchronisation
     {
         int batch = std::min(32, std::max(2, enqueued * 2));
@@ -607,6 +613,7 @@ struct DistCgAsync {
             G4S_TRY(enqueue(std::max(1, std::min(batch, steps - enqueued + 1))));
             G4S_TRY(read());
             G4S_HIP_TRY(hipStreamSynchronize(g4s::as_stream(stream)));
+            read_pending = false;
             batch = std::min(32, batch * 2);
         }
         return G4S_OK;
@@ -635,6 +642,7 @@ int dist_cg_async_start(DistCgAsync **out, g4s_cg_ws_t ws, g4s_spmv_dist_t A, co
 int dist_cg_async_read(DistCgAsync *c) { return c->read(); }
 int dist_cg_async_settle(DistCgAsync *c, bool *speculation_held, int32_t *cycles, double *residual)
 {
+    c->read_pending = false;
     *speculation_held = c->h.done != 0;
     if (!c->h.done) {
         G4S_TRY(c->complete());
@@ -645,7 +653,7 @@ int dist_cg_async_settle(DistCgAsync *c, bool *speculation_held, int32_t *cycles
     if (residual) *residual = c->h.residual;
     return G4S_OK;
 }
-void dist_cg_async_free(DistCgAsync *c) { delete c; }
+void dist_cg_async_free(DistCgAsync *c) { if (c && c->read_pending) (void)hipStreamSynchronize(g4s::as_stream(c->stream)); delete c; }
 } // namespace g4s
 
 G4S_API g4s_status g4s_conj_grad_dist_tr(g4s_spmv_dist_t A, const g4s_transport *tr, int32_t n_local, const double *BI_dev, const int32_t *zero_resid_dev,

@@ -576,6 +576,7 @@ G4S_API g4s_status g4s_spmv_dist_get_info(g4s_spmv_dist_t h, g4s_spmv_dist_info 
 G4S_API g4s_status g4s_spmv_dist_want(g4s_spmv_dist_t h, int32_t peer, int64_t *count, const int32_t **idx_dev)
 {
     G4S_REQUIRE(h && peer >= 0 && peer < h->nseg && count, "bad argument");
+    G4S_REQUIRE(!h->poisoned, "the handle was poisoned by a failed set-up exchange: destroy it and exit the process");
     *count = h->recv_cut[(size_t)peer + 1] - h->recv_cut[peer];
     if (idx_dev) *idx_dev = h->d_want + h->recv_cut[peer];
     return G4S_OK;
@@ -585,6 +586,7 @@ G4S_API g4s_status g4s_spmv_dist_want(g4s_spmv_dist_t h, int32_t peer, int64_t *
 G4S_API g4s_status g4s_spmv_dist_set_give(g4s_spmv_dist_t h, int32_t peer, int64_t count, const int32_t *idx, unsigned flags)
 {
     G4S_REQUIRE(h && peer >= 0 && peer < h->nseg && count >= 0 && (idx || count == 0), "bad argument");
+    G4S_REQUIRE(!h->poisoned, "the handle was poisoned by a failed set-up exchange: destroy it and exit the process");
     G4S_REQUIRE(!h->allgather, "the all-gather exchange has no give lists");
     G4S_REQUIRE(!h->d_send, "the give lists are final once a product has run");
     std::vector<int32_t> list((size_t)count);
@@ -663,20 +665,36 @@ struct DevFree {
 // kernels leave), mark the handle, and from here on free and synchronise nothing that belongs to it (g4s_spmv_dist_destroy then only drops the host side).
 // The communicator is gone after this; the process is expected to report the error and EXIT — a supervisor starts a fresh process (never a re-exec of one
 // that has touched the GPU).
+// The communicator belongs to the CALLER (g4s_comm_create → g4s_spmv_dist_connect_rccl → g4s_comm_destroy): once aborted here it is remembered, so that the
+// caller's g4s_comm_destroy — and any further library call on it — finds it gone instead of destroying or using it a second time.
+std::mutex g_aborted_mu;
+std::vector<void *> g_aborted_comms;
+bool comm_was_aborted(void *comm)
+{
+    std::lock_guard<std::mutex> lk(g_aborted_mu);
+    return std::find(g_aborted_comms.begin(), g_aborted_comms.end(), comm) != g_aborted_comms.end();
+}
 int dist_poison(g4s_spmv_dist_s *h, DevFree &in_flight, int st)
 {
     h->poisoned = true;
     in_flight.p = nullptr;                                         // deliberately leaked: the stuck operation may still read or write it
-    if (h->comm && g_rccl.CommAbort) (void)g_rccl.CommAbort(h->comm);
+    if (h->comm && g_rccl.CommAbort) {
+        (void)g_rccl.CommAbort(h->comm);
+        std::lock_guard<std::mutex> lk(g_aborted_mu);
+        g_aborted_comms.push_back(h->comm);
+    }
     h->comm = nullptr;
     return st;
 }
+#define G4S_REQUIRE_LIVE(h) G4S_REQUIRE(!(h)->poisoned, "the handle was poisoned by a failed set-up exchange (g4s_spmv_dist_connect_rccl aborted its communicator): destroy it and exit the process")
 
 } // namespace
 
 G4S_API g4s_status g4s_spmv_dist_connect_rccl(g4s_spmv_dist_t h, void *comm)
 {
     G4S_REQUIRE(h && comm, "NULL argument");
+    G4S_REQUIRE_LIVE(h);
+    G4S_REQUIRE(!comm_was_aborted(comm), "this communicator was aborted by a failed set-up exchange: it cannot be used again");
     G4S_TRY(rccl_load());
     h->comm = reinterpret_cast<ncclComm_t>(comm);
     if (h->allgather || h->columns) return G4S_OK;                 // no lists to exchange: the collective itself is the wiring
@@ -736,6 +754,7 @@ G4S_API g4s_status g4s_spmv_dist_connect_rccl(g4s_spmv_dist_t h, void *comm)
 G4S_API g4s_status g4s_spmv_dist_buffers(g4s_spmv_dist_t h, double **send_dev, const int64_t **send_cut, double **recv_dev, const int64_t **recv_cut)
 {
     G4S_REQUIRE(h, "NULL handle");
+    G4S_REQUIRE_LIVE(h);
     if (h->columns) {                                              // nothing of x travels: the caller's transport all-reduces y itself between _begin and _finish
         if (send_dev) *send_dev = nullptr;
         if (recv_dev) *recv_dev = nullptr;
@@ -830,6 +849,7 @@ G4S_API g4s_status g4s_spmv_dist_begin(g4s_spmv_dist_t h, const double *x_local_
 G4S_API g4s_status g4s_spmv_dist_finish(g4s_spmv_dist_t h, double *y_local_dev, void *stream)
 {
     G4S_REQUIRE(h && (y_local_dev || h->local_rows == 0), "NULL argument");   // (a rank of a rectangular operator may own x entries but no rows)
+    G4S_REQUIRE_LIVE(h);
     hipStream_t s = g4s::as_stream(stream);
     if (h->columns) {
         if (h->comm && h->world > 1 && h->local_rows) G4S_RCCL_TRY(g_rccl.AllReduce(y_local_dev, y_local_dev, (size_t)h->local_rows, ncclDouble, ncclSum, h->comm, s));
@@ -898,6 +918,11 @@ G4S_API g4s_status g4s_comm_create(void **comm, int32_t world, int32_t rank, con
 G4S_API g4s_status g4s_comm_destroy(void *comm)
 {
     if (!comm) return G4S_OK;
+    {   // a communicator that a failed set-up exchange aborted (dist_poison) is gone already: ncclCommAbort freed it — nothing to destroy a second time
+        std::lock_guard<std::mutex> lk(g_aborted_mu);
+        auto it = std::find(g_aborted_comms.begin(), g_aborted_comms.end(), comm);
+        if (it != g_aborted_comms.end()) { g_aborted_comms.erase(it); return G4S_OK; }
+    }
     G4S_TRY(rccl_load());
     G4S_RCCL_TRY(g_rccl.CommDestroy(reinterpret_cast<ncclComm_t>(comm)));
     return G4S_OK;
@@ -906,6 +931,7 @@ G4S_API g4s_status g4s_comm_destroy(void *comm)
 G4S_API g4s_status g4s_comm_allreduce_sum_f64(void *comm, double *buf_dev, int64_t count, void *stream)
 {
     G4S_REQUIRE(comm && (buf_dev || count == 0) && count >= 0, "bad argument");
+    G4S_REQUIRE(!comm_was_aborted(comm), "this communicator was aborted by a failed set-up exchange: it cannot be used again");
     G4S_TRY(rccl_load());
     if (count) G4S_RCCL_TRY(g_rccl.AllReduce(buf_dev, buf_dev, (size_t)count, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm), g4s::as_stream(stream)));
     return G4S_OK;

@@ -825,6 +825,7 @@ struct Pattern {
 
 std::mutex g_mu;
 std::atomic<int> g_host_policy{G4S_HOST_CALLBACKS_SERIAL};
+thread_local int t_host_policy = -1;                                // >= 0: this thread's calls use it instead of the process-wide policy (g4s::ScopedRaceFree, graph.hpp)
 std::map<std::pair<void *, void *>, std::unique_ptr<Pattern>> g_patterns;
 
 std::pair<void *, void *> key_of(fun_gather g, fun_apply a) { return {reinterpret_cast<void *>(g), reinterpret_cast<void *>(a)}; }
@@ -867,6 +868,14 @@ G4S_API g4s_status g4s_set_host_callback_policy(int32_t policy)
     return G4S_OK;
 }
 
+G4S_API g4s_status g4s_set_host_callback_policy_thread(int32_t policy, int32_t *previous)
+{
+    G4S_REQUIRE(policy == -1 || policy == G4S_HOST_CALLBACKS_SERIAL || policy == G4S_HOST_CALLBACKS_PARALLEL || policy == G4S_HOST_CALLBACKS_REFUSE, "unknown policy");
+    if (previous) *previous = t_host_policy;
+    t_host_policy = policy;
+    return G4S_OK;
+}
+
 G4S_API g4s_status g4s_unregister_pattern(fun_gather gather, fun_apply apply)
 {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -884,7 +893,7 @@ G4S_API g4s_status g4s_spmm_dense(uint32_t numNodes, uint32_t degree, const doub
         // "gather degree times per vertex, then apply" for ANY pair (deepmd/source/op/graph.h:21-32; citcoms/lib/global_defs.h:48-49,854-857),
         // so the general case runs the reference's driver loop on the host, in the reference's order. This is the interface's semantics for
         // callbacks, not a CPU version of a device kernel: the three patterns with kernels never come here.
-        const int policy = g_host_policy.load();
+        const int policy = t_host_policy >= 0 ? t_host_policy : g_host_policy.load();
         lk.unlock();                                               // callbacks may call back into the library
         if (policy == G4S_HOST_CALLBACKS_REFUSE)
             return g4s::set_error(G4S_ERR_UNSUPPORTED, "spmm_dense: this (gather, apply) pair is not registered with g4s_register_pattern and "

@@ -96,10 +96,14 @@ int scratch_alloc(void **p, size_t bytes, hipStream_t s)
     return G4S_OK;
 }
 
+static bool big_contains(const void *p);
 void scratch_free(void *p, hipStream_t s)
 {
     if (!p || arena_owns(p)) return;
-    (void)hipFreeAsync(p, s);
+    // A piece of an arena that is released AFTER its arena has ended, or on another thread, is an interior pointer of a big block (live or back in the cache), not
+    // a pool allocation: handing it to hipFreeAsync fails and leaves a HIP error behind for the next hipGetLastError. Its memory went back with its chunk.
+    if (big_contains(p)) return;
+    if (hipFreeAsync(p, s) != hipSuccess) (void)hipGetLastError();
 }
 
 // Large device blocks (product outputs, per-row bitmaps: tens of MB to tens of GB). On this stack a fresh allocation of that size —
@@ -119,6 +123,18 @@ size_t big_cache_limit()
     static const size_t lim = [] { const char *e = getenv("G4S_CACHE_MAX_BYTES"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)48 << 30; }();
     return lim;
 }
+} // namespace
+static bool big_contains(const void *p)
+{
+    std::lock_guard<std::mutex> lock(g_big_mutex);
+    const char *c = static_cast<const char *>(p);
+    for (const auto &kv : g_big_live)
+        if (c >= static_cast<const char *>(kv.second.p) && c < static_cast<const char *>(kv.second.p) + kv.second.bytes) return true;
+    for (const auto &b : g_big_cache)
+        if (c >= static_cast<const char *>(b.p) && c < static_cast<const char *>(b.p) + b.bytes) return true;
+    return false;
+}
+namespace {
 int current_device()
 {
     int d = 0;

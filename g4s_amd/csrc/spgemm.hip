@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void row_start_descents_kernel(int K, const in
 }
 
 // ------------------------------------------------------------------------------------------------ row classes
-enum { CLS_EMPTY = 0, CLS_TINY, CLS_SMALL, CLS_MEDIUM, CLS_LARGE, CLS_M2, CLS_M3, CLS_HUB, CLS_COUNT };
+enum { CLS_EMPTY = 0, CLS_TINY, CLS_SMALL, CLS_MEDIUM, CLS_LARGE, CLS_M2, CLS_M3, CLS_HUB, CLS_RANK /* numeric only: the rows whose symbolic pass wrote cuts (spgemm_rank.hpp); size < 0 */, CLS_COUNT };
 
 // Class i (1..6) takes a row whose size is <= lim[i-1]; sizes are the flop bound clipped at cols (BIN.h:164), except where
 // raw[i-1] is set (the unclipped bound decides). Beyond the last limit: hub.
@@ -261,6 +261,7 @@ constexpr ClassLimits kNumLimits{{32, 512, 1024, 2048, 4096, G4S_SPGEMM_BIG_LIMI
 constexpr int kClassBlocks = 512;
 __device__ __forceinline__ int class_of(long long u, const ClassLimits &lim, int cols_clip)
 {
+    if (u < 0) return CLS_RANK;
     if (u == 0) return CLS_EMPTY;
     const long long uc = (cols_clip > 0 && u > cols_clip) ? cols_clip : u;   // BIN.h:164 clips the bound at cols
     int c = CLS_HUB;
@@ -339,10 +340,12 @@ __global__ void gather_ranges_kernel(const int *__restrict__ rows, int n, const 
     if (i < n) { out[2 * i] = arpt[rows[i]]; out[2 * i + 1] = arpt[rows[i] + 1]; }
 }
 
-__global__ void nz_to_ll_kernel(int M, const int *__restrict__ crpt, long long *__restrict__ nz)
+__global__ void nz_to_ll_kernel(int M, const int *__restrict__ crpt, const long long *__restrict__ cut_off /* not NULL: rows with cuts get a negative size (CLS_RANK) */, long long *__restrict__ nz)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < M) nz[i] = (long long)crpt[i + 1] - crpt[i];
+    if (i >= M) return;
+    const long long v = (long long)crpt[i + 1] - crpt[i];
+    nz[i] = (cut_off && cut_off[i] >= 0) ? -1 - v : v;
 }
 
 // ------------------------------------------------------------------------------------------------ LDS hash kernels
@@ -855,9 +858,10 @@ __device__ __forceinline__ void window_bounds(const int *brpt, const int *wsplit
 #ifdef G4S_PROFILE_BIG
 // Section timers of the big-row kernels (tools/big_prof.py, tools/sym_prof.py): s_memtime deltas summed in registers, flushed with one atomic
 // per slot by thread 0 of every 16th workgroup at BIG_PROF_FLUSH (a global atomic per stamp would itself be the longest thing in an inner loop).
-__device__ unsigned long long g_big_prof[32];                     // [0, 16): numeric big-row kernel; [16, 32): symbolic window kernel and its emit step
+__device__ unsigned long long g_big_prof[48];                     // [0, 16): numeric big-row kernel; [16, 32): symbolic window kernel and its emit step; [32, 48): rank kernel
 #define BIG_PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[16] = {}; constexpr int prof_base = 0
 #define BIG_PROF_DECL_SYM unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[16] = {}; constexpr int prof_base = 16
+#define BIG_PROF_DECL_RANK unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[16] = {}; constexpr int prof_base = 32
 #define BIG_PROF(slot) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof_acc[slot] += n_ - prof_t; prof_t = n_; } while (0)
 #ifdef G4S_PROF_LAST_WAVE   /* the report of the LAST wavefront instead of the first: a section that is long in one and a barrier wait in the other is imbalance */
 #define BIG_PROF_TID (blockDim.x - 64)
@@ -868,6 +872,7 @@ __device__ unsigned long long g_big_prof[32];                     // [0, 16): nu
 #else
 #define BIG_PROF_DECL
 #define BIG_PROF_DECL_SYM
+#define BIG_PROF_DECL_RANK
 #define BIG_PROF(slot)
 #define BIG_PROF_FLUSH
 #endif
@@ -1230,6 +1235,8 @@ __global__ void sym_row_meta_kernel(int n, const int *__restrict__ rows, const i
 }
 
 struct __attribute__((aligned(8))) SymUnit { int bpos, len; };
+struct __attribute__((aligned(16))) UnitDesc { int bpos, len, av_lo, av_hi; };   // a numeric unit (unit_kernel below), 16 bytes: one s_load_dwordx4
+#include "spgemm_rank.hpp"
 __global__ void sym_items_kernel(int n, const int *__restrict__ rows, const int *__restrict__ arpt, int nwin, long long *__restrict__ items)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1268,7 +1275,8 @@ __global__ __launch_bounds__(256) void sym_unit_kernel(long long bound /* thread
     }
 }
 
-template <int T>
+// CUTS (round 5, spgemm_rank.hpp): pre_off / pre_cols are the rows' cut offsets and the cut array — the kernel counts and writes a row's cuts instead of its columns.
+template <int T, bool CUTS>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void spgemm_symbolic_units_kernel(
     const int *__restrict__ rows, int nrows, int *__restrict__ next_row /* not NULL: rows handed out one at a time (list sorted longest first) */,
     int N, const int *__restrict__ arpt, const int *__restrict__ bcol, int *__restrict__ row_nz,
@@ -1341,7 +1349,12 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
             __syncthreads();
             BIG_PROF(1);
             if (wi == 0 && next_row) { nridx = __builtin_amdgcn_readfirstlane(sd.ctrl[29]); nxt = load_meta(nridx); }   // (nobody writes the slot again before this row's last barrier)
-            if (po >= 0) {
+            if (CUTS && po >= 0) {
+                const int nseg = rank_segments(N), before = s_total;   // (s_total: written by thread 0 behind the barrier at the end of the previous window)
+                const int total = count_and_cut_window<T>(bm, wi, before, nseg, pre_cols + po, pre_cols + po + nseg, sd.scan, t);
+                if (t == 0) s_total = before + total;
+                BIG_PROF(3);
+            } else if (po >= 0) {
                 const int total = emit_window_columns<T>(bm, w0, pre_cols + po + s_total, sd.scan, sd.stage, t);
                 if (t == 0) s_total += total;
                 BIG_PROF(3);
@@ -1384,7 +1397,8 @@ __global__ __launch_bounds__(256) void chunk_splits_kernel(long long total, int 
                                                            const int *__restrict__ arpt, const int *__restrict__ acol, const int *__restrict__ brpt,
                                                            const int *__restrict__ bcol /* window ids */, const int *__restrict__ crpt,
                                                            const long long *__restrict__ pre_off, const int *__restrict__ pre_cols, const int *__restrict__ ccol /* window ids of the rows without carried columns */, int chunk,
-                                                           const long long *__restrict__ ct_off /* n + 1 */, int *__restrict__ ct)
+                                                           const long long *__restrict__ ct_off /* n + 1 */, int *__restrict__ ct,
+                                                           const int *__restrict__ choff = nullptr /* rank launch: the rows' chunk lists (rank_chunks_kernel) give the boundaries */, const RankChunk *__restrict__ chunks = nullptr)
 {
     const long long i0 = (long long)blockIdx.x * blockDim.x, i = i0 + threadIdx.x;
     // the list position whose items hold the workgroup's FIRST item — a uniform search (scalar loads, once per 256 items: a search per item was a chain of
@@ -1398,9 +1412,9 @@ __global__ __launch_bounds__(256) void chunk_splits_kernel(long long total, int 
     while (ct_off[rl + 1] <= i) ++rl;
     const int row = rows[rl], nz = crpt[row + 1] - crpt[row];
     const long long po = pre_off ? pre_off[row] : -1, idx = i - ct_off[rl];
-    const int a0 = arpt[row], nb = (nz + chunk - 1) / chunk - 1;
+    const int a0 = arpt[row], nb = choff ? choff[rl + 1] - choff[rl] - 1 : (nz + chunk - 1) / chunk - 1;
     const int e = (int)(idx / nb), b = (int)(idx - (long long)e * nb) + 1;
-    const int c = acol[a0 + e], cb = po >= 0 ? pre_cols[po + (long long)chunk * b] : ccol[crpt[row] + (long long)chunk * b];
+    const int c = acol[a0 + e], cb = choff ? chunks[choff[rl] + b].cstart : po >= 0 ? pre_cols[po + (long long)chunk * b] : ccol[crpt[row] + (long long)chunk * b];
     const int sb = split_bits(N), W = (N + (1 << sb) - 1) >> sb, wf = cb >> sb;
     int lo = (wsplit && wf > 0) ? wsplit[(size_t)(wf - 1) * K + c] : brpt[c];
     int hi = (wsplit && wf < W - 1) ? wsplit[(size_t)wf * K + c] : brpt[c + 1];
@@ -1419,7 +1433,6 @@ __global__ __launch_bounds__(256) void chunk_splits_kernel(long long total, int 
 //   item (list position i, chunk q, A-entry e), ordered by (i, q, e): piece [split(e, q), split(e, q + 1)) of B row acol[e]  (split(e, 0) = row start,
 //   split(e, chunks) = row end: every entry of a B row used by row i lands in exactly one of the row's chunks);
 //   unit_count_kernel: units of the item = ceil(piece / 64); an exclusive scan gives the item's first unit; unit_expand_kernel writes the descriptors.
-struct __attribute__((aligned(16))) UnitDesc { int bpos, len, av_lo, av_hi; };   // 16 bytes: one s_load_dwordx4
 __global__ void unit_items_kernel(int n, const int *__restrict__ rows, const int *__restrict__ arpt, const int *__restrict__ crpt, int chunk, int nz_lo, int nz_hi,
                                   long long *__restrict__ items)
 {
@@ -1487,7 +1500,8 @@ __global__ __launch_bounds__(256) void unit_task_kernel(long long bound /* threa
                                                         const int *__restrict__ brpt, const int *__restrict__ bcol /* window ids */, const int *__restrict__ crpt,
                                                         const long long *__restrict__ pre_off, const int *__restrict__ pre_cols, const int *__restrict__ ccol, int chunk,
                                                         int *__restrict__ ct /* splits: item_off[i] − task_off[i] + e·(chunks − 1) */, int *__restrict__ ucount,
-                                                        const int *__restrict__ uoff, UnitDesc *__restrict__ U, int have_ct /* !EXPAND: the splits are in ct already (chunk_splits_kernel) */)
+                                                        const int *__restrict__ uoff, UnitDesc *__restrict__ U, int have_ct /* !EXPAND: the splits are in ct already (chunk_splits_kernel) */,
+                                                        const int *__restrict__ choff = nullptr /* rank launch: chunks per row from the chunk lists */)
 {
     const long long t0 = (long long)blockIdx.x * blockDim.x, total = task_off[n];
     long long t = t0 + threadIdx.x;
@@ -1503,7 +1517,7 @@ __global__ __launch_bounds__(256) void unit_task_kernel(long long bound /* threa
     }
     while (task_off[rl + 1] <= t) ++rl;
     const int row = rows[rl], e = (int)(t - task_off[rl]);
-    const int a0 = arpt[row], na = arpt[row + 1] - a0, off = crpt[row], nz = crpt[row + 1] - off, nb = (nz + chunk - 1) / chunk - 1;
+    const int a0 = arpt[row], na = arpt[row + 1] - a0, off = crpt[row], nz = crpt[row + 1] - off, nb = choff ? choff[rl + 1] - choff[rl] - 1 : (nz + chunk - 1) / chunk - 1;
     const int c = acol[a0 + e];
     const int end = brpt[c + 1];
     int prev = brpt[c];
@@ -2173,8 +2187,9 @@ int check_ids(const int *ids, long long n, int bound, const char *what, hipStrea
 }
 
 // range check of B's column ids and the sorted-rows contract, one synchronisation
-int check_b(const int *brpt, const int *bcol, int K, long long bnnz, int N, hipStream_t s)
+int check_b(const int *brpt, const int *bcol, int K, long long bnnz, int N, hipStream_t s, bool *unsorted)
 {
+    *unsorted = false;
     if (bnnz <= 0) return G4S_OK;
     DevBuf buf;
     G4S_TRY(buf.alloc(sizeof(unsigned long long) * 3));
@@ -2187,18 +2202,103 @@ int check_b(const int *brpt, const int *bcol, int K, long long bnnz, int N, hipS
     G4S_HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s));
     G4S_HIP_TRY(hipStreamSynchronize(s));
     if (h[0] & 0xffffffffull) return g4s::set_error(G4S_ERR_INVALID, "SpGEMM: a column id of B outside its valid range [0,%d)", N);
-    if (h[1] != h[2]) return g4s::set_error(G4S_ERR_INVALID, "SpGEMM: the rows of B must be sorted by column (%llu descending neighbours inside rows)", h[1] - h[2]);
+    *unsorted = h[1] != h[2];                                       // the caller sorts a private copy of B's rows (sort_b_rows)
+    return G4S_OK;
+}
+
+// ---- B with unsorted rows (round 5). The reference takes any row order — the hash traversal never looks at it (mm/inc/hash_mult.h:579-600), HashSpGEMM<…, false>
+// emits unsorted rows itself (:530-551) and a chained product feeds them back in as B; mkl_sparse_spmm takes them too (mm/inc/mkl_mult.h:58). The merge and window
+// kernels here cut B's rows at column boundaries, so when the sortedness check fires the call sorts a PRIVATE copy of B's rows and works on that: two stable
+// LSD radix sorts of the entry indices (prims.hpp), by column and then by row = by (row, column); the caller's arrays are not touched. Only then: the check
+// itself rides on the opening pass of every call.
+__global__ void sortb_col_keys_kernel(int n, const int *__restrict__ col, int N, int *__restrict__ key, int *__restrict__ idx)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) { key[k] = N - 1 - col[k]; idx[k] = k; }            // (the sort is descending: ascending columns)
+}
+__global__ void sortb_row_keys_kernel(int n, int K, const int *__restrict__ rpt, const int *__restrict__ perm, int *__restrict__ key)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int e = perm[k];
+    int lo = 0, hi = K;                                            // the row that holds entry e: the last r with rpt[r] <= e
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (rpt[mid] <= e) lo = mid; else hi = mid;
+    }
+    key[k] = K - 1 - lo;
+}
+__global__ void sortb_gather_kernel(int n, const int *__restrict__ perm, const int *__restrict__ col, const double *__restrict__ val, int *__restrict__ col_out, double *__restrict__ val_out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int e = perm[k];
+    if (col_out) col_out[k] = col[e];
+    if (val_out) val_out[k] = val[e];
+}
+inline int bits_for(int n) { return n > 1 ? 32 - __builtin_clz((unsigned)(n - 1)) : 1; }
+// perm[k] = the entry of B that stands at position k once every row is sorted by column (ties keep their order)
+int sort_b_rows(int K, int N, int bnnz, const int *brpt, const int *bcol, int *perm, hipStream_t s)
+{
+    DevBuf key, idx, key2, perm1, tk, tv;
+    const size_t b = sizeof(int) * (size_t)bnnz;
+    G4S_TRY(key.alloc(b)); G4S_TRY(idx.alloc(b)); G4S_TRY(key2.alloc(b)); G4S_TRY(perm1.alloc(b)); G4S_TRY(tk.alloc(b)); G4S_TRY(tv.alloc(b));
+    const dim3 grid((unsigned)((bnnz + 255) / 256));
+    hipLaunchKernelGGL(sortb_col_keys_kernel, grid, dim3(256), 0, s, bnnz, bcol, N, key.as<int>(), idx.as<int>());
+    G4S_TRY(g4s::prims::sort_pairs_descending(key.as<int>(), idx.as<int>(), key2.as<int>(), perm1.as<int>(), tk.as<int>(), tv.as<int>(), bnnz, bits_for(N), s));
+    hipLaunchKernelGGL(sortb_row_keys_kernel, grid, dim3(256), 0, s, bnnz, K, brpt, perm1.as<int>(), key.as<int>());
+    G4S_TRY(g4s::prims::sort_pairs_descending(key.as<int>(), perm1.as<int>(), key2.as<int>(), perm, tk.as<int>(), tv.as<int>(), bnnz, bits_for(K), s));
+    G4S_HIP_TRY(hipGetLastError());
+    return G4S_OK;
+}
+int gather_b(int bnnz, const int *perm, const int *bcol, const double *bval, int *col_out, double *val_out, hipStream_t s)
+{
+    if (bnnz > 0) hipLaunchKernelGGL(sortb_gather_kernel, dim3((unsigned)((bnnz + 255) / 256)), dim3(256), 0, s, bnnz, perm, bcol, bval, col_out, val_out);
+    G4S_HIP_TRY(hipGetLastError());
+    return G4S_OK;
+}
+
+// ---- the key of a carried symbolic state: a position-dependent 64-bit sum over the five index arrays of the product. A numeric call takes the state
+// over only when its arrays still hash to the value the symbolic call saw — the pointers alone match a caller that refilled the same buffers with another pattern.
+__global__ __launch_bounds__(256) void pattern_hash_kernel(long long n0, const int *__restrict__ a0, long long n1, const int *__restrict__ a1, long long n2, const int *__restrict__ a2,
+                                                           long long n3, const int *__restrict__ a3, long long n4, const int *__restrict__ a4, unsigned long long *__restrict__ out)
+{
+    const long long total = n0 + n1 + n2 + n3 + n4;
+    unsigned long long sum = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long j = i;
+        const int *p = a0;
+        if (j >= n0) { j -= n0; p = a1; if (j >= n1) { j -= n1; p = a2; if (j >= n2) { j -= n2; p = a3; if (j >= n3) { j -= n3; p = a4; } } } }
+        unsigned long long v = (unsigned long long)(unsigned)p[j] ^ ((unsigned long long)(i + 1) * 0x9E3779B97F4A7C15ull);
+        v *= 0xff51afd7ed558ccdull; v ^= v >> 33;
+        sum += v;
+    }
+    sum = (unsigned long long)wave_sum_ll((long long)sum);
+    __shared__ unsigned long long s_p[4];
+    if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, s_p[0] + s_p[1] + s_p[2] + s_p[3]);
+}
+// enqueues the hash of (arpt, acol, brpt, bcol, crpt) into *d_out (zeroed here); the caller reads it behind its next synchronisation
+int enqueue_pattern_hash(int M, int K, long long annz, long long bnnz, const int *arpt, const int *acol, const int *brpt, const int *bcol, const int *crpt, unsigned long long *d_out, hipStream_t s)
+{
+    G4S_HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(unsigned long long), s));
+    const long long total = 2ll * (M + 1) + (K + 1) + annz + bnnz;
+    const int grid = (int)std::min<long long>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(pattern_hash_kernel, dim3(grid), dim3(256), 0, s, (long long)M + 1, arpt, annz, acol, (long long)K + 1, brpt, bnnz, bcol, (long long)M + 1, crpt, d_out);
+    G4S_HIP_TRY(hipGetLastError());
     return G4S_OK;
 }
 
 // The opening of a one-shot or symbolic call in ONE host wait (it was three: A's ids, B's ids and order, the flop total): B's checks, the per-entry flop with
 // the check of A's ids fused in, its scan, the per-row flop; flags and total come back together.
 int checked_row_flop(int M, int K, int N, const int *arpt, const int *acol, long long annz, const int *brpt, const int *bcol, long long bnnz,
-                     long long *d_row_flop, int64_t *total, hipStream_t s)
+                     long long *d_row_flop, int64_t *total, hipStream_t s, bool *b_unsorted)
 {
+    *b_unsorted = false;
     if (!(M > 0 && annz > 0 && annz < (1ll << 31))) {              // the row-parallel form keeps its own sequence
         G4S_TRY(check_ids(acol, annz, K, "a column id of A", s));
-        G4S_TRY(check_b(brpt, bcol, K, bnnz, N, s));
+        G4S_TRY(check_b(brpt, bcol, K, bnnz, N, s, b_unsorted));
         return compute_row_flop(M, arpt, acol, brpt, d_row_flop, total, s, annz);
     }
     DevBuf buf, f, P;
@@ -2223,7 +2323,7 @@ int checked_row_flop(int M, int K, int N, const int *arpt, const int *acol, long
     G4S_HIP_TRY(hipStreamSynchronize(s));
     if (h[3]) return g4s::set_error(G4S_ERR_INVALID, "SpGEMM: a column id of A outside its valid range [0,%d)", K);
     if (h[0] & 0xffffffffull) return g4s::set_error(G4S_ERR_INVALID, "SpGEMM: a column id of B outside its valid range [0,%d)", N);
-    if (h[1] != h[2]) return g4s::set_error(G4S_ERR_INVALID, "SpGEMM: the rows of B must be sorted by column (%llu descending neighbours inside rows)", h[1] - h[2]);
+    *b_unsorted = h[1] != h[2];                                     // (the flop does not depend on the order inside B's rows: everything computed here stands)
     if (total) *total = (int64_t)tot;
     return G4S_OK;
 }
@@ -2353,6 +2453,19 @@ struct PreSorted {
     bool holds_cache = false;
     bool complete = false;       // every row the numeric window kernels will take carries its columns (no hub rows, no overflowed optimistic tables)
     long long flop = -1;         // the product's flop: bounds the unit lists of the numeric launches without a count read back
+    // round 5 (spgemm_rank.hpp): the rows of the long symbolic classes carry CUTS instead of columns — cut_off[row] >= 0 marks them, cuts[cut_off[row] …] holds
+    // nseg segment starts, then the count cuts
+    DevBuf cut_off_buf, cuts_buf;
+    const long long *d_cut_off = nullptr;
+    int *d_cuts = nullptr;
+    int nseg = 0;
+    long long bnnz = -1, annz = -1;
+    bool rank = false;
+    // B arrived with unsorted rows (sort_b_rows): the sorted copy of its columns — what every kernel of the product reads — and the permutation behind it (the
+    // numeric phase gathers the values through it)
+    DevBuf b_cols_sorted, b_perm;
+    bool b_unsorted = false;
+    unsigned long long key_hash = 0;   // pattern_hash_kernel over the caller's five index arrays (two-call form)
     bool keep = false;           // carried from g4s_spgemm_symbolic to the g4s_spgemm_numeric call that follows it (see CarriedSymbolic): nothing of it may live in a call's arena
     ~PreSorted();
 };
@@ -2426,6 +2539,17 @@ __global__ void presorted_need_kernel(int M, const int *__restrict__ cls, unsign
     const bool take = ((class_mask >> cls[i]) & 1u) && f > min_flop;
     need[i] = take ? (f < N ? f : (long long)N) : 0;
 }
+__global__ void rank_need_kernel(int M, const int *__restrict__ cls, unsigned class_mask, const long long *__restrict__ row_flop, int N, int nseg, long long *__restrict__ need)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > M) return;
+    long long v = 0;
+    if (i < M && ((class_mask >> cls[i]) & 1u)) {
+        const long long f = row_flop[i], nzb = f < N ? f : (long long)N;   // the row's outputs are at most min(flop, columns): so many count cuts at most
+        v = nseg + nzb / kRankChunk + 1;
+    }
+    need[i] = v;
+}
 __global__ void presorted_mark_kernel(int M, const long long *__restrict__ need, long long *__restrict__ off)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2471,7 +2595,21 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     G4S_TRY(row_nz.alloc(sizeof(int) * ((size_t)M + 1)));
     G4S_HIP_TRY(hipMemsetAsync(row_nz.p, 0, sizeof(int) * ((size_t)M + 1), s));
     int64_t flop = 0;
-    G4S_TRY(checked_row_flop(M, K, N, arpt, acol, annz, brpt, bcol, bnnz, row_flop.as<long long>(), &flop, s));
+    bool b_unsorted = false;
+    const int32_t *bcol_caller = bcol;
+    G4S_TRY(checked_row_flop(M, K, N, arpt, acol, annz, brpt, bcol, bnnz, row_flop.as<long long>(), &flop, s, &b_unsorted));
+    DevBuf local_bs, local_perm;
+    if (b_unsorted) {                                              // the product runs on a private copy of B with sorted rows (sort_b_rows)
+        DevBuf &bs = pre ? pre->b_cols_sorted : local_bs, &pm = pre ? pre->b_perm : local_perm;
+        const bool keep = pre && pre->keep;
+        G4S_TRY(bs.alloc(sizeof(int) * (size_t)bnnz, keep));
+        G4S_TRY(pm.alloc(sizeof(int) * (size_t)bnnz, keep));
+        G4S_TRY(sort_b_rows(K, N, bnnz, brpt, bcol, pm.as<int>(), s));
+        G4S_TRY(gather_b(bnnz, pm.as<int>(), bcol, nullptr, bs.as<int>(), nullptr, s));
+        bcol = bs.as<int>();
+        if (pre) pre->b_unsorted = true;
+        if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s symbolic: the rows of B are not sorted by column — working on a sorted private copy\n");
+    }
 
     dbg.mark("row_flop");
     RowClasses rc;
@@ -2525,9 +2663,34 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     const bool x_med = N2 <= window_max_n(), x_large = x_med;
     const long long *pre_off = nullptr;
     int *pre_cols = nullptr;
+    const bool use_units = !getenv("G4S_SPGEMM_NO_UNITS");
+    const int t_med = shape_of("G4S_SPGEMM_T_SYM_MED", kShapeSymMedium), t_large = shape_of("G4S_SPGEMM_T_SYM_LARGE", kShapeSymLarge),
+              t_win = shape_of("G4S_SPGEMM_T_SYM_WINDOW", 1024);
+    const bool one_long_launch = x_large && t_large == t_win;   // LARGE and M2 share a shape and their lists are adjacent: one launch
+    // Round 5: the long classes (more than 8 K products) write CUTS instead of columns and take the rank kernel in the numeric phase (spgemm_rank.hpp). Needs what the
+    // carried columns needed (a PreSorted to carry them in) plus the unit lists and the one long launch.
+    const int n_long = rc.count[CLS_LARGE] + rc.count[CLS_M2];
+    bool use_rank = pre && one_long_launch && use_units && n_long > 0 && !getenv("G4S_SPGEMM_NO_RANK");
+    const int nseg = rank_segments(N2);
+    long long *cut_off = nullptr;
+    int *cuts = nullptr;
+    if (use_rank) {
+        const long long cut_bound = (long long)n_long * (nseg + 1) + flop / kRankChunk + 1;   // Σ (nseg + min(flop_i, N2) / chunk + 1) over the long rows: no count comes back
+        DevBuf need;
+        if (cut_bound >= (1ll << 30) || need.alloc(sizeof(long long) * ((size_t)M + 1)) != G4S_OK || pre->cut_off_buf.alloc(sizeof(long long) * ((size_t)M + 1), pre->keep) != G4S_OK ||
+            pre->cuts_buf.alloc(sizeof(int) * (size_t)cut_bound, pre->keep) != G4S_OK) { (void)hipGetLastError(); use_rank = false; }
+        else {
+            const unsigned long_mask = (1u << CLS_LARGE) | (1u << CLS_M2);
+            hipLaunchKernelGGL(rank_need_kernel, dim3((M + 256) / 256), dim3(256), 0, s, M, rc.cls.as<int>(), long_mask, row_flop.as<long long>(), N2, nseg, need.as<long long>());
+            G4S_TRY(g4s::prims::exclusive_scan(need.as<long long>(), pre->cut_off_buf.as<long long>(), (long long)M + 1, s));
+            hipLaunchKernelGGL(presorted_mark_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, need.as<long long>(), pre->cut_off_buf.as<long long>());
+            G4S_HIP_TRY(hipGetLastError());
+            cut_off = pre->cut_off_buf.as<long long>(); cuts = pre->cuts_buf.as<int>();
+        }
+    }
     if (pre) {
-        // which classes the window kernel counts in this call: M2 always, MEDIUM / LARGE while B is narrow enough
-        const unsigned class_mask = (1u << CLS_M2) | (x_med ? (1u << CLS_MEDIUM) : 0u) | (x_large ? (1u << CLS_LARGE) : 0u);
+        // which classes the window kernel counts AND EMITS in this call: M2 always, MEDIUM / LARGE while B is narrow enough — without the classes that write cuts
+        const unsigned class_mask = use_rank ? (x_med ? (1u << CLS_MEDIUM) : 0u) : ((1u << CLS_M2) | (x_med ? (1u << CLS_MEDIUM) : 0u) | (x_large ? (1u << CLS_LARGE) : 0u));
         DevBuf need;
         G4S_TRY(need.alloc(sizeof(long long) * ((size_t)M + 1)));
         G4S_TRY(pre->off.alloc(sizeof(long long) * ((size_t)M + 1), pre->keep));
@@ -2554,8 +2717,8 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     }
     dbg.mark("tables+presort");
     std::vector<std::unique_ptr<DevBuf>> unit_keep;                // unit lists of the window launches: live until the stream is synchronised below
-    const bool use_units = !getenv("G4S_SPGEMM_NO_UNITS");
-    auto window_t = [&](auto shape, const int *rows, int n, const long long *poff, int *pcols, int *next_row) -> int {
+    bool rank_done = false;                                        // the long launch ran in its cut-writing form
+    auto window_t = [&](auto shape, const int *rows, int n, const long long *poff, int *pcols, int *next_row, bool cuts_mode) -> int {
         constexpr int T = decltype(shape)::value;
         if (!n) return G4S_OK;
         const size_t lds = big_lds_bytes<T>();
@@ -2582,15 +2745,23 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
                 auto rmeta = std::make_unique<DevBuf>();
                 G4S_TRY(rmeta->alloc(sizeof(SymRowMeta) * (size_t)n));
                 hipLaunchKernelGGL(sym_row_meta_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, rows, arpt, poff, ioff->as<long long>(), uoff->as<int>(), rmeta->as<SymRowMeta>());
-                auto k = spgemm_symbolic_units_kernel<T>;
-                G4S_TRY(allow_lds(k, lds));
-                hipLaunchKernelGGL(k, grid, dim3(T), lds, s, rows, n, next_row, N2, arpt, wcol, nz, poff, pcols, ioff->as<long long>(), uoff->as<int>(), ud->as<SymUnit>(), rmeta->as<SymRowMeta>());
+                if (cuts_mode) {
+                    auto k = spgemm_symbolic_units_kernel<T, true>;
+                    G4S_TRY(allow_lds(k, lds));
+                    hipLaunchKernelGGL(k, grid, dim3(T), lds, s, rows, n, next_row, N2, arpt, wcol, nz, poff, pcols, ioff->as<long long>(), uoff->as<int>(), ud->as<SymUnit>(), rmeta->as<SymRowMeta>());
+                    rank_done = true;
+                } else {
+                    auto k = spgemm_symbolic_units_kernel<T, false>;
+                    G4S_TRY(allow_lds(k, lds));
+                    hipLaunchKernelGGL(k, grid, dim3(T), lds, s, rows, n, next_row, N2, arpt, wcol, nz, poff, pcols, ioff->as<long long>(), uoff->as<int>(), ud->as<SymUnit>(), rmeta->as<SymRowMeta>());
+                }
                 G4S_HIP_TRY(hipGetLastError());
                 unit_keep.push_back(std::move(rmeta));
                 unit_keep.push_back(std::move(items)); unit_keep.push_back(std::move(ioff)); unit_keep.push_back(std::move(ucnt)); unit_keep.push_back(std::move(uoff)); unit_keep.push_back(std::move(ud));
                 return G4S_OK;
             }
         }
+        if (cuts_mode) { poff = nullptr; pcols = nullptr; }       // (no unit lists: the rows are counted only, and the numeric phase emits their columns itself as in the two-call form)
         auto k = spgemm_symbolic_window_kernel<T>;
         G4S_TRY(allow_lds(k, lds));
         hipLaunchKernelGGL(k, grid, dim3(T), lds, s, rows, n, next_row, N2, K, wsplit, arpt, acol, brpt, wcol, row_flop.as<long long>(), nz, poff, pcols, (const int *)nullptr, 0, 0);
@@ -2598,27 +2769,25 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     };
     SortedRows sorted[3];                                          // live until the stream is synchronised below
     int n_sorted = 0;
-    auto window = [&](int threads, const int *rows, int n, const long long *poff, int *pcols, bool longest_first = false) -> int {
+    auto window = [&](int threads, const int *rows, int n, const long long *poff, int *pcols, bool longest_first = false, bool cuts_mode = false) -> int {
         int *next_row = nullptr;
         if (longest_first && n > 1 && !getenv("G4S_SPGEMM_STATIC_ROWS")) {
             SortedRows &sr = sorted[n_sorted++];
             G4S_TRY(sr.build(n, rows, row_flop.as<long long>(), nullptr, INT_MAX, s));
             rows = sr.rows.as<int>(); next_row = sr.counter.as<int>();
         }
-        if (threads == 256) return window_t(std::integral_constant<int, 256>{}, rows, n, poff, pcols, next_row);
-        if (threads == 512) return window_t(std::integral_constant<int, 512>{}, rows, n, poff, pcols, next_row);
-        return window_t(std::integral_constant<int, 1024>{}, rows, n, poff, pcols, next_row);
+        if (threads == 256) return window_t(std::integral_constant<int, 256>{}, rows, n, poff, pcols, next_row, cuts_mode);
+        if (threads == 512) return window_t(std::integral_constant<int, 512>{}, rows, n, poff, pcols, next_row, cuts_mode);
+        return window_t(std::integral_constant<int, 1024>{}, rows, n, poff, pcols, next_row, cuts_mode);
     };
-    const int t_med = shape_of("G4S_SPGEMM_T_SYM_MED", kShapeSymMedium), t_large = shape_of("G4S_SPGEMM_T_SYM_LARGE", kShapeSymLarge),
-              t_win = shape_of("G4S_SPGEMM_T_SYM_WINDOW", 1024);
     if (x_med) { G4S_TRY(window(t_med, rc.list(CLS_MEDIUM), rc.count[CLS_MEDIUM], pre_off, pre_cols, true)); }
     else if (int n = rc.count[CLS_MEDIUM]) {
         auto k = spgemm_symbolic_lds_kernel<256, 256, 16384, false>;
         G4S_TRY(allow_lds(k, sym_lds_bytes(1, 16384)));
         hipLaunchKernelGGL(k, dim3(n), dim3(256), sym_lds_bytes(1, 16384), s, rc.list(CLS_MEDIUM), n, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr, (const int *)nullptr);
     }
-    const bool one_long_launch = x_large && t_large == t_win;   // LARGE and M2 share a shape and their lists are adjacent: one launch
-    if (one_long_launch) { G4S_TRY(window(t_large, rc.list(CLS_LARGE), rc.count[CLS_LARGE] + rc.count[CLS_M2], pre_off, pre_cols, true)); }
+    if (one_long_launch && use_rank) { G4S_TRY(window(t_large, rc.list(CLS_LARGE), n_long, cut_off, cuts, true, true)); }
+    else if (one_long_launch) { G4S_TRY(window(t_large, rc.list(CLS_LARGE), rc.count[CLS_LARGE] + rc.count[CLS_M2], pre_off, pre_cols, true)); }
     else if (x_large) { G4S_TRY(window(t_large, rc.list(CLS_LARGE), rc.count[CLS_LARGE], pre_off, pre_cols, true)); }
     else if (int n = rc.count[CLS_LARGE]) {
         auto k = spgemm_symbolic_lds_kernel<1024, 1024, 32768, true>;
@@ -2636,7 +2805,13 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
         if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s symbolic: %d optimistic tables overflowed, %d window-class rows\n", n_ovf, rc.count[CLS_M2]);
         G4S_TRY(window(1024, ovf_rows.as<int>(), n_ovf, nullptr, nullptr));   // rows of the optimistic table class are not in the scratch
     }
-    if (pre) { pre->complete = pre_off != nullptr && n_ovf == 0 && rc.count[CLS_HUB] == 0 && x_med && x_large; pre->flop = flop; }
+    if (pre) {
+        pre->rank = rank_done; pre->nseg = nseg; pre->bnnz = bnnz; pre->annz = annz;
+        if (rank_done) { pre->d_cut_off = cut_off; pre->d_cuts = cuts; }
+        // complete: every row the numeric WINDOW kernels will take carries its columns (the rows with cuts take the rank kernel and need none)
+        pre->complete = pre_off != nullptr && n_ovf == 0 && rc.count[CLS_HUB] == 0 && x_med && x_large && (!use_rank || rank_done);
+        pre->flop = flop;
+    }
     if (!one_long_launch) G4S_TRY(window(t_win, rc.list(CLS_M2), rc.count[CLS_M2], pre_off, pre_cols, true));
     G4S_HIP_TRY(hipGetLastError());
     // hub rows (flop > 2 M): many workgroups per row on a bitmap in HBM
@@ -2661,7 +2836,15 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
         return g4s::set_error(G4S_ERR_OVERFLOW, "nnz(C) = %lld exceeds the reference's int32 row pointer (mm/inc/define.h:14)", h_total);
     hipLaunchKernelGGL(scan_write_kernel, dim3(nblocks), dim3(256), 0, s, M, nz, block_sums.as<long long>(), crpt);
     G4S_HIP_TRY(hipGetLastError());
+    DevBuf hash_buf;
+    unsigned long long h_hash = 0;
+    if (pre && pre->keep) {                                        // the two-call form: what the numeric call must find unchanged to take this state over
+        G4S_TRY(hash_buf.alloc(sizeof(unsigned long long)));
+        G4S_TRY(enqueue_pattern_hash(M, K, annz, bnnz, arpt, acol, brpt, bcol_caller, crpt, hash_buf.as<unsigned long long>(), s));
+        G4S_HIP_TRY(hipMemcpyAsync(&h_hash, hash_buf.p, sizeof(h_hash), hipMemcpyDeviceToHost, s));
+    }
     G4S_HIP_TRY(hipStreamSynchronize(s));
+    if (pre) pre->key_hash = h_hash;
     t_idle = true;
     dbg.mark("scan");
     return G4S_OK;
@@ -2725,17 +2908,40 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
     if (M == 0) return G4S_OK;
     DbgPhases dbg("numeric");
     ArenaScope arena;
+    // B with unsorted rows: the kernels read a sorted private copy (sort_b_rows) — the symbolic phase's columns and permutation when they were carried over, else made here.
+    // (Done in front of the short-row kernels: every kernel of the phase reads the same B.)
+    DevBuf local_perm, local_bs, local_bv;
+    bool sort_here = false;
+    int bnnz_local = 0;
+    if (!pre) {
+        // the numeric-only call may be handed a B that is not the one a symbolic call checked: the column map and the window kernels index by column id, so the
+        // ids are range-checked here too (the one-shot call checked them in its symbolic phase) — and B's rows are sorted here if they are not
+        G4S_TRY(read_last(brpt, K, &bnnz_local, s));
+        G4S_TRY(check_b(brpt, bcol, K, bnnz_local, N, s, &sort_here));
+        if (sort_here) {
+            G4S_TRY(local_perm.alloc(sizeof(int) * (size_t)bnnz_local)); G4S_TRY(local_bs.alloc(sizeof(int) * (size_t)bnnz_local)); G4S_TRY(local_bv.alloc(sizeof(double) * (size_t)bnnz_local));
+            G4S_TRY(sort_b_rows(K, N, bnnz_local, brpt, bcol, local_perm.as<int>(), s));
+            G4S_TRY(gather_b(bnnz_local, local_perm.as<int>(), bcol, bval, local_bs.as<int>(), local_bv.as<double>(), s));
+            bcol = local_bs.as<int>(); bval = local_bv.as<double>();
+        }
+    }
+    if (pre && pre->b_unsorted) {
+        G4S_TRY(local_bv.alloc(sizeof(double) * (size_t)std::max<long long>(pre->bnnz, 1)));
+        G4S_TRY(gather_b((int)pre->bnnz, pre->b_perm.as<int>(), nullptr, bval, nullptr, local_bv.as<double>(), s));
+        bcol = pre->b_cols_sorted.as<int>(); bval = local_bv.as<double>();
+    }
     // lanes per A-entry are sized from the row's average B-row length; the exact nz of the output row (known here) stands in for
     // the flop count of the symbolic phase (they differ by the row's compression ratio), which saves a pass over A
     DevBuf row_size;
     DevBuf &row_flop = row_size;
     G4S_TRY(row_size.alloc(sizeof(long long) * (size_t)M));
-    hipLaunchKernelGGL(nz_to_ll_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, crpt, row_size.as<long long>());
+    const bool rank = pre && pre->rank && pre->d_cut_off && !getenv("G4S_SPGEMM_NO_RANK");   // the rows with cuts take the rank kernel (spgemm_rank.hpp)
+    hipLaunchKernelGGL(nz_to_ll_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, crpt, rank ? pre->d_cut_off : (const long long *)nullptr, row_size.as<long long>());
     RowClasses rc;
     G4S_TRY(classify_rows(M, row_size.as<long long>(), kNumLimits, 0, rc, s));
     if (getenv("G4S_DEBUG"))
-        fprintf(stderr, "g4s numeric classes: empty %d <=32 %d <=512 %d <=1024 %d <=2048 %d <=4096 %d <=32768 %d hub %d\n", rc.count[CLS_EMPTY], rc.count[CLS_TINY],
-                rc.count[CLS_SMALL], rc.count[CLS_MEDIUM], rc.count[CLS_LARGE], rc.count[CLS_M2], rc.count[CLS_M3], rc.count[CLS_HUB]);
+        fprintf(stderr, "g4s numeric classes: empty %d <=32 %d <=512 %d <=1024 %d <=2048 %d <=4096 %d <=1M %d hub %d rank %d\n", rc.count[CLS_EMPTY], rc.count[CLS_TINY],
+                rc.count[CLS_SMALL], rc.count[CLS_MEDIUM], rc.count[CLS_LARGE], rc.count[CLS_M2], rc.count[CLS_M3], rc.count[CLS_HUB], rc.count[CLS_RANK]);
 
     dbg.mark("classes");
     // rows of at most 512 outputs: one wavefront merges a row (spgemm_small_wave_kernel); a row of more than 512 PRODUCTS (the classes are cut by output length) or
@@ -2763,12 +2969,7 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
     }
     ColumnMap local_map;                                           // see spgemm_symbolic_impl; the one-shot call hands its map over
     if (!pre) {
-        int bnnz = 0;
-        G4S_TRY(read_last(brpt, K, &bnnz, s));
-        // the numeric-only call may be handed a B that is not the one the symbolic call checked: the column map and the window kernels
-        // index by column id, so the ids are range-checked here too (the one-shot call checked them in its symbolic phase)
-        G4S_TRY(check_ids(bcol, bnnz, N, "a column id of B", s));
-        G4S_TRY(build_column_map(N, bnnz, bcol, local_map, s));
+        G4S_TRY(build_column_map(N, bnnz_local, bcol, local_map, s));
     }
     const ColumnMap &cmap = pre ? pre->cmap : local_map;
     const int *wcol = cmap.cols(bcol), *winv = cmap.inverse();
@@ -2969,6 +3170,70 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
     }
     }
     dbg.mark("mid-launch");
+    if (int n = rc.count[CLS_RANK]) {
+        // The rows with cuts (spgemm_rank.hpp), longest first: chunk lists from the cuts, exact splits and unit lists per chunk, then the rank kernel.
+        constexpr int T = kRankT;
+        SortedRows sr;
+        G4S_TRY(sr.build(n, rc.list(CLS_RANK), nullptr, crpt, N, s));
+        const int *rows = sr.rows.as<int>();
+        auto mk = [&]() { ct_keep.push_back(std::make_unique<DevBuf>()); return ct_keep.back().get(); };
+        DevBuf *tasks = mk(), *toff = mk(), *items = mk(), *ioff = mk(), *nch = mk(), *choff = mk(), *chunks = mk(), *ctoff = mk(), *ctb = mk(), *ucnt = mk(), *uoff = mk(), *ud = mk(), *rmeta = mk();
+        G4S_TRY(tasks->alloc(sizeof(long long) * ((size_t)n + 1))); G4S_TRY(toff->alloc(sizeof(long long) * ((size_t)n + 1)));
+        G4S_TRY(items->alloc(sizeof(long long) * ((size_t)n + 1))); G4S_TRY(ioff->alloc(sizeof(long long) * ((size_t)n + 1)));
+        G4S_TRY(nch->alloc(sizeof(int) * ((size_t)n + 1))); G4S_TRY(choff->alloc(sizeof(int) * ((size_t)n + 1)));
+        G4S_TRY(ctoff->alloc(sizeof(long long) * ((size_t)n + 1)));
+        const int nseg = pre->nseg;
+        hipLaunchKernelGGL(rank_chunks_kernel<false>, dim3((n + 256) / 256), dim3(256), 0, s, n, rows, arpt, crpt, pre->d_cut_off, pre->d_cuts, nseg, tasks->as<long long>(), items->as<long long>(),
+                           nch->as<int>(), (const int *)nullptr, (RankChunk *)nullptr);
+        G4S_TRY(g4s::prims::exclusive_scan(tasks->as<long long>(), toff->as<long long>(), (long long)n + 1, s));
+        G4S_TRY(g4s::prims::exclusive_scan(items->as<long long>(), ioff->as<long long>(), (long long)n + 1, s));
+        G4S_TRY(g4s::prims::exclusive_scan(nch->as<int>(), choff->as<int>(), (long long)n + 1, s));
+        long long totals[2] = {0, 0};
+        int nchunks = 0;
+        G4S_HIP_TRY(hipMemcpyAsync(&totals[0], toff->as<long long>() + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+        G4S_HIP_TRY(hipMemcpyAsync(&totals[1], ioff->as<long long>() + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+        G4S_HIP_TRY(hipMemcpyAsync(&nchunks, choff->as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, s));
+        G4S_HIP_TRY(hipStreamSynchronize(s));
+        const long long ntask = totals[0], nitem = totals[1], nct = nitem - ntask;
+        if (ntask <= 0 || nitem <= 0 || nitem > (1ll << 28) || nchunks <= 0)
+            return g4s::set_error(G4S_ERR_INVALID, "SpGEMM: the chunk lists of the carried symbolic state do not fit this product (%lld tasks, %lld items, %d chunks)", ntask, nitem, nchunks);
+        const long long ubound = (pre->flop >= 0 ? pre->flop : 0) / 64 + nitem + 1;
+        G4S_REQUIRE(pre->flop >= 0 && ubound <= (1ll << 28), "unit list of the rank launch past its cap");
+        G4S_TRY(chunks->alloc(sizeof(RankChunk) * (size_t)nchunks));
+        G4S_TRY(ctb->alloc(sizeof(int) * (size_t)std::max<long long>(nct, 1)));
+        G4S_TRY(ucnt->alloc(sizeof(int) * ((size_t)nitem + 1))); G4S_TRY(uoff->alloc(sizeof(int) * ((size_t)nitem + 1)));
+        G4S_TRY(ud->alloc(sizeof(UnitDesc) * (size_t)ubound));
+        G4S_TRY(rmeta->alloc(sizeof(RankRowMeta) * (size_t)n));
+        hipLaunchKernelGGL(rank_chunks_kernel<true>, dim3((n + 256) / 256), dim3(256), 0, s, n, rows, arpt, crpt, pre->d_cut_off, pre->d_cuts, nseg, (long long *)nullptr, (long long *)nullptr,
+                           (int *)nullptr, (const int *)choff->as<int>(), chunks->as<RankChunk>());
+        hipLaunchKernelGGL(diff_ll_kernel, dim3((n + 256) / 256), dim3(256), 0, s, n + 1, ioff->as<long long>(), toff->as<long long>(), ctoff->as<long long>());
+        if (nct > 0)
+            hipLaunchKernelGGL(chunk_splits_kernel, dim3((unsigned)((nct + 255) / 256)), dim3(256), 0, s, nct, n, rows, K, N2, wsplit, arpt, acol, brpt, wcol, crpt, (const long long *)nullptr, (const int *)nullptr,
+                               (const int *)nullptr, kRankChunk, ctoff->as<long long>(), ctb->as<int>(), (const int *)choff->as<int>(), (const RankChunk *)chunks->as<RankChunk>());
+        const unsigned tgrid = (unsigned)((ntask + 255) / 256);
+        hipLaunchKernelGGL(unit_task_kernel<false>, dim3(tgrid), dim3(256), 0, s, ntask, n, rows, toff->as<long long>(), ioff->as<long long>(), arpt, acol, aval, brpt, wcol, crpt,
+                           (const long long *)nullptr, (const int *)nullptr, (const int *)nullptr, kRankChunk, ctb->as<int>(), ucnt->as<int>(), (const int *)nullptr, (UnitDesc *)nullptr, 1, (const int *)choff->as<int>());
+        G4S_TRY(g4s::prims::exclusive_scan(ucnt->as<int>(), uoff->as<int>(), nitem + 1, s));
+        hipLaunchKernelGGL(unit_task_kernel<true>, dim3(tgrid), dim3(256), 0, s, ntask, n, rows, toff->as<long long>(), ioff->as<long long>(), arpt, acol, aval, brpt, wcol, crpt,
+                           (const long long *)nullptr, (const int *)nullptr, (const int *)nullptr, kRankChunk, ctb->as<int>(), (int *)nullptr, (const int *)uoff->as<int>(), ud->as<UnitDesc>(), 1, (const int *)choff->as<int>());
+        hipLaunchKernelGGL(rank_row_meta_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, rows, arpt, crpt, (const long long *)ioff->as<long long>(), (const int *)uoff->as<int>(), (const int *)choff->as<int>(),
+                           (const RankChunk *)chunks->as<RankChunk>(), rmeta->as<RankRowMeta>());
+        constexpr size_t lds = sizeof(int) * (3 * (size_t)kRankChunk + 2 * (size_t)kRankWords + 64);
+        auto k = spgemm_numeric_rank_kernel<T>;
+        G4S_TRY(allow_lds(k, lds));
+        DevBuf *bpack = mk();
+#if G4S_RANK_PACK
+        G4S_REQUIRE(pre->bnnz >= 0, "carried state without nnz(B)");
+        G4S_TRY(bpack->alloc(sizeof(BPack) * (size_t)std::max<long long>(pre->bnnz, 1)));
+        if (pre->bnnz > 0)
+            hipLaunchKernelGGL(pack_b_kernel, dim3((unsigned)((pre->bnnz + 255) / 256)), dim3(256), 0, s, pre->bnnz, wcol, bcol, bval, bpack->as<BPack>());
+#endif
+        hipLaunchKernelGGL(k, dim3(big_grid(n, 1024 / T)), dim3(T), lds, s, n, sr.counter.as<int>(), wcol, winv, bval, ccol, cval, (const long long *)ioff->as<long long>(), (const int *)uoff->as<int>(),
+                           (const UnitDesc *)ud->as<UnitDesc>(), (const RankRowMeta *)rmeta->as<RankRowMeta>(), (const RankChunk *)chunks->as<RankChunk>(), (const BPack *)bpack->as<BPack>());
+        G4S_HIP_TRY(hipGetLastError());
+        // (the sorted list and the counter are released in stream order — or with the call's arena: no wait here)
+    }
+    dbg.mark("rank-launch");
     if (int n = rc.count[CLS_M3]) {
         // the class spans 4 K … 128 K entries: its short rows go to the many-workgroups shape, the long ones keep 1 024 threads
         if (t_m3 != 1024 && m3_cut > 0) { G4S_TRY(big(t_m3, rc.list(CLS_M3), n, 0, m3_cut)); G4S_TRY(big(1024, rc.list(CLS_M3), n, m3_cut, INT_MAX)); }
@@ -3007,6 +3272,23 @@ G4S_API g4s_status g4s_spgemm_numeric(int32_t M, int32_t K, int32_t N,
         if (g_carried.pre && g_carried.M == M && g_carried.K == K && g_carried.N == N && g_carried.arpt == arpt && g_carried.acol == acol && g_carried.brpt == brpt &&
             g_carried.bcol == bcol && g_carried.crpt == crpt)
             pre = g_carried.pre;
+    }
+    if (pre) {
+        // The same pointers do not make it the same product: a caller may have refilled the buffers with another pattern, or brought its own crpt. The
+        // state is taken over only while the five index arrays still hash to what the symbolic call saw (one pass over them, ≈ 30 µs on configs[2], one host wait);
+        // otherwise this is an ordinary numeric call that works everything out again.
+        hipStream_t s = g4s::as_stream(stream);
+        unsigned long long *d_hash = nullptr, h_hash = 0;
+        G4S_TRY(g4s::scratch_alloc(reinterpret_cast<void **>(&d_hash), sizeof(unsigned long long), s));
+        int st = enqueue_pattern_hash(M, K, pre->annz, pre->bnnz, arpt, acol, brpt, bcol, crpt, d_hash, s);
+        if (st == G4S_OK && (hipMemcpyAsync(&h_hash, d_hash, sizeof(h_hash), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess))
+            st = g4s::set_error(G4S_ERR_HIP, "g4s_spgemm_numeric: reading the pattern hash failed");
+        g4s::scratch_free(d_hash, s);
+        G4S_TRY(st);
+        if (h_hash != pre->key_hash) {
+            if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s numeric: the index arrays changed since the symbolic call — its carried state is not used\n");
+            pre.reset();
+        }
     }
     return spgemm_numeric_impl(M, K, N, arpt, acol, aval, brpt, bcol, bval, crpt, ccol, cval, flags, stream, pre.get());
 }
@@ -3142,8 +3424,8 @@ G4S_API g4s_status g4s_spgemm_csr_i32_f64(const int32_t *arpt, const int32_t *ac
 #ifdef G4S_PROFILE_BIG
 extern "C" __attribute__((visibility("default"))) int g4s_debug_big_prof(unsigned long long *out, int reset)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_prof), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_big_prof), z, sizeof(z)) != hipSuccess) return 1; }
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_prof), sizeof(unsigned long long) * 48) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[48] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_big_prof), z, sizeof(z)) != hipSuccess) return 1; }
     return 0;
 }
 #endif

@@ -14,12 +14,12 @@
 // ≈62 B/nonzero of 128-byte line fetches.
 // The cell (column band c, row band r) holds its entries in CSR order (a stable regrouping), so the micro-runs of a cell are
 // numbered consecutively on both sides and one per-cell offset maps a producer micro-run to its consumer slot.
-// The regrouping is built once per matrix (g4s_csr_create) with rocPRIM's radix sort and scan (called directly); the values are stored a second
-// time in producer order. Sums are accumulated by LDS atomics: equal to the oracle within the fp64 tolerance, not bit for bit,
+// The regrouping is built once per matrix (g4s_csr_create) with the library's own radix sort and scan (prims.hpp; round 5 — rocPRIM was the last vendor-library
+// call in the product); the values are stored a second time in producer order. Sums are accumulated by LDS atomics: equal to the oracle within the fp64 tolerance, not bit for bit,
 // and the last bits may differ from run to run.
 #include "common.hpp"
 #include "spmv_pb.hpp"
-#include <rocprim/rocprim.hpp>
+#include "prims.hpp"
 #include <algorithm>
 #include <memory>
 #include <vector>
@@ -74,6 +74,7 @@ struct DevBuf {
 };
 
 inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 65536 ? 65536 : g)); }
+inline int prims_bits(int max_value) { int b = 1; while (b < 31 && (max_value >> b)) ++b; return b; }   // significant bits of the largest key
 
 // ================================================================================================ plan construction kernels
 // Hot column bands. In a power-law graph a few thousand columns hold a third of the nonzeros, but their ids are scattered over
@@ -82,9 +83,37 @@ inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g
 // now merges all its entries of one hot band into one micro-run), the rest keep their natural band. On C2 the distinct
 // (row, band) pairs per nonzero drop from 0.512 to 0.324 (tools/hot_band_probe.py). colmap[col] = (band' << 14) | local column;
 // the x values of the hot columns are gathered into a dense hot_x (H·128 KiB) at the start of every product.
-__global__ void pb_col_degree_kernel(long long nnz, const int *__restrict__ colids, int *__restrict__ deg)
+// (Round 5. The first form was a bare atomicAdd(&deg[colids[k]], 1) per nonzero: 9.4 ms of the 51 ms plan on configs[1] — a power-law column distribution puts
+// 10^5 increments on each of a few addresses, and same-address atomics serialise in L2. Now every workgroup counts its contiguous share of the entries through
+// a small direct-mapped table in LDS: a column that owns its slot is counted there (the popular columns claim theirs within the first few hundred entries), a
+// column that finds its slot taken by another goes to HBM as before — those are the unpopular ones, spread over millions of addresses — and the table is
+// flushed with one atomic per used slot. Same counts, whatever the interleaving.)
+constexpr int kDegSlots = 4096, kDegBlocks = 2048;
+__global__ __launch_bounds__(256) void pb_col_degree_kernel(long long nnz, const int *__restrict__ colids, int *__restrict__ deg)
 {
-    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long long)gridDim.x * blockDim.x) atomicAdd(&deg[colids[k]], 1);
+    __shared__ int s_key[kDegSlots], s_cnt[kDegSlots];
+    for (int i = threadIdx.x; i < kDegSlots; i += 256) { s_key[i] = -1; s_cnt[i] = 0; }
+    __syncthreads();
+    const long long per = (nnz + gridDim.x - 1) / gridDim.x, k0 = per * blockIdx.x, k1 = k0 + per < nnz ? k0 + per : nnz;
+    for (long long k = k0 + threadIdx.x; k < k1; k += 256) {
+        const int c = colids[k];
+        const int h = (int)(((unsigned)c * 2654435761u) >> 20);      // 12 bits
+        int owner = s_key[h];
+        if (owner == -1) { const int old = atomicCAS(&s_key[h], -1, c); owner = old == -1 ? c : old; }
+        if (owner == c) atomicAdd(&s_cnt[h], 1);
+        else atomicAdd(&deg[c], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kDegSlots; i += 256)
+        if (s_cnt[i]) atomicAdd(&deg[s_key[i]], s_cnt[i]);
+}
+__global__ __launch_bounds__(256) void pb_max_kernel(int n, const int *__restrict__ v, int *__restrict__ out)
+{
+    int m = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = max(m, v[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 __global__ void pb_iota_kernel(int n, int *__restrict__ v)
 {
@@ -105,9 +134,10 @@ __global__ void pb_colmap_hot_kernel(int nhot, const int *__restrict__ order, un
     if (r < nhot) colmap[order[r]] = (unsigned)r;                   // band' = r >> 14 < H, local = r & 16383
 }
 
-// key = (column band << bits) | row band; rowid[k] = row of CSR entry k; idx[k] = k
+// The regrouping key of CSR entry k is (column band, row band). The entries arrive in CSR order — their row band never decreases — so a STABLE sort by column band
+// alone gives the (column band, row band) order: key[k] = CB − 1 − band for prims' descending sort; rowid[k] = row of entry k; idx[k] = k.
 __global__ void pb_keys_kernel(int rows, long long nnz, const int *__restrict__ rowptr, const int *__restrict__ colids, const unsigned *__restrict__ colmap,
-                               int band_key_bits, unsigned *__restrict__ key, int *__restrict__ rowid, unsigned *__restrict__ idx)
+                               int CB, int *__restrict__ key, int *__restrict__ rowid, int *__restrict__ idx)
 {
     for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long long)gridDim.x * blockDim.x) {
         int lo = 0, hi = rows;                       // last r with rowptr[r] <= k
@@ -115,10 +145,23 @@ __global__ void pb_keys_kernel(int rows, long long nnz, const int *__restrict__ 
             const int mid = lo + ((hi - lo) >> 1);
             if (rowptr[mid] <= k) lo = mid; else hi = mid;
         }
-        key[k] = ((colmap[colids[k]] >> kBandBits) << band_key_bits) | ((unsigned)lo >> kBandBits);
+        key[k] = CB - 1 - (int)(colmap[colids[k]] >> kBandBits);
         rowid[k] = lo;
-        idx[k] = (unsigned)k;
+        idx[k] = (int)k;
     }
+}
+// the full key of every sorted position: (column band << bits) | row band
+__global__ void pb_full_keys_kernel(long long nnz, const int *__restrict__ sorted_ckey, const int *__restrict__ perm, const int *__restrict__ rowid, int CB, int band_key_bits,
+                                    unsigned *__restrict__ key_s)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (long long)gridDim.x * blockDim.x)
+        key_s[i] = ((unsigned)(CB - 1 - sorted_ckey[i]) << band_key_bits) | ((unsigned)rowid[perm[i]] >> kBandBits);
+}
+// the windows of the locality probe (pb_should_use), gathered into one buffer: window w = W consecutive column ids from position w·stride on
+__global__ void pb_sample_kernel(int W, int S, long long stride, const int *__restrict__ colids, int *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < W * S) out[i] = colids[(long long)(i / W) * stride + (i % W)];
 }
 
 // start[q] = first sorted position whose key >= key(q), q = c·RB + r; start[ncells] = nnz
@@ -487,13 +530,16 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
             G4S_TRY(deg.alloc(sizeof(int) * (size_t)cols)); G4S_TRY(deg_s.alloc(sizeof(int) * (size_t)cols));
             G4S_TRY(order_in.alloc(sizeof(int) * (size_t)cols)); G4S_TRY(order.alloc(sizeof(int) * (size_t)cols));
             G4S_HIP_TRY(hipMemset(deg.p, 0, deg.bytes));
-            hipLaunchKernelGGL(pb_col_degree_kernel, dim3(grid_for(nnz)), dim3(256), 0, nullptr, nnz, d_colids, deg.as<int>());
+            hipLaunchKernelGGL(pb_col_degree_kernel, dim3((unsigned)std::min<long long>(kDegBlocks, (nnz + 255) / 256)), dim3(256), 0, nullptr, nnz, d_colids, deg.as<int>());
             hipLaunchKernelGGL(pb_iota_kernel, dim3((cols + 255) / 256), dim3(256), 0, nullptr, cols, order_in.as<int>());
             G4S_HIP_TRY(hipGetLastError());
-            size_t tb = 0;
-            G4S_HIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, tb, deg.as<int>(), deg_s.as<int>(), order_in.as<int>(), order.as<int>(), (size_t)cols, 0, 32, nullptr));
-            G4S_TRY(tmp0.alloc(tb));
-            G4S_HIP_TRY(rocprim::radix_sort_pairs_desc(tmp0.p, tb, deg.as<int>(), deg_s.as<int>(), order_in.as<int>(), order.as<int>(), (size_t)cols, 0, 32, nullptr));
+            int *d_max = nullptr, h_max = 0;                        // the largest degree bounds the key bits of the ranking sort
+            G4S_TRY(tmp0.alloc(sizeof(int) * (2 * (size_t)cols + 1)));
+            d_max = tmp0.as<int>() + 2 * (size_t)cols;
+            G4S_HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(int), nullptr));
+            hipLaunchKernelGGL(pb_max_kernel, dim3(std::min(grid_for(cols), 1024)), dim3(256), 0, nullptr, cols, deg.as<int>(), d_max);
+            G4S_HIP_TRY(hipMemcpy(&h_max, d_max, sizeof(int), hipMemcpyDeviceToHost));
+            G4S_TRY(prims::sort_pairs_descending(deg.as<int>(), order_in.as<int>(), deg_s.as<int>(), order.as<int>(), tmp0.as<int>(), tmp0.as<int>() + cols, cols, prims_bits(h_max), nullptr));
             std::vector<int> top((size_t)Hmax * kBand);
             G4S_HIP_TRY(hipMemcpy(top.data(), deg_s.p, sizeof(int) * top.size(), hipMemcpyDeviceToHost));
             if (want > 0) H = std::min(want, Hmax);
@@ -531,19 +577,21 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     const long long ncells = (long long)CB * RB;
 
     // 1. regroup: stable sort of the CSR entries by (column band, row band)
-    DevBuf key, key_s, idx, perm, rowid, tmp, startP;
+    DevBuf key, key_s, idx, perm, rowid, startP;
     const size_t n4 = sizeof(unsigned) * (size_t)nnz;
     G4S_TRY(key.alloc(n4)); G4S_TRY(key_s.alloc(n4)); G4S_TRY(idx.alloc(n4)); G4S_TRY(perm.alloc(n4)); G4S_TRY(rowid.alloc(n4));
-    hipLaunchKernelGGL(pb_keys_kernel, dim3(grid_for(nnz)), dim3(256), 0, nullptr, rows, nnz, d_rowptr, d_colids, colmap.as<unsigned>(), bits, key.as<unsigned>(),
-                       rowid.as<int>(), idx.as<unsigned>());
+    if (nnz >= (1ll << 31)) return set_error(G4S_ERR_UNSUPPORTED, "pb_build: more than 2^31 - 1 nonzeros");
+    hipLaunchKernelGGL(pb_keys_kernel, dim3(grid_for(nnz)), dim3(256), 0, nullptr, rows, nnz, d_rowptr, d_colids, colmap.as<unsigned>(), CB, key.as<int>(),
+                       rowid.as<int>(), idx.as<int>());
     G4S_HIP_TRY(hipGetLastError());
-    size_t tmp_bytes = 0;
-    G4S_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key.as<unsigned>(), key_s.as<unsigned>(), idx.as<unsigned>(), perm.as<unsigned>(),
-                                             (size_t)nnz, 0, 2 * bits, nullptr));
-    G4S_TRY(tmp.alloc(tmp_bytes));
-    G4S_HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, key.as<unsigned>(), key_s.as<unsigned>(), idx.as<unsigned>(), perm.as<unsigned>(),
-                                             (size_t)nnz, 0, 2 * bits, nullptr));
-    G4S_HIP_TRY(hipDeviceSynchronize());
+    {
+        DevBuf ckey_s, tk, tv;                                      // sorted band keys, the sort's ping-pong partners
+        G4S_TRY(ckey_s.alloc(n4)); G4S_TRY(tk.alloc(n4)); G4S_TRY(tv.alloc(n4));
+        G4S_TRY(prims::sort_pairs_descending(key.as<int>(), idx.as<int>(), ckey_s.as<int>(), perm.as<int>(), tk.as<int>(), tv.as<int>(), (int)nnz, prims_bits(CB - 1), nullptr));
+        hipLaunchKernelGGL(pb_full_keys_kernel, dim3(grid_for(nnz)), dim3(256), 0, nullptr, nnz, ckey_s.as<int>(), perm.as<int>(), rowid.as<int>(), CB, bits, key_s.as<unsigned>());
+        G4S_HIP_TRY(hipGetLastError());
+        G4S_HIP_TRY(hipDeviceSynchronize());
+    }
     key.release(); idx.release();
     G4S_TRY(startP.alloc(sizeof(int) * (size_t)(ncells + 1)));
     hipLaunchKernelGGL(pb_cell_starts_kernel, dim3(grid_for(ncells + 1)), dim3(256), 0, nullptr, nnz, key_s.as<unsigned>(), CB, RB, bits, startP.as<int>());
@@ -595,9 +643,7 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     G4S_HIP_TRY(hipMemset(counts.p, 0, counts.bytes));
     hipLaunchKernelGGL(pb_span_heads_kernel, dim3(grid_for(nspans)), dim3(256), 0, nullptr, nspans, t_row.as<int>(), t_cell.as<int>(), P->masks.as<unsigned char>(), counts.as<int>());
     G4S_HIP_TRY(hipGetLastError());
-    G4S_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, counts.as<int>(), P->mbase.as<int>(), 0, (size_t)nspans + 1, rocprim::plus<int>(), nullptr));
-    G4S_TRY(tmp.alloc(tmp_bytes));
-    G4S_HIP_TRY(rocprim::exclusive_scan(tmp.p, tmp_bytes, counts.as<int>(), P->mbase.as<int>(), 0, (size_t)nspans + 1, rocprim::plus<int>(), nullptr));
+    G4S_TRY(prims::exclusive_scan(counts.as<int>(), P->mbase.as<int>(), nspans + 1, nullptr));
 
     // 4. micro-run index at every cell start → consumer layout (host): row band segments at multiples of 4
     std::vector<int> span_of_cell((size_t)ncells + 1), mstart((size_t)ncells + 1);
@@ -715,18 +761,20 @@ bool pb_should_use(int rows, int cols, long long nnz, const int *d_colids)
     (void)rows;
     if ((long long)cols * 8 < (8ll << 20) || nnz < (4ll << 20)) return false;   // x within ~2 L2s: the gathers mostly hit (a 15 MB x still ran 2.3× faster blocked)
     const int W = 2048, S = 64;
-    std::vector<int> h(W);
+    // (one gather kernel and one copy: the 64 separate 8 KB copies of the first form cost a millisecond of round trips)
+    DevBuf d_sample;
+    if (d_sample.alloc(sizeof(int) * (size_t)W * S) != G4S_OK) return false;
+    hipLaunchKernelGGL(pb_sample_kernel, dim3((W * S + 255) / 256), dim3(256), 0, nullptr, W, S, (nnz - W) / S, d_colids, d_sample.as<int>());
+    std::vector<int> all((size_t)W * S);
+    if (hipMemcpy(all.data(), d_sample.p, sizeof(int) * all.size(), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return false; }
     double ratio = 0.0;
-    int used = 0;
     for (int sidx = 0; sidx < S; ++sidx) {
-        const long long k0 = (nnz - W) / S * sidx;
-        if (hipMemcpy(h.data(), d_colids + k0, sizeof(int) * W, hipMemcpyDeviceToHost) != hipSuccess) return false;
-        for (auto &c : h) c >>= 4;
-        std::sort(h.begin(), h.end());
-        ratio += (double)(std::unique(h.begin(), h.end()) - h.begin()) / W;
-        ++used;
+        int *h = all.data() + (size_t)sidx * W;
+        for (int i = 0; i < W; ++i) h[i] >>= 4;
+        std::sort(h, h + W);
+        ratio += (double)(std::unique(h, h + W) - h) / W;
     }
-    return used > 0 && ratio / used > 0.5;
+    return ratio / S > 0.5;
 }
 
 } // namespace g4s

@@ -411,6 +411,14 @@ __global__ __launch_bounds__(kThreads) void finish_raw_kernel(const double *__re
     for (int k = 0; k < 3; ++k) r[k] = block_sum(part[k * kBlocks + threadIdx.x], sh);
     if (threadIdx.x == 0) { raw[0] = r[0]; raw[1] = r[1]; raw[2] = r[2]; }
 }
+__global__ __launch_bounds__(kThreads) void finish_raw6_kernel(const double *__restrict__ part, double *__restrict__ raw)
+{
+    __shared__ double sh[4];
+    for (int k = 0; k < 6; ++k) {
+        const double r = block_sum(part[k * kBlocks + threadIdx.x], sh);
+        if (threadIdx.x == 0) raw[k] = r;
+    }
+}
 template <typename E>
 __global__ void scalar_kernel(E ep) { if (threadIdx.x == 0 && blockIdx.x == 0) ep(); }
 } // namespace
@@ -429,20 +437,31 @@ G4S_API g4s_status g4s_stokes_uzawa_cg_dist(g4s_spmv_dist_t K, g4s_spmv_dist_t D
     hipStream_t s = g4s::as_stream(stream);
     const size_t nq = ((size_t)neq * 8 + 255) / 256 * 256, np = ((size_t)nel * 8 + 255) / 256 * 256;
     Scratch scr; scr.s = s;
-    G4S_TRY(g4s::scratch_alloc(&scr.p, 3 * nq + 6 * np + sizeof(double) * (3 * kBlocks + 32), s));
+    G4S_TRY(g4s::scratch_alloc(&scr.p, 3 * nq + 6 * np + sizeof(double) * (6 * kBlocks + 32), s));
     char *base = static_cast<char *>(scr.p);
     double *F = reinterpret_cast<double *>(base), *u1 = reinterpret_cast<double *>(base + nq), *tmp = reinterpret_cast<double *>(base + 2 * nq);
     double *r1 = reinterpret_cast<double *>(base + 3 * nq), *r2 = reinterpret_cast<double *>(base + 3 * nq + np),
            *z1 = reinterpret_cast<double *>(base + 3 * nq + 2 * np), *s1 = reinterpret_cast<double *>(base + 3 * nq + 3 * np),
            *s2 = reinterpret_cast<double *>(base + 3 * nq + 4 * np), *Fp = reinterpret_cast<double *>(base + 3 * nq + 5 * np);
-    double *part = reinterpret_cast<double *>(base + 3 * nq + 6 * np), *sc = part + 3 * kBlocks, *raw = sc + 16;
-    enum { R1Z1, R0Z0, DELTA, ALPHA, VDOTV, U1DOTU1, PDOTP, S2S2, DIVN, NSC };
+    double *part = reinterpret_cast<double *>(base + 3 * nq + 6 * np), *sc = part + 6 * kBlocks, *raw = sc + 16;
+    // Round 5: <r1, z1> of the NEXT outer iteration is formed in the closing reduction of the current one (r2 is final there), so the two slots of R1Z1 / DELTA
+    // alternate by the iteration's parity — the closing step may run twice (a speculation that did not hold) and must find the current pair untouched.
+    enum { R1Z1_0, R1Z1_1, DELTA_0, DELTA_1, ALPHA, VDOTV, U1DOTU1, PDOTP, S2S2, DIVN, NSC };
     double hsc[NSC] = {0};
     // a reduction: local partial sums in the fixed two-level shape → three raw sums → summed over the ranks → the derived scalars
     auto reduce = [&](int n, auto f, auto ep) -> int {
         hipLaunchKernelGGL(map_sum_kernel, dim3(kBlocks), dim3(kThreads), 0, s, n, f, part);
         hipLaunchKernelGGL(finish_raw_kernel, dim3(1), dim3(kThreads), 0, s, part, raw);
         G4S_TRY(tr->allreduce_sum_f64(tr->ctx, raw, 3, stream));
+        hipLaunchKernelGGL(scalar_kernel, dim3(1), dim3(64), 0, s, ep);
+        return G4S_OK;
+    };
+    // the same with six sums in ONE all-reduce message: everything an outer iteration can sum once its new V, P and r are known (round 5: was two reductions
+    // at its end and one at the head of the next — three all-reduces, now one; Global_operations.c:534-656 reduces each norm on its own)
+    auto reduce6 = [&](int n, auto f, auto ep) -> int {
+        hipLaunchKernelGGL(map_sum6_kernel, dim3(kBlocks), dim3(kThreads), 0, s, n, f, part);
+        hipLaunchKernelGGL(finish_raw6_kernel, dim3(1), dim3(kThreads), 0, s, part, raw);
+        G4S_TRY(tr->allreduce_sum_f64(tr->ctx, raw, 6, stream));
         hipLaunchKernelGGL(scalar_kernel, dim3(1), dim3(64), 0, s, ep);
         return G4S_OK;
     };
@@ -495,12 +514,16 @@ G4S_API g4s_status g4s_stokes_uzawa_cg_dist(g4s_spmv_dist_t K, g4s_spmv_dist_t D
 
     G4S_TRY(div_u(V, r1));
     G4S_HIP_TRY(hipMemsetAsync(sc, 0, sizeof(double) * NSC, s));
-    G4S_TRY(reduce(std::max(neq, nel), [=] __device__(int i) {
-        Sum3 o{0.0, 0.0, 0.0};
-        if (i < neq) o.a = V[i] * V[i] * vmass[i];
-        if (i < nel) { o.b = r1[i] * r1[i] / area[i]; o.c = P[i] * P[i] * area[i]; }
+    G4S_TRY(reduce6(std::max(neq, nel), [=] __device__(int i) {
+        Sum6 o{{0.0, 0.0, 0.0, 0.0, 0.0, 0.0}};
+        if (i < neq) o.v[0] = V[i] * V[i] * vmass[i];
+        if (i < nel) {
+            o.v[1] = r1[i] * r1[i] / area[i]; o.v[2] = P[i] * P[i] * area[i];
+            const double z = BPI[i] * r1[i];                          // z1 = BPI·r1 and <r1, z1> of the first outer iteration (:263-273)
+            z1[i] = z; o.v[3] = r1[i] * z;
+        }
         return o;
-    }, [=] __device__() { sc[VDOTV] = raw[0]; sc[DIVN] = raw[1]; sc[PDOTP] = raw[2]; }));
+    }, [=] __device__() { sc[VDOTV] = raw[0]; sc[DIVN] = raw[1]; sc[PDOTP] = raw[2]; sc[R1Z1_0] = raw[3]; }));
     G4S_TRY(fetch());
     double vdotv = hsc[VDOTV] / volume, pdotp = hsc[PDOTP] / volume;
     double incompressibility = std::sqrt(hsc[DIVN] / volume / (1e-32 + vdotv));
@@ -515,10 +538,10 @@ G4S_API g4s_status g4s_stokes_uzawa_cg_dist(g4s_spmv_dist_t K, g4s_spmv_dist_t D
         const bool keep = prm->check_continuity_convergence ? (incompressibility > prm->imp || converging < 2)
                                                             : (incompressibility > prm->imp && converging < 2);   // keep_iterating :150-162
         if (!(count < prm->steps_max && keep)) break;              // every rank holds the same all-reduced scalars: the same verdict everywhere
-        G4S_TRY(reduce(nel, [=] __device__(int i) { const double z = BPI[i] * r1[i]; z1[i] = z; return Sum3{r1[i] * z, 0.0, 0.0}; },
-                       [=] __device__() { sc[R1Z1] = raw[0]; sc[DELTA] = raw[0] / sc[R0Z0]; }));
+        const int cur = count & 1, nxt = cur ^ 1;                  // this iteration's <r1, z1> and δ sit in slot `cur` (written by the closing reduction of the previous one)
+        if (hsc[R1Z1_0 + cur] == 0.0) return g4s::set_error(G4S_ERR_INVALID, "g4s_stokes_uzawa_cg_dist: <r1, z1> = 0 at the head of iteration %d (the source asserts)", count);
         const bool first = count == 0;
-        each(nel, [=] __device__(int i) { s2[i] = first ? z1[i] : z1[i] + sc[DELTA] * s1[i]; });
+        each(nel, [=] __device__(int i) { s2[i] = first ? z1[i] : z1[i] + sc[DELTA_0 + cur] * s1[i]; });
         G4S_TRY(grad_p(s2, tmp));
         // K·u1 = grad(s2): the solve's first batch is only enqueued (products, exchanges and all-reduces included — with an RCCL transport none of them
         // waits for the host); the rest of the outer iteration goes behind it at once and ONE synchronisation brings back the solve's state and the
@@ -536,21 +559,27 @@ G4S_API g4s_status g4s_stokes_uzawa_cg_dist(g4s_spmv_dist_t K, g4s_spmv_dist_t D
         }
         auto rest_of_iteration = [&]() -> int {
             G4S_TRY(div_u(u1, Fp));
-            G4S_TRY(reduce(nel, [=] __device__(int i) { return Sum3{s2[i] * Fp[i], 0.0, 0.0}; }, [=] __device__() { sc[ALPHA] = sc[R1Z1] / raw[0]; }));
+            G4S_TRY(reduce(nel, [=] __device__(int i) { return Sum3{s2[i] * Fp[i], 0.0, 0.0}; }, [=] __device__() { sc[ALPHA] = sc[R1Z1_0 + cur] / raw[0]; }));
             each(std::max(nel, neq), [=] __device__(int i) {
                 const double alpha = sc[ALPHA];
                 if (i < nel) { r2[i] = r1[i] - alpha * Fp[i]; Pn[i] = Pc[i] + alpha * s2[i]; }
                 if (i < neq) Vn[i] = Vc[i] - alpha * u1[i];
             });
-            G4S_TRY(div_u(Vn, z1));
-            G4S_TRY(reduce(std::max(neq, nel), [=] __device__(int i) {
-                Sum3 o{0.0, 0.0, 0.0};
-                if (i < neq) { o.a = Vn[i] * Vn[i] * vmass[i]; o.b = u1[i] * u1[i] * vmass[i]; }
-                if (i < nel) o.c = Pn[i] * Pn[i] * area[i];
+            G4S_TRY(div_u(Vn, Fp));                                 // (Fp = D·u1 has gone into r2: the buffer is free)
+            // the five norms of this iteration and, since r2 is final, z1 = BPI·r2 and <r1, z1> of the NEXT one — one all-reduce message of six sums
+            G4S_TRY(reduce6(std::max(neq, nel), [=] __device__(int i) {
+                Sum6 o{{0.0, 0.0, 0.0, 0.0, 0.0, 0.0}};
+                if (i < neq) { o.v[0] = Vn[i] * Vn[i] * vmass[i]; o.v[1] = u1[i] * u1[i] * vmass[i]; }
+                if (i < nel) {
+                    o.v[2] = Pn[i] * Pn[i] * area[i]; o.v[3] = s2[i] * s2[i] * area[i]; o.v[4] = Fp[i] * Fp[i] / area[i];
+                    const double z = BPI[i] * r2[i];
+                    z1[i] = z; o.v[5] = r2[i] * z;
+                }
                 return o;
-            }, [=] __device__() { sc[VDOTV] = raw[0]; sc[U1DOTU1] = raw[1]; sc[PDOTP] = raw[2]; }));
-            G4S_TRY(reduce(nel, [=] __device__(int i) { return Sum3{s2[i] * s2[i] * area[i], z1[i] * z1[i] / area[i], 0.0}; },
-                           [=] __device__() { sc[S2S2] = raw[0]; sc[DIVN] = raw[1]; sc[R0Z0] = sc[R1Z1]; }));
+            }, [=] __device__() {
+                sc[VDOTV] = raw[0]; sc[U1DOTU1] = raw[1]; sc[PDOTP] = raw[2]; sc[S2S2] = raw[3]; sc[DIVN] = raw[4];
+                sc[R1Z1_0 + nxt] = raw[5]; sc[DELTA_0 + nxt] = raw[5] / sc[R1Z1_0 + cur];
+            }));
             return G4S_OK;
         };
         G4S_TRY(rest_of_iteration());
@@ -563,7 +592,6 @@ G4S_API g4s_status g4s_stokes_uzawa_cg_dist(g4s_spmv_dist_t K, g4s_spmv_dist_t D
         inner_total += cycles;
         valid = residual < inner_acc ? 1 : 0;
         if (!speculate || !held) G4S_TRY(fetch());
-        if (hsc[R1Z1] == 0.0) return g4s::set_error(G4S_ERR_INVALID, "g4s_stokes_uzawa_cg_dist: <r1, z1> = 0 at the head of iteration %d (the source asserts)", count);
         const double alpha = hsc[ALPHA];
         vdotv = hsc[VDOTV] / volume;
         pdotp = hsc[PDOTP] / volume;

@@ -397,6 +397,6 @@ class DistSpMV:
             self.lib.g4s_spmv_dist_destroy(self.h)
             self.h = None
         if getattr(self, "comm", None) is not None:
-            if self.comm and not poisoned:                         # (a poisoned handle has aborted its communicator already: nothing left to destroy)
+            if self.comm:                                          # (a poisoned handle has aborted its communicator already: the library remembers that and g4s_comm_destroy is then a no-op — a C caller need not know)
                 self.lib.g4s_comm_destroy(self.comm)
             self.comm = None

@@ -243,10 +243,11 @@ typedef struct g4s_timings {
 g4s_status g4s_spgemm_flop(int32_t M, const int32_t *arpt, const int32_t *acol, const int32_t *brpt,
                            int64_t *flop, int64_t *row_flop, unsigned flags);
 
-/* Input contract of the three SpGEMM entry points: zero-based CSR, the rows of B sorted by column (what CSR::construct produces, mm/inc/CSR.h:640-651;
- * repeated columns inside a row are allowed and are added up) — the merge and window kernels cut B's rows at column boundaries. A's rows may be in any
- * order. Column ids are range-checked (G4S_ERR_INVALID); a B with descending columns inside a row is refused (G4S_ERR_INVALID) by g4s_spgemm_symbolic and
- * the one-call form.
+/* Input contract of the three SpGEMM entry points: zero-based CSR; the rows of A and of B may be in any order, as for HashSpGEMM (its hash traversal never
+ * looks at the order, mm/inc/hash_mult.h:579-600, and HashSpGEMM<..., false> emits unsorted rows itself, :530-551) and mkl_sparse_spmm (mm/inc/mkl_mult.h:58);
+ * repeated columns inside a row are allowed and are added up. The kernels cut B's rows at column boundaries, so a B whose rows are NOT sorted by column (checked
+ * on the opening pass of every call) is sorted into a private copy first — the caller's arrays are never modified; sorted input (what CSR::construct produces,
+ * mm/inc/CSR.h:640-651) is the fast path. Column ids are range-checked (G4S_ERR_INVALID).
  * Raw-pointer SpGEMM with the call shape of mkl(...) (mm/inc/mkl_mult.h:40-43): inputs borrowed,
  * outputs allocated by the callee — with g4s_malloc for host pointers (free with g4s_free), with
  * g4s_dev_alloc for G4S_DEVICE_POINTERS (free with g4s_dev_free). A is M×K, B is K×N, C is M×N.
@@ -264,7 +265,9 @@ g4s_status g4s_spgemm_csr_i32_f64(const int32_t *arpt, const int32_t *acol, cons
  * call that follows it with THE SAME arrays (same pointers, unchanged contents — crpt describes this product and no other): that call then does not traverse
  * the structure again (the pair costs what the one-call form costs), nor do further numeric calls on the same arrays (new VALUES of A or B, same pattern: the
  * time-stepping case). One product at a time per process: the next symbolic or one-call product, g4s_trim
- * and g4s_shutdown release whatever is still held; a numeric call with other arrays, or without a symbolic call before it, works as before. */
+ * and g4s_shutdown release whatever is still held. The state is keyed by the pointers AND by a hash of the five index arrays (arpt, acol, brpt, bcol, crpt)
+ * taken at the end of the symbolic call and checked at the start of every numeric call that would use it: a numeric call with other arrays, with the same
+ * buffers refilled by another pattern, with its own crpt, or without a symbolic call before it derives everything it needs itself (no carried state is used). */
 g4s_status g4s_spgemm_symbolic(int32_t M, int32_t K, int32_t N,
                                const int32_t *arpt_dev, const int32_t *acol_dev,
                                const int32_t *brpt_dev, const int32_t *bcol_dev,
@@ -322,6 +325,9 @@ g4s_status g4s_unregister_pattern(fun_gather gather, fun_apply apply);
 #define G4S_HOST_CALLBACKS_PARALLEL 1
 #define G4S_HOST_CALLBACKS_REFUSE   2
 g4s_status g4s_set_host_callback_policy(int32_t policy);
+/* The same for the calling thread only (-1: back to the process-wide policy); *previous (may be NULL) receives what was set before, so that scopes nest
+ * (g4s::ScopedRaceFree, include/g4s/graph.hpp: a call site declares ITS gathers race-free without changing what other threads' callbacks get). */
+g4s_status g4s_set_host_callback_policy_thread(int32_t policy, int32_t *previous);
 
 /* The reference symbol, exactly (citcoms/lib/global_defs.h:854-857; bound at citcoms/bin/Citcom.c:93).
  * Registered pairs run as HIP kernels; any other pair runs the reference's host loop (policy above). spmm_dense returns

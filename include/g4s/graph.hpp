@@ -10,6 +10,10 @@
 //     caller has declared its gathers race-free, or refusal: g4s_set_host_callback_policy (include/g4s.h).
 //   * g4s::GraphProcess(graph, result, gather, apply, pattern[, seconds]) — the device form: the descriptor says which of the three patterns the
 //     callbacks implement and that pattern's kernel runs; the callbacks stay in the signature so the call keeps its shape, they are not invoked.
+//   * g4s::ScopedPattern p(desc); in front of an UNTOUCHED four-argument call (round 5): the descriptor sits in a thread-local slot that the four-argument
+//     form consults, so the call line stays byte-identical to the reference's (opt_matmul.cc:51) and still runs the pattern's kernel. Scopes nest; the
+//     innermost wins. g4s::ScopedRaceFree is the same kind of scope for the host loop: the four-argument calls inside it run the reference's 8 threads
+//     (graph.h:23) — the caller's declaration that ITS gathers do not race, without touching the process-wide policy.
 #pragma once
 #include <functional>
 #include <mutex>
@@ -57,12 +61,42 @@ inline void GraphProcess(struct Graph *graph, double *result,
     g4s_unregister_pattern(&detail::key_gather, &detail::key_apply);
     if (st != G4S_OK) throw std::runtime_error(std::string("GraphProcess: ") + g4s_last_error());
 }
+
+// The descriptor of the four-argument GraphProcess calls made by this thread while the object lives (see the header of this file).
+class ScopedPattern {
+  public:
+    explicit ScopedPattern(const g4s_pattern_desc &desc, double *seconds = nullptr) : desc_(desc), seconds_(seconds), prev_(current()) { current() = this; }
+    ~ScopedPattern() { current() = prev_; }
+    ScopedPattern(const ScopedPattern &) = delete;
+    ScopedPattern &operator=(const ScopedPattern &) = delete;
+    const g4s_pattern_desc &desc() const { return desc_; }
+    double *seconds() const { return seconds_; }
+    static ScopedPattern *&current() { static thread_local ScopedPattern *p = nullptr; return p; }
+  private:
+    g4s_pattern_desc desc_;
+    double *seconds_;
+    ScopedPattern *prev_;
+};
+// "The gathers of the four-argument calls in this scope do not race": their host loop runs with the reference's thread count (graph.h:23).
+class ScopedRaceFree {
+  public:
+    ScopedRaceFree() { g4s_set_host_callback_policy_thread(G4S_HOST_CALLBACKS_PARALLEL, &prev_); }
+    ~ScopedRaceFree() { g4s_set_host_callback_policy_thread(prev_, nullptr); }
+    ScopedRaceFree(const ScopedRaceFree &) = delete;
+    ScopedRaceFree &operator=(const ScopedRaceFree &) = delete;
+  private:
+    int32_t prev_ = -1;
+};
 } // namespace g4s
 
 // The reference's spelling (deepmd/source/op/graph.h:21-32), global like there.
 inline void GraphProcess(struct Graph *graph, double *result, std::function<void(int, int, struct Graph *, double *)> gather,
                          std::function<void(int, struct Graph *, double *)> apply)
 {
+    if (const g4s::ScopedPattern *sp = g4s::ScopedPattern::current()) {   // a scope in front of this call names its pattern: the device form
+        g4s::GraphProcess(graph, result, gather, apply, sp->desc(), sp->seconds());
+        return;
+    }
     std::lock_guard<std::mutex> turn(g4s::detail::host_call_mutex());
     g4s::detail::HostCall call{graph, &gather, &apply};
     g4s::detail::host_call() = &call;

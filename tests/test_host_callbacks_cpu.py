@@ -171,7 +171,7 @@ def test_four_argument_graphprocess_is_the_reference_spelling(tmp_path, ref):
     want = np.zeros(M * K)
     ref.ref_graph_process_dense(M, N, K, xx.ravel(), w.ravel(), want)
     payload = f"{M} {N} {K}\n".encode() + xx.tobytes() + w.tobytes()
-    for mode in ("serial", "parallel"):
+    for mode in ("serial", "parallel", "scoped_race_free"):        # scoped_race_free: g4s::ScopedRaceFree around the untouched call instead of the process-wide policy
         out = subprocess.run([exe, mode], input=payload, capture_output=True, timeout=120)
         assert out.returncode == 0, out.stderr.decode()
         got = np.frombuffer(out.stdout, dtype=np.float64)

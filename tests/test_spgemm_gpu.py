@@ -197,6 +197,59 @@ def test_spgemm_walk_forms(oracle, monkeypatch, walk, short_rows, two_phase):
     _three_window_case(oracle, two_phase)
 
 
+def _rank_cut_case(stride):
+    """B over 800 000 (× stride) columns = three 344 064-column segments of the rank kernel: rows 0 … 799 are blocks of 1 000 consecutive columns, the rest are
+    pieces that put a row's outputs exactly on the kernel's cuts. A's rows (all past 8 192 products, so that the symbolic phase writes cuts for them):
+      0  exactly 8 192 outputs (one full chunk, no count cut)      1  8 193 outputs (a count cut whose chunk holds one output)
+      2  a block straddling the first segment boundary             3  segment 1 empty (two segment starts at the same output)
+      4  output 8 192 is the first column of segment 1 (count cut = segment start)
+      5  20 equal B rows: 40 000 products for 2 000 outputs (five rounds of products in one chunk)      6  the same on top of 20 000 distinct columns
+      7  all three segments, the last one ending at the last column"""
+    seg = 344_064
+    blocks = [np.arange(1000 * k, 1000 * (k + 1)) for k in range(800)]
+    extra = {
+        800: np.arange(8000, 8192), 801: np.arange(8192, 8193), 802: np.arange(335_808, 336_000), 803: np.arange(seg, 345_000),
+        **{810 + i: np.arange(1000, 3000) for i in range(20)},
+    }
+    K = 830
+    brows = [blocks[k] if k < 800 else extra.get(k, np.zeros(0, dtype=np.int64)) for k in range(K)]
+    brp = np.concatenate([[0], np.cumsum([len(r) for r in brows])]).astype(np.int32)
+    bci = (np.concatenate(brows) * stride).astype(np.int32)
+    rng = np.random.default_rng(57)
+    bva = rng.uniform(0.5, 1, brp[-1])
+    dup = list(range(810, 830))
+    arows = [
+        list(range(0, 8)) + [800] + dup[:1],                       # 8 192 outputs … plus one repeated B row so that the row passes 8 192 products
+        list(range(0, 8)) + [800, 801] + dup[:1],
+        list(range(340, 352)),
+        list(range(0, 10)) + list(range(700, 710)),
+        [802] + list(range(336, 344)) + [803] + list(range(345, 351)),
+        dup,
+        list(range(0, 20)) + dup,
+        list(range(330, 346)) + list(range(680, 700)) + list(range(790, 800)) + dup[:3],
+        [5], [], [700, 810],
+    ]
+    arp = np.concatenate([[0], np.cumsum([len(r) for r in arows])]).astype(np.int32)
+    aci = np.concatenate([np.sort(np.array(r, dtype=np.int32)) for r in arows]).astype(np.int32)
+    ava = rng.uniform(0.5, 1, arp[-1])
+    return (arp, aci, ava), (brp, bci, bva), len(arows), K, 800_000 * stride
+
+
+@pytest.mark.parametrize("two_phase", [False, True])
+@pytest.mark.parametrize("path", ["rank", "columns"])
+@pytest.mark.parametrize("stride", [1, 2])
+def test_spgemm_rank_kernel_cuts(oracle, monkeypatch, stride, path, two_phase):
+    """Round 5 (spgemm_rank.hpp): the rows past 8 192 products carry cuts instead of columns and take the rank kernel. Outputs placed exactly on its cuts, with B's own
+    column ids (stride 1: every column holds an entry, no column map) and with the odd columns empty (stride 2: the map renumbers them to the same compact ids);
+    "columns" is the round-4 path on the same input (G4S_SPGEMM_NO_RANK)."""
+    if path == "columns":
+        monkeypatch.setenv("G4S_SPGEMM_NO_RANK", "1")
+    A, B, M, K, N = _rank_cut_case(stride)
+    c = _check(oracle, A, B, M, K, N, two_phase=two_phase)
+    nz = np.diff(c.to_host()[0])
+    assert list(nz[:6]) == [8192, 8193, 12000, 20000, 8192 + 936 + 6000, 2000]
+
+
 def test_spgemm_two_call_form_carries_its_columns(oracle, monkeypatch):
     """g4s_spgemm_symbolic leaves the sorted columns, the column map and the window splits of ITS product for the g4s_spgemm_numeric call that follows with the same
     arrays (round 4). Checked: the carried and the uncarried (G4S_SPGEMM_NO_CARRY) numeric calls give the same C; a symbolic call of another product in between
@@ -255,6 +308,17 @@ def test_spgemm_two_call_form_carries_its_columns(oracle, monkeypatch):
     cXb, nXb = torch.empty_like(cX), nX
     cXb.copy_(cX)
     same(numeric(Xb, cXb, nXb), cXb, wantX)
+    # the SAME buffers refilled with ANOTHER pattern (equal shape and entry counts: every row's columns shifted by one, cyclically) and the caller's own
+    # crpt — pointers, M, K, N all match the carried state, the index arrays do not: the state must not be used (it would apply X's cuts and columns to Z's crpt)
+    cX, nX = symbolic(X)
+    ciZ = ciX.copy()
+    for r in range(6000):
+        ciZ[rpX[r]:rpX[r + 1]] = np.sort((ciX[rpX[r]:rpX[r + 1]].astype(np.int64) + 1) % 6000)
+    wantZ = expect((rpX, ciZ, vaX), 6000)
+    X.colids.copy_(torch.from_numpy(ciZ))                          # in place: X.colids keeps its address
+    cZ = cX                                                        # … and so does crpt
+    cZ.copy_(torch.from_numpy(wantZ[0]))
+    same(numeric(X, cZ, int(wantZ[0][-1])), cZ, wantZ)
     capi.check(lib.g4s_trim())                                     # releases what the last symbolic call still holds
 
 
@@ -444,22 +508,73 @@ def test_spgemm_randomised_seams():
     assert r.returncode == 0 and "all ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_spgemm_refuses_unsorted_rows_of_b():
-    """The input contract (include/g4s.h): the rows of B sorted by column — the merge and window kernels cut them at column boundaries. A descent inside a row is
-    G4S_ERR_INVALID from the symbolic phase and the one-call form; a descent ACROSS a row boundary is what sorted rows look like, repeated columns are fine."""
+def _shuffle_rows(rp, ci, va, seed):
+    """the same matrix with every row's entries in random order"""
+    rng = np.random.default_rng(seed)
+    ci2, va2 = ci.copy(), va.copy()
+    for r in range(len(rp) - 1):
+        p = rng.permutation(rp[r + 1] - rp[r]) + rp[r]
+        ci2[rp[r]:rp[r + 1]], va2[rp[r]:rp[r + 1]] = ci[p], va[p]
+    return rp, ci2, va2
+
+
+@pytest.mark.parametrize("two_phase", [False, True])
+def test_spgemm_takes_unsorted_rows_of_b(oracle, two_phase):
+    """Round 5 (missing 1): HashSpGEMM takes any row order — its hash traversal never looks at it (mm/inc/hash_mult.h:579-600) — and so does the
+    drop-in now: when the sortedness check fires, the product runs on a private sorted copy of B's rows. Random unsorted B in every row class, both call forms;
+    index arrays bit for bit against the oracle (which walks the unsorted rows as the reference does), the caller's arrays untouched."""
+    from g4s_amd import host
+    rp, ci, va = power_law_csr(6000, 6000, 23, 1500)
+    B = _shuffle_rows(rp, ci, va, 11)
+    assert not np.array_equal(B[1], ci)
+    b = host.CSR.from_host(*B, 6000, 6000)
+    keep = b.colids.clone(), b.values.clone()
+    _check(oracle, (rp, ci, va), B, 6000, 6000, 6000, two_phase=two_phase)
+    a = host.CSR.from_host(rp, ci, va, 6000, 6000)
+    c = host.HashSpGEMM(a, b, two_phase=two_phase)
+    assert torch.equal(b.colids, keep[0]) and torch.equal(b.values, keep[1]), "the caller's B was modified"
+    cs = host.HashSpGEMM(a, a, two_phase=two_phase)                 # the sorted B gives the same C
+    assert torch.equal(c.rowptr, cs.rowptr) and torch.equal(c.colids, cs.colids)
+    assert torch.allclose(c.values, cs.values, rtol=1e-10, atol=1e-11)   # (sums of up to 1 500 signed products in another order; _check above holds the values to the oracle's)
+    # duplicates inside unsorted rows, empty rows, a single descent
+    rp2, ci2, va2 = random_csr(300, 300, 0.05, 9)
+    bad = ci2.copy()
+    r = int(np.argmax(np.diff(rp2) >= 2))
+    bad[rp2[r]], bad[rp2[r] + 1] = bad[rp2[r] + 1], bad[rp2[r]]
+    _check(oracle, (rp2, ci2, va2), (rp2, bad, va2), 300, 300, 300, two_phase=two_phase)
+    dup = ci2.copy()
+    dup[rp2[r]] = dup[rp2[r] + 1]                                   # a repeated column in an unsorted row
+    _check(oracle, (rp2, ci2, va2), _shuffle_rows(rp2, dup, va2, 5), 300, 300, 300, two_phase=two_phase)
+
+
+def test_spgemm_chained_product_with_unsorted_intermediate(oracle):
+    """C = HashSpGEMM<false, false>(A, A) — table order, unsorted rows (hash_mult.h:530-551) — fed back in as B of the next product, as a chained product does in
+    the reference: A·C through the drop-in == the oracle's A·C on the same unsorted C, index arrays bit for bit."""
+    rp, ci, va = power_law_csr(3000, 3000, 31, 800)
+    A = (rp, ci, np.abs(va))
+    crpt, ccol, cval = oracle.spgemm(A, A, 3000, sort_output=False)
+    srpt, scol, sval = oracle.spgemm(A, A, 3000, sort_output=True)
+    assert not np.array_equal(ccol, scol), "the oracle's table order happens to be sorted: the case tests nothing"
+    _check(oracle, A, (crpt, ccol, cval), 3000, 3000, 3000)
+    _check(oracle, A, (crpt, ccol, cval), 3000, 3000, 3000, two_phase=True)
+
+
+def test_spgemm_numeric_only_call_sorts_b_itself(oracle):
+    """g4s_spgemm_numeric without a symbolic call before it (the caller brings its own crpt), B unsorted: the numeric phase checks and sorts B itself."""
     from g4s_amd import capi, host
-    rng = np.random.default_rng(3)
-    rp, ci, va = random_csr(300, 300, 0.05, 9)
-    a = host.CSR.from_host(rp, ci, va, 300, 300)
-    host.HashSpGEMM(a, a)                                          # sorted: fine
-    bad = ci.copy()
-    r = int(np.argmax(np.diff(rp) >= 2))
-    bad[rp[r]], bad[rp[r] + 1] = bad[rp[r] + 1], bad[rp[r]]        # one swapped pair inside a row
-    b = host.CSR.from_host(rp, bad, va, 300, 300)
-    with pytest.raises(capi.G4SError, match="sorted by column"):
-        host.HashSpGEMM(a, b)
-    with pytest.raises(capi.G4SError, match="sorted by column"):
-        host.HashSpGEMM(a, b, two_phase=True)
-    dup = ci.copy()
-    dup[rp[r] + 1] = dup[rp[r]]                                    # a repeated column: allowed
-    host.HashSpGEMM(a, host.CSR.from_host(rp, dup, va, 300, 300))
+    lib = capi.load()
+    rp, ci, va = power_law_csr(4000, 4000, 7, 900)
+    B = _shuffle_rows(rp, ci, va, 3)
+    orpt, ocol, oval = oracle.spgemm((rp, ci, va), B, 4000)
+    a = host.CSR.from_host(rp, ci, va, 4000, 4000)
+    b = host.CSR.from_host(*B, 4000, 4000)
+    crpt = torch.from_numpy(orpt).cuda()
+    ccol = torch.empty(len(ocol), dtype=torch.int32, device="cuda")
+    cval = torch.empty(len(ocol), dtype=torch.float64, device="cuda")
+    capi.check(lib.g4s_trim())                                      # nothing carried from an earlier product
+    capi.check(lib.g4s_spgemm_numeric(4000, 4000, 4000, a.rowptr.data_ptr(), a.colids.data_ptr(), a.values.data_ptr(), b.rowptr.data_ptr(), b.colids.data_ptr(),
+                                      b.values.data_ptr(), crpt.data_ptr(), ccol.data_ptr(), cval.data_ptr(), capi.DEVICE_POINTERS | capi.SORT_OUTPUT, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(ccol.cpu().numpy(), ocol)
+    _, _, scale = oracle.spgemm(_abs((rp, ci, va)), _abs(B), 4000)
+    assert np.all(np.abs(cval.cpu().numpy() - oval) <= TOL * scale + 1e-300)

@@ -1,0 +1,26 @@
+"""Per-section cycle split of spgemm_numeric_rank_kernel (library built with -DG4S_PROFILE_BIG: tools/build_variant.sh prof spgemm.hip -DG4S_PROFILE_BIG). Usage: G4S_LIB=… python tools/rank_prof.py [--ef 3]"""
+import argparse, ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from g4s_amd import capi, host
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scale", type=int, default=21)
+ap.add_argument("--ef", type=float, default=3.0)
+a = ap.parse_args()
+lib = capi.load()
+n = 1 << a.scale
+A = host.rmat_csr(n, a.scale, int(a.ef * n), 20240522)
+host.HashSpGEMM(A, A)
+buf = (C.c_ulonglong * 48)()
+lib.g4s_debug_big_prof.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+lib.g4s_debug_big_prof(buf, 1)
+host.HashSpGEMM(A, A)
+lib.g4s_debug_big_prof(buf, 0)
+names = ["mark (round 0 from registers + further rounds)", "barrier 1 (marks done)", "ranks: read words, scan, barrier 2", "ranks: write words, barrier 3", "accumulate (+ lgkmcnt drain)",
+         "next chunk's round requested", "barrier 4 (sums done)", "store (+ clean)", "barrier 5"]
+buf = buf[32:]
+tot = sum(buf[:9])
+for nm, v in zip(names, buf):
+    print(f"{nm:55s} {v:16d} ticks {100.0 * v / max(tot, 1):6.2f} %")
+ch = max(buf[9], 1)
+print(f"chunks seen by the reporting wavefronts: {buf[9]}, units per chunk {buf[10] / ch:.1f}, outputs per chunk {buf[11] / ch:.1f}, ticks per chunk {tot / ch:.0f} (100 MHz: {tot / ch / 100:.2f} us)")
