@@ -430,12 +430,13 @@ def main():
         try:
             tj = json.load(open(tpath))
             if tj.get("workload") == args.workload and tj.get("n_gpus") == world and not args.small and tj.get("spmv_path", info["spmv_path"]) == info["spmv_path"]:
-                sys.path.insert(0, os.path.join(ROOT, "tools"))
-                import kernel_hash
-                now = kernel_hash.spmv_kernel_hash()
+                # the hash the LOADED library was built from (g4s_build_info), not the tree's: a stale build, or an A/B variant loaded through G4S_LIB, is not
+                # what the stored profile was taken on
+                binfo = dict(kv.split("=", 1) for kv in capi.load().g4s_build_info().decode().split(";") if "=" in kv)
+                now = binfo.get("spmv_kernel_sources_sha256", "unknown") + ("" if not binfo.get("variant") else "+variant:" + binfo["variant"])
                 if tj.get("kernel_sources_sha256") == now:
                     traffic = tj.get("hbm_bytes_per_launch")
-                    traffic_source = f"stored PMC profile profiles/{tj.get('source', 'traffic_latest.json')} of the same kernel sources (sha256 {now[:12]}…; not measured by this run)"
+                    traffic_source = f"stored PMC profile profiles/{tj.get('source', 'traffic_latest.json')} of the kernel sources the loaded library was built from (sha256 {now[:12]}…; not measured by this run)"
                 else:
                     traffic_source = (f"REFUSED: profiles/traffic_latest.json was taken on kernel sources {str(tj.get('kernel_sources_sha256'))[:12]}…, this build is {now[:12]}… "
                                       "— re-take it with tools/r04_profile.sh")

@@ -96,10 +96,34 @@ __global__ __launch_bounds__(kScanThreads) void scan_write_kernel(long long n, c
     }
 }
 
+// a short input (round 5): one workgroup, one launch — thread t owns ceil(n / 1024) consecutive elements (the three-launch form costs 15–20 µs of launches and
+// boundaries whatever n is, and a small product makes dozens of scans over a few thousand rows)
+constexpr int kScanSmallThreads = 1024, kScanSmallMax = kScanSmallThreads * 64;
+template <typename T>
+__global__ __launch_bounds__(kScanSmallThreads) void scan_small_kernel(int n, const T *__restrict__ in, T *__restrict__ out)
+{
+    __shared__ T s[kScanSmallThreads / 64];
+    const int per = (n + kScanSmallThreads - 1) / kScanSmallThreads, i0 = (int)threadIdx.x * per, i1 = min(n, i0 + per);
+    T sum = 0;
+    for (int i = i0; i < i1; ++i) sum += in[i];
+    const T incl = wave_inclusive(sum);
+    if ((threadIdx.x & 63) == 63) s[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    T run = incl - sum;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += s[w];
+    for (int i = i0; i < i1; ++i) { const T v = in[i]; out[i] = run; run += v; }
+}
+
 template <typename T>
 int exclusive_scan(const T *in, T *out, long long n, hipStream_t s)
 {
     if (n <= 0) return G4S_OK;
+    if (n <= kScanSmallMax && in != out) {
+        hipLaunchKernelGGL(scan_small_kernel<T>, dim3(1), dim3(kScanSmallThreads), 0, s, (int)n, in, out);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return set_error(G4S_ERR_HIP, "exclusive_scan: %s", hipGetErrorString(e));
+        return G4S_OK;
+    }
     const int ntiles = (int)((n + kScanTile - 1) / kScanTile);
     void *sums = nullptr;
     G4S_TRY(scratch_alloc(&sums, sizeof(T) * (size_t)ntiles, s));
@@ -180,6 +204,46 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(int n, const
 }
 
 } // namespace
+
+// A short list by descending key in ONE launch (round 5): one workgroup counts the keys (< 2^11: the logarithmic size keys of the row lists) in LDS, scans the
+// 2 048 counters and places the pairs through per-key cursors. NOT stable — equal keys come out in any order — so only for callers to whom the order among equal
+// keys means nothing (the longest-first row lists: it decides which workgroup takes a row first, never a result).
+constexpr int kSortSmallMax = 1 << 16, kSortSmallBins = 2048;
+namespace {
+__global__ __launch_bounds__(1024) void sort_small_desc_kernel(int n, const int *__restrict__ keys, const int *__restrict__ vals, int *__restrict__ keys_out, int *__restrict__ vals_out)
+{
+    __shared__ int cnt[kSortSmallBins];
+    __shared__ int wsum[16];
+    for (int i = threadIdx.x; i < kSortSmallBins; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) atomicAdd(&cnt[kSortSmallBins - 1 - (keys[i] & (kSortSmallBins - 1))], 1);   // bin 0 = the largest key
+    __syncthreads();
+    // exclusive scan of the 2 048 counters: two per thread
+    const int a = cnt[2 * threadIdx.x], b = cnt[2 * threadIdx.x + 1];
+    const int incl = wave_inclusive(a + b);
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int base = incl - (a + b);
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wsum[w];
+    __syncthreads();
+    cnt[2 * threadIdx.x] = base;
+    cnt[2 * threadIdx.x + 1] = base + a;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const int k = keys[i], pos = atomicAdd(&cnt[kSortSmallBins - 1 - (k & (kSortSmallBins - 1))], 1);
+        keys_out[pos] = k;
+        vals_out[pos] = vals[i];
+    }
+}
+} // namespace
+inline int sort_pairs_descending_small_unstable(const int *keys_in, const int *vals_in, int *keys_out, int *vals_out, int n, hipStream_t s)
+{
+    if (n <= 0) return G4S_OK;
+    hipLaunchKernelGGL(sort_small_desc_kernel, dim3(1), dim3(1024), 0, s, n, keys_in, vals_in, keys_out, vals_out);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(G4S_ERR_HIP, "sort_pairs_descending_small_unstable: %s", hipGetErrorString(e));
+    return G4S_OK;
+}
 
 // keys_in / vals_in are not modified; the result lands in keys_out / vals_out. key_bits: an upper bound on the significant bits of the
 // (non-negative) keys. tmp_keys / tmp_vals: n ints each (ping-pong partners of the outputs).

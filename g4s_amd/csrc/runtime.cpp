@@ -39,7 +39,7 @@ namespace {
 struct ArenaChunk { char *p; size_t bytes, used; };
 struct Arena { std::vector<ArenaChunk> chunks; int depth = 0; };
 thread_local Arena t_arena;
-constexpr size_t kArenaChunk = (size_t)256 << 20, kArenaAlign = 256;
+constexpr size_t kArenaChunk = (size_t)1 << 30, kArenaAlign = 256;   // (1 GiB since round 5: every small transient of a plan build or a product in ONE block that has been used before — the first host copy into a fresh 256 MB block measured 8.6 ms inside g4s_csr_create)
 } // namespace
 
 void arena_enter() { ++t_arena.depth; }
@@ -58,7 +58,8 @@ static int arena_alloc(void **p, size_t bytes)
     for (auto &c : t_arena.chunks)
         if (c.bytes - c.used >= bytes) { *p = c.p + c.used; c.used += bytes; return G4S_OK; }
     void *q = nullptr;
-    const size_t want = bytes > kArenaChunk ? bytes : kArenaChunk;
+    static const size_t chunk = [] { const char *e = getenv("G4S_ARENA_CHUNK_MB"); return e ? (size_t)atoll(e) << 20 : kArenaChunk; }();
+    const size_t want = bytes > chunk ? bytes : chunk;
     G4S_TRY(big_alloc(&q, want));
     t_arena.chunks.push_back(ArenaChunk{static_cast<char *>(q), want, bytes});
     *p = q;
@@ -246,6 +247,15 @@ int scratch_shutdown()
 } // namespace g4s
 
 G4S_API const char *g4s_version(void) { return "g4s-hip 0.1 (gfx950)"; }
+#ifndef G4S_SPMV_KERNEL_HASH
+#define G4S_SPMV_KERNEL_HASH "unknown"
+#endif
+#ifndef G4S_BUILD_VARIANT
+#define G4S_BUILD_VARIANT ""
+#endif
+// What this library was built from, for tools that pair stored measurements with a build (bench.py's roofline.traffic): the SHA-256 of the SpMV kernel sources
+// (tools/kernel_hash.py, taken by the Makefile when runtime.cpp is compiled) and the name of an A/B variant build (tools/build_variant.sh; empty for the regular one).
+G4S_API const char *g4s_build_info(void) { return "spmv_kernel_sources_sha256=" G4S_SPMV_KERNEL_HASH ";variant=" G4S_BUILD_VARIANT; }
 G4S_API const char *g4s_last_error(void) { return g4s::last_error_buf(); }
 
 G4S_API g4s_status g4s_device_count(int *count)

@@ -726,7 +726,7 @@ __device__ __forceinline__ unsigned wave_inclusive_sum(unsigned x)
 // classes are cut by output length, not by products) is appended to a list that the table kernels take afterwards.
 constexpr int kSmallCap = 512;
 template <bool NUMERIC>
-constexpr int small_wave_ints() { return kSmallCap + (NUMERIC ? 2 * kSmallCap : 0) + kSmallCap / 2; }   // columns | products (fp64) | source index per rank (u16)
+constexpr int small_wave_ints() { return kSmallCap + (NUMERIC ? 2 * kSmallCap : 0) + kSmallCap / 2 + kSmallCap / 4; }   // columns | products (fp64) | source index per rank (u16) | run per product (u8)
 template <bool NUMERIC>
 __global__ __launch_bounds__(256) void spgemm_small_wave_kernel(
     const int *__restrict__ rows, int nrows, const int *__restrict__ arpt, const int *__restrict__ acol, const double *__restrict__ aval,
@@ -758,47 +758,60 @@ __global__ __launch_bounds__(256) void spgemm_small_wave_kernel(
         return;
     }
     auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
-    auto run = [&](int e, int &rb0, int &rlen, int &rP, double &rav) {   // uniform e: the run's data out of its lane
-        rb0 = __builtin_amdgcn_readlane(b0, e); rlen = __builtin_amdgcn_readlane(len, e); rP = __builtin_amdgcn_readlane(P, e);
-        if (NUMERIC) {
-            const long long bits = __double_as_longlong(av);
-            const int lo = __builtin_amdgcn_readlane((int)(bits & 0xFFFFFFFFll), e), hi = __builtin_amdgcn_readlane((int)(bits >> 32), e);
-            rav = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+    // 1. + 2. flat over the row's PRODUCTS (round 5): lane l of a pass takes product i0 + l, whatever run it sits in — its run by a binary search over the lanes'
+    // prefix sums (six shuffles), then one coalesced-as-can-be load per product. The first form walked the runs one after the other, a pass of 64 lanes per run:
+    // a row of seven 7-entry runs (a stencil squared: 1.7 M such rows at 120³) spent seven mostly idle passes in step 1 and seven more, each with its own loop
+    // over the other runs, in step 2 — 13.9 ms per product for 84 M flop (profiles/r05_small_sizes.txt).
+    auto run_of = [&](int i) {                                      // the run e with P[e] <= i < P[e] + len[e] (runs without entries share their successor's P: skipped by the search)
+        int lo = 0, hi = na - 1;
+#pragma unroll
+        for (int step = 0; step < 6; ++step) {
+            const int mid = (lo + hi) >> 1;
+            const bool above = __shfl(incl, mid, 64) > i;
+            hi = above ? mid : hi;
+            lo = above ? lo : min(mid + 1, na - 1);
         }
+        return lo;
     };
-    // 1. products → LDS, run by run
-    for (int e = 0; e < na; ++e) {
-        int rb0, rlen, rP;
-        double rav = 0.0;
-        run(e, rb0, rlen, rP, rav);
-        for (int k = lane; k < rlen; k += 64) {
-            Cin[rP + k] = bcol[rb0 + k];
-            if (NUMERIC) Vin[rP + k] = rav * bval[rb0 + k];         // multop, hash_mult.h:583
+    unsigned char *Run = reinterpret_cast<unsigned char *>(Src + kSmallCap);   // the run of every product (na <= 64)
+    for (int i0 = 0; i0 < flop; i0 += 64) {
+        const int i = min(i0 + lane, flop - 1);
+        const int e = run_of(i);
+        const int rb0 = __shfl(b0, e, 64), rP = __shfl(P, e, 64);
+        const int col = bcol[rb0 + (i - rP)];
+        double prod = 0.0;
+        if (NUMERIC) {                                             // (every lane takes part in the shuffles: a run's owner lane may hold no product of this pass)
+            const long long bits = __double_as_longlong(av);
+            const int lo32 = __shfl((int)(bits & 0xFFFFFFFFll), e, 64), hi32 = __shfl((int)(bits >> 32), e, 64);
+            prod = __longlong_as_double(((long long)hi32 << 32) | (unsigned)lo32) * bval[rb0 + (i - rP)];   // multop, hash_mult.h:583
+        }
+        if (i0 + lane < flop) {
+            Cin[i] = col;
+            Run[i] = (unsigned char)e;
+            if (NUMERIC) Vin[i] = prod;
         }
     }
     wave_sync();
-    // 2. rank of every product in the merged order
-    for (int e = 0; e < na; ++e) {
-        int rb0, rlen, rP;
-        double rav;
-        run(e, rb0, rlen, rP, rav);
-        for (int k = lane; k < rlen; k += 64) {
-            const int col = Cin[rP + k];
-            int rank = k;
-            for (int e2 = 0; e2 < na; ++e2) {
-                const int l2 = __builtin_amdgcn_readlane(len, e2), P2 = __builtin_amdgcn_readlane(P, e2);
-                if (e2 == e || l2 == 0) continue;                  // uniform
-                int lo = 0, hi = l2;                               // entries of run e2 in front of this one: smaller columns, and equal ones of an earlier run
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1, v = Cin[P2 + mid];
-                    const bool before = e2 < e ? v <= col : v < col;
-                    lo = before ? mid + 1 : lo;
-                    hi = before ? hi : mid;
-                }
-                rank += lo;
+    // rank of every product in the merged order: its index in its own run + the entries of every other run in front of it
+    for (int i0 = 0; i0 < flop; i0 += 64) {
+        const int i = i0 + lane;
+        const bool valid = i < flop;
+        const int e = valid ? (int)Run[i] : 0, col = valid ? Cin[i] : 0;
+        int rank = i - __shfl(P, e, 64);
+        for (int e2 = 0; e2 < na; ++e2) {
+            const int l2 = __builtin_amdgcn_readlane(len, e2), P2 = __builtin_amdgcn_readlane(P, e2);
+            if (l2 == 0) continue;                                 // uniform
+            int lo = 0, hi = e2 == e ? 0 : l2;                     // (its own run counts through its index)
+            while (__any(lo < hi)) {
+                const int mid = (lo + hi) >> 1, v = Cin[P2 + min(mid, l2 - 1)];
+                const bool before = e2 < e ? v <= col : v < col;   // entries of run e2 in front of this one: smaller columns, and equal ones of an earlier run
+                const bool go = lo < hi;
+                lo = (go && before) ? mid + 1 : lo;
+                hi = (go && !before) ? mid : hi;
             }
-            Src[rank] = (unsigned short)(rP + k);
+            rank += lo;
         }
+        if (valid) Src[rank] = (unsigned short)i;
     }
     wave_sync();
     // 3. equal neighbours → one column; place the columns
@@ -839,7 +852,7 @@ __global__ void window_splits_kernel(int K, int W, int sbits, const int *__restr
     const int bound = j << sbits;
     int lo = brpt[c], hi = brpt[c + 1];
     while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
+        const int mid = lo + ((hi - lo) >> 1);
         if (bcol[mid] < bound) lo = mid + 1; else hi = mid;
     }
     wsplit[idx] = lo;
@@ -912,14 +925,11 @@ struct FlatNoTail { __device__ __forceinline__ void operator()() const {} };
 template <int T, bool WITH_VAL, int UPR, typename Body, typename Tail = FlatNoTail>
 __device__ __forceinline__ void flat_products(int a0, int a1, const int *__restrict__ acol, const double *__restrict__ aval,
                                               const int *__restrict__ lo, const int *__restrict__ hi, const int *__restrict__ bcol,
-                                              const double *__restrict__ bval, const BigSide<T> &sd, int t, Body body,
-                                              const int *__restrict__ xlo = nullptr, const int *__restrict__ xhi = nullptr, int xs = 0, Tail tail = Tail())
+                                              const double *__restrict__ bval, const BigSide<T> &sd, int t, Body body, Tail tail = Tail())
 {
     // tail(): called once by every thread in front of the LAST barrier of the walk (or at the end when there is none): loads issued there have the
     // barrier's skew to arrive in (the numeric kernel starts the column-id gather of its store step there)
     bool tail_done = false;
-    // xlo / xhi (value chunks with exact splits, chunk_splits_kernel): the bounds of A-entry e of the row are xlo[(e − a0)·xs] / xhi[(e − a0)·xs]
-    // instead of lo[c] / hi[c]
     constexpr int kWaves = T / 64, kUB = BigSide<T>::kUnitBatch;
     const int lane = t & 63, wave = t >> 6;
     BIG_PROF_DECL;
@@ -928,8 +938,7 @@ __device__ __forceinline__ void flat_products(int a0, int a1, const int *__restr
         int units = 0;
         if (t < ne) {
             const int c = acol[e0 + t];
-            const size_t xi = (size_t)(e0 + t - a0) * (size_t)xs;
-            const int b0 = xlo ? xlo[xi] : lo[c], b1 = xhi ? xhi[xi] : hi[c];
+            const int b0 = lo[c], b1 = hi[c];
             const long long bits = WITH_VAL ? __double_as_longlong(aval[e0 + t]) : 0ll;
             sd.E[t] = make_int4(b0, b1, (int)(bits & 0xFFFFFFFFll), (int)(bits >> 32));
             units = b1 > b0 ? (b1 - b0 + 63) >> 6 : 0;
@@ -1253,7 +1262,7 @@ __global__ __launch_bounds__(256) void sym_unit_kernel(long long bound /* thread
     if (i >= total) { if constexpr (!EXPAND) ucount[i] = 0; return; }   // (the scan runs over bound + 1 entries)
     int rl = 0, rh = n;                                             // the list position that holds the workgroup's first item (uniform), then a short walk forward
     while (rl < rh) {
-        const int mid = (rl + rh) >> 1;
+        const int mid = rl + ((rh - rl) >> 1);
         if (item_off[mid + 1] > i0) rh = mid; else rl = mid + 1;
     }
     while (item_off[rl + 1] <= i) ++rl;
@@ -1309,6 +1318,23 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     const int nwin = (N + (1 << kBigWindowBits) - 1) >> kBigWindowBits;
     for (int i = t; i < kBigWindowWords / 4; i += T) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);   // once: every window leaves the bitmap clean
     __syncthreads();
+    // Round 0 of the NEXT window — of this row, or the first of the workgroup's next row — is requested behind the current window's mark barrier and arrives under
+    // its count / emit step (round 5): requested at the top of its own window, every window of every row began with an exposed ≈ 2 µs round trip (unit descriptors,
+    // then the columns), four times per row in the mid-size class.
+    int c[kU];
+    bool ok[kU];
+    bool have = false;                                             // c / ok hold round 0 of the window about to be marked
+    auto request_round = [&](int u0, int nu, int g, int (&cc)[kU], bool (&okk)[kU]) {
+        SymUnit d[kU];                                              // all of the round's descriptors first (see the numeric kernel's request_round)
+#pragma unroll
+        for (int q = 0; q < kU; ++q) d[q] = U[u0 + min(g + q, max(nu, 1) - 1)];   // uniform: one s_load_dwordx2 each (a window without units reads a neighbour's or the pad entry: not used)
+#pragma unroll
+        for (int q = 0; q < kU; ++q) {
+            const int len = nu > 0 ? d[q].len : 1, bpos = nu > 0 ? d[q].bpos : 0;
+            okk[q] = g + q < nu && lane < len;
+            cc[q] = bcol[bpos + min(lane, len - 1)];
+        }
+    };
     for (; ridx < nrows; ridx = nridx, cur = nxt) {
         if (next_row) { if (t == 0) sd.ctrl[29] = atomicAdd(next_row, 1); }   // read below, behind the first barrier of the row
         else { nridx = ridx + gridDim.x; nxt = load_meta(nridx); }
@@ -1320,35 +1346,34 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         for (int wi = 0; wi < nwin; ++wi) {
             const int w0 = wi << kBigWindowBits, w1 = min(N, w0 + (1 << kBigWindowBits));
             const int nu = cu1 - cu0;
-            int c[kU];
-            bool ok[kU];
-            auto request_round = [&](int g) {
-                SymUnit d[kU];                                      // all of the round's descriptors first (see the numeric kernel's request_round)
-#pragma unroll
-                for (int q = 0; q < kU; ++q) d[q] = U[cu0 + min(g + q, max(nu, 1) - 1)];   // uniform: one s_load_dwordx2 each (a window without units reads a neighbour's or the pad entry: not used)
-#pragma unroll
-                for (int q = 0; q < kU; ++q) {
-                    const int len = nu > 0 ? d[q].len : 1, bpos = nu > 0 ? d[q].bpos : 0;
-                    ok[q] = g + q < nu && lane < len;
-                    c[q] = bcol[bpos + min(lane, len - 1)];
-                }
-            };
-            auto mark_round = [&]() {
+            auto mark_round = [&](const int (&cc)[kU], const bool (&okk)[kU]) {
 #pragma unroll
                 for (int q = 0; q < kU; ++q)
-                    if (ok[q] && c[q] >= w0 && c[q] < w1) atomicOr(&bm[bm_slot((c[q] - w0) >> 5)], 1u << ((c[q] - w0) & 31));
+                    if (okk[q] && cc[q] >= w0 && cc[q] < w1) atomicOr(&bm[bm_slot((cc[q] - w0) >> 5)], 1u << ((cc[q] - w0) & 31));
             };
-            request_round(wave * kU);
+            if (!have) request_round(cu0, nu, wave * kU, c, ok);   // (the workgroup's first window only)
             cu2 = uoff[min(cur.ioff + (long long)min(wi + 2, nwin) * na, total_items)];   // (consumed a window later)
             BIG_PROF(0);
-            mark_round();                                          // (the bitmap is clean: zeroed at the kernel's start, left clean by every window since)
+            mark_round(c, ok);                                     // (the bitmap is clean: zeroed at the kernel's start, left clean by every window since)
             for (int g = (wave + kWaves) * kU; g < nu; g += kWaves * kU) {
-                request_round(g);
-                mark_round();
+                int cx[kU];
+                bool okx[kU];
+                request_round(cu0, nu, g, cx, okx);
+                mark_round(cx, okx);
             }
             __syncthreads();
             BIG_PROF(1);
             if (wi == 0 && next_row) { nridx = __builtin_amdgcn_readfirstlane(sd.ctrl[29]); nxt = load_meta(nridx); }   // (nobody writes the slot again before this row's last barrier)
+            {   // the next window's round 0 (this row's, or the next row's first): c / ok are free — every mark of this window has been issued
+                const bool last_win = wi + 1 >= nwin;              // uniform
+#ifdef G4S_SYM_NO_PREFETCH
+                have = false;                                      // (A/B build: every window requests its own round 0 at its top, as until round 5)
+#else
+                have = !last_win || nridx < nrows;
+#endif
+                const int n0 = last_win ? nxt.u0 : cu1, n1 = last_win ? nxt.u1 : cu2;
+                if (have) request_round(n0, n1 - n0, wave * kU, c, ok);
+            }
             if (CUTS && po >= 0) {
                 const int nseg = rank_segments(N), before = s_total;   // (s_total: written by thread 0 behind the barrier at the end of the previous window)
                 const int total = count_and_cut_window<T>(bm, wi, before, nseg, pre_cols + po, pre_cols + po + nseg, sd.scan, t);
@@ -1383,14 +1408,6 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
 // search inside the window piece that holds C_b. Chunk q of entry e is then exactly [split(e, q), split(e, q + 1)) — no over-visit, no range test, and
 // the entry pass reads its bounds by entry index (no acol → wsplit dependence). need[i] = entries · (chunks − 1) of the i-th row of the launch's list (0 for
 // rows of one chunk); ct_off = its exclusive scan, indexed by list position like the kernel's own walk.
-__global__ void chunk_split_need_kernel(int n, const int *__restrict__ rows, const int *__restrict__ arpt, const int *__restrict__ crpt,
-                                        int chunk, int nz_lo, int nz_hi, long long *__restrict__ need)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int row = rows[i], nz = crpt[row + 1] - crpt[row];
-    need[i] = (nz > nz_lo && nz <= nz_hi && nz > chunk) ? (long long)(arpt[row + 1] - arpt[row]) * ((nz + chunk - 1) / chunk - 1) : 0;
-}
 // One thread per (row, entry, boundary) item, the items numbered through ct_off (a hub row alone holds millions of them: one workgroup per row took 2.6 ms
 // per launch for work of a few hundred µs).
 __global__ __launch_bounds__(256) void chunk_splits_kernel(long long total, int n, const int *__restrict__ rows, int K, int N, const int *__restrict__ wsplit,
@@ -1405,7 +1422,7 @@ __global__ __launch_bounds__(256) void chunk_splits_kernel(long long total, int 
     // 17 dependent loads in front of every 10-step split search) — then a short walk forward for the lanes whose item belongs to a later row
     int rl = 0, rh = n;
     while (rl < rh) {
-        const int mid = (rl + rh) >> 1;
+        const int mid = rl + ((rh - rl) >> 1);
         if (ct_off[mid + 1] > i0) rh = mid; else rl = mid + 1;
     }
     if (i >= total) return;
@@ -1419,7 +1436,7 @@ __global__ __launch_bounds__(256) void chunk_splits_kernel(long long total, int 
     int lo = (wsplit && wf > 0) ? wsplit[(size_t)(wf - 1) * K + c] : brpt[c];
     int hi = (wsplit && wf < W - 1) ? wsplit[(size_t)wf * K + c] : brpt[c + 1];
     while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
+        const int mid = lo + ((hi - lo) >> 1);
         if (bcol[mid] < cb) lo = mid + 1; else hi = mid;
     }
     ct[i] = lo;
@@ -1433,48 +1450,9 @@ __global__ __launch_bounds__(256) void chunk_splits_kernel(long long total, int 
 //   item (list position i, chunk q, A-entry e), ordered by (i, q, e): piece [split(e, q), split(e, q + 1)) of B row acol[e]  (split(e, 0) = row start,
 //   split(e, chunks) = row end: every entry of a B row used by row i lands in exactly one of the row's chunks);
 //   unit_count_kernel: units of the item = ceil(piece / 64); an exclusive scan gives the item's first unit; unit_expand_kernel writes the descriptors.
-__global__ void unit_items_kernel(int n, const int *__restrict__ rows, const int *__restrict__ arpt, const int *__restrict__ crpt, int chunk, int nz_lo, int nz_hi,
-                                  long long *__restrict__ items)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int row = rows[i], nz = crpt[row + 1] - crpt[row];
-    items[i] = (nz > nz_lo && nz <= nz_hi) ? (long long)(arpt[row + 1] - arpt[row]) * ((nz + chunk - 1) / chunk) : 0;
-}
-template <bool EXPAND>
-__global__ __launch_bounds__(256) void unit_kernel(long long total, int n, const int *__restrict__ rows, const long long *__restrict__ item_off /* n + 1 */,
-                                                   const int *__restrict__ arpt, const int *__restrict__ acol, const double *__restrict__ aval,
-                                                   const int *__restrict__ brpt, const int *__restrict__ crpt, int chunk,
-                                                   const long long *__restrict__ ct_off, const int *__restrict__ ct,
-                                                   int *__restrict__ ucount /* !EXPAND: out */, const int *__restrict__ uoff /* EXPAND: in */, UnitDesc *__restrict__ U)
-{
-    const long long i0 = (long long)blockIdx.x * blockDim.x, i = i0 + threadIdx.x;
-    int rl = 0, rh = n;                                             // the list position that holds the workgroup's first item (uniform), then a short walk forward
-    while (rl < rh) {
-        const int mid = (rl + rh) >> 1;
-        if (item_off[mid + 1] > i0) rh = mid; else rl = mid + 1;
-    }
-    if (i >= total) return;
-    while (item_off[rl + 1] <= i) ++rl;
-    const int row = rows[rl], nz = crpt[row + 1] - crpt[row];
-    const int a0 = arpt[row], na = arpt[row + 1] - a0, nb = (nz + chunk - 1) / chunk - 1;
-    const long long idx = i - item_off[rl];
-    const int q = (int)(idx / na), e = (int)(idx - (long long)q * na);
-    const int c = acol[a0 + e];
-    const int *ctr = nb > 0 ? ct + ct_off[rl] + (long long)e * nb : nullptr;
-    const int lo = q == 0 ? brpt[c] : ctr[q - 1], hi = q == nb ? brpt[c + 1] : ctr[q];
-    if constexpr (!EXPAND) ucount[i] = hi > lo ? (hi - lo + 63) >> 6 : 0;
-    else {
-        const long long bits = __double_as_longlong(aval[a0 + e]);
-        UnitDesc *dst = U + uoff[i];
-        for (int k = lo; k < hi; k += 64) *dst++ = UnitDesc{k, min(64, hi - k), (int)(bits & 0xFFFFFFFFll), (int)(bits >> 32)};
-    }
-}
-
-// The same lists built by TASKS (round 4, second form): one thread per (row, A-entry) walks the row's chunk boundaries in order — every search starts where the
-// previous one ended, the entry's B-row bounds and value are loaded once for all its chunks — and writes both the splits and the unit counts; a second pass over
-// the same tasks writes the descriptors. Replaces chunk_splits_kernel + unit_kernel<false> + unit_kernel<true> (one thread per (entry, boundary) / per item, each
-// re-deriving its row and re-loading its bounds: 0.75 + 0.36 + 0.69 ms per product) on the default path, with one count read back instead of three.
+// The lists are built by TASKS: one thread per (row, A-entry) writes the unit counts of the entry's chunks from the splits (chunk_splits_kernel: one thread per
+// (entry, boundary) — 10^7 short independent searches beat 10^6 chains of them), a second pass over the same tasks writes the descriptors. (The first form, one
+// thread per item re-deriving its row and re-loading its bounds, cost 0.75 + 0.36 + 0.69 ms per product; it left the tree in round 5.)
 __global__ void unit_rows_kernel(int n, const int *__restrict__ rows, const int *__restrict__ arpt, const int *__restrict__ crpt, int chunk, int nz_lo, int nz_hi,
                                  long long *__restrict__ tasks, long long *__restrict__ items)
 {
@@ -1512,7 +1490,7 @@ __global__ __launch_bounds__(256) void unit_task_kernel(long long bound /* threa
     if (!valid) { if constexpr (!EXPAND) return; t = total - 1; }
     int rl = 0, rh = n;                                             // the list position that holds the workgroup's first task (uniform), then a short walk forward
     while (rl < rh) {
-        const int mid = (rl + rh) >> 1;
+        const int mid = rl + ((rh - rl) >> 1);
         if (task_off[mid + 1] > t0) rh = mid; else rl = mid + 1;
     }
     while (task_off[rl + 1] <= t) ++rl;
@@ -1532,7 +1510,7 @@ __global__ __launch_bounds__(256) void unit_task_kernel(long long bound /* threa
             else {
                 const int cb = cols[(long long)chunk * b];
                 while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
+                    const int mid = lo + ((hi - lo) >> 1);
                     if (bcol[mid] < cb) lo = mid + 1; else hi = mid;
                 }
                 ctr[b - 1] = lo;
@@ -1588,8 +1566,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     const double *__restrict__ bval, const long long *__restrict__ row_flop,
     const int *__restrict__ crpt, int *__restrict__ ccol, double *__restrict__ cval,
     const long long *__restrict__ pre_off, const int *__restrict__ pre_cols,
-    const long long *__restrict__ ct_off /* exact chunk splits (chunk_splits_kernel), or NULL */, const int *__restrict__ ct,
-    const long long *__restrict__ item_off /* UNITS: first item of the list's i-th row (unit_kernel) */, const int *__restrict__ uoff /* first unit of an item */,
+    const long long *__restrict__ item_off /* UNITS: first item of the list's i-th row (unit_task_kernel) */, const int *__restrict__ uoff /* first unit of an item */,
     const UnitDesc *__restrict__ U, const NumRowMeta *__restrict__ meta /* per list position (num_row_meta_kernel) */)
 {
     // No static __shared__ in this kernel: it would sit in front of the dynamic region and push the fp64 table of phase 2 off its
@@ -1663,9 +1640,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     static_assert(4 * kBigChunk <= kBigWindowWords && kBigChunk <= 65536, "phase 2 reuses the bitmap region; slots are packed in 16 bits");
     constexpr int kU = kFlatUnitsPerRound;
     int kfirst = 0, klast = 0, shift = 0;
-    const bool exact = UNITS || (ct && nz > kBigChunk);            // uniform: this row's chunks have exact splits — every product visited lies in the chunk
-    const int nbnd = exact ? (nz + kBigChunk - 1) / kBigChunk - 1 : 0;
-    const int *ctr = (!UNITS && exact) ? ct + ct_off[ridx] : nullptr;   // (by position in this launch's row list)
+    constexpr bool exact = UNITS;                                  // unit lists carry exact chunk splits — every product visited lies in the chunk; the entry-pass walk runs on the window pieces
     // One round of a lane's products: their slots are found in lock-step (the dependent LDS reads of the kU searches interleave) for as many
     // halvings as the wave's deepest bucket needs — a unit is 64 consecutive entries of a sorted B row, so a wave's lanes sit in neighbouring
     // buckets — and the atomics come last. A round whose units all lie outside the chunk's column range is skipped by the whole wave.
@@ -1827,8 +1802,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
             __syncthreads();
             cu0 = cu1; cu1 = cu2;
         } else {
-            flat_products<T, true, kU>(a0, a1, acol, aval, clo, chi, bcol, bval, sd, t, accumulate,
-                                       (exact && qi > 0) ? ctr + (qi - 1) : nullptr, (exact && qi < nbnd) ? ctr + qi : nullptr, nbnd, gather_ids);
+            flat_products<T, true, kU>(a0, a1, acol, aval, clo, chi, bcol, bval, sd, t, accumulate, gather_ids);
         }
         BIG_PROF(8);
         {   // the chunk's values and column ids (gathered above).
@@ -2223,7 +2197,7 @@ __global__ void sortb_row_keys_kernel(int n, int K, const int *__restrict__ rpt,
     const int e = perm[k];
     int lo = 0, hi = K;                                            // the row that holds entry e: the last r with rpt[r] <= e
     while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
+        const int mid = lo + ((hi - lo) >> 1);
         if (rpt[mid] <= e) lo = mid; else hi = mid;
     }
     key[k] = K - 1 - lo;
@@ -2524,8 +2498,10 @@ struct SortedRows {
         G4S_TRY(counter.alloc(sizeof(int)));
         G4S_HIP_TRY(hipMemsetAsync(counter.p, 0, sizeof(int), s));
         hipLaunchKernelGGL(row_size_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, list, size, crpt, keys.as<int>());
-        G4S_TRY(tmp.alloc(sizeof(int) * 2 * (size_t)n));
         (void)key_bound;
+        if (n <= g4s::prims::kSortSmallMax)                       // a short list: one launch (the keys are < 2^11; the order among equal keys decides nothing but who takes a row first)
+            return g4s::prims::sort_pairs_descending_small_unstable(keys.as<int>(), list, keys_sorted.as<int>(), rows.as<int>(), n, s);
+        G4S_TRY(tmp.alloc(sizeof(int) * 2 * (size_t)n));
         G4S_TRY(g4s::prims::sort_pairs_descending(keys.as<int>(), list, keys_sorted.as<int>(), rows.as<int>(), tmp.as<int>(), tmp.as<int>() + n, n, 11, s));   // (31 + 1) << 6 | 63 < 2^11
         return G4S_OK;
     }
@@ -2780,6 +2756,8 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
         if (threads == 512) return window_t(std::integral_constant<int, 512>{}, rows, n, poff, pcols, next_row, cuts_mode);
         return window_t(std::integral_constant<int, 1024>{}, rows, n, poff, pcols, next_row, cuts_mode);
     };
+    // (Round 5 measured the long classes' launch on a side stream, its pre-passes beside the mid-size class's kernel, and the same for the numeric phase: 31.9 / 31.0 ms
+    // against 31.3 / 31.6 on one stream — nothing. The persistent kernels run four waves of 128 registers per SIMD: no wave of another kernel fits beside them.)
     if (x_med) { G4S_TRY(window(t_med, rc.list(CLS_MEDIUM), rc.count[CLS_MEDIUM], pre_off, pre_cols, true)); }
     else if (int n = rc.count[CLS_MEDIUM]) {
         auto k = spgemm_symbolic_lds_kernel<256, 256, 16384, false>;
@@ -2938,12 +2916,106 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
     const bool rank = pre && pre->rank && pre->d_cut_off && !getenv("G4S_SPGEMM_NO_RANK");   // the rows with cuts take the rank kernel (spgemm_rank.hpp)
     hipLaunchKernelGGL(nz_to_ll_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, crpt, rank ? pre->d_cut_off : (const long long *)nullptr, row_size.as<long long>());
     RowClasses rc;
-    G4S_TRY(classify_rows(M, row_size.as<long long>(), kNumLimits, 0, rc, s));
+    // With the rank path on, what is left for the window kernels past 4 096 outputs is the rows of at most 8 192 products (and symbolic hub rows): those of up to
+    // 8 192 outputs join the mid-size launch (four 2 048-output chunks at most) instead of being a launch — a row sort, unit lists, a persistent kernel — of their own.
+    ClassLimits num_limits = kNumLimits;
+    if (rank) num_limits.lim[4] = 8192;
+    G4S_TRY(classify_rows(M, row_size.as<long long>(), num_limits, 0, rc, s));
     if (getenv("G4S_DEBUG"))
         fprintf(stderr, "g4s numeric classes: empty %d <=32 %d <=512 %d <=1024 %d <=2048 %d <=4096 %d <=1M %d hub %d rank %d\n", rc.count[CLS_EMPTY], rc.count[CLS_TINY],
                 rc.count[CLS_SMALL], rc.count[CLS_MEDIUM], rc.count[CLS_LARGE], rc.count[CLS_M2], rc.count[CLS_M3], rc.count[CLS_HUB], rc.count[CLS_RANK]);
 
     dbg.mark("classes");
+    ColumnMap local_map;                                           // see spgemm_symbolic_impl; the one-shot call hands its map over
+    if (!pre) {
+        G4S_TRY(build_column_map(N, bnnz_local, bcol, local_map, s));
+    }
+    const ColumnMap &cmap = pre ? pre->cmap : local_map;
+    const int *wcol = cmap.cols(bcol), *winv = cmap.inverse();
+    const int N2 = cmap.width(N);
+    DevBuf wsplit_buf;
+    const int *wsplit = pre && pre->has_wsplit ? pre->wsplit : nullptr;
+    if (!(pre && pre->has_wsplit)) G4S_TRY(build_window_splits(K, N2, brpt, wcol, wsplit_buf, &wsplit, s));
+    std::vector<std::unique_ptr<DevBuf>> ct_keep;                  // transients of the launches below: live until the end of this call
+    // ---- the rows with cuts (spgemm_rank.hpp), longest first: chunk lists from the cuts, exact splits and unit lists per chunk, then the rank kernel. In two stages:
+    // stage 1 (row order, chunk counts, their scans, B's records) is enqueued before the short rows and the mid-size classes, so that its three totals have long
+    // arrived when stage 2 (chunk lists, splits, unit lists, the kernel) is enqueued behind them — the host never waits for the rank launch's counts.
+    const int rank_n = rc.count[CLS_RANK];
+    SortedRows rank_sr;
+    auto mk = [&]() { ct_keep.push_back(std::make_unique<DevBuf>()); return ct_keep.back().get(); };
+    DevBuf *tasks = mk(), *toff = mk(), *items = mk(), *ioff = mk(), *nch = mk(), *choff = mk(), *chunks = mk(), *ctoff = mk(), *ctb = mk(), *ucnt = mk(), *uoff = mk(), *ud = mk(), *bpack = mk();
+    long long rank_totals[2] = {0, 0};
+    int rank_nchunks = 0;
+    hipEvent_t rank_totals_ready = nullptr;
+    auto rank_stage1 = [&]() -> int {
+        const int n = rank_n;
+        G4S_TRY(rank_sr.build(n, rc.list(CLS_RANK), nullptr, crpt, N, s));
+        const int *rows = rank_sr.rows.as<int>();
+        G4S_TRY(tasks->alloc(sizeof(long long) * ((size_t)n + 1))); G4S_TRY(toff->alloc(sizeof(long long) * ((size_t)n + 1)));
+        G4S_TRY(items->alloc(sizeof(long long) * ((size_t)n + 1))); G4S_TRY(ioff->alloc(sizeof(long long) * ((size_t)n + 1)));
+        G4S_TRY(nch->alloc(sizeof(int) * ((size_t)n + 1))); G4S_TRY(choff->alloc(sizeof(int) * ((size_t)n + 1)));
+        G4S_TRY(ctoff->alloc(sizeof(long long) * ((size_t)n + 1)));
+        hipLaunchKernelGGL(rank_chunks_kernel<false>, dim3((n + 256) / 256), dim3(256), 0, s, n, rows, arpt, crpt, pre->d_cut_off, pre->d_cuts, pre->nseg, tasks->as<long long>(), items->as<long long>(),
+                           nch->as<int>(), (const int *)nullptr, (RankChunk *)nullptr);
+        G4S_TRY(g4s::prims::exclusive_scan(tasks->as<long long>(), toff->as<long long>(), (long long)n + 1, s));
+        G4S_TRY(g4s::prims::exclusive_scan(items->as<long long>(), ioff->as<long long>(), (long long)n + 1, s));
+        G4S_TRY(g4s::prims::exclusive_scan(nch->as<int>(), choff->as<int>(), (long long)n + 1, s));
+        G4S_HIP_TRY(hipMemcpyAsync(&rank_totals[0], toff->as<long long>() + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+        G4S_HIP_TRY(hipMemcpyAsync(&rank_totals[1], ioff->as<long long>() + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+        G4S_HIP_TRY(hipMemcpyAsync(&rank_nchunks, choff->as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, s));
+        {   // an event behind the three copies: stage 2 waits for IT, not for the stream — the mid-size kernel enqueued in between is still running then
+            thread_local hipEvent_t ev = nullptr;
+            if (!ev) G4S_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            G4S_HIP_TRY(hipEventRecord(ev, s));
+            rank_totals_ready = ev;
+        }
+        G4S_REQUIRE(pre->bnnz >= 0, "carried state without nnz(B)");
+        G4S_TRY(bpack->alloc(sizeof(BPack) * (size_t)std::max<long long>(pre->bnnz, 1)));
+        if (pre->bnnz > 0)
+            hipLaunchKernelGGL(pack_b_kernel, dim3((unsigned)((pre->bnnz + 255) / 256)), dim3(256), 0, s, pre->bnnz, wcol, bcol, bval, bpack->as<BPack>());
+        G4S_HIP_TRY(hipGetLastError());
+        return G4S_OK;
+    };
+    auto rank_stage2 = [&]() -> int {
+        constexpr int T = kRankT;
+        const int n = rank_n, nseg = pre->nseg;
+        const int *rows = rank_sr.rows.as<int>();
+        G4S_HIP_TRY(hipEventSynchronize(rank_totals_ready));        // stage 1's totals: there long ago (the mid-size launch in between has synchronised the stream)
+        const int nchunks = rank_nchunks;
+        const long long ntask = rank_totals[0], nitem = rank_totals[1], nct = nitem - ntask;
+        if (ntask <= 0 || nitem <= 0 || nitem > (1ll << 28) || nchunks <= 0)
+            return g4s::set_error(G4S_ERR_INVALID, "SpGEMM: the chunk lists of the carried symbolic state do not fit this product (%lld tasks, %lld items, %d chunks)", ntask, nitem, nchunks);
+        const long long ubound = (pre->flop >= 0 ? pre->flop : 0) / 64 + nitem + 1;
+        G4S_REQUIRE(pre->flop >= 0 && ubound <= (1ll << 28), "unit list of the rank launch past its cap");
+        G4S_TRY(chunks->alloc(sizeof(RankChunk) * (size_t)nchunks));
+        G4S_TRY(ctb->alloc(sizeof(int) * (size_t)std::max<long long>(nct, 1)));
+        G4S_TRY(ucnt->alloc(sizeof(int) * ((size_t)nitem + 1))); G4S_TRY(uoff->alloc(sizeof(int) * ((size_t)nitem + 1)));
+        G4S_TRY(ud->alloc(sizeof(UnitDesc) * (size_t)ubound));
+        hipLaunchKernelGGL(rank_chunks_kernel<true>, dim3((n + 256) / 256), dim3(256), 0, s, n, rows, arpt, crpt, pre->d_cut_off, pre->d_cuts, nseg, (long long *)nullptr, (long long *)nullptr,
+                           (int *)nullptr, (const int *)choff->as<int>(), chunks->as<RankChunk>());
+        hipLaunchKernelGGL(diff_ll_kernel, dim3((n + 256) / 256), dim3(256), 0, s, n + 1, ioff->as<long long>(), toff->as<long long>(), ctoff->as<long long>());
+        if (nct > 0)
+            hipLaunchKernelGGL(chunk_splits_kernel, dim3((unsigned)((nct + 255) / 256)), dim3(256), 0, s, nct, n, rows, K, N2, wsplit, arpt, acol, brpt, wcol, crpt, (const long long *)nullptr, (const int *)nullptr,
+                               (const int *)nullptr, kRankChunk, ctoff->as<long long>(), ctb->as<int>(), (const int *)choff->as<int>(), (const RankChunk *)chunks->as<RankChunk>());
+        const unsigned tgrid = (unsigned)((ntask + 255) / 256);
+        hipLaunchKernelGGL(unit_task_kernel<false>, dim3(tgrid), dim3(256), 0, s, ntask, n, rows, toff->as<long long>(), ioff->as<long long>(), arpt, acol, aval, brpt, wcol, crpt,
+                           (const long long *)nullptr, (const int *)nullptr, (const int *)nullptr, kRankChunk, ctb->as<int>(), ucnt->as<int>(), (const int *)nullptr, (UnitDesc *)nullptr, 1, (const int *)choff->as<int>());
+        G4S_TRY(g4s::prims::exclusive_scan(ucnt->as<int>(), uoff->as<int>(), nitem + 1, s));
+        hipLaunchKernelGGL(unit_task_kernel<true>, dim3(tgrid), dim3(256), 0, s, ntask, n, rows, toff->as<long long>(), ioff->as<long long>(), arpt, acol, aval, brpt, wcol, crpt,
+                           (const long long *)nullptr, (const int *)nullptr, (const int *)nullptr, kRankChunk, ctb->as<int>(), (int *)nullptr, (const int *)uoff->as<int>(), ud->as<UnitDesc>(), 1, (const int *)choff->as<int>());
+        constexpr size_t lds = sizeof(int) * (3 * (size_t)kRankChunk + 2 * (size_t)kRankWords + 64);
+        // the flat chunk list (spgemm_numeric_rank2_kernel): one self-contained item per chunk, dealt round-robin
+        DevBuf *ritems = mk();
+        G4S_TRY(ritems->alloc(sizeof(RankItem) * (size_t)nchunks));
+        hipLaunchKernelGGL(rank_items_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, rows, arpt, crpt, (const long long *)ioff->as<long long>(), (const int *)uoff->as<int>(), (const int *)choff->as<int>(),
+                           (const RankChunk *)chunks->as<RankChunk>(), ritems->as<RankItem>());
+        auto k = spgemm_numeric_rank2_kernel<T>;
+        G4S_TRY(allow_lds(k, lds));
+        hipLaunchKernelGGL(k, dim3(big_grid(nchunks, 1024 / T)), dim3(T), lds, s, nchunks, (const RankItem *)ritems->as<RankItem>(), wcol, (const BPack *)bpack->as<BPack>(), (const UnitDesc *)ud->as<UnitDesc>(), ccol, cval);
+        G4S_HIP_TRY(hipGetLastError());
+        return G4S_OK;
+    };
+    if (rank_n) G4S_TRY(rank_stage1());
     // rows of at most 512 outputs: one wavefront merges a row (spgemm_small_wave_kernel); a row of more than 512 PRODUCTS (the classes are cut by output length) or
     // more than 64 A-entries lands on a list that the table kernel takes, its count read on the device
     DevBuf small_ovf, small_ovf_n;
@@ -2967,81 +3039,14 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         hipLaunchKernelGGL(k, dim3(n), dim3(256), num_lds_bytes(1024), s, rc.list(CLS_SMALL), n, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval, (const int *)nullptr);
     }
     }
-    ColumnMap local_map;                                           // see spgemm_symbolic_impl; the one-shot call hands its map over
-    if (!pre) {
-        G4S_TRY(build_column_map(N, bnnz_local, bcol, local_map, s));
-    }
-    const ColumnMap &cmap = pre ? pre->cmap : local_map;
-    const int *wcol = cmap.cols(bcol), *winv = cmap.inverse();
-    const int N2 = cmap.width(N);
-    DevBuf wsplit_buf;
-    const int *wsplit = pre && pre->has_wsplit ? pre->wsplit : nullptr;
-    if (!(pre && pre->has_wsplit)) G4S_TRY(build_window_splits(K, N2, brpt, wcol, wsplit_buf, &wsplit, s));
     // Rows past 1 K entries: bitmap windows + bucketed slots beat table + in-LDS bitonic sort while the column range is <= 4 windows.
     const bool xn_large = N2 <= window_max_n(), xn_m2 = xn_large;
     // exact chunk splits (chunk_splits_kernel) for the rows of one launch that hold more than one value chunk: one-shot call only (the sorted columns must
     // exist before the numeric kernel runs); the buffers live until the end of this call
-    std::vector<std::unique_ptr<DevBuf>> ct_keep;
-    const bool use_units = !getenv("G4S_SPGEMM_NO_UNITS") && !getenv("G4S_SPGEMM_NO_EXACT_SPLITS");
-    auto chunk_splits = [&](int threads, const int *rows, int n, int nz_lo, int nz_hi, const long long **ct_off, const int **ct, bool *complete) -> int {
-        *ct_off = nullptr; *ct = nullptr; *complete = false;       // complete: every row of more than one chunk has its splits (or there is no such row)
-        if (n == 0 || getenv("G4S_SPGEMM_NO_EXACT_SPLITS")) return G4S_OK;
-        if (!use_units && (!wsplit || (threads != 1024 && !getenv("G4S_SPGEMM_EXACT_SPLITS_ALL")))) return G4S_OK;   // without unit lists the 256-thread launches (rows of at most two chunks) gain nothing from the splits
-        const int chunk = 8 * threads;                             // BigCfg<T>::kChunk
-        auto need = std::make_unique<DevBuf>(), off = std::make_unique<DevBuf>(), tab = std::make_unique<DevBuf>();
-        G4S_TRY(need->alloc(sizeof(long long) * ((size_t)n + 1)));
-        G4S_TRY(off->alloc(sizeof(long long) * ((size_t)n + 1)));
-        G4S_HIP_TRY(hipMemsetAsync(need->as<long long>() + n, 0, sizeof(long long), s));
-        hipLaunchKernelGGL(chunk_split_need_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, rows, arpt, crpt, chunk, nz_lo, nz_hi, need->as<long long>());
-        G4S_TRY(g4s::prims::exclusive_scan(need->as<long long>(), off->as<long long>(), (long long)n + 1, s));
-        long long total = 0;
-        G4S_HIP_TRY(hipMemcpyAsync(&total, off->as<long long>() + n, sizeof(long long), hipMemcpyDeviceToHost, s));
-        G4S_HIP_TRY(hipStreamSynchronize(s));
-        // an optimisation, never a reason to fail: entries × chunks can outgrow any sensible table (rows of 10^5 entries and 10^6 outputs) — those products, and
-        // a table that cannot be allocated, run with the window pieces as before
-        if (total == 0) { *complete = true; *ct_off = off->as<long long>(); ct_keep.push_back(std::move(need)); ct_keep.push_back(std::move(off)); return G4S_OK; }
-        if (total < 0 || total > (1ll << 28)) return G4S_OK;
-        if (tab->alloc(sizeof(int) * (size_t)total) != G4S_OK) { (void)hipGetLastError(); return G4S_OK; }
-        hipLaunchKernelGGL(chunk_splits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, n, rows, K, N2, wsplit, arpt, acol, brpt, wcol, crpt, pre_off, pre_cols, ccol, chunk,
-                           off->as<long long>(), tab->as<int>());
-        G4S_HIP_TRY(hipGetLastError());
-        *ct_off = off->as<long long>(); *ct = tab->as<int>(); *complete = true;
-        ct_keep.push_back(std::move(need)); ct_keep.push_back(std::move(off)); ct_keep.push_back(std::move(tab));
-        return G4S_OK;
-    };
-    // Unit lists of one launch (unit_kernel): items per row → scan → units per item → scan → descriptors. Never a reason to fail: without them (no splits, a table
-    // past its cap, no memory) the kernel walks its rows with the entry pass as before.
+    const bool use_units = !getenv("G4S_SPGEMM_NO_UNITS");
+    // Unit lists of one launch, by (row, A-entry) tasks (unit_task_kernel): splits, counts and descriptors in two passes over the tasks, ONE count read back. Never a
+    // reason to fail: without them (a table past its cap, no memory) the kernel walks its rows with the per-chunk entry pass and the window pieces (no exact splits).
     struct UnitLists { const long long *item_off = nullptr; const int *uoff = nullptr; const UnitDesc *U = nullptr; };
-    auto unit_lists = [&](int threads, const int *rows, int n, int nz_lo, int nz_hi, const long long *ct_off, const int *ct, UnitLists *out) -> int {
-        *out = UnitLists{};
-        const int chunk = 8 * threads;
-        auto items = std::make_unique<DevBuf>(), ioff = std::make_unique<DevBuf>(), ucnt = std::make_unique<DevBuf>(), uoff = std::make_unique<DevBuf>(), ud = std::make_unique<DevBuf>();
-        G4S_TRY(items->alloc(sizeof(long long) * ((size_t)n + 1)));
-        G4S_TRY(ioff->alloc(sizeof(long long) * ((size_t)n + 1)));
-        G4S_HIP_TRY(hipMemsetAsync(items->as<long long>() + n, 0, sizeof(long long), s));
-        hipLaunchKernelGGL(unit_items_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, rows, arpt, crpt, chunk, nz_lo, nz_hi, items->as<long long>());
-        G4S_TRY(g4s::prims::exclusive_scan(items->as<long long>(), ioff->as<long long>(), (long long)n + 1, s));
-        long long total = 0;
-        G4S_HIP_TRY(hipMemcpyAsync(&total, ioff->as<long long>() + n, sizeof(long long), hipMemcpyDeviceToHost, s));
-        G4S_HIP_TRY(hipStreamSynchronize(s));
-        if (total <= 0 || total > (1ll << 28)) return G4S_OK;
-        if (ucnt->alloc(sizeof(int) * ((size_t)total + 1)) != G4S_OK || uoff->alloc(sizeof(int) * ((size_t)total + 1)) != G4S_OK) { (void)hipGetLastError(); return G4S_OK; }
-        G4S_HIP_TRY(hipMemsetAsync(ucnt->as<int>() + total, 0, sizeof(int), s));
-        const unsigned grid = (unsigned)((total + 255) / 256);
-        hipLaunchKernelGGL(unit_kernel<false>, dim3(grid), dim3(256), 0, s, total, n, rows, ioff->as<long long>(), arpt, acol, aval, brpt, crpt, chunk, ct_off, ct, ucnt->as<int>(), (const int *)nullptr, (UnitDesc *)nullptr);
-        G4S_TRY(g4s::prims::exclusive_scan(ucnt->as<int>(), uoff->as<int>(), total + 1, s));
-        int total_units = 0;
-        G4S_HIP_TRY(hipMemcpyAsync(&total_units, uoff->as<int>() + total, sizeof(int), hipMemcpyDeviceToHost, s));
-        G4S_HIP_TRY(hipStreamSynchronize(s));
-        if (total_units <= 0 || total_units > (1 << 27)) return G4S_OK;          // (a sum past 2^31 shows up as a negative total)
-        if (ud->alloc(sizeof(UnitDesc) * (size_t)total_units) != G4S_OK) { (void)hipGetLastError(); return G4S_OK; }
-        hipLaunchKernelGGL(unit_kernel<true>, dim3(grid), dim3(256), 0, s, total, n, rows, ioff->as<long long>(), arpt, acol, aval, brpt, crpt, chunk, ct_off, ct, (int *)nullptr, uoff->as<int>(), ud->as<UnitDesc>());
-        G4S_HIP_TRY(hipGetLastError());
-        out->item_off = ioff->as<long long>(); out->uoff = uoff->as<int>(); out->U = ud->as<UnitDesc>();
-        ct_keep.push_back(std::move(items)); ct_keep.push_back(std::move(ioff)); ct_keep.push_back(std::move(ucnt)); ct_keep.push_back(std::move(uoff)); ct_keep.push_back(std::move(ud));
-        return G4S_OK;
-    };
-    // the same lists by (row, A-entry) tasks (unit_task_kernel): splits, counts and descriptors in two passes over the tasks, ONE count read back
     const long long class_flop_bound = pre ? pre->flop : -1;       // units <= flop / 64 + items; the one-shot call knows the product's flop (−1: unknown → the count is read back)
     auto unit_lists_by_tasks = [&](int threads, const int *rows, int n, int nz_lo, int nz_hi, UnitLists *out) -> int {
         *out = UnitLists{};
@@ -3107,16 +3112,9 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         constexpr int T = decltype(shape)::value;
         if (!n) return G4S_OK;
         const size_t lds = big_lds_bytes<T>();   // value chunk (fp64 sums, columns, bucket index) + scan scratch + the flat lists
-        const long long *ct_off = nullptr;
-        const int *ct = nullptr;
-        bool splits_complete = false;
         UnitLists ul;
         if (!carried_complete) G4S_TRY(emit_pass(shape, rows, n, nz_lo, nz_hi));
-        if (use_units && !getenv("G4S_SPGEMM_UNITS_BY_ITEMS")) G4S_TRY(unit_lists_by_tasks(T, rows, n, nz_lo, nz_hi, &ul));
-        if (!ul.U) {                                               // the item-parallel pre-pass (tests keep it alive: G4S_SPGEMM_UNITS_BY_ITEMS), and the walk without unit lists
-            G4S_TRY(chunk_splits(T, rows, n, nz_lo, nz_hi, &ct_off, &ct, &splits_complete));
-            if (use_units && splits_complete) G4S_TRY(unit_lists(T, rows, n, nz_lo, nz_hi, ct_off, ct, &ul));
-        }
+        if (use_units) G4S_TRY(unit_lists_by_tasks(T, rows, n, nz_lo, nz_hi, &ul));
         const dim3 grid(big_grid(n, BigCfg<T>::kPerCu));
         auto rmeta = std::make_unique<DevBuf>();
         G4S_TRY(rmeta->alloc(sizeof(NumRowMeta) * (size_t)n));
@@ -3124,12 +3122,12 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         if (ul.U) {
             auto k = spgemm_numeric_big_kernel<T, true>;
             G4S_TRY(allow_lds(k, lds));
-            hipLaunchKernelGGL(k, grid, dim3(T), lds, s, rows, n, nz_lo, nz_hi, next_row, N2, K, wsplit, arpt, acol, aval, brpt, wcol, winv, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols, ct_off, ct,
+            hipLaunchKernelGGL(k, grid, dim3(T), lds, s, rows, n, nz_lo, nz_hi, next_row, N2, K, wsplit, arpt, acol, aval, brpt, wcol, winv, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols,
                                ul.item_off, ul.uoff, ul.U, rmeta->as<NumRowMeta>());
         } else {
             auto k = spgemm_numeric_big_kernel<T, false>;
             G4S_TRY(allow_lds(k, lds));
-            hipLaunchKernelGGL(k, grid, dim3(T), lds, s, rows, n, nz_lo, nz_hi, next_row, N2, K, wsplit, arpt, acol, aval, brpt, wcol, winv, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols, ct_off, ct,
+            hipLaunchKernelGGL(k, grid, dim3(T), lds, s, rows, n, nz_lo, nz_hi, next_row, N2, K, wsplit, arpt, acol, aval, brpt, wcol, winv, bval, row_flop.as<long long>(), crpt, ccol, cval, pre_off, pre_cols,
                                (const long long *)nullptr, (const int *)nullptr, (const UnitDesc *)nullptr, rmeta->as<NumRowMeta>());
         }
         ct_keep.push_back(std::move(rmeta));
@@ -3170,69 +3168,7 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
     }
     }
     dbg.mark("mid-launch");
-    if (int n = rc.count[CLS_RANK]) {
-        // The rows with cuts (spgemm_rank.hpp), longest first: chunk lists from the cuts, exact splits and unit lists per chunk, then the rank kernel.
-        constexpr int T = kRankT;
-        SortedRows sr;
-        G4S_TRY(sr.build(n, rc.list(CLS_RANK), nullptr, crpt, N, s));
-        const int *rows = sr.rows.as<int>();
-        auto mk = [&]() { ct_keep.push_back(std::make_unique<DevBuf>()); return ct_keep.back().get(); };
-        DevBuf *tasks = mk(), *toff = mk(), *items = mk(), *ioff = mk(), *nch = mk(), *choff = mk(), *chunks = mk(), *ctoff = mk(), *ctb = mk(), *ucnt = mk(), *uoff = mk(), *ud = mk(), *rmeta = mk();
-        G4S_TRY(tasks->alloc(sizeof(long long) * ((size_t)n + 1))); G4S_TRY(toff->alloc(sizeof(long long) * ((size_t)n + 1)));
-        G4S_TRY(items->alloc(sizeof(long long) * ((size_t)n + 1))); G4S_TRY(ioff->alloc(sizeof(long long) * ((size_t)n + 1)));
-        G4S_TRY(nch->alloc(sizeof(int) * ((size_t)n + 1))); G4S_TRY(choff->alloc(sizeof(int) * ((size_t)n + 1)));
-        G4S_TRY(ctoff->alloc(sizeof(long long) * ((size_t)n + 1)));
-        const int nseg = pre->nseg;
-        hipLaunchKernelGGL(rank_chunks_kernel<false>, dim3((n + 256) / 256), dim3(256), 0, s, n, rows, arpt, crpt, pre->d_cut_off, pre->d_cuts, nseg, tasks->as<long long>(), items->as<long long>(),
-                           nch->as<int>(), (const int *)nullptr, (RankChunk *)nullptr);
-        G4S_TRY(g4s::prims::exclusive_scan(tasks->as<long long>(), toff->as<long long>(), (long long)n + 1, s));
-        G4S_TRY(g4s::prims::exclusive_scan(items->as<long long>(), ioff->as<long long>(), (long long)n + 1, s));
-        G4S_TRY(g4s::prims::exclusive_scan(nch->as<int>(), choff->as<int>(), (long long)n + 1, s));
-        long long totals[2] = {0, 0};
-        int nchunks = 0;
-        G4S_HIP_TRY(hipMemcpyAsync(&totals[0], toff->as<long long>() + n, sizeof(long long), hipMemcpyDeviceToHost, s));
-        G4S_HIP_TRY(hipMemcpyAsync(&totals[1], ioff->as<long long>() + n, sizeof(long long), hipMemcpyDeviceToHost, s));
-        G4S_HIP_TRY(hipMemcpyAsync(&nchunks, choff->as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, s));
-        G4S_HIP_TRY(hipStreamSynchronize(s));
-        const long long ntask = totals[0], nitem = totals[1], nct = nitem - ntask;
-        if (ntask <= 0 || nitem <= 0 || nitem > (1ll << 28) || nchunks <= 0)
-            return g4s::set_error(G4S_ERR_INVALID, "SpGEMM: the chunk lists of the carried symbolic state do not fit this product (%lld tasks, %lld items, %d chunks)", ntask, nitem, nchunks);
-        const long long ubound = (pre->flop >= 0 ? pre->flop : 0) / 64 + nitem + 1;
-        G4S_REQUIRE(pre->flop >= 0 && ubound <= (1ll << 28), "unit list of the rank launch past its cap");
-        G4S_TRY(chunks->alloc(sizeof(RankChunk) * (size_t)nchunks));
-        G4S_TRY(ctb->alloc(sizeof(int) * (size_t)std::max<long long>(nct, 1)));
-        G4S_TRY(ucnt->alloc(sizeof(int) * ((size_t)nitem + 1))); G4S_TRY(uoff->alloc(sizeof(int) * ((size_t)nitem + 1)));
-        G4S_TRY(ud->alloc(sizeof(UnitDesc) * (size_t)ubound));
-        G4S_TRY(rmeta->alloc(sizeof(RankRowMeta) * (size_t)n));
-        hipLaunchKernelGGL(rank_chunks_kernel<true>, dim3((n + 256) / 256), dim3(256), 0, s, n, rows, arpt, crpt, pre->d_cut_off, pre->d_cuts, nseg, (long long *)nullptr, (long long *)nullptr,
-                           (int *)nullptr, (const int *)choff->as<int>(), chunks->as<RankChunk>());
-        hipLaunchKernelGGL(diff_ll_kernel, dim3((n + 256) / 256), dim3(256), 0, s, n + 1, ioff->as<long long>(), toff->as<long long>(), ctoff->as<long long>());
-        if (nct > 0)
-            hipLaunchKernelGGL(chunk_splits_kernel, dim3((unsigned)((nct + 255) / 256)), dim3(256), 0, s, nct, n, rows, K, N2, wsplit, arpt, acol, brpt, wcol, crpt, (const long long *)nullptr, (const int *)nullptr,
-                               (const int *)nullptr, kRankChunk, ctoff->as<long long>(), ctb->as<int>(), (const int *)choff->as<int>(), (const RankChunk *)chunks->as<RankChunk>());
-        const unsigned tgrid = (unsigned)((ntask + 255) / 256);
-        hipLaunchKernelGGL(unit_task_kernel<false>, dim3(tgrid), dim3(256), 0, s, ntask, n, rows, toff->as<long long>(), ioff->as<long long>(), arpt, acol, aval, brpt, wcol, crpt,
-                           (const long long *)nullptr, (const int *)nullptr, (const int *)nullptr, kRankChunk, ctb->as<int>(), ucnt->as<int>(), (const int *)nullptr, (UnitDesc *)nullptr, 1, (const int *)choff->as<int>());
-        G4S_TRY(g4s::prims::exclusive_scan(ucnt->as<int>(), uoff->as<int>(), nitem + 1, s));
-        hipLaunchKernelGGL(unit_task_kernel<true>, dim3(tgrid), dim3(256), 0, s, ntask, n, rows, toff->as<long long>(), ioff->as<long long>(), arpt, acol, aval, brpt, wcol, crpt,
-                           (const long long *)nullptr, (const int *)nullptr, (const int *)nullptr, kRankChunk, ctb->as<int>(), (int *)nullptr, (const int *)uoff->as<int>(), ud->as<UnitDesc>(), 1, (const int *)choff->as<int>());
-        hipLaunchKernelGGL(rank_row_meta_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, rows, arpt, crpt, (const long long *)ioff->as<long long>(), (const int *)uoff->as<int>(), (const int *)choff->as<int>(),
-                           (const RankChunk *)chunks->as<RankChunk>(), rmeta->as<RankRowMeta>());
-        constexpr size_t lds = sizeof(int) * (3 * (size_t)kRankChunk + 2 * (size_t)kRankWords + 64);
-        auto k = spgemm_numeric_rank_kernel<T>;
-        G4S_TRY(allow_lds(k, lds));
-        DevBuf *bpack = mk();
-#if G4S_RANK_PACK
-        G4S_REQUIRE(pre->bnnz >= 0, "carried state without nnz(B)");
-        G4S_TRY(bpack->alloc(sizeof(BPack) * (size_t)std::max<long long>(pre->bnnz, 1)));
-        if (pre->bnnz > 0)
-            hipLaunchKernelGGL(pack_b_kernel, dim3((unsigned)((pre->bnnz + 255) / 256)), dim3(256), 0, s, pre->bnnz, wcol, bcol, bval, bpack->as<BPack>());
-#endif
-        hipLaunchKernelGGL(k, dim3(big_grid(n, 1024 / T)), dim3(T), lds, s, n, sr.counter.as<int>(), wcol, winv, bval, ccol, cval, (const long long *)ioff->as<long long>(), (const int *)uoff->as<int>(),
-                           (const UnitDesc *)ud->as<UnitDesc>(), (const RankRowMeta *)rmeta->as<RankRowMeta>(), (const RankChunk *)chunks->as<RankChunk>(), (const BPack *)bpack->as<BPack>());
-        G4S_HIP_TRY(hipGetLastError());
-        // (the sorted list and the counter are released in stream order — or with the call's arena: no wait here)
-    }
+    if (rank_n) G4S_TRY(rank_stage2());                            // (its totals have arrived while the mid-size classes were being enqueued)
     dbg.mark("rank-launch");
     if (int n = rc.count[CLS_M3]) {
         // the class spans 4 K … 128 K entries: its short rows go to the many-workgroups shape, the long ones keep 1 024 threads

@@ -10,28 +10,23 @@
 //              and the row's output count at every multiple of kRankWin columns — a few ints per row instead of the whole list;
 //   pre-pass   rank_chunks_kernel merges the two kinds of cuts into the row's chunk list: a chunk is at most kRankChunk consecutive outputs whose columns lie in
 //              one kRankWin-column segment; the exact B-row splits and the unit lists are built per chunk as before (chunk_splits_kernel, unit_task_kernel);
-//   numeric    spgemm_numeric_rank_kernel, one chunk at a time: the chunk's products are loaded ONCE (the first round stays in registers), their columns are
+//   numeric    spgemm_numeric_rank2_kernel, one chunk at a time: the chunk's products are loaded ONCE (the first round stays in registers), their columns are
 //              marked in an LDS bitmap of 48-column words, the owner threads turn the top 16 bits of every word into the word's exclusive rank, and a product's
 //              slot is then rank(word) + popcount(bits below) — one LDS read, no search, no bucket index, no column list; the product adds its value into
 //              V[slot] (ds_add_f64) and stores its column into KC[slot] (every product of a slot stores the same id), and the chunk leaves as two coalesced
 //              streams (cval, ccol through the column map). LDS per output: 8 B sum + 4 B column + 7 B of bitmap share = 152 KiB per workgroup.
 #pragma once
 
-#ifndef G4S_RANK_T
-#define G4S_RANK_T 1024                                    /* threads of the rank kernel's workgroup: 1024 (one per CU, 152 KiB) or 512 (two per CU, 76 KiB each, half the chunk and segment) */
-#endif
-constexpr int kRankT = G4S_RANK_T;
-constexpr int kRankChunk = 8 * kRankT;                     // outputs per value chunk (8 192)
+constexpr int kRankT = 1024;                               // threads of the rank kernel's workgroup, one per CU (512 threads with half-size chunks, two per CU: 47.5 ms against 30.5)
+constexpr int kRankChunk = 8 * kRankT;                     // outputs per value chunk: 8 192 (6 144 / 5 120 / 4 096 with wider bitmaps measured 32.7 / 33.0 / 38.5 ms against 30.0)
 constexpr int kRankWordCols = 48;                          // columns per 64-bit LDS word: bits 0–47 presence, bits 48–63 the word's exclusive rank within the chunk (< 8192)
 constexpr int kRankWords = 7 * kRankT;                     // words of a chunk's bitmap: 7 per thread (7 168 words, 56 KiB)
+static_assert(sizeof(int) * (3 * (size_t)kRankChunk + 2 * (size_t)kRankWords + 64) <= 160 * 1024, "the chunk's sums, columns and bitmap must fit one CU's LDS");
 constexpr int kRankWin = kRankWords * kRankWordCols;       // 344 064 columns per segment = 336 symbolic threads of 1 024 columns each
 constexpr int kRankSegThreads = kRankWin / 1024;
 static_assert(kRankWin % 1024 == 0 && kRankChunk >= 1024, "a symbolic thread (1 024 columns) holds at most one count cut and never straddles a segment");
-#ifndef G4S_RANK_PACK
-#define G4S_RANK_PACK 1                                    /* 1: B's entries as {compact column, column, value} records, one 16-byte load per product and no gather in the store step */
-#endif
 #ifndef G4S_SPGEMM_RANK_UPR
-#define G4S_SPGEMM_RANK_UPR 8                              /* 64-entry units a wave keeps in registers per chunk (16 waves × 8 × 64 = one chunk of products at compression 1) */
+#define G4S_SPGEMM_RANK_UPR 8                              /* 64-entry units a wave keeps in registers per chunk (16 waves × 8 × 64 = one chunk of products at compression 1); 10: equal, 12 / 14: register spills, 31–36 ms */
 #endif
 
 // A row's cuts live at cuts[cut_off[row] …]: nseg segment starts (the row's output count in front of column s·kRankWin), then the count cuts (the compact column of
@@ -135,128 +130,130 @@ __global__ void pack_b_kernel(long long nnz, const int *__restrict__ c2, const i
     if (k < nnz) out[k] = BPack{c2[k], col[k], val[k]};
 }
 
-// A row of the rank launch, packed per list position (one 64-byte scalar load): its place in C, its units, its chunk list and the first chunk itself.
-struct __attribute__((aligned(16))) RankRowMeta { int row, na, off, nch; int u0, u1, ch0, pad; long long ioff, pad2; RankChunk first; };
-__global__ void rank_row_meta_kernel(int n, const int *__restrict__ rows, const int *__restrict__ arpt, const int *__restrict__ crpt, const long long *__restrict__ item_off,
-                                     const int *__restrict__ uoff, const int *__restrict__ choff, const RankChunk *__restrict__ chunks, RankRowMeta *__restrict__ meta)
+// ---- the rank kernel, on a FLAT chunk list. (Its first form took rows through a ticket counter like the round-4 kernels: ticket → row metadata → unit
+// descriptors → loads, three dependent round trips at every row boundary, and a chunk's products requested only once the previous chunk's registers were free:
+// +1.1 ms, profiles/r05_spgemm_ab.txt.) Every chunk of every
+// row is one self-contained 32-byte item (where its outputs go, its segment, its units), the items stand in the launch's row order (longest rows first) and
+// workgroup b takes items b, b + G, b + 2G, … — nothing to draw, so everything about a workgroup's next chunk is known a chunk ahead and is requested then:
+//   item(g + 2G) and the unit descriptors of g + G                 at the top of chunk g (a scalar load; one vector load, lane q = unit q's descriptor),
+//   the COMPACT columns of g + G (what its mark step needs)          behind chunk g's first barrier,
+//   the {column, value} records of g + G (its accumulate step)       behind chunk g's accumulate step, when those registers are free.
+// Chunks are bounded pieces of work (at most kRankChunk outputs), so the round-robin deal balances without tickets.
+struct __attribute__((aligned(32))) RankItem { int out0, qn, wbase, u0, u1, pad0, pad1, pad2; };
+__global__ void rank_items_kernel(int n, const int *__restrict__ rows, const int *__restrict__ arpt, const int *__restrict__ crpt, const long long *__restrict__ item_off,
+                                  const int *__restrict__ uoff, const int *__restrict__ choff, const RankChunk *__restrict__ chunks, RankItem *__restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int r = rows[i];
-    const long long total_items = item_off[n];
-    RankRowMeta m;
-    m.row = r; m.na = arpt[r + 1] - arpt[r]; m.off = crpt[r]; m.nch = choff[i + 1] - choff[i]; m.ch0 = choff[i]; m.pad = 0; m.pad2 = 0;
-    m.ioff = item_off[i]; m.u0 = uoff[m.ioff]; m.u1 = uoff[min(m.ioff + m.na, total_items)];
-    m.first = chunks[m.ch0];
-    meta[i] = m;
+    const int r = rows[i], na = arpt[r + 1] - arpt[r], off = crpt[r], c0 = choff[i], nch = choff[i + 1] - c0;
+    const long long io = item_off[i], total_items = item_off[n];
+    for (int q = 0; q < nch; ++q) {
+        const RankChunk c = chunks[c0 + q];
+        out[c0 + q] = RankItem{off + c.o_lo, c.qn, c.seg * kRankWin, uoff[io + (long long)q * na], uoff[min(io + (long long)(q + 1) * na, total_items)], 0, 0, 0};
+    }
 }
 
-// ---- numeric: see the header of this file. One 1024-thread workgroup per CU (152 KiB of LDS), rows longest first through a counter, a row's metadata one row
-// ahead, the NEXT chunk's first round of products requested before the current chunk is stored.
 template <int T>
-__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void spgemm_numeric_rank_kernel(
-    int nrows, int *__restrict__ next_row, const int *__restrict__ bcol /* compact ids when col_of is given */, const int *__restrict__ col_of, const double *__restrict__ bval,
-    int *__restrict__ ccol, double *__restrict__ cval, const long long *__restrict__ item_off, const int *__restrict__ uoff, const UnitDesc *__restrict__ U,
-    const RankRowMeta *__restrict__ meta, const RankChunk *__restrict__ chunks, const BPack *__restrict__ bpack /* G4S_RANK_PACK */)
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void spgemm_numeric_rank2_kernel(
+    int nitems, const RankItem *__restrict__ items, const int *__restrict__ bcol2 /* compact column per entry of B */, const BPack *__restrict__ bpack,
+    const UnitDesc *__restrict__ U, int *__restrict__ ccol, double *__restrict__ cval)
 {
     static_assert(T == kRankT, "7 bitmap words and 8 outputs per thread");
     constexpr int kU = G4S_SPGEMM_RANK_UPR, kWaves = T / 64, kPer = kRankChunk / T, kWPT = kRankWords / T;
-    extern __shared__ int lds_i[];                                 // dynamic only (Guideline 17): [V: 8192 fp64][KC: 8192 int][BM: 7168 × 64 bit][ctrl: 64 int]
+    extern __shared__ int lds_i[];                                 // [V: 8192 fp64][KC: 8192 int][BM: 7168 × 64 bit][ctrl: 64 int]
     double *V = reinterpret_cast<double *>(lds_i);
     int *KC = lds_i + 2 * kRankChunk;
     unsigned long long *BM = reinterpret_cast<unsigned long long *>(lds_i + 3 * kRankChunk);
     unsigned *BM32 = reinterpret_cast<unsigned *>(BM);
     int *ctrl = lds_i + 3 * kRankChunk + 2 * kRankWords;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const long long total_items = item_off[nrows];
-    auto load_meta = [&](int idx) { return meta[min(idx, nrows - 1)]; };   // uniform index: one scalar load (a ticket past the end reads the last row: never used)
-
-    // round data of the chunk in flight: kU units per wave, a lane's entry of each
-    int rc[kU], ro[kU];                                            // compact column (bitmap), column as it goes to ccol
-    double rv[kU], rav[kU];
-    bool rok[kU];
+    const int G = gridDim.x;
     BIG_PROF_DECL_RANK;
-    auto issue_round = [&](const UnitDesc (&d)[kU], int nu, int g) {   // a lane's entry of each of the wave's kU units
-#pragma unroll
-        for (int q = 0; q < kU; ++q) {
-            const int len = nu > 0 ? d[q].len : 1, bpos = nu > 0 ? d[q].bpos : 0;
-            rok[q] = g + q < nu && lane < len;
-            const int kk = bpos + min(lane, len - 1);
-#if G4S_RANK_PACK
-            const int4 e = reinterpret_cast<const int4 *>(bpack)[kk];
-            rc[q] = e.x; ro[q] = e.y;
-            rv[q] = __longlong_as_double(((long long)e.w << 32) | (unsigned)e.z);
-#else
-            rc[q] = bcol[kk]; ro[q] = rc[q];
-            rv[q] = bval[kk];
-#endif
-            rav[q] = __longlong_as_double(((long long)d[q].av_hi << 32) | (unsigned)d[q].av_lo);
-        }
+    auto item_at = [&](int g) { return items[min(g, nitems - 1)]; };   // uniform: one s_load_dwordx8 (an index past the end reads the last item: never used)
+    auto desc_load = [&](const RankItem &it) {                    // lane q < kU: the descriptor of the wave's unit q in the chunk's first round
+        int4 d = make_int4(0, 1, 0, 0);
+        const int nu = it.u1 - it.u0;
+        if (lane < kU) d = reinterpret_cast<const int4 *>(U)[it.u0 + min(wave * kU + lane, max(nu, 1) - 1)];
+        return d;
     };
-    auto request_round = [&](int cu0, int nu, int g) {             // descriptors first (uniform: one s_load_dwordx4 each, all in flight), then the vector loads
-        UnitDesc d[kU];
-#pragma unroll
-        for (int q = 0; q < kU; ++q) d[q] = U[cu0 + min(g + q, max(nu, 1) - 1)];
-        issue_round(d, nu, g);
-    };
-    // (word << 6 | bit) of a column inside the chunk's segment; −1 for a column outside it (only with arrays that changed under a carried symbolic state)
     auto place_of = [&](int col, int wbase, bool ok) {
         const unsigned rel = (unsigned)(col - wbase);
         const unsigned w = __umulhi(rel, 0xAAAAAAABu) >> 5;        // rel / 48
         return (ok && rel < (unsigned)kRankWin) ? (int)((w << 6) | (rel - w * 48u)) : -1;
     };
-    auto mark = [&](int wr) {
-        if (wr >= 0) atomicOr(&BM32[2 * (wr >> 6) + ((wr >> 5) & 1)], 1u << (wr & 31));
-    };
+    auto mark = [&](int wr) { if (wr >= 0) atomicOr(&BM32[2 * (wr >> 6) + ((wr >> 5) & 1)], 1u << (wr & 31)); };
     auto accumulate = [&](int wr, int col, double prod) {
         if (wr < 0) return;
         const unsigned long long w = BM[wr >> 6];
-        const int slot = ((int)(w >> 48) + __popcll(w & ((1ull << (wr & 63)) - 1ull))) & (kRankChunk - 1);   // (the mask: stay inside the chunk whatever the arrays hold)
+        const int slot = min((int)(w >> 48) + __popcll(w & ((1ull << (wr & 63)) - 1ull)), kRankChunk - 1);   // (the clamp: stay inside the chunk whatever the arrays hold)
         atomicAdd(&V[slot], prod);
         KC[slot] = col;
     };
-
-    // clean slate once; every chunk leaves V and BM clean behind it
 #pragma unroll
-    for (int u = 0; u < kPer; ++u) { V[t + u * T] = 0.0; KC[t + u * T] = 0; }   // (KC: a slot no product writes — an empty chunk's slot 0 — must still hold a valid column id)
+    for (int u = 0; u < kPer; ++u) { V[t + u * T] = 0.0; KC[t + u * T] = 0; }
 #pragma unroll
     for (int j = 0; j < kWPT; ++j) BM[t + j * T] = 0ull;
-    if (t == 0) ctrl[32] = atomicAdd(next_row, 1);
-    __syncthreads();
-    int ridx = __builtin_amdgcn_readfirstlane(ctrl[32]);
-    if (ridx >= nrows) return;                                      // uniform
-    RankRowMeta cur = load_meta(ridx), nxt = cur;
-    RankChunk rec = cur.first;
-    int qi = 0, cu0 = cur.u0, cu1 = cur.u1, nridx = nrows;
-    bool have_next_row = false;                                    // nxt / nridx are valid for the current row
-    request_round(cu0, cu1 - cu0, wave * kU);
+    int g = blockIdx.x;
+    if (g >= nitems) return;                                       // uniform
+    // prologue: the first chunk's data the slow way, the second chunk's item
+    RankItem cur = item_at(g), nxt = item_at(g + G);
+    // The wave's kU descriptors of a chunk stay in ONE int4 per lane (lane q = unit q) and are read out with v_readlane where they are needed: as SGPR arrays
+    // (position, length, value × current and next chunk) they alone took more scalar registers than a wave has.
+    int4 dc = desc_load(cur);
+    auto d_pos = [&](const int4 &d, int q) { return __builtin_amdgcn_readlane(d.x, q); };
+    auto d_len = [&](const int4 &d, int q, int nu) { return wave * kU + q < nu ? __builtin_amdgcn_readlane(d.y, q) : 0; };   // (a unit past the chunk's last: no lane is valid)
+    auto d_val = [&](const int4 &d, int q) { return __longlong_as_double(((long long)__builtin_amdgcn_readlane(d.w, q) << 32) | (unsigned)__builtin_amdgcn_readlane(d.z, q)); };
+    auto entry_of = [&](const int4 &d, int q, int nu) { return d_pos(d, q) + min(lane, max(d_len(d, q, nu), 1) - 1); };
+    int c2[kU];                                                    // compact columns of the CURRENT chunk's first round
+#pragma unroll
+    for (int q = 0; q < kU; ++q) c2[q] = bcol2[entry_of(dc, q, cur.u1 - cur.u0)];
+    int ro[kU];
+    double rv[kU];
+    auto load_pack = [&](const int4 &d, int nu) {
+#pragma unroll
+        for (int q = 0; q < kU; ++q) {
+            typedef int int3_t __attribute__((ext_vector_type(3)));
+            const int3_t e = *reinterpret_cast<const int3_t *>(&bpack[entry_of(d, q, nu)].col);   // {column, value}: one global_load_dwordx3 (the record's compact column came in a chunk ago)
+            ro[q] = e.x;
+            rv[q] = __longlong_as_double(((long long)e.z << 32) | (unsigned)e.y);
+        }
+    };
+    load_pack(dc, cur.u1 - cur.u0);
     for (;;) {
-        const int nu = cu1 - cu0;
-        const bool first_chunk = qi == 0, last_chunk = qi + 1 >= cur.nch;   // uniform
-        if (first_chunk && t == 0) ctrl[33] = atomicAdd(next_row, 1);        // the next row's ticket: read behind this chunk's first barrier
-        // the next chunk of this row: its units end where the chunk after it begins; its record
-        const int cu2 = uoff[min(cur.ioff + (long long)min(qi + 2, cur.nch) * cur.na, total_items)];
-        const RankChunk rec_n = chunks[cur.ch0 + min(qi + 1, cur.nch - 1)];
-        const int wbase = rec.seg * kRankWin;
-        // ---- mark: round 0 from the registers requested a chunk ago, further rounds (crowded chunks) by column only
+        const int nu = cur.u1 - cur.u0;
+        const bool more = g + G < nitems;                          // uniform
+        // what the NEXT chunk needs first: its descriptors (the item arrived a chunk ago); the item behind it
+        int4 dn = make_int4(0, 1, 0, 0);
+        if (more) dn = desc_load(nxt);
+        const RankItem nxt2 = item_at(g + 2 * G);
+        // ---- mark
         int wr[kU];
 #pragma unroll
-        for (int q = 0; q < kU; ++q) { wr[q] = place_of(rc[q], wbase, rok[q]); mark(wr[q]); }
-        for (int g = (wave + kWaves) * kU; g < nu; g += kWaves * kU) {   // (uniform per wave)
-            UnitDesc d[kU];
+        for (int q = 0; q < kU; ++q) { wr[q] = place_of(c2[q], cur.wbase, lane < d_len(dc, q, nu)); mark(wr[q]); }
+        // crowded chunks: further rounds, by column only (uniform per wave), four units at a time — they are rare once kU covers a typical chunk, and their
+        // temporaries must not set the kernel's register count
+        constexpr int kX = 4;
+        for (int r0 = (wave + kWaves) * kU; r0 < nu; r0 += kWaves * kU)
+            for (int x0 = r0; x0 < min(r0 + kU, nu); x0 += kX) {
+                UnitDesc d[kX];
 #pragma unroll
-            for (int q = 0; q < kU; ++q) d[q] = U[cu0 + min(g + q, nu - 1)];
-            int c2[kU];
+                for (int q = 0; q < kX; ++q) d[q] = U[cur.u0 + min(x0 + q, nu - 1)];
+                int cx[kX];
 #pragma unroll
-            for (int q = 0; q < kU; ++q) c2[q] = bcol[d[q].bpos + min(lane, d[q].len - 1)];
+                for (int q = 0; q < kX; ++q) cx[q] = bcol2[d[q].bpos + min(lane, d[q].len - 1)];
 #pragma unroll
-            for (int q = 0; q < kU; ++q) mark(place_of(c2[q], wbase, g + q < nu && lane < d[q].len));
-        }
+                for (int q = 0; q < kX; ++q) mark(place_of(cx[q], cur.wbase, x0 + q < min(r0 + kU, nu) && lane < d[q].len));
+            }
         BIG_PROF(0);
         __syncthreads();
         BIG_PROF(1);
-        if (first_chunk) { nridx = __builtin_amdgcn_readfirstlane(ctrl[33]); nxt = load_meta(nridx); have_next_row = true; }
-        // ---- ranks: thread t owns the words [7t, 7t + 7); the top 16 bits of a word become the number of set bits in front of it
+        // the next chunk's compact columns: its descriptors have had the mark step to arrive
+        int c2n[kU];
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < kU; ++q) c2n[q] = bcol2[entry_of(dn, q, nxt.u1 - nxt.u0)];
+        }
+        // ---- ranks
         unsigned long long w7[kWPT];
         int cnt = 0;
 #pragma unroll
@@ -274,58 +271,52 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         }
         __syncthreads();
         BIG_PROF(3);
-        // the next chunk (of this row, or the first one of the next row): its wave's kU descriptors are requested here, a whole accumulate step before they are
-        // needed (requested at the point of use, the scalar loads of the descriptors were a round trip in front of the round's vector loads: 14 % of the kernel)
-        const bool more = !last_chunk || nridx < nrows;            // uniform (nxt is valid: the next row's ticket was read behind the first barrier of this row's first chunk)
-        const int ncu0 = last_chunk ? nxt.u0 : cu1, ncu1 = last_chunk ? nxt.u1 : cu2;
-        int4 dq = make_int4(0, 1, 0, 0);
-        if (more && lane < kU) dq = reinterpret_cast<const int4 *>(U)[ncu0 + min(wave * kU + lane, max(ncu1 - ncu0, 1) - 1)];
-        // ---- accumulate: round 0 from registers, further rounds loaded again (columns and values)
+        // ---- accumulate
 #pragma unroll
-        for (int q = 0; q < kU; ++q) accumulate(wr[q], ro[q], rav[q] * rv[q]);   // multop / addop, hash_mult.h:583-593
-        for (int g = (wave + kWaves) * kU; g < nu; g += kWaves * kU) {
-            request_round(cu0, nu, g);
+        for (int q = 0; q < kU; ++q) accumulate(wr[q], ro[q], d_val(dc, q) * rv[q]);   // multop / addop, hash_mult.h:583-593
+        for (int r0 = (wave + kWaves) * kU; r0 < nu; r0 += kWaves * kU)
+            for (int x0 = r0; x0 < min(r0 + kU, nu); x0 += kX) {
+                UnitDesc d[kX];
 #pragma unroll
-            for (int q = 0; q < kU; ++q) accumulate(place_of(rc[q], wbase, rok[q]), ro[q], rav[q] * rv[q]);
-        }
+                for (int q = 0; q < kX; ++q) d[q] = U[cur.u0 + min(x0 + q, nu - 1)];
+                int4 e[kX];
+#pragma unroll
+                for (int q = 0; q < kX; ++q) e[q] = reinterpret_cast<const int4 *>(bpack)[d[q].bpos + min(lane, d[q].len - 1)];
+#pragma unroll
+                for (int q = 0; q < kX; ++q) {
+                    const double a = __longlong_as_double(((long long)d[q].av_hi << 32) | (unsigned)d[q].av_lo);
+                    accumulate(place_of(e[q].x, cur.wbase, x0 + q < min(r0 + kU, nu) && lane < d[q].len), e[q].y, a * __longlong_as_double(((long long)e[q].w << 32) | (unsigned)e[q].z));
+                }
+            }
 #ifdef G4S_PROFILE_BIG
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         BIG_PROF(4);
-        prof_acc[9] += 1; prof_acc[10] += nu; prof_acc[11] += rec.qn;
+        prof_acc[9] += 1; prof_acc[10] += nu; prof_acc[11] += cur.qn;
 #endif
-        // ---- the next chunk's first round, requested now: it arrives under the barrier and the store step
+        // the next chunk's records: the registers of this chunk's are free
         if (more) {
-            UnitDesc d[kU];                                        // the descriptors came in as one vector load (lane q holds unit q's): no scalar round trip in front of the loads
 #pragma unroll
-            for (int q = 0; q < kU; ++q)
-                d[q] = UnitDesc{__builtin_amdgcn_readlane(dq.x, q), __builtin_amdgcn_readlane(dq.y, q), __builtin_amdgcn_readlane(dq.z, q), __builtin_amdgcn_readlane(dq.w, q)};
-            issue_round(d, ncu1 - ncu0, wave * kU);
+            for (int q = 0; q < kU; ++q) c2[q] = c2n[q];
+            dc = dn;
+            load_pack(dc, nxt.u1 - nxt.u0);
         }
         BIG_PROF(5);
         __syncthreads();
         BIG_PROF(6);
-        // ---- store: the chunk's sums and columns; leave V and the bitmap clean
+        // ---- store, clean
         {
-            double val[kPer];
-            int col[kPer];
+            constexpr int kH = (kPer + 1) / 2;                      // in two parts: the step's temporaries stay under the register count the products' state sets
 #pragma unroll
-            for (int u = 0; u < kPer; ++u) { const int i = min(t + u * T, max(rec.qn, 1) - 1); val[u] = V[i]; col[u] = KC[i]; }
-#if !G4S_RANK_PACK
-            if (col_of) {
+            for (int h = 0; h < 2; ++h) {
+                double val[kH];
+                int col[kH];
 #pragma unroll
-                for (int u = 0; u < kPer; ++u) col[u] = col_of[col[u]];
-            }
-#endif
-            const long long o = (long long)cur.off + rec.o_lo;
+                for (int u = 0; u < kH; ++u) { const int i = min(t + (h * kH + u) * T, max(cur.qn, 1) - 1); val[u] = V[i]; col[u] = KC[i]; }
 #pragma unroll
-            for (int u = 0; u < kPer; ++u) {
-                const int i = t + u * T;
-                if (i < rec.qn) { cval[o + i] = val[u]; V[i] = 0.0; }
-            }
-#pragma unroll
-            for (int u = 0; u < kPer; ++u) {
-                const int i = t + u * T;
-                if (i < rec.qn) ccol[o + i] = col[u];
+                for (int u = 0; u < kH; ++u) {
+                    const int i = t + (h * kH + u) * T;
+                    if (h * kH + u < kPer && i < cur.qn) { cval[(long long)cur.out0 + i] = val[u]; ccol[(long long)cur.out0 + i] = col[u]; V[i] = 0.0; }
+                }
             }
 #pragma unroll
             for (int j = 0; j < kWPT; ++j) BM[t * kWPT + j] = 0ull;
@@ -334,10 +325,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         __syncthreads();
         BIG_PROF(8);
         if (!more) break;
-        if (last_chunk) { ridx = nridx; cur = nxt; rec = cur.first; qi = 0; have_next_row = false; }
-        else { rec = rec_n; ++qi; }
-        cu0 = ncu0; cu1 = ncu1;
+        g += G; cur = nxt; nxt = nxt2;
     }
     BIG_PROF_FLUSH;
-    (void)have_next_row; (void)ridx; (void)col_of; (void)bval; (void)bpack;
 }

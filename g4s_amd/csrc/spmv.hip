@@ -581,6 +581,9 @@ G4S_API g4s_status g4s_csr_create(g4s_csr_t *out, int32_t rows, int32_t cols, in
     G4S_HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev <= 0) return g4s::set_error(G4S_ERR_HIP, "no HIP device");
 
+    // the create's scratch requests (scans, flags) come from a per-call arena, not from the stream-ordered pool: the pool's first use in a process creates it — 3 ms
+    // in the middle of the first create (round 5); everything the plan KEEPS is allocated on its own
+    struct CreateArena { CreateArena() { g4s::arena_enter(); } ~CreateArena() { g4s::arena_leave(nullptr, false); } } create_arena;
     g4s_csr_s *A = new (std::nothrow) g4s_csr_s();
     if (!A) return g4s::set_error(G4S_ERR_NOMEM, "host allocation failed");
     A->rows = rows; A->cols = cols; A->nnz = nnz;

@@ -73,6 +73,19 @@ struct DevBuf {
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// A transient of the plan build: a piece of the build's arena (runtime.cpp: arena_enter … arena_leave around pb_build) — no driver call to get it and none to
+// give it back. (Round 5: the transients were hipMalloc / hipFree pairs, twenty of them per create, every hipFree a device-wide wait; and the first scratch
+// request of a process created the stream-ordered pool, 3 ms in the middle of the first create.)
+struct TmpBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~TmpBuf() { release(); }
+    int alloc(size_t n) { release(); bytes = n; return scratch_alloc(&p, n ? n : 1, nullptr); }
+    void release() { if (p) { scratch_free(p, nullptr); p = nullptr; bytes = 0; } }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+struct BuildArena { BuildArena() { arena_enter(); } ~BuildArena() { arena_leave(nullptr, false); } };
+
 inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 65536 ? 65536 : g)); }
 inline int prims_bits(int max_value) { int b = 1; while (b < 31 && (max_value >> b)) ++b; return b; }   // significant bits of the largest key
 
@@ -106,6 +119,48 @@ __global__ __launch_bounds__(256) void pb_col_degree_kernel(long long nnz, const
     __syncthreads();
     for (int i = threadIdx.x; i < kDegSlots; i += 256)
         if (s_cnt[i]) atomicAdd(&deg[s_key[i]], s_cnt[i]);
+}
+// Large matrices (round 5): even with the popular columns counted in LDS the kernel above took 7.9 ms on configs[1] — 10^8 atomics on 10^7 counters are scattered
+// 64-byte read-modify-writes, and the chip does about 2·10^10 of those per second whoever collides (MI355X_MICROARCH.md, global atomics: 64 lanes in 64 rows).
+// So the column ids are first PARTITIONED by their top 12 bits (three passes of the library's radix sort: bins of at most 4 096 columns, in descending bin
+// order), and every 64 K-entry piece of the partitioned list is counted by one workgroup: bin by bin in a 4 096-counter LDS table, flushed with one atomic per
+// non-zero counter (a bin's piece of fewer than 1 024 entries goes to HBM directly). A first form with 256 bins and one workgroup per (bin, 8 192-column
+// sub-range) ran 17.9 ms: R-MAT puts 11 % of the entries into bin 0, and its eight workgroups walked 11 M entries each.
+constexpr int kDegBinBits = 12, kDegPiece = 1 << 16;
+__global__ void pb_bin_keys_kernel(long long nnz, const int *__restrict__ colids, int shift, int *__restrict__ key)
+{
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long long)gridDim.x * blockDim.x) key[k] = colids[k] >> shift;
+}
+__global__ __launch_bounds__(256) void pb_bin_degree_kernel(int n, const int *__restrict__ bins_desc /* sorted, descending */, const int *__restrict__ cols_sorted, int shift,
+                                                            int *__restrict__ deg /* zeroed */)
+{
+    extern __shared__ int s_cnt[];                                 // 1 << shift counters
+    __shared__ int s_end;
+    const int width = 1 << shift;
+    const int k0 = blockIdx.x * kDegPiece, k1 = min(n, k0 + kDegPiece);
+    int k = k0;
+    while (k < k1) {                                               // uniform: one bin's part of the piece per turn
+        const int bin = bins_desc[k];
+        if (threadIdx.x == 0) {                                    // the end of this bin inside the piece: first index whose key is smaller
+            int lo = k, hi = k1;
+            while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (bins_desc[mid] >= bin) lo = mid + 1; else hi = mid; }   // (lo + hi overflows int past 2^30 entries: C of configs[2] has 1.94e9)
+            s_end = lo;
+        }
+        __syncthreads();
+        const int e = s_end, base = bin << shift;
+        if (e - k < 1024) {
+            for (int i = k + threadIdx.x; i < e; i += 256) atomicAdd(&deg[cols_sorted[i]], 1);
+        } else {
+            for (int i = threadIdx.x; i < width; i += 256) s_cnt[i] = 0;
+            __syncthreads();
+            for (int i = k + threadIdx.x; i < e; i += 256) atomicAdd(&s_cnt[cols_sorted[i] - base], 1);
+            __syncthreads();
+            for (int i = threadIdx.x; i < width; i += 256)
+                if (s_cnt[i]) atomicAdd(&deg[base + i], s_cnt[i]);
+        }
+        __syncthreads();                                           // (s_end and the table are rewritten by the next turn)
+        k = e;
+    }
 }
 __global__ __launch_bounds__(256) void pb_max_kernel(int n, const int *__restrict__ v, int *__restrict__ out)
 {
@@ -517,9 +572,10 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     if (!P) return set_error(G4S_ERR_NOMEM, "host allocation failed");
     std::unique_ptr<PbPlan> guard(P);
     P->rows = rows; P->cols = cols; P->nnz = nnz;
+    BuildArena arena;                                              // the build's transients (TmpBuf) live in it; declared before them, so it ends after them
     // 0. hot column bands: rank the columns by degree, take the leading 16 K-column groups that are much denser than a natural band
     const int CBnat = (cols + kBand - 1) >> kBandBits;
-    DevBuf colmap, deg, deg_s, order_in, order, tmp0;
+    TmpBuf colmap, deg, deg_s, order_in, order, tmp0;
     G4S_TRY(colmap.alloc(sizeof(unsigned) * (size_t)cols));
     int H = 0;
     {
@@ -529,8 +585,20 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
         if (want != 0 && Hmax > 0) {
             G4S_TRY(deg.alloc(sizeof(int) * (size_t)cols)); G4S_TRY(deg_s.alloc(sizeof(int) * (size_t)cols));
             G4S_TRY(order_in.alloc(sizeof(int) * (size_t)cols)); G4S_TRY(order.alloc(sizeof(int) * (size_t)cols));
-            G4S_HIP_TRY(hipMemset(deg.p, 0, deg.bytes));
-            hipLaunchKernelGGL(pb_col_degree_kernel, dim3((unsigned)std::min<long long>(kDegBlocks, (nnz + 255) / 256)), dim3(256), 0, nullptr, nnz, d_colids, deg.as<int>());
+            const int cbits = prims_bits(cols - 1), shift = std::max(0, cbits - kDegBinBits);
+            G4S_HIP_TRY(hipMemsetAsync(deg.p, 0, deg.bytes, nullptr));
+            if (cols >= (1 << 20) && nnz >= (1ll << 24) && nnz < (1ll << 31) && shift <= 13) {
+                // partition by the top 12 bits of the column id, then count piece by piece in LDS (pb_bin_degree_kernel)
+                TmpBuf bkey, bkey_s, bcol_s, tk, tv;
+                const size_t nb = sizeof(int) * (size_t)nnz;
+                G4S_TRY(bkey.alloc(nb)); G4S_TRY(bkey_s.alloc(nb)); G4S_TRY(bcol_s.alloc(nb)); G4S_TRY(tk.alloc(nb)); G4S_TRY(tv.alloc(nb));
+                hipLaunchKernelGGL(pb_bin_keys_kernel, dim3(grid_for(nnz)), dim3(256), 0, nullptr, nnz, d_colids, shift, bkey.as<int>());
+                G4S_TRY(prims::sort_pairs_descending(bkey.as<int>(), d_colids, bkey_s.as<int>(), bcol_s.as<int>(), tk.as<int>(), tv.as<int>(), (int)nnz, prims_bits((cols - 1) >> shift), nullptr));
+                hipLaunchKernelGGL(pb_bin_degree_kernel, dim3((unsigned)((nnz + kDegPiece - 1) / kDegPiece)), dim3(256), sizeof(int) << shift, nullptr, (int)nnz, bkey_s.as<int>(), bcol_s.as<int>(), shift,
+                                   deg.as<int>());
+            } else {
+                hipLaunchKernelGGL(pb_col_degree_kernel, dim3((unsigned)std::min<long long>(kDegBlocks, (nnz + 255) / 256)), dim3(256), 0, nullptr, nnz, d_colids, deg.as<int>());
+            }
             hipLaunchKernelGGL(pb_iota_kernel, dim3((cols + 255) / 256), dim3(256), 0, nullptr, cols, order_in.as<int>());
             G4S_HIP_TRY(hipGetLastError());
             int *d_max = nullptr, h_max = 0;                        // the largest degree bounds the key bits of the ranking sort
@@ -577,7 +645,7 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     const long long ncells = (long long)CB * RB;
 
     // 1. regroup: stable sort of the CSR entries by (column band, row band)
-    DevBuf key, key_s, idx, perm, rowid, startP;
+    TmpBuf key, key_s, idx, perm, rowid, startP;
     const size_t n4 = sizeof(unsigned) * (size_t)nnz;
     G4S_TRY(key.alloc(n4)); G4S_TRY(key_s.alloc(n4)); G4S_TRY(idx.alloc(n4)); G4S_TRY(perm.alloc(n4)); G4S_TRY(rowid.alloc(n4));
     if (nnz >= (1ll << 31)) return set_error(G4S_ERR_UNSUPPORTED, "pb_build: more than 2^31 - 1 nonzeros");
@@ -585,7 +653,7 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
                        rowid.as<int>(), idx.as<int>());
     G4S_HIP_TRY(hipGetLastError());
     {
-        DevBuf ckey_s, tk, tv;                                      // sorted band keys, the sort's ping-pong partners
+        TmpBuf ckey_s, tk, tv;                                      // sorted band keys, the sort's ping-pong partners
         G4S_TRY(ckey_s.alloc(n4)); G4S_TRY(tk.alloc(n4)); G4S_TRY(tv.alloc(n4));
         G4S_TRY(prims::sort_pairs_descending(key.as<int>(), idx.as<int>(), ckey_s.as<int>(), perm.as<int>(), tk.as<int>(), tv.as<int>(), (int)nnz, prims_bits(CB - 1), nullptr));
         hipLaunchKernelGGL(pb_full_keys_kernel, dim3(grid_for(nnz)), dim3(256), 0, nullptr, nnz, ckey_s.as<int>(), perm.as<int>(), rowid.as<int>(), CB, bits, key_s.as<unsigned>());
@@ -613,7 +681,7 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     padP[ncells] = (int)totP;
     if (totP + 64 > INT32_MAX) return set_error(G4S_ERR_UNSUPPORTED, "pb_build: padded length exceeds int32");
     const long long nspans = totP / kSpan;
-    DevBuf d_shP, t_row, t_cell, counts;
+    TmpBuf d_shP, t_row, t_cell, counts;
     G4S_TRY(d_shP.alloc(sizeof(int) * shP.size()));
     G4S_HIP_TRY(hipMemcpy(d_shP.p, shP.data(), sizeof(int) * shP.size(), hipMemcpyHostToDevice));
     G4S_TRY(P->p_lcol.alloc(sizeof(unsigned short) * (size_t)(totP + 64)));
@@ -648,7 +716,7 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     // 4. micro-run index at every cell start → consumer layout (host): row band segments at multiples of 4
     std::vector<int> span_of_cell((size_t)ncells + 1), mstart((size_t)ncells + 1);
     for (long long q = 0; q <= ncells; ++q) span_of_cell[q] = padP[q] / kSpan;
-    DevBuf d_soc, d_mstart;
+    TmpBuf d_soc, d_mstart;
     G4S_TRY(d_soc.alloc(sizeof(int) * span_of_cell.size())); G4S_TRY(d_mstart.alloc(sizeof(int) * mstart.size()));
     G4S_HIP_TRY(hipMemcpy(d_soc.p, span_of_cell.data(), sizeof(int) * span_of_cell.size(), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(pb_gather_kernel, dim3(grid_for(ncells + 1)), dim3(256), 0, nullptr, ncells + 1, d_soc.as<int>(), P->mbase.as<int>(), d_mstart.as<int>());
@@ -686,6 +754,9 @@ int pb_build(PbPlan **out, int rows, int cols, long long nnz, const int *d_rowpt
     // for staging its band of x whatever its length — and 128 K / 64 K 20 % slower: too few items for 256 CUs)
     const long long auto_pc = std::min<long long>(kProducerChunk, std::max<long long>(32768, pow2_at_most(totP / 128)));
     const long long auto_cc = std::min<long long>(kConsumerChunk, std::max<long long>(16384, pow2_at_most(P->micro_runs / 128)));
+    // (Round 5, VERDICT r4 item 4: items cut so that the heavy ones make a WHOLE number of rounds over the CUs — total / 256 entries per producer item for a 12 M-entry
+    // slab of configs[1] instead of 64 K — measured SLOWER: 73.0 against 65.3 µs per product, tools/small_sizes.py rmat12m. The 413 items of the power-of-two rule
+    // are not one and a half rounds of equal items: the hot bands' items are long, the natural bands' short, and longer items only lengthen the round's tail.)
     const int kPC = (std::max<long long>(kSpan * kPbThreads, getenv("G4S_PB_PCHUNK") ? atoll(getenv("G4S_PB_PCHUNK")) : auto_pc) / kWindow) * (kWindow / kSpan);   // spans per item, whole windows
     const int kCC = (int)std::max<long long>(4, (getenv("G4S_PB_CCHUNK") ? atoll(getenv("G4S_PB_CCHUNK")) : auto_cc) & ~3ll);
     std::vector<ProducerItem> pit;
@@ -760,9 +831,10 @@ bool pb_should_use(int rows, int cols, long long nnz, const int *d_colids)
 {
     (void)rows;
     if ((long long)cols * 8 < (8ll << 20) || nnz < (4ll << 20)) return false;   // x within ~2 L2s: the gathers mostly hit (a 15 MB x still ran 2.3× faster blocked)
-    const int W = 2048, S = 64;
+    const int W = 2048, S = 16;                                     // (round 5: 16 windows instead of 64 — the ratio is ≈ 0.9 for power-law graphs and ≈ 0.05 for stencils, and the 64 host-side sorts were 2 ms of every create)
     // (one gather kernel and one copy: the 64 separate 8 KB copies of the first form cost a millisecond of round trips)
-    DevBuf d_sample;
+    BuildArena arena;
+    TmpBuf d_sample;
     if (d_sample.alloc(sizeof(int) * (size_t)W * S) != G4S_OK) return false;
     hipLaunchKernelGGL(pb_sample_kernel, dim3((W * S + 255) / 256), dim3(256), 0, nullptr, W, S, (nnz - W) / S, d_colids, d_sample.as<int>());
     std::vector<int> all((size_t)W * S);

@@ -50,6 +50,9 @@ typedef int g4s_status;
 
 /* ------------------------------------------------------------------ runtime */
 const char *g4s_version(void);
+/* "spmv_kernel_sources_sha256=<hex>;variant=<name>": the SpMV kernel sources this library was built from (tools/kernel_hash.py) and the name of an A/B
+ * variant build (empty for the regular one) — for tools that pair a stored measurement with the LOADED build (bench.py's roofline.traffic). */
+const char *g4s_build_info(void);
 const char *g4s_last_error(void);                 /* thread-local, never NULL                              */
 g4s_status  g4s_device_count(int *count);
 g4s_status  g4s_set_device(int device);           /* also honours HIP_VISIBLE_DEVICES                      */

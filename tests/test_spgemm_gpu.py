@@ -162,24 +162,7 @@ def test_spgemm_workgroup_shapes(oracle, monkeypatch, shape, static_rows):
     _three_window_case(oracle, False)
 
 
-@pytest.mark.parametrize("splits", ["pieces", "exact_all_shapes"])
-def test_spgemm_value_chunk_splits(oracle, monkeypatch, splits):
-    """The value chunks of rows with several chunks: bracketed by the window pieces only (G4S_SPGEMM_NO_EXACT_SPLITS, the round-2 form), and with the exact
-    splits of chunk_splits_kernel in every workgroup shape (by default only the 1 024-thread launches build them; here the 256-thread shape takes every class,
-    so rows of 2 049 … outputs hold several 2 048-entry chunks). The default form runs in every other test of this file."""
-    if splits == "pieces":
-        monkeypatch.setenv("G4S_SPGEMM_NO_EXACT_SPLITS", "1")
-    else:
-        monkeypatch.setenv("G4S_SPGEMM_EXACT_SPLITS_ALL", "1")
-        for v in ("NUM_MED", "NUM_LARGE", "NUM_M2", "NUM_M3"):
-            monkeypatch.setenv("G4S_SPGEMM_T_" + v, "256")
-        monkeypatch.setenv("G4S_SPGEMM_M3_CUT", "2000000")
-    rp, ci, va = power_law_csr(6000, 6000, 23, 1500)
-    _check(oracle, (rp, ci, va), (rp, ci, va), 6000, 6000, 6000)
-    _three_window_case(oracle, False)
-
-
-@pytest.mark.parametrize("walk", ["units", "units_by_items", "entry_pass"])
+@pytest.mark.parametrize("walk", ["units", "entry_pass"])
 @pytest.mark.parametrize("short_rows", ["wave", "tables"])
 @pytest.mark.parametrize("two_phase", [False, True])
 def test_spgemm_walk_forms(oracle, monkeypatch, walk, short_rows, two_phase):
@@ -188,8 +171,6 @@ def test_spgemm_walk_forms(oracle, monkeypatch, walk, short_rows, two_phase):
     kernels that also take what the wavefront kernel hands back (G4S_SPGEMM_NO_WAVE_ROWS). Every combination, both call forms, every row class."""
     if walk == "entry_pass":
         monkeypatch.setenv("G4S_SPGEMM_NO_UNITS", "1")
-    if walk == "units_by_items":                                   # the item-parallel pre-pass behind the same lists (the fall-back of the task-parallel one)
-        monkeypatch.setenv("G4S_SPGEMM_UNITS_BY_ITEMS", "1")
     if short_rows == "tables":
         monkeypatch.setenv("G4S_SPGEMM_NO_WAVE_ROWS", "1")
     rp, ci, va = power_law_csr(6000, 6000, 23, 1500)
