@@ -249,7 +249,10 @@ struct ClassLimits { long long lim[6]; int raw[6]; };
 // symbolic: tables are keys only. TINY 64 slots, SMALL 1 K, MEDIUM 16 K, LARGE = optimistic 32 K-slot table — a failed attempt costs
 // more than the bitmap path, so only rows whose raw bound is within 4/3 of the table's 24 K-entry limit try it. M2 (raw flop <= 2 M):
 // LDS bitmap windows (spgemm_symbolic_window_kernel), which also takes the rows whose optimistic table filled up. Beyond: hub.
-constexpr ClassLimits kSymLimits{{32, 512, 8192, 32768, 2097152, -1}, {0, 0, 0, 1, 1, 0}};
+#ifndef G4S_SPGEMM_SYM_MEDIUM
+#define G4S_SPGEMM_SYM_MEDIUM 4096                            /* rows of more products (clipped bound) write cuts and take the rank kernel: 8192 → 4096 −0.7 ms, 2048 +0.1, 1024 +1.8 on configs[2] (profiles/r05_spgemm_ab.txt) */
+#endif
+constexpr ClassLimits kSymLimits{{32, 512, G4S_SPGEMM_SYM_MEDIUM, 32768, 2097152, -1}, {0, 0, 0, 1, 1, 0}};
 // numeric: by the exact nz of the output row; tables hold keys + fp64 at <= 50 % fill: TINY 64, SMALL 1 K, MEDIUM 2 K, LARGE 4 K, M2 8 K slots.
 #ifndef G4S_SPGEMM_BIG_LIMIT
 #define G4S_SPGEMM_BIG_LIMIT 1048576

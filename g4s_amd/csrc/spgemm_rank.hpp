@@ -28,6 +28,15 @@ static_assert(kRankWin % 1024 == 0 && kRankChunk >= 1024, "a symbolic thread (1 
 #ifndef G4S_SPGEMM_RANK_UPR
 #define G4S_SPGEMM_RANK_UPR 8                              /* 64-entry units a wave keeps in registers per chunk (16 waves × 8 × 64 = one chunk of products at compression 1); 10: equal, 12 / 14: register spills, 31–36 ms */
 #endif
+#ifndef G4S_SPGEMM_RANK_GM
+#define G4S_SPGEMM_RANK_GM 8
+#endif
+#ifndef G4S_SPGEMM_RANK_GA
+#define G4S_SPGEMM_RANK_GA 4
+#endif
+#ifndef G4S_SPGEMM_RANK_ROUNDS
+#define G4S_SPGEMM_RANK_ROUNDS 1                           /* rounds of RANK_UPR units per wave whose columns and records are requested ahead and held in registers */
+#endif
 
 // A row's cuts live at cuts[cut_off[row] …]: nseg segment starts (the row's output count in front of column s·kRankWin), then the count cuts (the compact column of
 // output b·kRankChunk, b = 1, 2, …).
@@ -123,11 +132,11 @@ __global__ void rank_chunks_kernel(int n, const int *__restrict__ rows, const in
 
 // B's entries as the rank kernel reads them: the column in both numberings and the value, one global_load_dwordx4 per product instead of two loads, and the
 // chunk's ccol leaves LDS as final ids (the store step's gather through the column map was a dependent load in front of every chunk's stores).
-struct __attribute__((aligned(16))) BPack { int c2, col; double val; };
+struct __attribute__((aligned(16))) BPack { int place, col; double val; };   // place: the compact column c as (c / 48) << 6 | c % 48 — a segment's place word is this minus the segment's base, no division in the kernel
 __global__ void pack_b_kernel(long long nnz, const int *__restrict__ c2, const int *__restrict__ col, const double *__restrict__ val, BPack *__restrict__ out)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < nnz) out[k] = BPack{c2[k], col[k], val[k]};
+    if (k < nnz) { const int c = c2[k], w = c / kRankWordCols; out[k] = BPack{(w << 6) | (c - w * kRankWordCols), col[k], val[k]}; }
 }
 
 // ---- the rank kernel, on a FLAT chunk list. (Its first form took rows through a ticket counter like the round-4 kernels: ticket → row metadata → unit
@@ -139,7 +148,7 @@ __global__ void pack_b_kernel(long long nnz, const int *__restrict__ c2, const i
 //   the COMPACT columns of g + G (what its mark step needs)          behind chunk g's first barrier,
 //   the {column, value} records of g + G (its accumulate step)       behind chunk g's accumulate step, when those registers are free.
 // Chunks are bounded pieces of work (at most kRankChunk outputs), so the round-robin deal balances without tickets.
-struct __attribute__((aligned(32))) RankItem { int out0, qn, wbase, u0, u1, pad0, pad1, pad2; };
+struct __attribute__((aligned(32))) RankItem { int out0, qn, wbase /* the segment's first compact column */, u0, u1, pbase /* … and its first place word */, pad1, pad2; };
 __global__ void rank_items_kernel(int n, const int *__restrict__ rows, const int *__restrict__ arpt, const int *__restrict__ crpt, const long long *__restrict__ item_off,
                                   const int *__restrict__ uoff, const int *__restrict__ choff, const RankChunk *__restrict__ chunks, RankItem *__restrict__ out)
 {
@@ -149,7 +158,24 @@ __global__ void rank_items_kernel(int n, const int *__restrict__ rows, const int
     const long long io = item_off[i], total_items = item_off[n];
     for (int q = 0; q < nch; ++q) {
         const RankChunk c = chunks[c0 + q];
-        out[c0 + q] = RankItem{off + c.o_lo, c.qn, c.seg * kRankWin, uoff[io + (long long)q * na], uoff[min(io + (long long)(q + 1) * na, total_items)], 0, 0, 0};
+        out[c0 + q] = RankItem{off + c.o_lo, c.qn, c.seg * kRankWin, uoff[io + (long long)q * na], uoff[min(io + (long long)(q + 1) * na, total_items)], c.seg * (kRankWords << 6), 0, 0};
+    }
+}
+
+// A wave's units past its register rounds, in two alternating groups of G: while one group's loads are in flight the other is consumed, and nothing is copied
+// between the two (a copy of a register that is still being loaded is a wait for the load). On configs[2] a third of all units take this route even with 256 units
+// in registers (23 % of the chunks are more crowded than that, 525 units on average), so it is a main path, not an overflow path; the first form — descriptors,
+// wait, columns, wait, four units at a time — was 29 % of the kernel (profiles/r05_rank_sections_fine.txt, r05_rank_hist.txt).
+template <int G, typename P, typename Issue, typename Use>
+__device__ __forceinline__ void stream_unit_groups(int ne /* ≥ 1, uniform */, Issue issue, Use use)
+{
+    P a[G], b[G];
+    issue(a, 0);
+    for (int e0 = 0; e0 < ne; e0 += 2 * G) {
+        if (e0 + G < ne) issue(b, e0 + G);
+        use(a, e0);
+        if (e0 + 2 * G < ne) issue(a, e0 + 2 * G);
+        if (e0 + G < ne) use(b, e0 + G);
     }
 }
 
@@ -159,7 +185,15 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     const UnitDesc *__restrict__ U, int *__restrict__ ccol, double *__restrict__ cval)
 {
     static_assert(T == kRankT, "7 bitmap words and 8 outputs per thread");
-    constexpr int kU = G4S_SPGEMM_RANK_UPR, kWaves = T / 64, kPer = kRankChunk / T, kWPT = kRankWords / T;
+    // kR ROUNDS of kU units per wave live in registers (16 waves × 2 × 8 = 256 units: a typical chunk of configs[2] has 196). With one round the units past 128
+    // went through the loops below the slow way — request, wait a full memory latency, use — once in the mark step and once in the accumulate step: 39 % of
+    // the kernel (profiles/r05_rank_sections_fine.txt). A product is ONE 16-byte record {compact column, column, value} in four registers: requested when the
+    // previous chunk's accumulate step has freed them (its store step and barriers cover the latency), the mark step turns .x into the place word, the
+    // accumulate step uses the rest. (Columns and records requested separately, columns a whole chunk ahead: 96 registers of state with the 3-register tuples
+    // padded to 4, spills, and a spill reload waits for EVERY load in flight — 38.9 ms against 31.2.)
+    constexpr int kGM = G4S_SPGEMM_RANK_GM, kGA = G4S_SPGEMM_RANK_GA;   // group sizes of the streamed units: mark (one register a unit), accumulate (four)
+    constexpr int kU = G4S_SPGEMM_RANK_UPR, kR = G4S_SPGEMM_RANK_ROUNDS, kWaves = T / 64, kPer = kRankChunk / T, kWPT = kRankWords / T;
+    static_assert(kR >= 1 && kR * kU <= 64, "a round's descriptors are lanes of one register");
     extern __shared__ int lds_i[];                                 // [V: 8192 fp64][KC: 8192 int][BM: 7168 × 64 bit][ctrl: 64 int]
     double *V = reinterpret_cast<double *>(lds_i);
     int *KC = lds_i + 2 * kRankChunk;
@@ -170,10 +204,12 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     const int G = gridDim.x;
     BIG_PROF_DECL_RANK;
     auto item_at = [&](int g) { return items[min(g, nitems - 1)]; };   // uniform: one s_load_dwordx8 (an index past the end reads the last item: never used)
-    auto desc_load = [&](const RankItem &it) {                    // lane q < kU: the descriptor of the wave's unit q in the chunk's first round
+    // The chunk's units are DEALT to the waves (unit i → wave i % 16, the wave's k-th unit is k·16 + wave): in blocks of kU a chunk of 195 units gave eight waves
+    // 16 units and seven waves 8, and every step between two barriers lasts as long as its busiest wave.
+    auto desc_load = [&](const RankItem &it) {                    // lane k = r·kU + q: the descriptor of the wave's unit q of round r
         int4 d = make_int4(0, 1, 0, 0);
         const int nu = it.u1 - it.u0;
-        if (lane < kU) d = reinterpret_cast<const int4 *>(U)[it.u0 + min(wave * kU + lane, max(nu, 1) - 1)];
+        if (lane < kR * kU) d = reinterpret_cast<const int4 *>(U)[it.u0 + min(lane * kWaves + wave, max(nu, 1) - 1)];
         return d;
     };
     auto place_of = [&](int col, int wbase, bool ok) {
@@ -181,11 +217,15 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         const unsigned w = __umulhi(rel, 0xAAAAAAABu) >> 5;        // rel / 48
         return (ok && rel < (unsigned)kRankWin) ? (int)((w << 6) | (rel - w * 48u)) : -1;
     };
-    auto mark = [&](int wr) { if (wr >= 0) atomicOr(&BM32[2 * (wr >> 6) + ((wr >> 5) & 1)], 1u << (wr & 31)); };
+    auto place_rec = [&](int place, int pbase, bool ok) {         // the same from a record's place field
+        const unsigned rel = (unsigned)(place - pbase);
+        return (ok && rel < (unsigned)(kRankWords << 6)) ? (int)rel : -1;
+    };
+    auto mark = [&](int wr) { if (wr >= 0) atomicOr(&BM32[wr >> 5], 1u << (wr & 31)); };
     auto accumulate = [&](int wr, int col, double prod) {
         if (wr < 0) return;
         const unsigned long long w = BM[wr >> 6];
-        const int slot = min((int)(w >> 48) + __popcll(w & ((1ull << (wr & 63)) - 1ull)), kRankChunk - 1);   // (the clamp: stay inside the chunk whatever the arrays hold)
+        const int slot = min((int)(w >> 48) + (int)__popcll(w & ((1ull << (wr & 63)) - 1ull)), (int)kRankChunk - 1);   // (the clamp: stay inside the chunk whatever the arrays hold; all-int, or min() goes through fp64)
         atomicAdd(&V[slot], prod);
         KC[slot] = col;
     };
@@ -197,72 +237,88 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     if (g >= nitems) return;                                       // uniform
     // prologue: the first chunk's data the slow way, the second chunk's item
     RankItem cur = item_at(g), nxt = item_at(g + G);
-    // The wave's kU descriptors of a chunk stay in ONE int4 per lane (lane q = unit q) and are read out with v_readlane where they are needed: as SGPR arrays
+    // The wave's kU descriptors of a round stay in ONE int4 per lane (lane q = unit q) and are read out with v_readlane where they are needed: as SGPR arrays
     // (position, length, value × current and next chunk) they alone took more scalar registers than a wave has.
     int4 dc = desc_load(cur);
-    auto d_pos = [&](const int4 &d, int q) { return __builtin_amdgcn_readlane(d.x, q); };
-    auto d_len = [&](const int4 &d, int q, int nu) { return wave * kU + q < nu ? __builtin_amdgcn_readlane(d.y, q) : 0; };   // (a unit past the chunk's last: no lane is valid)
-    auto d_val = [&](const int4 &d, int q) { return __longlong_as_double(((long long)__builtin_amdgcn_readlane(d.w, q) << 32) | (unsigned)__builtin_amdgcn_readlane(d.z, q)); };
-    auto entry_of = [&](const int4 &d, int q, int nu) { return d_pos(d, q) + min(lane, max(d_len(d, q, nu), 1) - 1); };
-    int c2[kU];                                                    // compact columns of the CURRENT chunk's first round
+    auto d_pos = [&](const int4 &d, int r, int q) { return __builtin_amdgcn_readlane(d.x, r * kU + q); };
+    auto units_of_wave = [&](int nu) { return __builtin_amdgcn_readfirstlane((nu - wave + kWaves - 1) / kWaves); };   // (nu ≥ 0 > wave - 16: never negative)
+    auto units_in = [&](int r, int nu) { return max(0, min(kU, units_of_wave(nu) - r * kU)); };   // the wave's units in round r, a scalar
+    auto d_len = [&](const int4 &d, int r, int q, int nu) { return q < units_in(r, nu) ? __builtin_amdgcn_readlane(d.y, r * kU + q) : 0; };   // (a unit past the chunk's last: no lane is valid)
+    auto d_val = [&](const int4 &d, int r, int q) { return __longlong_as_double(((long long)__builtin_amdgcn_readlane(d.w, r * kU + q) << 32) | (unsigned)__builtin_amdgcn_readlane(d.z, r * kU + q)); };
+    auto entry_of = [&](const int4 &d, int r, int q, int nu) { return d_pos(d, r, q) + min(lane, max(d_len(d, r, q, nu), 1) - 1); };
+    // … and the wave's units past the register rounds (k = kR·kU + e), a batch is 64 of them
+    auto extra_unit = [&](int e) { return (kR * kU + e) * kWaves + wave; };
+    auto extras_in = [&](int eb, int nu) { return max(0, min(64, units_of_wave(nu) - kR * kU - eb)); };   // uniform
+    auto extras_load = [&](const RankItem &it, int eb) { return reinterpret_cast<const int4 *>(U)[it.u0 + min(extra_unit(eb + lane), max(it.u1 - it.u0, 1) - 1)]; };
+    int4 dx = extras_load(cur, 0);
+    int4 rec[kR][kU];                                              // the chunk's products in the register rounds
+    auto load_recs = [&](const int4 &d, int nu) {
 #pragma unroll
-    for (int q = 0; q < kU; ++q) c2[q] = bcol2[entry_of(dc, q, cur.u1 - cur.u0)];
-    int ro[kU];
-    double rv[kU];
-    auto load_pack = [&](const int4 &d, int nu) {
+        for (int r = 0; r < kR; ++r)
 #pragma unroll
-        for (int q = 0; q < kU; ++q) {
-            typedef int int3_t __attribute__((ext_vector_type(3)));
-            const int3_t e = *reinterpret_cast<const int3_t *>(&bpack[entry_of(d, q, nu)].col);   // {column, value}: one global_load_dwordx3 (the record's compact column came in a chunk ago)
-            ro[q] = e.x;
-            rv[q] = __longlong_as_double(((long long)e.z << 32) | (unsigned)e.y);
-        }
+            for (int q = 0; q < kU; ++q) rec[r][q] = reinterpret_cast<const int4 *>(bpack)[entry_of(d, r, q, nu)];
     };
-    load_pack(dc, cur.u1 - cur.u0);
+    load_recs(dc, cur.u1 - cur.u0);
     for (;;) {
         const int nu = cur.u1 - cur.u0;
         const bool more = g + G < nitems;                          // uniform
         // what the NEXT chunk needs first: its descriptors (the item arrived a chunk ago); the item behind it
-        int4 dn = make_int4(0, 1, 0, 0);
-        if (more) dn = desc_load(nxt);
+        int4 dn = make_int4(0, 1, 0, 0), dxn = make_int4(0, 1, 0, 0);
+        if (more) { dn = desc_load(nxt); dxn = extras_load(nxt, 0); }
         const RankItem nxt2 = item_at(g + 2 * G);
         // ---- mark
-        int wr[kU];
+#ifdef G4S_PROFILE_BIG
+#ifndef G4S_PROFILE_HIST
+        BIG_PROF(13);                                              // (loop top: item / descriptor requests)
+#endif
 #pragma unroll
-        for (int q = 0; q < kU; ++q) { wr[q] = place_of(c2[q], cur.wbase, lane < d_len(dc, q, nu)); mark(wr[q]); }
-        // crowded chunks: further rounds, by column only (uniform per wave), four units at a time — they are rare once kU covers a typical chunk, and their
-        // temporaries must not set the kernel's register count
-        constexpr int kX = 4;
-        for (int r0 = (wave + kWaves) * kU; r0 < nu; r0 += kWaves * kU)
-            for (int x0 = r0; x0 < min(r0 + kU, nu); x0 += kX) {
-                UnitDesc d[kX];
+        for (int r = 0; r < kR; ++r)
 #pragma unroll
-                for (int q = 0; q < kX; ++q) d[q] = U[cur.u0 + min(x0 + q, nu - 1)];
-                int cx[kX];
+            for (int q = 0; q < kU; ++q) asm volatile("" :: "v"(rec[r][q].x));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef G4S_PROFILE_HIST
+        BIG_PROF(12);                                              // waiting for this chunk's records (requested behind the previous chunk's accumulate step)
+#endif
+#endif
+        int wr[kR][kU];                                            // (the record's .x is dead from here on: the compiler reuses that register of the tuple)
 #pragma unroll
-                for (int q = 0; q < kX; ++q) cx[q] = bcol2[d[q].bpos + min(lane, d[q].len - 1)];
+        for (int r = 0; r < kR; ++r)
 #pragma unroll
-                for (int q = 0; q < kX; ++q) mark(place_of(cx[q], cur.wbase, x0 + q < min(r0 + kU, nu) && lane < d[q].len));
-            }
+            for (int q = 0; q < kU; ++q) { wr[r][q] = place_rec(rec[r][q].x, cur.pbase, lane < d_len(dc, r, q, nu)); mark(wr[r][q]); }
+#ifdef G4S_PROFILE_BIG
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        BIG_PROF(14);                                              // the register rounds' marks alone
+#endif
+        // crowded chunks: the wave's units past the register rounds, by column only, 64 per batch (lane e of dx = the descriptor of the batch's e-th unit)
+        for (int eb = 0;; eb += 64) {
+            const int ne = extras_in(eb, nu);
+            if (ne <= 0) break;
+            if (eb) dx = extras_load(cur, eb);
+            stream_unit_groups<kGM, int>(ne,
+                [&](int (&c)[kGM], int e0) {
+#pragma unroll
+                    for (int q = 0; q < kGM; ++q) { const int e = min(e0 + q, ne - 1); c[q] = bcol2[__builtin_amdgcn_readlane(dx.x, e) + min(lane, __builtin_amdgcn_readlane(dx.y, e) - 1)]; }
+                },
+                [&](int (&c)[kGM], int e0) {
+#pragma unroll
+                    for (int q = 0; q < kGM; ++q)
+                        if (e0 + q < ne) mark(place_of(c[q], cur.wbase, lane < __builtin_amdgcn_readlane(dx.y, e0 + q)));
+                });
+            if (ne < 64) break;
+        }
         BIG_PROF(0);
         __syncthreads();
         BIG_PROF(1);
-        // the next chunk's compact columns: its descriptors have had the mark step to arrive
-        int c2n[kU];
-        if (more) {
-#pragma unroll
-            for (int q = 0; q < kU; ++q) c2n[q] = bcol2[entry_of(dn, q, nxt.u1 - nxt.u0)];
-        }
         // ---- ranks
-        unsigned long long w7[kWPT];
-        int cnt = 0;
-#pragma unroll
-        for (int j = 0; j < kWPT; ++j) { w7[j] = BM[t * kWPT + j]; cnt += __popcll(w7[j]); }
-        const int incl = (int)wave_inclusive_sum((unsigned)cnt);
-        if (lane == 63) ctrl[wave] = incl;
-        __syncthreads();
-        BIG_PROF(2);
         {
+            unsigned long long w7[kWPT];
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < kWPT; ++j) { w7[j] = BM[t * kWPT + j]; cnt += __popcll(w7[j]); }
+            const int incl = (int)wave_inclusive_sum((unsigned)cnt);
+            if (lane == 63) ctrl[wave] = incl;
+            __syncthreads();
+            BIG_PROF(2);
             const unsigned sc = wave_inclusive_sum(lane < kWaves ? (unsigned)ctrl[lane] : 0u);
             int run = incl - cnt;
             if (wave > 0) run += (int)__builtin_amdgcn_readlane(sc, wave - 1);
@@ -273,33 +329,50 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         BIG_PROF(3);
         // ---- accumulate
 #pragma unroll
-        for (int q = 0; q < kU; ++q) accumulate(wr[q], ro[q], d_val(dc, q) * rv[q]);   // multop / addop, hash_mult.h:583-593
-        for (int r0 = (wave + kWaves) * kU; r0 < nu; r0 += kWaves * kU)
-            for (int x0 = r0; x0 < min(r0 + kU, nu); x0 += kX) {
-                UnitDesc d[kX];
+        for (int r = 0; r < kR; ++r)
 #pragma unroll
-                for (int q = 0; q < kX; ++q) d[q] = U[cur.u0 + min(x0 + q, nu - 1)];
-                int4 e[kX];
+            for (int q = 0; q < kU; ++q)                             // multop / addop, hash_mult.h:583-593
+                accumulate(wr[r][q], rec[r][q].y, d_val(dc, r, q) * __longlong_as_double(((long long)rec[r][q].w << 32) | (unsigned)rec[r][q].z));
+#ifdef G4S_PROFILE_BIG
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        BIG_PROF(15);                                              // the register rounds' accumulate alone
+#endif
+        for (int eb = 0;; eb += 64) {
+            const int ne = extras_in(eb, nu);
+            if (ne <= 0) break;
+            if (eb) dx = extras_load(cur, eb); else if (extras_in(64, nu) > 0) dx = extras_load(cur, 0);   // (the mark step went through further batches: the first one again)
+            stream_unit_groups<kGA, int4>(ne,
+                [&](int4 (&c)[kGA], int e0) {
 #pragma unroll
-                for (int q = 0; q < kX; ++q) e[q] = reinterpret_cast<const int4 *>(bpack)[d[q].bpos + min(lane, d[q].len - 1)];
+                    for (int q = 0; q < kGA; ++q) {
+                        const int e = min(e0 + q, ne - 1);
+                        c[q] = reinterpret_cast<const int4 *>(bpack)[__builtin_amdgcn_readlane(dx.x, e) + min(lane, __builtin_amdgcn_readlane(dx.y, e) - 1)];
+                    }
+                },
+                [&](int4 (&c)[kGA], int e0) {
 #pragma unroll
-                for (int q = 0; q < kX; ++q) {
-                    const double a = __longlong_as_double(((long long)d[q].av_hi << 32) | (unsigned)d[q].av_lo);
-                    accumulate(place_of(e[q].x, cur.wbase, x0 + q < min(r0 + kU, nu) && lane < d[q].len), e[q].y, a * __longlong_as_double(((long long)e[q].w << 32) | (unsigned)e[q].z));
-                }
-            }
+                    for (int q = 0; q < kGA; ++q)
+                        if (e0 + q < ne) {
+                            const double av = __longlong_as_double(((long long)__builtin_amdgcn_readlane(dx.w, e0 + q) << 32) | (unsigned)__builtin_amdgcn_readlane(dx.z, e0 + q));
+                            accumulate(place_rec(c[q].x, cur.pbase, lane < __builtin_amdgcn_readlane(dx.y, e0 + q)), c[q].y, av * __longlong_as_double(((long long)c[q].w << 32) | (unsigned)c[q].z));
+                        }
+                });
+            if (ne < 64) break;
+        }
 #ifdef G4S_PROFILE_BIG
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         BIG_PROF(4);
-        prof_acc[9] += 1; prof_acc[10] += nu; prof_acc[11] += cur.qn;
+        prof_acc[9] += 1; prof_acc[10] += nu;
+#ifdef G4S_PROFILE_HIST                                            // how crowded are the chunks? (slots 11-13: chunks past the register rounds, their units, the units past the rounds)
+        prof_acc[11] += nu > kR * kWaves * kU; prof_acc[12] += nu > kR * kWaves * kU ? nu : 0; prof_acc[13] += max(nu - kR * kWaves * kU, 0);
+#else
+        prof_acc[11] += cur.qn;
 #endif
-        // the next chunk's records: the registers of this chunk's are free
-        if (more) {
-#pragma unroll
-            for (int q = 0; q < kU; ++q) c2[q] = c2n[q];
-            dc = dn;
-            load_pack(dc, nxt.u1 - nxt.u0);
-        }
+#endif
+        // the next chunk's records: the registers are free, and the store step and two barriers stand between here and the next mark step. (Unconditional —
+        // past the last chunk the descriptors are the empty ones and entry 0 is read: under `if (more)` the records became phi nodes whose register shuffles
+        // waited for the loads on the spot.)
+        load_recs(dn, more ? nxt.u1 - nxt.u0 : 0);
         BIG_PROF(5);
         __syncthreads();
         BIG_PROF(6);
@@ -325,6 +398,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         __syncthreads();
         BIG_PROF(8);
         if (!more) break;
+        dc = dn; dx = dxn;
         g += G; cur = nxt; nxt = nxt2;
     }
     BIG_PROF_FLUSH;

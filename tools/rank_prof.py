@@ -19,7 +19,9 @@ lib.g4s_debug_big_prof(buf, 0)
 names = ["mark (round 0 from registers + further rounds)", "barrier 1 (marks done)", "ranks: read words, scan, barrier 2", "ranks: write words, barrier 3", "accumulate (+ lgkmcnt drain)",
          "next chunk's round requested", "barrier 4 (sums done)", "store (+ clean)", "barrier 5"]
 buf = buf[32:]
-tot = sum(buf[:9])
+tot = sum(buf[:9]) + sum(buf[12:16])
+names += ["(count) chunks", "(count) units", "(count) outputs", "  mark: wait for the chunk's first-round columns", "  mark: loop top (next item / descriptors requested)", "  mark: round 0's marks",
+          "  accumulate: round 0 (its records' wait included)"]
 for nm, v in zip(names, buf):
     print(f"{nm:55s} {v:16d} ticks {100.0 * v / max(tot, 1):6.2f} %")
 ch = max(buf[9], 1)
