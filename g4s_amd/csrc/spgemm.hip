@@ -1288,6 +1288,10 @@ __global__ __launch_bounds__(256) void sym_unit_kernel(long long bound /* thread
 }
 
 // CUTS (round 5, spgemm_rank.hpp): pre_off / pre_cols are the rows' cut offsets and the cut array — the kernel counts and writes a row's cuts instead of its columns.
+#ifndef G4S_SPGEMM_SYM_STREAM_GROUP
+#define G4S_SPGEMM_SYM_STREAM_GROUP 8
+#endif
+constexpr int kSymStreamGroup = G4S_SPGEMM_SYM_STREAM_GROUP;
 template <int T, bool CUTS>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void spgemm_symbolic_units_kernel(
     const int *__restrict__ rows, int nrows, int *__restrict__ next_row /* not NULL: rows handed out one at a time (list sorted longest first) */,
@@ -1327,14 +1331,16 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     int c[kU];
     bool ok[kU];
     bool have = false;                                             // c / ok hold round 0 of the window about to be marked
-    auto request_round = [&](int u0, int nu, int g, int (&cc)[kU], bool (&okk)[kU]) {
+    // A window's units are DEALT to the waves (unit i → wave i % kWaves; the wave's k-th unit is k·kWaves + wave), as in the rank kernel: in blocks of kU the
+    // waves of a window with a few units more than a multiple of kU·kWaves differed by kU units, and the window lasts as long as its busiest wave.
+    auto request_round = [&](int u0, int nu, int (&cc)[kU], bool (&okk)[kU]) {   // the wave's first kU units
         SymUnit d[kU];                                              // all of the round's descriptors first (see the numeric kernel's request_round)
 #pragma unroll
-        for (int q = 0; q < kU; ++q) d[q] = U[u0 + min(g + q, max(nu, 1) - 1)];   // uniform: one s_load_dwordx2 each (a window without units reads a neighbour's or the pad entry: not used)
+        for (int q = 0; q < kU; ++q) d[q] = U[u0 + min(q * kWaves + wave, max(nu, 1) - 1)];   // uniform: one s_load_dwordx2 each (a window without units reads a neighbour's or the pad entry: not used)
 #pragma unroll
         for (int q = 0; q < kU; ++q) {
             const int len = nu > 0 ? d[q].len : 1, bpos = nu > 0 ? d[q].bpos : 0;
-            okk[q] = g + q < nu && lane < len;
+            okk[q] = q * kWaves + wave < nu && lane < len;
             cc[q] = bcol[bpos + min(lane, len - 1)];
         }
     };
@@ -1354,15 +1360,31 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
                 for (int q = 0; q < kU; ++q)
                     if (okk[q] && cc[q] >= w0 && cc[q] < w1) atomicOr(&bm[bm_slot((cc[q] - w0) >> 5)], 1u << ((cc[q] - w0) & 31));
             };
-            if (!have) request_round(cu0, nu, wave * kU, c, ok);   // (the workgroup's first window only)
+            if (!have) request_round(cu0, nu, c, ok);              // (the workgroup's first window only)
             cu2 = uoff[min(cur.ioff + (long long)min(wi + 2, nwin) * na, total_items)];   // (consumed a window later)
             BIG_PROF(0);
             mark_round(c, ok);                                     // (the bitmap is clean: zeroed at the kernel's start, left clean by every window since)
-            for (int g = (wave + kWaves) * kU; g < nu; g += kWaves * kU) {
-                int cx[kU];
-                bool okx[kU];
-                request_round(cu0, nu, g, cx, okx);
-                mark_round(cx, okx);
+            // the wave's units past the first kU, streamed (stream_unit_groups, spgemm_rank.hpp): 64 descriptors per vector load (lane e = the e-th of the batch),
+            // the columns in two alternating groups. (Round by round — descriptors, wait, columns, wait, marks — a hub row's window of thousands of units paid two
+            // memory round trips per kU units.)
+            {
+                const int mine = __builtin_amdgcn_readfirstlane((nu - wave + kWaves - 1) / kWaves);   // the wave's units in this window
+                for (int eb = 0;; eb += 64) {
+                    const int ne = max(0, min(64, mine - kU - eb));
+                    if (ne <= 0) break;
+                    const int2 dx = reinterpret_cast<const int2 *>(U)[cu0 + min((kU + eb + lane) * kWaves + wave, nu - 1)];
+                    stream_unit_groups<kSymStreamGroup, int>(ne,
+                        [&](int (&cc)[kSymStreamGroup], int e0) {
+#pragma unroll
+                            for (int q = 0; q < kSymStreamGroup; ++q) { const int e = min(e0 + q, ne - 1); cc[q] = bcol[__builtin_amdgcn_readlane(dx.x, e) + min(lane, __builtin_amdgcn_readlane(dx.y, e) - 1)]; }
+                        },
+                        [&](int (&cc)[kSymStreamGroup], int e0) {
+#pragma unroll
+                            for (int q = 0; q < kSymStreamGroup; ++q)
+                                if (e0 + q < ne && lane < __builtin_amdgcn_readlane(dx.y, e0 + q) && cc[q] >= w0 && cc[q] < w1) atomicOr(&bm[bm_slot((cc[q] - w0) >> 5)], 1u << ((cc[q] - w0) & 31));
+                        });
+                    if (ne < 64) break;
+                }
             }
             __syncthreads();
             BIG_PROF(1);
@@ -1375,7 +1397,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
                 have = !last_win || nridx < nrows;
 #endif
                 const int n0 = last_win ? nxt.u0 : cu1, n1 = last_win ? nxt.u1 : cu2;
-                if (have) request_round(n0, n1 - n0, wave * kU, c, ok);
+                if (have) request_round(n0, n1 - n0, c, ok);
             }
             if (CUTS && po >= 0) {
                 const int nseg = rank_segments(N), before = s_total;   // (s_total: written by thread 0 behind the barrier at the end of the previous window)
