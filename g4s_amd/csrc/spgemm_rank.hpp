@@ -28,6 +28,9 @@ static_assert(kRankWin % 1024 == 0 && kRankChunk >= 1024, "a symbolic thread (1 
 #ifndef G4S_SPGEMM_RANK_UPR
 #define G4S_SPGEMM_RANK_UPR 8                              /* 64-entry units a wave keeps in registers per chunk (16 waves × 8 × 64 = one chunk of products at compression 1); 10: equal, 12 / 14: register spills, 31–36 ms */
 #endif
+#ifndef G4S_SPGEMM_RANK_AHEAD
+#define G4S_SPGEMM_RANK_AHEAD 0                            /* 1: the next chunk's records are requested behind the first barrier into registers of their own — measured 28.18 ms against 28.0 (profiles/r05_spgemm_ab.txt): the wait moves, the time stays */
+#endif
 #ifndef G4S_SPGEMM_RANK_GM
 #define G4S_SPGEMM_RANK_GM 8
 #endif
@@ -252,13 +255,13 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     auto extras_load = [&](const RankItem &it, int eb) { return reinterpret_cast<const int4 *>(U)[it.u0 + min(extra_unit(eb + lane), max(it.u1 - it.u0, 1) - 1)]; };
     int4 dx = extras_load(cur, 0);
     int4 rec[kR][kU];                                              // the chunk's products in the register rounds
-    auto load_recs = [&](const int4 &d, int nu) {
+    auto load_recs = [&](int4 (&into)[kR][kU], const int4 &d, int nu) {
 #pragma unroll
         for (int r = 0; r < kR; ++r)
 #pragma unroll
-            for (int q = 0; q < kU; ++q) rec[r][q] = reinterpret_cast<const int4 *>(bpack)[entry_of(d, r, q, nu)];
+            for (int q = 0; q < kU; ++q) into[r][q] = reinterpret_cast<const int4 *>(bpack)[entry_of(d, r, q, nu)];
     };
-    load_recs(dc, cur.u1 - cur.u0);
+    load_recs(rec, dc, cur.u1 - cur.u0);
     for (;;) {
         const int nu = cur.u1 - cur.u0;
         const bool more = g + G < nitems;                          // uniform
@@ -309,6 +312,12 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         BIG_PROF(0);
         __syncthreads();
         BIG_PROF(1);
+#if G4S_SPGEMM_RANK_AHEAD
+        // the next chunk's records, into registers of their own: they have this chunk's rank, accumulate and store steps to arrive (requested behind the accumulate
+        // step, when this chunk's registers are free, the mark step still waited 1.7 K cycles per chunk for them: profiles/r05_spgemm_rank_sections.txt)
+        int4 recn[kR][kU];
+        load_recs(recn, dn, more ? nxt.u1 - nxt.u0 : 0);
+#endif
         // ---- ranks
         {
             unsigned long long w7[kWPT];
@@ -372,7 +381,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         // the next chunk's records: the registers are free, and the store step and two barriers stand between here and the next mark step. (Unconditional —
         // past the last chunk the descriptors are the empty ones and entry 0 is read: under `if (more)` the records became phi nodes whose register shuffles
         // waited for the loads on the spot.)
-        load_recs(dn, more ? nxt.u1 - nxt.u0 : 0);
+#if !G4S_SPGEMM_RANK_AHEAD
+        load_recs(rec, dn, more ? nxt.u1 - nxt.u0 : 0);
+#endif
         BIG_PROF(5);
         __syncthreads();
         BIG_PROF(6);
@@ -399,6 +410,12 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         BIG_PROF(8);
         if (!more) break;
         dc = dn; dx = dxn;
+#if G4S_SPGEMM_RANK_AHEAD
+#pragma unroll
+        for (int r = 0; r < kR; ++r)
+#pragma unroll
+            for (int q = 0; q < kU; ++q) rec[r][q] = recn[r][q];
+#endif
         g += G; cur = nxt; nxt = nxt2;
     }
     BIG_PROF_FLUSH;
