@@ -1,5 +1,7 @@
 // runtime.cpp — device selection, allocators and error reporting of the C-ABI (include/g4s.h, "runtime").
 #include "common.hpp"
+#include "readback.hpp"
+#include <cstring>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -242,6 +244,48 @@ int scratch_shutdown()
     for (auto &pool : g_pools)
         if (pool) { G4S_HIP_TRY(hipMemPoolDestroy(pool)); pool = nullptr; }
     return G4S_OK;
+}
+
+// ---- small reads through pinned memory (common.hpp)
+namespace {
+struct PendingRead { void *dst; size_t off, bytes; };
+struct ReadBlock {
+    static constexpr size_t kBytes = 4096;
+    char *p = nullptr;                                             // pinned, portable; lives as long as the process (a thread's block is not returned: freeing pinned
+    size_t used = 0;                                               // memory from a thread_local destructor can run behind the runtime's own shutdown)
+    std::vector<PendingRead> pending;
+};
+thread_local ReadBlock t_reads;
+void deliver_reads()
+{
+    for (const PendingRead &r : t_reads.pending) std::memcpy(r.dst, t_reads.p + r.off, r.bytes);
+    t_reads.pending.clear();
+    t_reads.used = 0;
+}
+} // namespace
+hipError_t read_small(void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+    ReadBlock &b = t_reads;
+    if (!b.p && hipHostMalloc(reinterpret_cast<void **>(&b.p), ReadBlock::kBytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); b.p = nullptr; }
+    const size_t need = (bytes + 15) & ~(size_t)15;
+    if (!b.p || b.used + need > ReadBlock::kBytes) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s);   // (the plain way: correct, only slower)
+    const hipError_t e = hipMemcpyAsync(b.p + b.used, src, bytes, hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return e;
+    b.pending.push_back(PendingRead{dst, b.used, bytes});
+    b.used += need;
+    return hipSuccess;
+}
+hipError_t reads_sync(hipStream_t s)
+{
+    const hipError_t e = hipStreamSynchronize(s);
+    if (e == hipSuccess) deliver_reads(); else { t_reads.pending.clear(); t_reads.used = 0; }
+    return e;
+}
+hipError_t reads_sync_event(hipEvent_t ev)
+{
+    const hipError_t e = hipEventSynchronize(ev);
+    if (e == hipSuccess) deliver_reads(); else { t_reads.pending.clear(); t_reads.used = 0; }
+    return e;
 }
 
 } // namespace g4s

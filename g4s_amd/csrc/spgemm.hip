@@ -33,6 +33,7 @@
 #define G4S_KO 0   // timing-only knock-outs of the big-row numeric kernel (wrong results; tools/ab_variants.sh): 1 no halvings, 2 no LDS atomics, 4 no bucket index, 8 no stores, 16 no accumulate step
 #endif
 #include "prims.hpp"
+#include "readback.hpp"
 #include <algorithm>
 #include <chrono>
 #include <memory>
@@ -2062,8 +2063,8 @@ int classify_rows(int M, const long long *d_size, const ClassLimits &lim, int co
     G4S_HIP_TRY(hipMemsetAsync(rc.hist.p, 0, sizeof(int) * 2 * CLS_COUNT, s));
     const int grid = std::min(kClassBlocks, (M + 255) / 256);
     hipLaunchKernelGGL(classify_kernel, dim3(grid), dim3(256), 0, s, M, d_size, lim, cols_clip, rc.cls.as<int>(), rc.hist.as<int>());
-    G4S_HIP_TRY(hipMemcpyAsync(rc.count, rc.hist.p, sizeof(int) * CLS_COUNT, hipMemcpyDeviceToHost, s));
-    G4S_HIP_TRY(hipStreamSynchronize(s));
+    G4S_HIP_TRY(g4s::read_small(rc.count, rc.hist.p, sizeof(int) * CLS_COUNT, s));
+    G4S_HIP_TRY(g4s::reads_sync(s));
     rc.offset[0] = 0;
     for (int c = 0; c < CLS_COUNT; ++c) rc.offset[c + 1] = rc.offset[c] + rc.count[c];
     int *cursor = rc.hist.as<int>() + CLS_COUNT;
@@ -2119,7 +2120,7 @@ int run_hub_rows(bool numeric, const std::vector<int> &hub_rows, const std::vect
                                    bcol, bval, bitmap.as<unsigned>(), prefix.as<int>(), crpt, cval);
         }
         G4S_HIP_TRY(hipGetLastError());
-        G4S_HIP_TRY(hipStreamSynchronize(s)); // h_items is reused; workspace is reused by the next batch
+        G4S_HIP_TRY(g4s::reads_sync(s)); // h_items is reused; workspace is reused by the next batch
     }
     return G4S_OK;
 }
@@ -2130,7 +2131,7 @@ int fetch_rows_and_ranges(const int *d_list, int n, const int *d_arpt, std::vect
     ranges.resize(2 * (size_t)n);
     if (!n) return G4S_OK;
     G4S_HIP_TRY(hipMemcpyAsync(rows.data(), d_list, sizeof(int) * n, hipMemcpyDeviceToHost, s));
-    G4S_HIP_TRY(hipStreamSynchronize(s));
+    G4S_HIP_TRY(g4s::reads_sync(s));
     std::sort(rows.begin(), rows.end());
     DevBuf d_rows, d_rng;
     G4S_TRY(d_rows.alloc(sizeof(int) * (size_t)n));
@@ -2138,7 +2139,7 @@ int fetch_rows_and_ranges(const int *d_list, int n, const int *d_arpt, std::vect
     G4S_HIP_TRY(hipMemcpyAsync(d_rows.p, rows.data(), sizeof(int) * n, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(gather_ranges_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_rows.as<int>(), n, d_arpt, d_rng.as<int>());
     G4S_HIP_TRY(hipMemcpyAsync(ranges.data(), d_rng.p, sizeof(int) * 2 * (size_t)n, hipMemcpyDeviceToHost, s));
-    G4S_HIP_TRY(hipStreamSynchronize(s));
+    G4S_HIP_TRY(g4s::reads_sync(s));
     return G4S_OK;
 }
 
@@ -2153,8 +2154,8 @@ int compute_row_flop(int M, const int *arpt, const int *acol, const int *brpt, l
         hipLaunchKernelGGL(row_flop_from_scan_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, arpt, P.as<long long>(), d_row_flop);
         G4S_HIP_TRY(hipGetLastError());
         long long h = 0;
-        G4S_HIP_TRY(hipMemcpyAsync(&h, P.as<long long>() + annz, sizeof(h), hipMemcpyDeviceToHost, s));
-        G4S_HIP_TRY(hipStreamSynchronize(s));
+        G4S_HIP_TRY(g4s::read_small(&h, P.as<long long>() + annz, sizeof(h), s));
+        G4S_HIP_TRY(g4s::reads_sync(s));
         if (total) *total = (int64_t)h;
         return G4S_OK;
     }
@@ -2164,8 +2165,8 @@ int compute_row_flop(int M, const int *arpt, const int *acol, const int *brpt, l
     if (M > 0) hipLaunchKernelGGL(row_flop_kernel, dim3((M + 31) / 32), dim3(256), 0, s, M, arpt, acol, brpt, d_row_flop, tot.as<unsigned long long>());
     G4S_HIP_TRY(hipGetLastError());
     unsigned long long h = 0;
-    G4S_HIP_TRY(hipMemcpyAsync(&h, tot.p, sizeof(h), hipMemcpyDeviceToHost, s));
-    G4S_HIP_TRY(hipStreamSynchronize(s));
+    G4S_HIP_TRY(g4s::read_small(&h, tot.p, sizeof(h), s));
+    G4S_HIP_TRY(g4s::reads_sync(s));
     if (total) *total = (int64_t)h;
     return G4S_OK;
 }
@@ -2179,8 +2180,8 @@ int check_ids(const int *ids, long long n, int bound, const char *what, hipStrea
     const int grid = (int)std::min<long long>((n + 255) / 256, 4096);
     hipLaunchKernelGGL(check_range_kernel, dim3(grid), dim3(256), 0, s, ids, n, bound, flag.as<int>());
     int h = 0;
-    G4S_HIP_TRY(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    G4S_HIP_TRY(hipStreamSynchronize(s));
+    G4S_HIP_TRY(g4s::read_small(&h, flag.p, sizeof(int), s));
+    G4S_HIP_TRY(g4s::reads_sync(s));
     if (h) return g4s::set_error(G4S_ERR_INVALID, "SpGEMM: %s outside its valid range [0,%d)", what, bound);
     return G4S_OK;
 }
@@ -2198,8 +2199,8 @@ int check_b(const int *brpt, const int *bcol, int K, long long bnnz, int N, hipS
     hipLaunchKernelGGL(check_descents_kernel, dim3(grid), dim3(256), 0, s, bcol, bnnz, N, reinterpret_cast<int *>(d), d + 1);
     hipLaunchKernelGGL(row_start_descents_kernel, dim3(std::min((K + 255) / 256, 2048)), dim3(256), 0, s, K, brpt, bcol, d + 2);
     unsigned long long h[3] = {0, 0, 0};
-    G4S_HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s));
-    G4S_HIP_TRY(hipStreamSynchronize(s));
+    G4S_HIP_TRY(g4s::read_small(h, d, sizeof(h), s));
+    G4S_HIP_TRY(g4s::reads_sync(s));
     if (h[0] & 0xffffffffull) return g4s::set_error(G4S_ERR_INVALID, "SpGEMM: a column id of B outside its valid range [0,%d)", N);
     *unsorted = h[1] != h[2];                                       // the caller sorts a private copy of B's rows (sort_b_rows)
     return G4S_OK;
@@ -2317,9 +2318,9 @@ int checked_row_flop(int M, int K, int N, const int *arpt, const int *acol, long
     G4S_HIP_TRY(hipGetLastError());
     unsigned long long h[4] = {0, 0, 0, 0};
     long long tot = 0;
-    G4S_HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s));
-    G4S_HIP_TRY(hipMemcpyAsync(&tot, P.as<long long>() + annz, sizeof(tot), hipMemcpyDeviceToHost, s));
-    G4S_HIP_TRY(hipStreamSynchronize(s));
+    G4S_HIP_TRY(g4s::read_small(h, d, sizeof(h), s));
+    G4S_HIP_TRY(g4s::read_small(&tot, P.as<long long>() + annz, sizeof(tot), s));
+    G4S_HIP_TRY(g4s::reads_sync(s));
     if (h[3]) return g4s::set_error(G4S_ERR_INVALID, "SpGEMM: a column id of A outside its valid range [0,%d)", K);
     if (h[0] & 0xffffffffull) return g4s::set_error(G4S_ERR_INVALID, "SpGEMM: a column id of B outside its valid range [0,%d)", N);
     *b_unsorted = h[1] != h[2];                                     // (the flop does not depend on the order inside B's rows: everything computed here stands)
@@ -2330,16 +2331,16 @@ int checked_row_flop(int M, int K, int N, const int *arpt, const int *acol, long
 // the last entries of two row-pointer arrays (nnz(A), nnz(B)) in one host wait
 int read_last2(const int *a_rpt, int na, int *a_out, const int *b_rpt, int nb, int *b_out, hipStream_t s)
 {
-    G4S_HIP_TRY(hipMemcpyAsync(a_out, a_rpt + na, sizeof(int), hipMemcpyDeviceToHost, s));
-    G4S_HIP_TRY(hipMemcpyAsync(b_out, b_rpt + nb, sizeof(int), hipMemcpyDeviceToHost, s));
-    G4S_HIP_TRY(hipStreamSynchronize(s));
+    G4S_HIP_TRY(g4s::read_small(a_out, a_rpt + na, sizeof(int), s));
+    G4S_HIP_TRY(g4s::read_small(b_out, b_rpt + nb, sizeof(int), s));
+    G4S_HIP_TRY(g4s::reads_sync(s));
     return G4S_OK;
 }
 
 int read_last(const int *d_rpt, int n, int *out, hipStream_t s)
 {
-    G4S_HIP_TRY(hipMemcpyAsync(out, d_rpt + n, sizeof(int), hipMemcpyDeviceToHost, s));
-    G4S_HIP_TRY(hipStreamSynchronize(s));
+    G4S_HIP_TRY(g4s::read_small(out, d_rpt + n, sizeof(int), s));
+    G4S_HIP_TRY(g4s::reads_sync(s));
     return G4S_OK;
 }
 
@@ -2427,8 +2428,8 @@ int build_column_map(int N, long long bnnz, const int *bcol, ColumnMap &cm, hipS
     hipLaunchKernelGGL(colmap_popc_kernel, dim3((W + 256) / 256), dim3(256), 0, s, W, N, seen.as<unsigned char>(), bm.as<unsigned>(), cnt.as<int>());
     G4S_TRY(g4s::prims::exclusive_scan(cnt.as<int>(), prefix.as<int>(), (long long)W + 1, s));
     int n2 = 0;
-    G4S_HIP_TRY(hipMemcpyAsync(&n2, prefix.as<int>() + W, sizeof(int), hipMemcpyDeviceToHost, s));
-    G4S_HIP_TRY(hipStreamSynchronize(s));
+    G4S_HIP_TRY(g4s::read_small(&n2, prefix.as<int>() + W, sizeof(int), s));
+    G4S_HIP_TRY(g4s::reads_sync(s));
     if (n2 <= 0 || (long long)n2 * 8 > (long long)N * 7) return G4S_OK;
     G4S_TRY(cm.bcol2.alloc(sizeof(int) * (size_t)bnnz, cm.keep));
     G4S_TRY(cm.inv.alloc(sizeof(int) * (size_t)n2, cm.keep));
@@ -2700,8 +2701,8 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
         hipLaunchKernelGGL(presorted_need_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, rc.cls.as<int>(), class_mask, row_flop.as<long long>(), N2, min_flop, need.as<long long>());
         G4S_TRY(g4s::prims::exclusive_scan(need.as<long long>(), pre->off.as<long long>(), (long long)M + 1, s));
         long long total_cols = 0;
-        G4S_HIP_TRY(hipMemcpyAsync(&total_cols, pre->off.as<long long>() + M, sizeof(long long), hipMemcpyDeviceToHost, s));
-        G4S_HIP_TRY(hipStreamSynchronize(s));
+        G4S_HIP_TRY(g4s::read_small(&total_cols, pre->off.as<long long>() + M, sizeof(long long), s));
+        G4S_HIP_TRY(g4s::reads_sync(s));
         size_t free_b = 0, total_b = 0;
         G4S_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         int *cols = nullptr;
@@ -2803,8 +2804,8 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     // rows too wide for a key table in LDS: the rows whose optimistic table filled up, and the window class → LDS bitmap windows
     int n_ovf = 0;
     if (!x_large) {                                                // (only the optimistic table kernel can overflow)
-        G4S_HIP_TRY(hipMemcpyAsync(&n_ovf, ovf_count.p, sizeof(int), hipMemcpyDeviceToHost, s));
-        G4S_HIP_TRY(hipStreamSynchronize(s));
+        G4S_HIP_TRY(g4s::read_small(&n_ovf, ovf_count.p, sizeof(int), s));
+        G4S_HIP_TRY(g4s::reads_sync(s));
         if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s symbolic: %d optimistic tables overflowed, %d window-class rows\n", n_ovf, rc.count[CLS_M2]);
         G4S_TRY(window(1024, ovf_rows.as<int>(), n_ovf, nullptr, nullptr));   // rows of the optimistic table class are not in the scratch
     }
@@ -2832,8 +2833,8 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     // block sums → block offsets by one workgroup in parallel (a single thread walking the ≈ 1 000 sums took 116 µs of every call)
     hipLaunchKernelGGL(g4s::prims::scan_tile_offsets_kernel<long long>, dim3(1), dim3(g4s::prims::kScanThreads), 0, s, nblocks + 1, block_sums.as<long long>());
     long long h_total = 0;
-    G4S_HIP_TRY(hipMemcpyAsync(&h_total, block_sums.as<long long>() + nblocks, sizeof(long long), hipMemcpyDeviceToHost, s));
-    G4S_HIP_TRY(hipStreamSynchronize(s));
+    G4S_HIP_TRY(g4s::read_small(&h_total, block_sums.as<long long>() + nblocks, sizeof(long long), s));
+    G4S_HIP_TRY(g4s::reads_sync(s));
     *cnnz = h_total;
     if (h_total > INT32_MAX)
         return g4s::set_error(G4S_ERR_OVERFLOW, "nnz(C) = %lld exceeds the reference's int32 row pointer (mm/inc/define.h:14)", h_total);
@@ -2844,9 +2845,9 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     if (pre && pre->keep) {                                        // the two-call form: what the numeric call must find unchanged to take this state over
         G4S_TRY(hash_buf.alloc(sizeof(unsigned long long)));
         G4S_TRY(enqueue_pattern_hash(M, K, annz, bnnz, arpt, acol, brpt, bcol_caller, crpt, hash_buf.as<unsigned long long>(), s));
-        G4S_HIP_TRY(hipMemcpyAsync(&h_hash, hash_buf.p, sizeof(h_hash), hipMemcpyDeviceToHost, s));
+        G4S_HIP_TRY(g4s::read_small(&h_hash, hash_buf.p, sizeof(h_hash), s));
     }
-    G4S_HIP_TRY(hipStreamSynchronize(s));
+    G4S_HIP_TRY(g4s::reads_sync(s));
     if (pre) pre->key_hash = h_hash;
     t_idle = true;
     dbg.mark("scan");
@@ -2985,9 +2986,9 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         G4S_TRY(g4s::prims::exclusive_scan(tasks->as<long long>(), toff->as<long long>(), (long long)n + 1, s));
         G4S_TRY(g4s::prims::exclusive_scan(items->as<long long>(), ioff->as<long long>(), (long long)n + 1, s));
         G4S_TRY(g4s::prims::exclusive_scan(nch->as<int>(), choff->as<int>(), (long long)n + 1, s));
-        G4S_HIP_TRY(hipMemcpyAsync(&rank_totals[0], toff->as<long long>() + n, sizeof(long long), hipMemcpyDeviceToHost, s));
-        G4S_HIP_TRY(hipMemcpyAsync(&rank_totals[1], ioff->as<long long>() + n, sizeof(long long), hipMemcpyDeviceToHost, s));
-        G4S_HIP_TRY(hipMemcpyAsync(&rank_nchunks, choff->as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, s));
+        G4S_HIP_TRY(g4s::read_small(&rank_totals[0], toff->as<long long>() + n, sizeof(long long), s));
+        G4S_HIP_TRY(g4s::read_small(&rank_totals[1], ioff->as<long long>() + n, sizeof(long long), s));
+        G4S_HIP_TRY(g4s::read_small(&rank_nchunks, choff->as<int>() + n, sizeof(int), s));
         {   // an event behind the three copies: stage 2 waits for IT, not for the stream — the mid-size kernel enqueued in between is still running then
             thread_local hipEvent_t ev = nullptr;
             if (!ev) G4S_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -3005,7 +3006,7 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         constexpr int T = kRankT;
         const int n = rank_n, nseg = pre->nseg;
         const int *rows = rank_sr.rows.as<int>();
-        G4S_HIP_TRY(hipEventSynchronize(rank_totals_ready));        // stage 1's totals: there long ago (the mid-size launch in between has synchronised the stream)
+        G4S_HIP_TRY(g4s::reads_sync_event(rank_totals_ready));        // stage 1's totals: there long ago (the mid-size launch in between has synchronised the stream)
         const int nchunks = rank_nchunks;
         const long long ntask = rank_totals[0], nitem = rank_totals[1], nct = nitem - ntask;
         if (ntask <= 0 || nitem <= 0 || nitem > (1ll << 28) || nchunks <= 0)
@@ -3084,9 +3085,9 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         G4S_TRY(g4s::prims::exclusive_scan(tasks->as<long long>(), toff->as<long long>(), (long long)n + 1, s));
         G4S_TRY(g4s::prims::exclusive_scan(items->as<long long>(), ioff->as<long long>(), (long long)n + 1, s));
         long long totals[2] = {0, 0};
-        G4S_HIP_TRY(hipMemcpyAsync(&totals[0], toff->as<long long>() + n, sizeof(long long), hipMemcpyDeviceToHost, s));
-        G4S_HIP_TRY(hipMemcpyAsync(&totals[1], ioff->as<long long>() + n, sizeof(long long), hipMemcpyDeviceToHost, s));
-        G4S_HIP_TRY(hipStreamSynchronize(s));
+        G4S_HIP_TRY(g4s::read_small(&totals[0], toff->as<long long>() + n, sizeof(long long), s));
+        G4S_HIP_TRY(g4s::read_small(&totals[1], ioff->as<long long>() + n, sizeof(long long), s));
+        G4S_HIP_TRY(g4s::reads_sync(s));
         const long long ntask = totals[0], nitem = totals[1];
         if (ntask <= 0 || nitem <= 0 || nitem > (1ll << 28)) return G4S_OK;
         if (ctb->alloc(sizeof(int) * (size_t)std::max<long long>(nitem - ntask, 1)) != G4S_OK || ucnt->alloc(sizeof(int) * ((size_t)nitem + 1)) != G4S_OK ||
@@ -3106,8 +3107,8 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         long long ubound = class_flop_bound >= 0 ? class_flop_bound / 64 + nitem : -1;
         if (ubound < 0 || ubound > (1ll << 27)) {                   // no bound from the caller (or a loose one): read the count
             int total_units = 0;
-            G4S_HIP_TRY(hipMemcpyAsync(&total_units, uoff->as<int>() + nitem, sizeof(int), hipMemcpyDeviceToHost, s));
-            G4S_HIP_TRY(hipStreamSynchronize(s));
+            G4S_HIP_TRY(g4s::read_small(&total_units, uoff->as<int>() + nitem, sizeof(int), s));
+            G4S_HIP_TRY(g4s::reads_sync(s));
             if (total_units <= 0 || total_units > (1 << 27)) return G4S_OK;      // (a sum past 2^31 shows up as a negative total)
             ubound = total_units;
         }
@@ -3215,7 +3216,7 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
     std::vector<int> hub, ranges;
     G4S_TRY(fetch_rows_and_ranges(rc.list(CLS_HUB), rc.count[CLS_HUB], arpt, hub, ranges, s));
     G4S_TRY(run_hub_rows(true, hub, ranges, N, arpt, acol, aval, brpt, bcol, bval, nullptr, crpt, ccol, cval, s));
-    G4S_HIP_TRY(hipStreamSynchronize(s));
+    G4S_HIP_TRY(g4s::reads_sync(s));
     t_idle = true;                                                 // (cleared by the next call on this thread)
     dbg.mark("hub+sync");
     return G4S_OK;
@@ -3242,7 +3243,7 @@ G4S_API g4s_status g4s_spgemm_numeric(int32_t M, int32_t K, int32_t N,
         unsigned long long *d_hash = nullptr, h_hash = 0;
         G4S_TRY(g4s::scratch_alloc(reinterpret_cast<void **>(&d_hash), sizeof(unsigned long long), s));
         int st = enqueue_pattern_hash(M, K, pre->annz, pre->bnnz, arpt, acol, brpt, bcol, crpt, d_hash, s);
-        if (st == G4S_OK && (hipMemcpyAsync(&h_hash, d_hash, sizeof(h_hash), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess))
+        if (st == G4S_OK && (g4s::read_small(&h_hash, d_hash, sizeof(h_hash), s) != hipSuccess || g4s::reads_sync(s) != hipSuccess))
             st = g4s::set_error(G4S_ERR_HIP, "g4s_spgemm_numeric: reading the pattern hash failed");
         g4s::scratch_free(d_hash, s);
         G4S_TRY(st);
