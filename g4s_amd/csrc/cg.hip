@@ -12,6 +12,7 @@
 // (sized from the previous solve and a geometric fit of the residual) and reads 40 bytes of state after each batch, so the GPU runs launches back to back instead of idling across a
 // D2H round trip per iteration (62 → see DESIGN.md §4.4 µs per Cookbook2 iteration).
 #include "common.hpp"
+#include "readback.hpp"
 #include "cg_async.hpp"
 namespace g4s { int64_t dist_smallest_slab(g4s_spmv_dist_t h); }   // dist.hip
 #include <algorithm>
@@ -283,7 +284,7 @@ struct CgRun {
         return enqueue(std::max(1, std::min(batch, steps + 1)));
     }
 
-    int read_state_async(CgState *h) { G4S_HIP_TRY(hipMemcpyAsync(h, st, sizeof(CgState), hipMemcpyDeviceToHost, s)); return G4S_OK; }
+    int read_state_async(CgState *h) { G4S_HIP_TRY(g4s::read_small(h, st, sizeof(CgState), s)); return G4S_OK; }
 
     // h: the state after the batches enqueued so far (read by the caller after a synchronisation). Runs on until the loop test is met.
     int complete(CgState &h)
@@ -298,7 +299,7 @@ struct CgRun {
             }
             G4S_TRY(enqueue(std::max(1, std::min(batch, steps - enqueued + 1))));
             G4S_TRY(read_state_async(&h));
-            G4S_HIP_TRY(hipStreamSynchronize(s));
+            G4S_HIP_TRY(g4s::reads_sync(s));
             batch = std::min(32, batch * 2);
         }
         return G4S_OK;
@@ -337,13 +338,13 @@ int conj_grad_impl(const MatVec &matvec, int32_t neq, const double *BI, const in
     G4S_TRY(run.start(matvec, neq, BI, zero_resid, n_zero, F, d0, acc, *cycles, cg_first_batch(), s));
     CgState h{};
     G4S_TRY(run.read_state_async(&h));
-    G4S_HIP_TRY(hipStreamSynchronize(s));
+    G4S_HIP_TRY(g4s::reads_sync(s));
     G4S_TRY(run.complete(h));
     if (getenv("G4S_DEBUG")) fprintf(stderr, "g4s conj_grad: %d iterations, %d enqueued, residual %.3e (acc %.3e)\n", h.count, run.enqueued, h.residual, acc);
     cg_last_iterations() = h.count;
     *cycles = h.count;
     G4S_TRY(run.finish());
-    G4S_HIP_TRY(hipStreamSynchronize(s));
+    G4S_HIP_TRY(g4s::reads_sync(s));
     if (residual_out) *residual_out = h.residual;
     return G4S_OK;
 }
@@ -393,7 +394,7 @@ int cg_async_settle(CgAsync *c, bool *speculation_held, int32_t *cycles, double 
 }
 
 // An error between read and settle (the caller's own work failed) frees the object while the copy into c->h may still be in flight: wait for it first.
-void cg_async_free(CgAsync *c) { if (c && c->read_pending) (void)hipStreamSynchronize(c->s); delete c; }
+void cg_async_free(CgAsync *c) { if (c && c->read_pending) (void)g4s::reads_sync(c->s); if (c) g4s::reads_forget(c, c + 1); delete c; }
 } // namespace g4s
 
 
@@ -487,8 +488,8 @@ G4S_API g4s_status g4s_cg_state(g4s_cg_ws_t ws, int32_t *count, int32_t *done, d
     G4S_REQUIRE(ws, "ws is NULL");
     hipStream_t s = g4s::as_stream(stream);
     CgState h{};
-    G4S_HIP_TRY(hipMemcpyAsync(&h, ws->st, sizeof(CgState), hipMemcpyDeviceToHost, s));
-    G4S_HIP_TRY(hipStreamSynchronize(s));
+    G4S_HIP_TRY(g4s::read_small(&h, ws->st, sizeof(CgState), s));
+    G4S_HIP_TRY(g4s::reads_sync(s));
     if (count) *count = h.count;
     if (done) *done = h.done;
     if (residual) *residual = h.residual;
@@ -530,7 +531,7 @@ G4S_API g4s_status g4s_cg_end(g4s_cg_ws_t ws, double *d0_dev, const int32_t *zer
     hipStream_t s = g4s::as_stream(stream);
     if (n_zero) hipLaunchKernelGGL(cg_strip_kernel, dim3((n_zero + kThreads - 1) / kThreads), dim3(kThreads), 0, s, n_zero, zero_resid_dev, d0_dev);   // :409
     G4S_HIP_TRY(hipGetLastError());
-    G4S_HIP_TRY(hipStreamSynchronize(s));
+    G4S_HIP_TRY(g4s::reads_sync(s));
     return G4S_OK;
 }
 
@@ -605,14 +606,14 @@ struct DistCgAsync {
         return enqueue(std::max(1, std::min(batch, steps + 1)));
     }
     bool read_pending = false;                                                              // see CgAsync
-    int read() { read_pending = true; G4S_HIP_TRY(hipMemcpyAsync(&h, ws->st, sizeof(CgState), hipMemcpyDeviceToHost, g4s::as_stream(stream))); return G4S_OK; }
+    int read() { read_pending = true; G4S_HIP_TRY(g4s::read_small(&h, ws->st, sizeof(CgState), g4s::as_stream(stream))); return G4S_OK; }
     int complete()                                                                          // h: read after a synchronisation
     {
         int batch = std::min(32, std::max(2, enqueued * 2));
         while (!h.done) {
             G4S_TRY(enqueue(std::max(1, std::min(batch, steps - enqueued + 1))));
             G4S_TRY(read());
-            G4S_HIP_TRY(hipStreamSynchronize(g4s::as_stream(stream)));
+            G4S_HIP_TRY(g4s::reads_sync(g4s::as_stream(stream)));
             read_pending = false;
             batch = std::min(32, batch * 2);
         }
@@ -653,7 +654,7 @@ int dist_cg_async_settle(DistCgAsync *c, bool *speculation_held, int32_t *cycles
     if (residual) *residual = c->h.residual;
     return G4S_OK;
 }
-void dist_cg_async_free(DistCgAsync *c) { if (c && c->read_pending) (void)hipStreamSynchronize(g4s::as_stream(c->stream)); delete c; }
+void dist_cg_async_free(DistCgAsync *c) { if (c && c->read_pending) (void)g4s::reads_sync(g4s::as_stream(c->stream)); if (c) g4s::reads_forget(c, c + 1); delete c; }
 } // namespace g4s
 
 G4S_API g4s_status g4s_conj_grad_dist_tr(g4s_spmv_dist_t A, const g4s_transport *tr, int32_t n_local, const double *BI_dev, const int32_t *zero_resid_dev,
@@ -675,10 +676,10 @@ G4S_API g4s_status g4s_conj_grad_dist_tr(g4s_spmv_dist_t A, const g4s_transport 
         G4S_TRY(g4s::dist_cg_async_start(&c, ws, A, tr, BI_dev, zero_resid_dev, n_zero, F_dev, d0_dev, acc, steps, stream));
         struct Free { g4s::DistCgAsync *c; ~Free() { g4s::dist_cg_async_free(c); } } guard{c};
         G4S_TRY(g4s::dist_cg_async_read(c));
-        G4S_HIP_TRY(hipStreamSynchronize(g4s::as_stream(stream)));
+        G4S_HIP_TRY(g4s::reads_sync(g4s::as_stream(stream)));
         bool held = true;
         G4S_TRY(g4s::dist_cg_async_settle(c, &held, cycles, residual));
-        G4S_HIP_TRY(hipStreamSynchronize(g4s::as_stream(stream)));
+        G4S_HIP_TRY(g4s::reads_sync(g4s::as_stream(stream)));
         return G4S_OK;
     };
     const int st = run();

@@ -246,9 +246,9 @@ int scratch_shutdown()
     return G4S_OK;
 }
 
-// ---- small reads through pinned memory (common.hpp)
+// ---- small reads through pinned memory (readback.hpp)
 namespace {
-struct PendingRead { void *dst; size_t off, bytes; };
+struct PendingRead { void *dst; size_t off, bytes; hipStream_t s; };
 struct ReadBlock {
     static constexpr size_t kBytes = 4096;
     char *p = nullptr;                                             // pinned, portable; lives as long as the process (a thread's block is not returned: freeing pinned
@@ -256,11 +256,16 @@ struct ReadBlock {
     std::vector<PendingRead> pending;
 };
 thread_local ReadBlock t_reads;
-void deliver_reads()
+void settle_reads(hipStream_t s, bool deliver)                     // the reads enqueued on s: handed out (or dropped); the block is reused once nothing is noted
 {
-    for (const PendingRead &r : t_reads.pending) std::memcpy(r.dst, t_reads.p + r.off, r.bytes);
-    t_reads.pending.clear();
-    t_reads.used = 0;
+    ReadBlock &b = t_reads;
+    size_t keep = 0;
+    for (const PendingRead &r : b.pending) {
+        if (r.s != s) { b.pending[keep++] = r; continue; }
+        if (deliver) std::memcpy(r.dst, b.p + r.off, r.bytes);
+    }
+    b.pending.resize(keep);
+    if (!keep) b.used = 0;
 }
 } // namespace
 hipError_t read_small(void *dst, const void *src, size_t bytes, hipStream_t s)
@@ -271,21 +276,30 @@ hipError_t read_small(void *dst, const void *src, size_t bytes, hipStream_t s)
     if (!b.p || b.used + need > ReadBlock::kBytes) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s);   // (the plain way: correct, only slower)
     const hipError_t e = hipMemcpyAsync(b.p + b.used, src, bytes, hipMemcpyDeviceToHost, s);
     if (e != hipSuccess) return e;
-    b.pending.push_back(PendingRead{dst, b.used, bytes});
+    b.pending.push_back(PendingRead{dst, b.used, bytes, s});
     b.used += need;
     return hipSuccess;
 }
 hipError_t reads_sync(hipStream_t s)
 {
     const hipError_t e = hipStreamSynchronize(s);
-    if (e == hipSuccess) deliver_reads(); else { t_reads.pending.clear(); t_reads.used = 0; }
+    settle_reads(s, e == hipSuccess);
     return e;
 }
-hipError_t reads_sync_event(hipEvent_t ev)
+hipError_t reads_sync_event(hipEvent_t ev, hipStream_t s)
 {
     const hipError_t e = hipEventSynchronize(ev);
-    if (e == hipSuccess) deliver_reads(); else { t_reads.pending.clear(); t_reads.used = 0; }
+    settle_reads(s, e == hipSuccess);
     return e;
+}
+void reads_forget(const void *lo, const void *hi)
+{
+    ReadBlock &b = t_reads;
+    size_t keep = 0;
+    for (const PendingRead &r : b.pending)
+        if (!(static_cast<const char *>(r.dst) >= static_cast<const char *>(lo) && static_cast<const char *>(r.dst) < static_cast<const char *>(hi))) b.pending[keep++] = r;
+    b.pending.resize(keep);
+    if (!keep) b.used = 0;
 }
 
 } // namespace g4s

@@ -3006,7 +3006,7 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         constexpr int T = kRankT;
         const int n = rank_n, nseg = pre->nseg;
         const int *rows = rank_sr.rows.as<int>();
-        G4S_HIP_TRY(g4s::reads_sync_event(rank_totals_ready));        // stage 1's totals: there long ago (the mid-size launch in between has synchronised the stream)
+        G4S_HIP_TRY(g4s::reads_sync_event(rank_totals_ready, s));        // stage 1's totals: there long ago (the mid-size launch in between has synchronised the stream)
         const int nchunks = rank_nchunks;
         const long long ntask = rank_totals[0], nitem = rank_totals[1], nct = nitem - ntask;
         if (ntask <= 0 || nitem <= 0 || nitem > (1ll << 28) || nchunks <= 0)

@@ -9,6 +9,7 @@
 // (keep_iterating :150-162, the "two consecutive converging iterations" rule); δ, α and the norms are computed on the device and
 // nine doubles come back once per outer iteration.
 #include "common.hpp"
+#include "readback.hpp"
 #include "cg_async.hpp"
 #include <algorithm>
 #include <cmath>
@@ -253,8 +254,8 @@ G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, g4s_csr_t K_csr, const 
     };
     auto fetch = [&]() -> int {
         G4S_HIP_TRY(hipGetLastError());
-        G4S_HIP_TRY(hipMemcpyAsync(hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, s));
-        G4S_HIP_TRY(hipStreamSynchronize(s));
+        G4S_HIP_TRY(g4s::read_small(hsc, sc, sizeof(hsc), s));
+        G4S_HIP_TRY(g4s::reads_sync(s));
         return G4S_OK;
     };
     auto each = [&](int n, auto f) { hipLaunchKernelGGL(map_kernel, dim3(grid_for(n)), dim3(kThreads), 0, s, n, f); };
@@ -329,7 +330,7 @@ G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, g4s_csr_t K_csr, const 
         bool held = true;
         if (!speculate) {
             G4S_TRY(g4s::cg_async_read(cg));
-            G4S_HIP_TRY(hipStreamSynchronize(s));
+            G4S_HIP_TRY(g4s::reads_sync(s));
             G4S_TRY(g4s::cg_async_settle(cg, &held, &cycles, &residual));
         }
         auto rest_of_iteration = [&]() -> int {
@@ -387,7 +388,7 @@ G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, g4s_csr_t K_csr, const 
         G4S_HIP_TRY(hipMemcpyAsync(P, Pc, sizeof(double) * (size_t)nel, hipMemcpyDeviceToDevice, s));
     }
     G4S_HIP_TRY(hipGetLastError());
-    G4S_HIP_TRY(hipStreamSynchronize(s));
+    G4S_HIP_TRY(g4s::reads_sync(s));
     res->outer_iterations = count;
     res->inner_iterations = inner_total;
     res->last_solve_valid = valid;
@@ -467,8 +468,8 @@ G4S_API g4s_status g4s_stokes_uzawa_cg_dist(g4s_spmv_dist_t K, g4s_spmv_dist_t D
     };
     auto fetch = [&]() -> int {
         G4S_HIP_TRY(hipGetLastError());
-        G4S_HIP_TRY(hipMemcpyAsync(hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, s));
-        G4S_HIP_TRY(hipStreamSynchronize(s));
+        G4S_HIP_TRY(g4s::read_small(hsc, sc, sizeof(hsc), s));
+        G4S_HIP_TRY(g4s::reads_sync(s));
         return G4S_OK;
     };
     auto each = [&](int n, auto f) { hipLaunchKernelGGL(map_kernel, dim3(grid_for(n)), dim3(kThreads), 0, s, n, f); };
@@ -502,7 +503,7 @@ G4S_API g4s_status g4s_stokes_uzawa_cg_dist(g4s_spmv_dist_t K, g4s_spmv_dist_t D
         G4S_TRY(g4s::dist_cg_async_start(&cg, ws.w, K, tr, BI, zero_resid, n_zero, F, u1, inner_acc, prm->v_steps_low, stream));
         CgFree guard{cg};
         G4S_TRY(g4s::dist_cg_async_read(cg));
-        G4S_HIP_TRY(hipStreamSynchronize(s));
+        G4S_HIP_TRY(g4s::reads_sync(s));
         bool held = true;
         int32_t cycles = 0;
         double residual = 0.0;
@@ -554,7 +555,7 @@ G4S_API g4s_status g4s_stokes_uzawa_cg_dist(g4s_spmv_dist_t K, g4s_spmv_dist_t D
         bool held = true;
         if (!speculate) {
             G4S_TRY(g4s::dist_cg_async_read(cg));
-            G4S_HIP_TRY(hipStreamSynchronize(s));
+            G4S_HIP_TRY(g4s::reads_sync(s));
             G4S_TRY(g4s::dist_cg_async_settle(cg, &held, &cycles, &residual));
         }
         auto rest_of_iteration = [&]() -> int {
@@ -613,7 +614,7 @@ G4S_API g4s_status g4s_stokes_uzawa_cg_dist(g4s_spmv_dist_t K, g4s_spmv_dist_t D
         G4S_HIP_TRY(hipMemcpyAsync(P, Pc, sizeof(double) * (size_t)nel, hipMemcpyDeviceToDevice, s));
     }
     G4S_HIP_TRY(hipGetLastError());
-    G4S_HIP_TRY(hipStreamSynchronize(s));
+    G4S_HIP_TRY(g4s::reads_sync(s));
     res->outer_iterations = count;
     res->inner_iterations = inner_total;
     res->last_solve_valid = valid;
