@@ -300,10 +300,16 @@ __global__ __launch_bounds__(256) void classify_kernel(int M, const long long *_
 }
 
 // the same ranges: count the range's rows per class, reserve the places with one atomic per class, then place the rows (wave ballots rank them)
-__global__ __launch_bounds__(256) void scatter_rows_kernel(int M, const int *__restrict__ cls, int *__restrict__ cursor, int *__restrict__ lists)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(int M, const int *__restrict__ cls, const int *__restrict__ hist /* the class counts (classify_kernel) */,
+                                                           int *__restrict__ cursor /* zeroed */, int *__restrict__ lists)
 {
-    __shared__ int s_cnt[CLS_COUNT], s_base[CLS_COUNT];
-    if (threadIdx.x < CLS_COUNT) s_cnt[threadIdx.x] = 0;
+    __shared__ int s_cnt[CLS_COUNT], s_base[CLS_COUNT], s_off[CLS_COUNT];
+    if (threadIdx.x < CLS_COUNT) {                                 // a class's list starts behind the classes in front of it: nine counts, summed here (they came from the
+        s_cnt[threadIdx.x] = 0;                                    // host by a copy of their prefix sums until round 5: a host→device copy per classification)
+        int o = 0;
+        for (int k = 0; k < (int)threadIdx.x; ++k) o += hist[k];
+        s_off[threadIdx.x] = o;
+    }
     __syncthreads();
     const int per = (M + (int)gridDim.x - 1) / (int)gridDim.x, r0 = blockIdx.x * per, r1 = min(M, r0 + per), lane = threadIdx.x & 63;
     int cnt[CLS_COUNT] = {0};
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(int M, const int *__r
         if (lane == 0 && v) atomicAdd(&s_cnt[k], v);
     }
     __syncthreads();
-    if (threadIdx.x < CLS_COUNT) { s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], s_cnt[threadIdx.x]) : 0; s_cnt[threadIdx.x] = 0; }   // cursor[c] starts at the class offset
+    if (threadIdx.x < CLS_COUNT) { s_base[threadIdx.x] = s_off[threadIdx.x] + (s_cnt[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], s_cnt[threadIdx.x]) : 0); s_cnt[threadIdx.x] = 0; }   // cursor[c] starts at the class offset
     __syncthreads();
     for (int i0 = r0; i0 < r1; i0 += blockDim.x) {                 // uniform trip count: the ballots below need every lane
         const int i = i0 + threadIdx.x;
@@ -2064,13 +2070,12 @@ int classify_rows(int M, const long long *d_size, const ClassLimits &lim, int co
     const int grid = std::min(kClassBlocks, (M + 255) / 256);
     hipLaunchKernelGGL(classify_kernel, dim3(grid), dim3(256), 0, s, M, d_size, lim, cols_clip, rc.cls.as<int>(), rc.hist.as<int>());
     G4S_HIP_TRY(g4s::read_small(rc.count, rc.hist.p, sizeof(int) * CLS_COUNT, s));
-    G4S_HIP_TRY(g4s::reads_sync(s));
+    int *cursor = rc.hist.as<int>() + CLS_COUNT;                   // (zeroed with the counts)
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid), dim3(256), 0, s, M, rc.cls.as<int>(), (const int *)rc.hist.as<int>(), cursor, rc.lists.as<int>());
+    G4S_HIP_TRY(hipGetLastError());
+    G4S_HIP_TRY(g4s::reads_sync(s));                               // (the host's wait for the counts covers the scatter: it no longer needs anything from the host)
     rc.offset[0] = 0;
     for (int c = 0; c < CLS_COUNT; ++c) rc.offset[c + 1] = rc.offset[c] + rc.count[c];
-    int *cursor = rc.hist.as<int>() + CLS_COUNT;
-    G4S_HIP_TRY(hipMemcpyAsync(cursor, rc.offset, sizeof(int) * CLS_COUNT, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid), dim3(256), 0, s, M, rc.cls.as<int>(), cursor, rc.lists.as<int>());
-    G4S_HIP_TRY(hipGetLastError());
     return G4S_OK;
 }
 
@@ -2466,6 +2471,11 @@ struct PreSorted {
     DevBuf b_cols_sorted, b_perm;
     bool b_unsorted = false;
     unsigned long long key_hash = 0;   // pattern_hash_kernel over the caller's five index arrays (two-call form)
+    // A product whose rows all have at most 512 products (the reference's own examples: can_24, patents_main) needs no column map, no window splits, no column
+    // scratch, and its numeric phase takes the symbolic phase's row lists (nz ≤ flop ≤ 512: the same rows go to the same kernel) — one-call form only, the lists
+    // live in the call's arena.
+    RowClasses sym_rc;
+    bool sym_rc_valid = false;
     bool keep = false;           // carried from g4s_spgemm_symbolic to the g4s_spgemm_numeric call that follows it (see CarriedSymbolic): nothing of it may live in a call's arena
     ~PreSorted();
 };
@@ -2614,8 +2624,11 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     }
 
     dbg.mark("row_flop");
-    RowClasses rc;
+    RowClasses local_rc;
+    RowClasses &rc = pre ? pre->sym_rc : local_rc;
     G4S_TRY(classify_rows(M, row_flop.as<long long>(), kSymLimits, N, rc, s));
+    const bool only_short = rc.count[CLS_MEDIUM] + rc.count[CLS_LARGE] + rc.count[CLS_M2] + rc.count[CLS_M3] + rc.count[CLS_HUB] == 0;   // every row ≤ 512 products
+    if (pre) pre->sym_rc_valid = only_short && !pre->keep;
     dbg.mark("classes");
     if (getenv("G4S_DEBUG"))
         fprintf(stderr, "g4s symbolic classes: empty %d tiny %d small %d medium %d large %d hub %d (flop %lld)\n", rc.count[CLS_EMPTY], rc.count[CLS_TINY],
@@ -2623,13 +2636,15 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     // the bitmap-window kernels work on B's non-empty columns, renumbered (N2 of them; the original ids when that would not pay)
     ColumnMap local_map;
     ColumnMap &cmap = pre ? pre->cmap : local_map;
-    G4S_TRY(build_column_map(N, bnnz, bcol, cmap, s));
+    if (!only_short) G4S_TRY(build_column_map(N, bnnz, bcol, cmap, s));   // (left out, the map is the identity)
     const int *wcol = cmap.cols(bcol);
     const int N2 = cmap.width(N);
     DevBuf wsplit_local;
     const int *wsplit = nullptr;
-    G4S_TRY(build_window_splits(K, N2, brpt, wcol, pre ? pre->wsplit_buf : wsplit_local, &wsplit, s, pre && pre->keep));
-    if (pre) { pre->wsplit = wsplit; pre->has_wsplit = true; }
+    if (!only_short) {
+        G4S_TRY(build_window_splits(K, N2, brpt, wcol, pre ? pre->wsplit_buf : wsplit_local, &wsplit, s, pre && pre->keep));
+        if (pre) { pre->wsplit = wsplit; pre->has_wsplit = true; }
+    }
     dbg.mark("colmap+splits");
     G4S_TRY(ovf_rows.alloc(sizeof(int) * (size_t)std::max(1, rc.count[CLS_LARGE])));
     G4S_TRY(ovf_count.alloc(sizeof(int)));
@@ -2690,7 +2705,7 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
             cut_off = pre->cut_off_buf.as<long long>(); cuts = pre->cuts_buf.as<int>();
         }
     }
-    if (pre) {
+    if (pre && !only_short) {
         // which classes the window kernel counts AND EMITS in this call: M2 always, MEDIUM / LARGE while B is narrow enough — without the classes that write cuts
         const unsigned class_mask = use_rank ? (x_med ? (1u << CLS_MEDIUM) : 0u) : ((1u << CLS_M2) | (x_med ? (1u << CLS_MEDIUM) : 0u) | (x_large ? (1u << CLS_LARGE) : 0u));
         DevBuf need;
@@ -2941,19 +2956,22 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
     G4S_TRY(row_size.alloc(sizeof(long long) * (size_t)M));
     const bool rank = pre && pre->rank && pre->d_cut_off && !getenv("G4S_SPGEMM_NO_RANK");   // the rows with cuts take the rank kernel (spgemm_rank.hpp)
     hipLaunchKernelGGL(nz_to_ll_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, crpt, rank ? pre->d_cut_off : (const long long *)nullptr, row_size.as<long long>());
-    RowClasses rc;
+    RowClasses local_rc;
+    const bool reuse_rc = pre && pre->sym_rc_valid;                // (see PreSorted::sym_rc)
     // With the rank path on, what is left for the window kernels past 4 096 outputs is the rows of at most 8 192 products (and symbolic hub rows): those of up to
     // 8 192 outputs join the mid-size launch (four 2 048-output chunks at most) instead of being a launch — a row sort, unit lists, a persistent kernel — of their own.
     ClassLimits num_limits = kNumLimits;
     if (rank) num_limits.lim[4] = 8192;
-    G4S_TRY(classify_rows(M, row_size.as<long long>(), num_limits, 0, rc, s));
+    if (!reuse_rc) G4S_TRY(classify_rows(M, row_size.as<long long>(), num_limits, 0, local_rc, s));
+    const RowClasses &rc = reuse_rc ? pre->sym_rc : local_rc;
+    const bool num_only_short = rc.count[CLS_MEDIUM] + rc.count[CLS_LARGE] + rc.count[CLS_M2] + rc.count[CLS_M3] + rc.count[CLS_HUB] + rc.count[CLS_RANK] == 0;
     if (getenv("G4S_DEBUG"))
         fprintf(stderr, "g4s numeric classes: empty %d <=32 %d <=512 %d <=1024 %d <=2048 %d <=4096 %d <=1M %d hub %d rank %d\n", rc.count[CLS_EMPTY], rc.count[CLS_TINY],
                 rc.count[CLS_SMALL], rc.count[CLS_MEDIUM], rc.count[CLS_LARGE], rc.count[CLS_M2], rc.count[CLS_M3], rc.count[CLS_HUB], rc.count[CLS_RANK]);
 
     dbg.mark("classes");
     ColumnMap local_map;                                           // see spgemm_symbolic_impl; the one-shot call hands its map over
-    if (!pre) {
+    if (!pre && !num_only_short) {
         G4S_TRY(build_column_map(N, bnnz_local, bcol, local_map, s));
     }
     const ColumnMap &cmap = pre ? pre->cmap : local_map;
@@ -2961,7 +2979,7 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
     const int N2 = cmap.width(N);
     DevBuf wsplit_buf;
     const int *wsplit = pre && pre->has_wsplit ? pre->wsplit : nullptr;
-    if (!(pre && pre->has_wsplit)) G4S_TRY(build_window_splits(K, N2, brpt, wcol, wsplit_buf, &wsplit, s));
+    if (!(pre && pre->has_wsplit) && !num_only_short) G4S_TRY(build_window_splits(K, N2, brpt, wcol, wsplit_buf, &wsplit, s));
     std::vector<std::unique_ptr<DevBuf>> ct_keep;                  // transients of the launches below: live until the end of this call
     // ---- the rows with cuts (spgemm_rank.hpp), longest first: chunk lists from the cuts, exact splits and unit lists per chunk, then the rank kernel. In two stages:
     // stage 1 (row order, chunk counts, their scans, B's records) is enqueued before the short rows and the mid-size classes, so that its three totals have long

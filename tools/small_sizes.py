@@ -5,7 +5,8 @@ can_24 by default (mm/src/mkl_spgemm.cpp:8-9), patents_main 240 547², nnz 560 9
 One case per process (so that rocprofv3 can count its dispatches and host waits):
     python tools/small_sizes.py --case rmat5e5 --op spmv      [--reps 200]
     python tools/small_sizes.py --case rmat5e5 --op spgemm    [--reps 20]
-Cases: rmat5e5 (2^18 rows, 5e5 draws), rmat2e6 (2^19 rows, 2e6 draws), rmat12m (1.25 M rows, 1.25e7 draws: an 8-way slab of configs[1]), lap120 (120^3 7-point stencil).
+Cases: rmat5e5 (2^18 rows, 5e5 draws), rmat2e6 (2^19 rows, 2e6 draws), rmat12m (1.25 M rows, 1.25e7 draws: an 8-way slab of configs[1]), lap120 (120^3 7-point stencil),
+er5e5 (240 547 rows, 560 943 uniform draws: the shape of patents_main), can24 (24 rows, 160 uniform draws: the shape of can_24).
 Prints one JSON line: wall time per call (host clock around a synchronised loop) and, for SpMV, the stream time per call (events around the loop).
 tools/small_sizes.sh runs every case, once plain and once under rocprofv3, and writes the table (profiles/r05_small_sizes.txt)."""
 import argparse
@@ -35,6 +36,16 @@ def build(case):
         return host.rmat_csr(1_250_000, 21, 12_500_000, 20240523)
     if case == "lap120":
         return host.laplacian_csr(7, 120, 120, 120)
+    if case in ("er5e5", "can24"):                                 # uniform draws in the shape of the reference's own examples: patents_main (mm/README.md:9), can_24 (mkl_spgemm.cpp:8-9)
+        import ctypes as C
+        n, draws = (240547, 560943) if case == "er5e5" else (24, 160)
+        g = torch.Generator(device="cuda"); g.manual_seed(20240526)
+        keys = torch.unique(torch.randint(0, n * n, (draws,), dtype=torch.int64, device="cuda", generator=g), sorted=True)
+        nnz = keys.numel()
+        rowptr = torch.empty(n + 1, dtype=torch.int32, device="cuda"); colids = torch.empty(nnz, dtype=torch.int32, device="cuda"); values = torch.empty(nnz, dtype=torch.float64, device="cuda")
+        capi.check(capi.load().g4s_synth_csr_from_keys(7, n, n, C.c_void_p(keys.data_ptr()), nnz, C.c_void_p(rowptr.data_ptr()), C.c_void_p(colids.data_ptr()), C.c_void_p(values.data_ptr()), None))
+        torch.cuda.synchronize()
+        return host.CSR(rowptr, colids, values, n, n)
     raise SystemExit(f"unknown case {case}")
 
 

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """The latency table of VERDICT r4 item 4 (profiles/r05_small_sizes.txt): every case of tools/small_sizes.py, timed plain, then run twice under rocprofv3
 (kernel + HIP API trace) with N and 2N calls — the differences of the two runs are the dispatches and the host waits of N calls, set-up excluded.
-Usage (on the GPU box): python tools/small_sizes_table.py [--out gpurun_out/r05_small_sizes.txt] [--cases rmat5e5,rmat2e6,rmat12m,lap120]"""
+Usage (on the GPU box): python tools/small_sizes_table.py [--out gpurun_out/r05_small_sizes.txt] [--cases can24,er5e5,rmat5e5,rmat2e6,rmat12m,lap120]"""
 import argparse, csv, glob, json, os, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ap = argparse.ArgumentParser()
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_small_sizes.txt"))
-ap.add_argument("--cases", default="rmat5e5,rmat2e6,rmat12m,lap120")
+ap.add_argument("--cases", default="can24,er5e5,rmat5e5,rmat2e6,rmat12m,lap120")
 ap.add_argument("--ops", default="spmv,spgemm")
 a = ap.parse_args()
 WAITS = ("hipStreamSynchronize", "hipDeviceSynchronize", "hipEventSynchronize", "hipMemcpy", "hipMemcpyDtoH", "hipMemcpyHtoD", "hipStreamWaitEvent")
