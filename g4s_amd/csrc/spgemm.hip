@@ -693,6 +693,7 @@ __host__ __device__ __forceinline__ int split_bits(int N)
 // (MI355X_MICROARCH.md §LDS) the sixteen lanes land on sixteen different slots.
 __device__ __forceinline__ int bm_slot(int w) { return w ^ (((w >> 6) & 7) << 2); }
 constexpr int kWindowMaxN = 4 << 20;                  // widest B for which the window kernels take the mid-size rows too
+inline int mid_tables() { const char *e = getenv("G4S_SPGEMM_MID_TABLES"); return e ? atoi(e) : 0; }   // A/B: bit 0 the ≤ 1024 class (and the symbolic mid class), 1: ≤ 2048, 2: ≤ 4096 through key tables
 inline int window_max_n() { const char *e = getenv("G4S_SPGEMM_WINDOW_MAX_N"); return e ? atoi(e) : kWindowMaxN; }   // tests force the table kernels with 0
 // grid of the persistent big-row kernels: one workgroup per CU (their LDS allows no more), fewer when the class is small
 inline int big_grid(int nrows, int wgs_per_cu = 1)
@@ -2677,7 +2678,7 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     }
     // Up to kWindowMaxN columns (4 bitmap windows) the window kernel beats the key tables for every row past 512 products (it has no
     // probe chains and cannot overflow); with more windows each row would re-walk its products once per window, so tables take over.
-    const bool x_med = N2 <= window_max_n(), x_large = x_med;
+    const bool x_large = N2 <= window_max_n(), x_med = x_large && !mid_tables();
     const long long *pre_off = nullptr;
     int *pre_cols = nullptr;
     const bool use_units = !getenv("G4S_SPGEMM_NO_UNITS");
@@ -3084,7 +3085,7 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
     }
     }
     // Rows past 1 K entries: bitmap windows + bucketed slots beat table + in-LDS bitonic sort while the column range is <= 4 windows.
-    const bool xn_large = N2 <= window_max_n(), xn_m2 = xn_large;
+    const bool xn_wide = N2 <= window_max_n(), xn_large = xn_wide && !(mid_tables() & 2), xn_m2 = xn_wide && !(mid_tables() & 4);
     // exact chunk splits (chunk_splits_kernel) for the rows of one launch that hold more than one value chunk: one-shot call only (the sorted columns must
     // exist before the numeric kernel runs); the buffers live until the end of this call
     const bool use_units = !getenv("G4S_SPGEMM_NO_UNITS");
@@ -3186,7 +3187,7 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
               t_m3 = shape_of("G4S_SPGEMM_T_NUM_M3", kShapeNumM3);
     const int m3_cut = getenv("G4S_SPGEMM_M3_CUT") ? atoi(getenv("G4S_SPGEMM_M3_CUT")) : kNumM3Cut;
     const char *e_med = getenv("G4S_SPGEMM_T_NUM_MED");
-    const int t_med = e_med ? (atoi(e_med) ? shape_of("G4S_SPGEMM_T_NUM_MED", 1024) : 0) : kShapeNumMedium;   // 0: the table kernel
+    const int t_med = (mid_tables() & 1) ? 0 : e_med ? (atoi(e_med) ? shape_of("G4S_SPGEMM_T_NUM_MED", 1024) : 0) : kShapeNumMedium;   // 0: the table kernel
     dbg.mark("table-kernels+maps");
     const bool one_mid_launch = t_med && xn_large && xn_m2 && t_med == t_large && t_large == t_m2;
     if (one_mid_launch) {
