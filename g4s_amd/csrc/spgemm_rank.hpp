@@ -18,9 +18,15 @@
 #pragma once
 
 constexpr int kRankT = 1024;                               // threads of the rank kernel's workgroup, one per CU (512 threads with half-size chunks, two per CU: 47.5 ms against 30.5)
-constexpr int kRankChunk = 8 * kRankT;                     // outputs per value chunk: 8 192 (6 144 / 5 120 / 4 096 with wider bitmaps measured 32.7 / 33.0 / 38.5 ms against 30.0)
+#ifndef G4S_SPGEMM_RANK_PER
+#define G4S_SPGEMM_RANK_PER 8
+#endif
+#ifndef G4S_SPGEMM_RANK_WPT
+#define G4S_SPGEMM_RANK_WPT 7
+#endif
+constexpr int kRankChunk = G4S_SPGEMM_RANK_PER * kRankT;                     // outputs per value chunk: 8 192 (6 144 / 5 120 / 4 096 with wider bitmaps measured 32.7 / 33.0 / 38.5 ms against 30.0)
 constexpr int kRankWordCols = 48;                          // columns per 64-bit LDS word: bits 0–47 presence, bits 48–63 the word's exclusive rank within the chunk (< 8192)
-constexpr int kRankWords = 7 * kRankT;                     // words of a chunk's bitmap: 7 per thread (7 168 words, 56 KiB)
+constexpr int kRankWords = G4S_SPGEMM_RANK_WPT * kRankT;                     // words of a chunk's bitmap: 7 per thread (7 168 words, 56 KiB)
 static_assert(sizeof(int) * (3 * (size_t)kRankChunk + 2 * (size_t)kRankWords + 64) <= 160 * 1024, "the chunk's sums, columns and bitmap must fit one CU's LDS");
 constexpr int kRankWin = kRankWords * kRankWordCols;       // 344 064 columns per segment = 336 symbolic threads of 1 024 columns each
 constexpr int kRankSegThreads = kRankWin / 1024;
