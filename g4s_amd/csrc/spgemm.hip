@@ -736,9 +736,11 @@ __device__ __forceinline__ unsigned wave_inclusive_sum(unsigned x)
 // Duplicate columns inside one B row are merged like any others. A row that does not fit (more than 64 A-entries, or more products than the cap — the numeric
 // classes are cut by output length, not by products) is appended to a list that the table kernels take afterwards.
 constexpr int kSmallCap = 512;
-template <bool NUMERIC>
-constexpr int small_wave_ints() { return kSmallCap + (NUMERIC ? 2 * kSmallCap : 0) + kSmallCap / 2 + kSmallCap / 4; }   // columns | products (fp64) | source index per rank (u16) | run per product (u8)
-template <bool NUMERIC>
+constexpr int kTinyCap = 64;                                     // the same kernel for the rows of at most 32 products (the tiny class of the symbolic phase): 1 KB of LDS per wave
+                                                                  // instead of 7.5 — the CU holds 32 such waves instead of 20, and these rows are all latency (round 5)
+template <bool NUMERIC, int CAP = kSmallCap>
+constexpr int small_wave_ints() { return CAP + (NUMERIC ? 2 * CAP : 0) + CAP / 2 + CAP / 4; }   // columns | products (fp64) | source index per rank (u16) | run per product (u8)
+template <bool NUMERIC, int CAP = kSmallCap>
 __global__ __launch_bounds__(256) void spgemm_small_wave_kernel(
     const int *__restrict__ rows, int nrows, const int *__restrict__ arpt, const int *__restrict__ acol, const double *__restrict__ aval,
     const int *__restrict__ brpt, const int *__restrict__ bcol, const double *__restrict__ bval,
@@ -747,9 +749,9 @@ __global__ __launch_bounds__(256) void spgemm_small_wave_kernel(
 {
     extern __shared__ int lds_i[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int *Cin = lds_i + wave * small_wave_ints<NUMERIC>();
-    double *Vin = reinterpret_cast<double *>(Cin + kSmallCap);      // (byte offset a multiple of 8: every region is)
-    unsigned short *Src = reinterpret_cast<unsigned short *>(Cin + kSmallCap + (NUMERIC ? 2 * kSmallCap : 0));
+    int *Cin = lds_i + wave * small_wave_ints<NUMERIC, CAP>();
+    double *Vin = reinterpret_cast<double *>(Cin + CAP);      // (byte offset a multiple of 8: every region is)
+    unsigned short *Src = reinterpret_cast<unsigned short *>(Cin + CAP + (NUMERIC ? 2 * CAP : 0));
     const int ridx = blockIdx.x * 4 + wave;
     if (ridx >= nrows) return;                                     // (no block barrier in this kernel: waves come and go on their own)
     const int row = rows[ridx];
@@ -764,7 +766,7 @@ __global__ __launch_bounds__(256) void spgemm_small_wave_kernel(
     }
     const int incl = (int)wave_inclusive_sum((unsigned)len), P = incl - len;
     const int flop = __builtin_amdgcn_readlane(incl, 63);
-    if (na > 64 || flop > kSmallCap) {                             // uniform
+    if (na > 64 || flop > CAP) {                             // uniform
         if (lane == 0) ovf_rows[atomicAdd(ovf_count, 1)] = row;
         return;
     }
@@ -784,7 +786,7 @@ __global__ __launch_bounds__(256) void spgemm_small_wave_kernel(
         }
         return lo;
     };
-    unsigned char *Run = reinterpret_cast<unsigned char *>(Src + kSmallCap);   // the run of every product (na <= 64)
+    unsigned char *Run = reinterpret_cast<unsigned char *>(Src + CAP);   // the run of every product (na <= 64)
     for (int i0 = 0; i0 < flop; i0 += 64) {
         const int i = min(i0 + lane, flop - 1);
         const int e = run_of(i);
@@ -2201,9 +2203,9 @@ int check_b(const int *brpt, const int *bcol, int K, long long bnnz, int N, hipS
     G4S_TRY(buf.alloc(sizeof(unsigned long long) * 3));
     G4S_HIP_TRY(hipMemsetAsync(buf.p, 0, sizeof(unsigned long long) * 3, s));
     unsigned long long *d = buf.as<unsigned long long>();
-    const int grid = (int)std::min<long long>((bnnz + 255) / 256, 4096);
+    const int grid = (int)std::min<long long>((bnnz + 255) / 256, 512);   // (one atomic per workgroup on one counter: 4 096 of them were 20 of the pass's 28 µs on a 5.6e5-entry B)
     hipLaunchKernelGGL(check_descents_kernel, dim3(grid), dim3(256), 0, s, bcol, bnnz, N, reinterpret_cast<int *>(d), d + 1);
-    hipLaunchKernelGGL(row_start_descents_kernel, dim3(std::min((K + 255) / 256, 2048)), dim3(256), 0, s, K, brpt, bcol, d + 2);
+    hipLaunchKernelGGL(row_start_descents_kernel, dim3(std::min((K + 255) / 256, 512)), dim3(256), 0, s, K, brpt, bcol, d + 2);
     unsigned long long h[3] = {0, 0, 0};
     G4S_HIP_TRY(g4s::read_small(h, d, sizeof(h), s));
     G4S_HIP_TRY(g4s::reads_sync(s));
@@ -2312,9 +2314,9 @@ int checked_row_flop(int M, int K, int N, const int *arpt, const int *acol, long
     G4S_HIP_TRY(hipMemsetAsync(buf.p, 0, sizeof(unsigned long long) * 4, s));
     unsigned long long *d = buf.as<unsigned long long>();
     if (bnnz > 0) {
-        const int grid = (int)std::min<long long>((bnnz + 255) / 256, 4096);
+        const int grid = (int)std::min<long long>((bnnz + 255) / 256, 512);   // (one atomic per workgroup on one counter: 4 096 of them were 20 of the pass's 28 µs on a 5.6e5-entry B)
         hipLaunchKernelGGL(check_descents_kernel, dim3(grid), dim3(256), 0, s, bcol, bnnz, N, reinterpret_cast<int *>(d), d + 1);
-        hipLaunchKernelGGL(row_start_descents_kernel, dim3(std::min((K + 255) / 256, 2048)), dim3(256), 0, s, K, brpt, bcol, d + 2);
+        hipLaunchKernelGGL(row_start_descents_kernel, dim3(std::min((K + 255) / 256, 512)), dim3(256), 0, s, K, brpt, bcol, d + 2);
     }
     G4S_TRY(f.alloc(sizeof(long long) * ((size_t)annz + 1)));
     G4S_TRY(P.alloc(sizeof(long long) * ((size_t)annz + 1)));
@@ -2660,9 +2662,17 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
         G4S_TRY(small_ovf.alloc(sizeof(int) * (size_t)n));
         G4S_TRY(small_ovf_n.alloc(sizeof(int)));
         G4S_HIP_TRY(hipMemsetAsync(small_ovf_n.p, 0, sizeof(int), s));
-        auto k = spgemm_small_wave_kernel<false>;
-        hipLaunchKernelGGL(k, dim3((n + 3) / 4), dim3(256), sizeof(int) * 4 * small_wave_ints<false>(), s, rc.list(CLS_TINY), n, arpt, acol, (const double *)nullptr, brpt, bcol,
-                           (const double *)nullptr, nz, (const int *)nullptr, (int *)nullptr, (double *)nullptr, small_ovf.as<int>(), small_ovf_n.as<int>());
+        if (int nt = rc.count[CLS_TINY]) {                          // at most 32 products each
+            auto k = spgemm_small_wave_kernel<false, kTinyCap>;
+            constexpr size_t lds = sizeof(int) * 4 * small_wave_ints<false, kTinyCap>();
+            hipLaunchKernelGGL(k, dim3((nt + 3) / 4), dim3(256), lds, s, rc.list(CLS_TINY), nt, arpt, acol, (const double *)nullptr, brpt, bcol,
+                               (const double *)nullptr, nz, (const int *)nullptr, (int *)nullptr, (double *)nullptr, small_ovf.as<int>(), small_ovf_n.as<int>());
+        }
+        if (int ns = rc.count[CLS_SMALL]) {
+            auto k = spgemm_small_wave_kernel<false>;
+            hipLaunchKernelGGL(k, dim3((ns + 3) / 4), dim3(256), sizeof(int) * 4 * small_wave_ints<false>(), s, rc.list(CLS_SMALL), ns, arpt, acol, (const double *)nullptr, brpt, bcol,
+                               (const double *)nullptr, nz, (const int *)nullptr, (int *)nullptr, (double *)nullptr, small_ovf.as<int>(), small_ovf_n.as<int>());
+        }
         auto k2 = spgemm_symbolic_lds_kernel<256, 256, 1024, false>;
         hipLaunchKernelGGL(k2, dim3(std::min(n, 256)), dim3(256), sym_lds_bytes(1, 1024), s, small_ovf.as<int>(), 0, arpt, acol, brpt, bcol, row_flop.as<long long>(), nz, nullptr, nullptr,
                            (const int *)small_ovf_n.as<int>());
@@ -3068,9 +3078,19 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         G4S_TRY(small_ovf.alloc(sizeof(int) * (size_t)n));
         G4S_TRY(small_ovf_n.alloc(sizeof(int)));
         G4S_HIP_TRY(hipMemsetAsync(small_ovf_n.p, 0, sizeof(int), s));
-        auto k = spgemm_small_wave_kernel<true>;
-        hipLaunchKernelGGL(k, dim3((n + 3) / 4), dim3(256), sizeof(int) * 4 * small_wave_ints<true>(), s, rc.list(CLS_TINY), n, arpt, acol, aval, brpt, bcol, bval, (int *)nullptr, crpt, ccol, cval,
-                           small_ovf.as<int>(), small_ovf_n.as<int>());
+        // (the lists of a carried symbolic classification are cut by PRODUCTS: its tiny class fits the 64-product form; the numeric classes are cut by outputs)
+        const int nt = reuse_rc ? rc.count[CLS_TINY] : 0;
+        if (nt) {
+            auto k = spgemm_small_wave_kernel<true, kTinyCap>;
+            constexpr size_t lds = sizeof(int) * 4 * small_wave_ints<true, kTinyCap>();
+            hipLaunchKernelGGL(k, dim3((nt + 3) / 4), dim3(256), lds, s, rc.list(CLS_TINY), nt, arpt, acol, aval, brpt, bcol, bval, (int *)nullptr, crpt, ccol,
+                               cval, small_ovf.as<int>(), small_ovf_n.as<int>());
+        }
+        if (n - nt) {
+            auto k = spgemm_small_wave_kernel<true>;
+            hipLaunchKernelGGL(k, dim3((n - nt + 3) / 4), dim3(256), sizeof(int) * 4 * small_wave_ints<true>(), s, rc.list(CLS_TINY) + nt, n - nt, arpt, acol, aval, brpt, bcol, bval, (int *)nullptr, crpt,
+                               ccol, cval, small_ovf.as<int>(), small_ovf_n.as<int>());
+        }
         auto k2 = spgemm_numeric_lds_kernel<256, 256, 1024>;
         hipLaunchKernelGGL(k2, dim3(std::min(n, 256)), dim3(256), num_lds_bytes(1024), s, small_ovf.as<int>(), 0, arpt, acol, aval, brpt, bcol, bval, row_flop.as<long long>(), crpt, ccol, cval,
                            (const int *)small_ovf_n.as<int>());
