@@ -30,8 +30,9 @@ constexpr int TILE_NNZ = 2048;            // fp64 products staged in LDS per wor
 #define G4S_TILE_ROWS 1024
 #endif
 constexpr int TILE_ROWS = G4S_TILE_ROWS;  // row cap per stream block (4 KiB of staged row pointers)
-constexpr int LONG_CHUNK = 8192;          // nonzeros per long-row chunk
+constexpr int LONG_CHUNK = 2048;          // nonzeros per long-row chunk (8192 until round 5: a chunk is one workgroup's serial loop of eight rounds)
 constexpr int UNROLL = TILE_NNZ / WG;     // independent loads in flight per lane
+constexpr int kLaneRowMax = 64;           // a longer row inside a many-row block is summed by a wavefront, not by one lane
 
 struct LongChunk { int32_t row, k0, k1, slot; };
 struct LongRow { int32_t row, slot0, nslots, pad; };
@@ -130,11 +131,27 @@ __global__ __launch_bounds__(WG) void spmv_csr_adaptive_kernel(
     if (nrows * 2 > WG || nnzb <= 16 * nrows) {
         // one lane per row, left-to-right (the oracle's summation order): blocks of many rows, and blocks of short rows however few
         // (a stencil's last block, the forced cuts of the device-side plan builder) — rows of a stencil or band are exact everywhere
+        // (Round 5: a row of more than kLaneRowMax entries in such a block — a block of a power-law matrix: hundreds of short rows and one of a thousand
+        // entries — is left to a whole wavefront below. As one lane's loop it was a thousand dependent LDS reads: 20 of the 24 µs of a product on a 5e5-entry
+        // R-MAT, profiles/r05_small_sizes.txt. Stencil and band rows are far shorter, so their exact order stays.)
+        __shared__ int heavy[TILE_NNZ / kLaneRowMax], n_heavy;
+        if (tid == 0) n_heavy = 0;
+        __syncthreads();
         for (int r = tid; r < nrows; r += WG) {
             const int a = rp[r] - k0, b = rp[r + 1] - k0;
+            if (b - a > kLaneRowMax) { const int h = atomicAdd(&n_heavy, 1); if (h < TILE_NNZ / kLaneRowMax) heavy[h] = r; else { double s = 0.0; for (int j = a; j < b; ++j) s += prod[j]; store_y(y, r0 + r, s, alpha, beta); } continue; }
             double s = 0.0;
             for (int j = a; j < b; ++j) s += prod[j];
             store_y(y, r0 + r, s, alpha, beta);
+        }
+        __syncthreads();
+        const int nh = min(n_heavy, TILE_NNZ / kLaneRowMax);        // (no more such rows fit a block; the guard above is for safety)
+        for (int h = tid >> 6; h < nh; h += WG / 64) {              // one wavefront per heavy row: strided partial sums, then a shuffle reduction
+            const int r = heavy[h], a = rp[r] - k0, b = rp[r + 1] - k0;
+            double s = 0.0;
+            for (int j = a + (tid & 63); j < b; j += 64) s += prod[j];
+            s = wave_sum(s);
+            if ((tid & 63) == 0) store_y(y, r0 + r, s, alpha, beta);
         }
     } else {
         // tpr lanes per row (power of two, <= 64, tpr·nrows <= WG), strided partials + shuffle reduction
