@@ -52,6 +52,33 @@ def test_spmv_short_rows_bit_exact(oracle):
     assert inf["long_rows"] == 0 and inf["stream_blocks"] >= 30000 * 5 // 2048
 
 
+def test_spmv_heavy_rows_inside_many_row_blocks(oracle):
+    # A block of the streaming path with hundreds of short rows AND a row of several hundred entries (what a power-law matrix looks like between its hubs):
+    # the short rows are summed by one lane each in the oracle's order — bit-identical — the heavy one by a whole wavefront (within the tolerance, run to run equal).
+    from g4s_amd import capi, host
+    rng = np.random.default_rng(5)
+    rows = cols = 4000
+    lens = np.full(rows, 2)
+    heavy = [7, 700, 701, 1500, 3999]
+    for r, n in zip(heavy, [900, 65, 64, 1999, 300]):
+        lens[r] = n
+    lens[[0, 100, 2000]] = 0
+    rp = np.zeros(rows + 1, dtype=np.int32)
+    rp[1:] = np.cumsum(lens)
+    ci = np.concatenate([np.sort(rng.choice(cols, n, replace=False)) for n in lens]).astype(np.int32)
+    va = rng.uniform(-1, 1, ci.size)
+    A = host.CSR.from_host(rp, ci, va, rows, cols, spmv_flags=capi.SPMV_STREAM)
+    assert A.info()["spmv_path"] == 0 and A.info()["long_rows"] == 0
+    x = rng.uniform(-1, 1, cols)
+    y = _check(oracle, A, rp, ci, va, x)
+    want = oracle.spmv(rp, ci, va, x, None, 1.0, 0.0)
+    short = lens <= 64
+    assert np.array_equal(y[short], want[short])
+    _check(oracle, A, rp, ci, va, x, alpha=-0.5, beta=2.0, y0=rng.uniform(-1, 1, rows))
+    xd = torch.from_numpy(x).cuda()
+    assert torch.equal(A.spmv(xd), A.spmv(xd))
+
+
 def test_spmv_power_law_with_hubs(oracle):
     # empty rows, short rows, medium rows (shuffle path) and hubs > TILE_NNZ / > LONG_CHUNK (chunked path)
     from g4s_amd import host
