@@ -10,11 +10,13 @@
 //              and the row's output count at every multiple of kRankWin columns — a few ints per row instead of the whole list;
 //   pre-pass   rank_chunks_kernel merges the two kinds of cuts into the row's chunk list: a chunk is at most kRankChunk consecutive outputs whose columns lie in
 //              one kRankWin-column segment; the exact B-row splits and the unit lists are built per chunk as before (chunk_splits_kernel, unit_task_kernel);
-//   numeric    spgemm_numeric_rank2_kernel, one chunk at a time: the chunk's products are loaded ONCE (the first round stays in registers), their columns are
-//              marked in an LDS bitmap of 48-column words, the owner threads turn the top 16 bits of every word into the word's exclusive rank, and a product's
-//              slot is then rank(word) + popcount(bits below) — one LDS read, no search, no bucket index, no column list; the product adds its value into
-//              V[slot] (ds_add_f64) and stores its column into KC[slot] (every product of a slot stores the same id), and the chunk leaves as two coalesced
-//              streams (cval, ccol through the column map). LDS per output: 8 B sum + 4 B column + 7 B of bitmap share = 152 KiB per workgroup.
+//   numeric    spgemm_numeric_rank2_kernel, one chunk at a time: a chunk's units are dealt to the 16 waves; a product is one 16-byte record {place, column,
+//              value} of B (pack_b_kernel). The first kU units of a wave are requested a step ahead and stay in registers, the rest is streamed in two
+//              alternating groups (stream_unit_groups). The products' places are marked in an LDS bitmap of 48-column words, the owner threads turn the top 16
+//              bits of every word into the word's exclusive rank, and a product's slot is then rank(word) + popcount(bits below) — one LDS read, no search, no
+//              bucket index, no column list; the product adds its value into V[slot] (ds_add_f64) and stores its column into KC[slot] (every product of a slot
+//              stores the same id), and the chunk leaves as two coalesced streams. LDS per output: 8 B sum + 4 B column + 7 B of bitmap share = 152 KiB.
+// Rows from 4 096 products take this path (G4S_SPGEMM_SYM_MEDIUM, spgemm.hip); DESIGN.md §4.2 has the step table of the round.
 #pragma once
 
 constexpr int kRankT = 1024;                               // threads of the rank kernel's workgroup, one per CU (512 threads with half-size chunks, two per CU: 47.5 ms against 30.5)
@@ -24,9 +26,9 @@ constexpr int kRankT = 1024;                               // threads of the ran
 #ifndef G4S_SPGEMM_RANK_WPT
 #define G4S_SPGEMM_RANK_WPT 7
 #endif
-constexpr int kRankChunk = G4S_SPGEMM_RANK_PER * kRankT;                     // outputs per value chunk: 8 192 (6 144 / 5 120 / 4 096 with wider bitmaps measured 32.7 / 33.0 / 38.5 ms against 30.0)
+constexpr int kRankChunk = G4S_SPGEMM_RANK_PER * kRankT; // outputs per value chunk: 8 192 (6 144 / 5 120 with wider bitmaps: 30.9 / 31.1 ms against 28.0 on the final kernel)
 constexpr int kRankWordCols = 48;                          // columns per 64-bit LDS word: bits 0–47 presence, bits 48–63 the word's exclusive rank within the chunk (< 8192)
-constexpr int kRankWords = G4S_SPGEMM_RANK_WPT * kRankT;                     // words of a chunk's bitmap: 7 per thread (7 168 words, 56 KiB)
+constexpr int kRankWords = G4S_SPGEMM_RANK_WPT * kRankT; // words of a chunk's bitmap: 7 per thread (7 168 words, 56 KiB; 8 per thread is a 64-byte stride: 32-way bank conflicts)
 static_assert(sizeof(int) * (3 * (size_t)kRankChunk + 2 * (size_t)kRankWords + 64) <= 160 * 1024, "the chunk's sums, columns and bitmap must fit one CU's LDS");
 constexpr int kRankWin = kRankWords * kRankWordCols;       // 344 064 columns per segment = 336 symbolic threads of 1 024 columns each
 constexpr int kRankSegThreads = kRankWin / 1024;
@@ -38,10 +40,10 @@ static_assert(kRankWin % 1024 == 0 && kRankChunk >= 1024, "a symbolic thread (1 
 #define G4S_SPGEMM_RANK_AHEAD 0                            /* 1: the next chunk's records are requested behind the first barrier into registers of their own — measured 28.18 ms against 28.0 (profiles/r05_spgemm_ab.txt): the wait moves, the time stays */
 #endif
 #ifndef G4S_SPGEMM_RANK_GM
-#define G4S_SPGEMM_RANK_GM 8
+#define G4S_SPGEMM_RANK_GM 8                               /* units per streamed group in the mark step (one register each) */
 #endif
 #ifndef G4S_SPGEMM_RANK_GA
-#define G4S_SPGEMM_RANK_GA 4
+#define G4S_SPGEMM_RANK_GA 4                               /* … in the accumulate step (four registers each); 16 / 8 and 12 / 6: equal within the boxes' spread */
 #endif
 #ifndef G4S_SPGEMM_RANK_ROUNDS
 #define G4S_SPGEMM_RANK_ROUNDS 1                           /* rounds of RANK_UPR units per wave whose columns and records are requested ahead and held in registers */
