@@ -244,7 +244,9 @@ G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, g4s_csr_t K_csr, const 
 
     // sc: device scalars of the loop. A reduction = map_sum over the vectors + a one-workgroup finish whose epilogue writes the
     // derived scalars; nothing comes to the host until fetch() at the end of an outer iteration.
-    enum { R1Z1, R0Z0, DELTA, ALPHA, VDOTV, U1DOTU1, PDOTP, S2S2, DIVN, NSC };
+    // <r1, z1> of the NEXT outer iteration is formed in the closing reduction of the current one (r2 is final there; round 5, as in g4s_stokes_uzawa_cg_dist): the two
+    // slots of R1Z1 / DELTA alternate by the iteration's parity — the closing step may run twice (a speculation that did not hold) and must find the current pair untouched.
+    enum { R1Z1_0, R1Z1_1, DELTA_0, DELTA_1, ALPHA, VDOTV, U1DOTU1, PDOTP, S2S2, DIVN, NSC };
     static_assert(NSC <= 16, "scalar slots");
     double *sc = sums_dev;
     double hsc[NSC] = {0};
@@ -292,12 +294,19 @@ G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, g4s_csr_t K_csr, const 
     // ---- r1 = div(V); incompressibility = sqrt(|r1|²_div / (1e-32 + |V|²))
     G4S_TRY(g4s_elem_op_div_u(op, g, V, r1, s));
     G4S_HIP_TRY(hipMemsetAsync(sc, 0, sizeof(double) * NSC, s));
-    reduce(std::max(nno, nel), [=] __device__(int i) {
-        Sum3 o{0.0, 0.0, 0.0};
-        if (i < nno) o.a = v_terms(V, i);
-        if (i < nel) { o.b = r1[i] * r1[i] / area[i]; o.c = P[i] * P[i] * area[i]; }
+    hipLaunchKernelGGL(map_sum6_kernel, dim3(kBlocks), dim3(kThreads), 0, s, std::max(nno, nel), [=] __device__(int i) {
+        Sum6 o{{0.0, 0.0, 0.0, 0.0, 0.0, 0.0}};
+        if (i < nno) o.v[0] = v_terms(V, i);
+        if (i < nel) {
+            o.v[1] = r1[i] * r1[i] / area[i]; o.v[2] = P[i] * P[i] * area[i];
+            const double z = BPI[i] * r1[i];                          // z1 = BPI∘r1 and <r1, z1> of the first outer iteration (:296-318)
+            z1[i] = z; o.v[3] = r1[i] * z;
+        }
         return o;
-    }, [=] __device__(double a, double b, double c) { sc[VDOTV] = a; sc[DIVN] = b; sc[PDOTP] = c; });
+    }, part);
+    hipLaunchKernelGGL(finish_sums6_kernel, dim3(1), dim3(kThreads), 0, s, part, [=] __device__(const double (&r)[6]) {
+        sc[VDOTV] = r[0]; sc[DIVN] = r[1]; sc[PDOTP] = r[2]; sc[R1Z1_0] = r[3];
+    });
     G4S_TRY(fetch());
     double vdotv = hsc[VDOTV] / volume, pdotp = hsc[PDOTP] / volume;
     double incompressibility = std::sqrt(hsc[DIVN] / volume / (1e-32 + vdotv));
@@ -312,11 +321,11 @@ G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, g4s_csr_t K_csr, const 
         const bool keep = prm->check_continuity_convergence ? (incompressibility > prm->imp || converging < 2)
                                                             : (incompressibility > prm->imp && converging < 2);   // keep_iterating :150-162
         if (!(count < prm->steps_max && keep)) break;
-        // z1 = BPI∘r1; r1dotz1 = <r1, z1>; δ = r1dotz1 / r0dotz0 (:296-318)
-        reduce(nel, [=] __device__(int i) { const double z = BPI[i] * r1[i]; z1[i] = z; return Sum3{r1[i] * z, 0.0, 0.0}; },
-               [=] __device__(double a, double, double) { sc[R1Z1] = a; sc[DELTA] = a / sc[R0Z0]; });
+        // z1 = BPI∘r1, <r1, z1> and δ = <r1, z1> / <r0, z0> (:296-318) sit in slot `cur`: written by the closing reduction of the previous iteration
+        const int cur = count & 1, nxt = cur ^ 1;
+        if (hsc[R1Z1_0 + cur] == 0.0) return g4s::set_error(G4S_ERR_INVALID, "g4s_stokes_uzawa_cg: <r1, z1> = 0 at the head of iteration %d (the source asserts)", count);
         const bool first = count == 0;
-        each(nel, [=] __device__(int i) { s2[i] = first ? z1[i] : z1[i] + sc[DELTA] * s1[i]; });
+        each(nel, [=] __device__(int i) { s2[i] = first ? z1[i] : z1[i] + sc[DELTA_0 + cur] * s1[i]; });
         // K·u1 = grad(s2). The solve's first batch (one iteration more than the previous solve needed) is only enqueued; everything that follows it
         // in this outer iteration is enqueued behind it at once, and ONE synchronisation brings back the solve's state and the nine scalars.
         // Before round 3 the host waited for the solve, then enqueued the rest and waited again: at Cookbook2's size the loop was host-bound
@@ -337,22 +346,27 @@ G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, g4s_csr_t K_csr, const 
             G4S_TRY(g4s_elem_op_div_u(op, g, u1, Fp, s));
             // α = <r1, z1> / <s2, div(u1)>; r2, P, V (:336-354)
             reduce(nel, [=] __device__(int i) { return Sum3{s2[i] * Fp[i], 0.0, 0.0}; },
-                   [=] __device__(double a, double, double) { sc[ALPHA] = sc[R1Z1] / a; });
+                   [=] __device__(double a, double, double) { sc[ALPHA] = sc[R1Z1_0 + cur] / a; });
             each(std::max(nel, neq), [=] __device__(int i) {        // one launch for the three updates
                 const double alpha = sc[ALPHA];
                 if (i < nel) { r2[i] = r1[i] - alpha * Fp[i]; Pn[i] = Pc[i] + alpha * s2[i]; }
                 if (i < neq) Vn[i] = Vc[i] - alpha * u1[i];
             });
-            G4S_TRY(g4s_elem_op_div_u(op, g, Vn, z1, s));
-            // the five norms of the iteration in one two-level pass (they were two passes of three: two launches less)
+            G4S_TRY(g4s_elem_op_div_u(op, g, Vn, Fp, s));           // (Fp = div(u1) has gone into r2: the buffer is free)
+            // the five norms of the iteration and, since r2 is final, z1 = BPI∘r2 and <r1, z1> of the NEXT one, in one two-level pass
             hipLaunchKernelGGL(map_sum6_kernel, dim3(kBlocks), dim3(kThreads), 0, s, std::max(nno, nel), [=] __device__(int i) {
                 Sum6 o{{0.0, 0.0, 0.0, 0.0, 0.0, 0.0}};
                 if (i < nno) { o.v[0] = v_terms(Vn, i); o.v[1] = v_terms(u1, i); }
-                if (i < nel) { o.v[2] = Pn[i] * Pn[i] * area[i]; o.v[3] = s2[i] * s2[i] * area[i]; o.v[4] = z1[i] * z1[i] / area[i]; }
+                if (i < nel) {
+                    o.v[2] = Pn[i] * Pn[i] * area[i]; o.v[3] = s2[i] * s2[i] * area[i]; o.v[4] = Fp[i] * Fp[i] / area[i];
+                    const double z = BPI[i] * r2[i];
+                    z1[i] = z; o.v[5] = r2[i] * z;
+                }
                 return o;
             }, part);
             hipLaunchKernelGGL(finish_sums6_kernel, dim3(1), dim3(kThreads), 0, s, part, [=] __device__(const double (&r)[6]) {
-                sc[VDOTV] = r[0]; sc[U1DOTU1] = r[1]; sc[PDOTP] = r[2]; sc[S2S2] = r[3]; sc[DIVN] = r[4]; sc[R0Z0] = sc[R1Z1];   // shift <r0, z0> = <r1, z1> (:405)
+                sc[VDOTV] = r[0]; sc[U1DOTU1] = r[1]; sc[PDOTP] = r[2]; sc[S2S2] = r[3]; sc[DIVN] = r[4];
+                sc[R1Z1_0 + nxt] = r[5]; sc[DELTA_0 + nxt] = r[5] / sc[R1Z1_0 + cur];      // δ of the next iteration = its <r1, z1> over this one's (:296-318, :405)
             });
             return G4S_OK;
         };
@@ -366,7 +380,6 @@ G4S_API g4s_status g4s_stokes_uzawa_cg(g4s_elem_op_t op, g4s_csr_t K_csr, const 
         inner_total += cycles;
         valid = residual < inner_acc ? 1 : 0;
         if (!speculate || !held) G4S_TRY(fetch());                 // (speculation that held: the scalars came back with the solve's state)
-        if (hsc[R1Z1] == 0.0) return g4s::set_error(G4S_ERR_INVALID, "g4s_stokes_uzawa_cg: <r1, z1> = 0 at the head of iteration %d (the source asserts)", count);
         const double alpha = hsc[ALPHA];
         vdotv = hsc[VDOTV] / volume;
         pdotp = hsc[PDOTP] / volume;
