@@ -231,6 +231,26 @@ def test_spgemm_rank_kernel_cuts(oracle, monkeypatch, stride, path, two_phase):
     assert list(nz[:6]) == [8192, 8193, 12000, 20000, 8192 + 936 + 6000, 2000]
 
 
+@pytest.mark.parametrize("two_phase", [False, True])
+def test_spgemm_crowded_chunk_streams_its_units_in_batches(oracle, two_phase):
+    """One chunk / one window with thousands of 64-entry units: 100 equal B rows of 2 000 entries give 200 000 products for 2 000 outputs — 3 125 units, 195 per
+    wavefront, so the rank kernel and the symbolic window kernel stream the units past their register round in three batches of 64 descriptors (stream_unit_groups);
+    a second row repeats it on top of 30 000 distinct columns (two chunks, the crowded one not the first)."""
+    N, K = 400_000, 160
+    hot = np.arange(0, 4000, 2)
+    brows = [hot] * 100 + [np.arange(10_000 + 1000 * k, 10_000 + 1000 * (k + 1)) for k in range(30)] + [np.zeros(0, dtype=np.int64)] * 30
+    brp = np.concatenate([[0], np.cumsum([len(r) for r in brows])]).astype(np.int32)
+    bci = np.concatenate(brows).astype(np.int32)
+    rng = np.random.default_rng(63)
+    bva = rng.uniform(-1, 1, brp[-1])
+    arows = [list(range(100)), list(range(130)), [3, 7, 150], [], list(range(100, 130))]
+    arp = np.concatenate([[0], np.cumsum([len(r) for r in arows])]).astype(np.int32)
+    aci = np.concatenate([np.array(r, dtype=np.int32) for r in arows]).astype(np.int32)
+    ava = rng.uniform(-1, 1, arp[-1])
+    c = _check(oracle, (arp, aci, ava), (brp, bci, bva), len(arows), K, N, two_phase=two_phase)
+    assert list(np.diff(c.to_host()[0])) == [2000, 32000, 2000, 0, 30000]
+
+
 def test_spgemm_two_call_form_carries_its_columns(oracle, monkeypatch):
     """g4s_spgemm_symbolic leaves the sorted columns, the column map and the window splits of ITS product for the g4s_spgemm_numeric call that follows with the same
     arrays (round 4). Checked: the carried and the uncarried (G4S_SPGEMM_NO_CARRY) numeric calls give the same C; a symbolic call of another product in between
