@@ -41,6 +41,28 @@ def test_spgemm_random(oracle, M, K, N, da, db, seed):
     _check(oracle, A, B, M, K, N)
 
 
+@pytest.mark.parametrize("two_phase", [False, True])
+def test_spgemm_short_rows_only_product(oracle, two_phase):
+    """Every row at most 512 products (the reference's own examples: can_24, patents_main): no column map, no window splits, no column scratch, the numeric phase of
+    the one-call form takes the symbolic phase's row lists; rows of at most 32 products go through the 64-product form of the wave kernel, a row of more than 64
+    A-entries through the table kernel behind it. Bit-identical values: these rows are summed in the reference's order."""
+    from g4s_amd import host
+    rng = np.random.default_rng(71)
+    M = K = N = 3000
+    lens = rng.integers(0, 5, M)
+    lens[[5, 900]] = [20, 100]                                      # 20 × ≤ 5 entries: ≤ 512 products; 100 A-entries: past the wave kernel's 64
+    arp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    aci = np.concatenate([np.sort(rng.choice(K, n, replace=False)) for n in lens]).astype(np.int32)
+    A = (arp, aci, rng.uniform(-1, 1, aci.size))
+    blens = rng.integers(0, 5, K)
+    brp = np.concatenate([[0], np.cumsum(blens)]).astype(np.int32)
+    bci = np.concatenate([np.sort(rng.choice(N, n, replace=False)) for n in blens]).astype(np.int32)
+    B = (brp, bci, rng.uniform(-1, 1, bci.size))
+    c = _check(oracle, A, B, M, K, N, two_phase=two_phase)
+    _, _, oval = oracle.spgemm(A, B, N, sort_output=True)
+    assert np.array_equal(c.to_host()[2], oval)
+
+
 def test_spgemm_golden_fixture(oracle):
     import os
     from g4s_amd import host
