@@ -884,7 +884,7 @@ __device__ __forceinline__ void window_bounds(const int *brpt, const int *wsplit
 #ifdef G4S_PROFILE_BIG
 // Section timers of the big-row kernels (tools/big_prof.py, tools/sym_prof.py): s_memtime deltas summed in registers, flushed with one atomic
 // per slot by thread 0 of every 16th workgroup at BIG_PROF_FLUSH (a global atomic per stamp would itself be the longest thing in an inner loop).
-__device__ unsigned long long g_big_prof[48];                     // [0, 16): numeric big-row kernel; [16, 32): symbolic window kernel and its emit step; [32, 48): rank kernel
+__device__ unsigned long long g_big_prof[64];                     // [0, 16): numeric big-row kernel; [16, 32): symbolic window kernel and its emit step; [32, 48): rank kernel; [48, 56): its chunks by size
 #define BIG_PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[16] = {}; constexpr int prof_base = 0
 #define BIG_PROF_DECL_SYM unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[16] = {}; constexpr int prof_base = 16
 #define BIG_PROF_DECL_RANK unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[16] = {}; constexpr int prof_base = 32
@@ -3425,8 +3425,8 @@ G4S_API g4s_status g4s_spgemm_csr_i32_f64(const int32_t *arpt, const int32_t *ac
 #ifdef G4S_PROFILE_BIG
 extern "C" __attribute__((visibility("default"))) int g4s_debug_big_prof(unsigned long long *out, int reset)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_prof), sizeof(unsigned long long) * 48) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[48] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_big_prof), z, sizeof(z)) != hipSuccess) return 1; }
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_prof), sizeof(unsigned long long) * 64) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[64] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_big_prof), z, sizeof(z)) != hipSuccess) return 1; }
     return 0;
 }
 #endif

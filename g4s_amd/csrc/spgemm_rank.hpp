@@ -270,6 +270,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
             for (int q = 0; q < kU; ++q) into[r][q] = reinterpret_cast<const int4 *>(bpack)[entry_of(d, r, q, nu)];
     };
     load_recs(rec, dc, cur.u1 - cur.u0);
+#if defined(G4S_PROFILE_BIG) && defined(G4S_PROFILE_SIZES)
+    unsigned long long chunk_t0 = __builtin_amdgcn_s_memtime(), size_cnt[4] = {0, 0, 0, 0}, size_ticks[4] = {0, 0, 0, 0};
+#endif
     for (;;) {
         const int nu = cur.u1 - cur.u0;
         const bool more = g + G < nitems;                          // uniform
@@ -416,6 +419,13 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         BIG_PROF(7);
         __syncthreads();
         BIG_PROF(8);
+#if defined(G4S_PROFILE_BIG) && defined(G4S_PROFILE_SIZES)          // (a third build: chunks and their clock by output count — slots 12 … 15 and 5 are reused, see tools/rank_prof.py --sizes)
+        {
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();
+            const int b_ = cur.qn <= 512 ? 0 : cur.qn <= 2048 ? 1 : cur.qn <= 6144 ? 2 : 3;
+            size_cnt[b_] += 1; size_ticks[b_] += now_ - chunk_t0; chunk_t0 = now_;
+        }
+#endif
         if (!more) break;
         dc = dn; dx = dxn;
 #if G4S_SPGEMM_RANK_AHEAD
@@ -426,5 +436,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
 #endif
         g += G; cur = nxt; nxt = nxt2;
     }
+#if defined(G4S_PROFILE_BIG) && defined(G4S_PROFILE_SIZES)
+    if (threadIdx.x == BIG_PROF_TID && (blockIdx.x & 15) == 0)
+        for (int b_ = 0; b_ < 4; ++b_) { atomicAdd(&g_big_prof[48 + 2 * b_], size_cnt[b_]); atomicAdd(&g_big_prof[48 + 2 * b_ + 1], size_ticks[b_]); }
+#endif
     BIG_PROF_FLUSH;
 }

@@ -11,11 +11,18 @@ lib = capi.load()
 n = 1 << a.scale
 A = host.rmat_csr(n, a.scale, int(a.ef * n), 20240522)
 host.HashSpGEMM(A, A)
-buf = (C.c_ulonglong * 48)()
+buf = (C.c_ulonglong * 64)()
 lib.g4s_debug_big_prof.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 lib.g4s_debug_big_prof(buf, 1)
 host.HashSpGEMM(A, A)
 lib.g4s_debug_big_prof(buf, 0)
+if os.environ.get("G4S_RANK_PROF_SIZES"):                           # library built with -DG4S_PROFILE_BIG -DG4S_PROFILE_SIZES: chunks and their clock by output count
+    sz = buf[48:56]
+    tot_t = sum(sz[1::2]) or 1
+    for b, lab in enumerate(["<= 512 outputs", "<= 2048", "<= 6144", "more"]):
+        n, tk = sz[2 * b], sz[2 * b + 1]
+        print(f"chunks of {lab:15s}: {n:8d} ({100.0 * n / max(sum(sz[0::2]), 1):5.1f} %)  clock share {100.0 * tk / tot_t:5.1f} %  ticks per chunk {tk / max(n, 1):9.0f}")
+    sys.exit(0)
 names = ["mark (round 0 from registers + further rounds)", "barrier 1 (marks done)", "ranks: read words, scan, barrier 2", "ranks: write words, barrier 3", "accumulate (+ lgkmcnt drain)",
          "next chunk's round requested", "barrier 4 (sums done)", "store (+ clean)", "barrier 5"]
 buf = buf[32:]

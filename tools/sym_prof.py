@@ -12,7 +12,7 @@ lib = capi.load()
 n = 1 << a.scale
 A = host.rmat_csr(n, a.scale, int(a.ef * n), 20240522)
 host.HashSpGEMM(A, A)
-buf = (C.c_ulonglong * 48)()
+buf = (C.c_ulonglong * 64)()
 lib.g4s_debug_big_prof.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 lib.g4s_debug_big_prof(buf, 1)
 host.HashSpGEMM(A, A)                                            # the one-call form: the symbolic window kernels also emit the sorted columns
