@@ -3064,9 +3064,30 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
         G4S_TRY(ritems->alloc(sizeof(RankItem) * (size_t)nchunks));
         hipLaunchKernelGGL(rank_items_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, rows, arpt, crpt, (const long long *)ioff->as<long long>(), (const int *)uoff->as<int>(), (const int *)choff->as<int>(),
                            (const RankChunk *)chunks->as<RankChunk>(), ritems->as<RankItem>());
-        auto k = spgemm_numeric_rank2_kernel<T>;
+        // split by size (spgemm_rank.hpp): the chunks of at most kRankSmallCap outputs take the 512-thread shape, two workgroups per CU
+        const bool two_shapes = !getenv("G4S_SPGEMM_RANK_ONE_SHAPE");
+        auto *sflag = mk(), *spos = mk(), *rbig = mk(), *rsmall = mk(), *rcounts = mk();
+        const RankItem *big_items = ritems->as<RankItem>();
+        const int *n_big = nullptr;
+        if (two_shapes) {
+            G4S_TRY(sflag->alloc(sizeof(int) * ((size_t)nchunks + 1))); G4S_TRY(spos->alloc(sizeof(int) * ((size_t)nchunks + 1)));
+            G4S_TRY(rbig->alloc(sizeof(RankItem) * (size_t)nchunks)); G4S_TRY(rsmall->alloc(sizeof(RankItem) * (size_t)nchunks)); G4S_TRY(rcounts->alloc(sizeof(int) * 2));
+            hipLaunchKernelGGL(rank_small_flags_kernel, dim3((nchunks + 256) / 256), dim3(256), 0, s, nchunks, (const RankItem *)ritems->as<RankItem>(), sflag->as<int>());
+            G4S_TRY(g4s::prims::exclusive_scan(sflag->as<int>(), spos->as<int>(), (long long)nchunks + 1, s));
+            hipLaunchKernelGGL(rank_split_items_kernel, dim3((nchunks + 255) / 256), dim3(256), 0, s, nchunks, (const RankItem *)ritems->as<RankItem>(), (const int *)spos->as<int>(), rbig->as<RankItem>(),
+                               rsmall->as<RankItem>(), rcounts->as<int>());
+            big_items = rbig->as<RankItem>(); n_big = rcounts->as<int>();
+        }
+        auto k = spgemm_numeric_rank2_kernel<T, kRankChunk>;
         G4S_TRY(allow_lds(k, lds));
-        hipLaunchKernelGGL(k, dim3(big_grid(nchunks, 1024 / T)), dim3(T), lds, s, nchunks, (const RankItem *)ritems->as<RankItem>(), wcol, (const BPack *)bpack->as<BPack>(), (const UnitDesc *)ud->as<UnitDesc>(), ccol, cval);
+        hipLaunchKernelGGL(k, dim3(big_grid(nchunks, 1)), dim3(T), lds, s, nchunks, n_big, big_items, wcol, (const BPack *)bpack->as<BPack>(), (const UnitDesc *)ud->as<UnitDesc>(), ccol, cval);
+        if (two_shapes) {
+            auto ks = spgemm_numeric_rank2_kernel<kRankSmallT, kRankSmallCap>;
+            constexpr size_t lds_s = rank_lds_bytes(kRankSmallCap);
+            G4S_TRY(allow_lds(ks, lds_s));
+            hipLaunchKernelGGL(ks, dim3(big_grid(nchunks, 2)), dim3(kRankSmallT), lds_s, s, nchunks, (const int *)(rcounts->as<int>() + 1), (const RankItem *)rsmall->as<RankItem>(), wcol,
+                               (const BPack *)bpack->as<BPack>(), (const UnitDesc *)ud->as<UnitDesc>(), ccol, cval);
+        }
         G4S_HIP_TRY(hipGetLastError());
         return G4S_OK;
     };

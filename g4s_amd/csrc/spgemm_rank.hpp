@@ -190,12 +190,34 @@ __device__ __forceinline__ void stream_unit_groups(int ne /* ≥ 1, uniform */, 
     }
 }
 
-template <int T>
+// Two shapes (round 5): 1 024 threads and 8 192 outputs, one workgroup per CU; and, for the chunks of at most kRankSmallCap outputs — the sparse tail segments of
+// mid-size rows: 44 % of configs[2]'s chunks, 13.7 K cycles each whatever their size, all of it barriers and exposed round trips (profiles/r05_rank_chunk_sizes.txt)
+// — 512 threads and 80 KiB of LDS (the same 344 064-column bitmap, sums and columns for 2 000 outputs), TWO workgroups per CU that fill each other's waits.
+constexpr int kRankSmallT = 512, kRankSmallCap = 2000;
+constexpr size_t rank_lds_bytes(int cap) { return sizeof(int) * (3 * (size_t)cap + 2 * (size_t)kRankWords + 64); }
+static_assert(2 * rank_lds_bytes(kRankSmallCap) <= 160 * 1024 && kRankSmallCap % 2 == 0, "two small-chunk workgroups share a CU's LDS; the bitmap behind the columns is 8-byte aligned");
+// the chunk items of a launch, split by size: flags → scan → scatter (the order inside either list stays the launch's row order)
+__global__ void rank_small_flags_kernel(int n, const RankItem *__restrict__ items, int *__restrict__ flag)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) flag[i] = i < n && items[i].qn <= kRankSmallCap ? 1 : 0;
+}
+__global__ void rank_split_items_kernel(int n, const RankItem *__restrict__ items, const int *__restrict__ spos /* n + 1: exclusive scan of the flags */, RankItem *__restrict__ big,
+                                        RankItem *__restrict__ small, int *__restrict__ counts /* [2]: big, small */)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { counts[0] = n - spos[n]; counts[1] = spos[n]; }
+    if (i >= n) return;
+    const RankItem it = items[i];
+    if (it.qn <= kRankSmallCap) small[spos[i]] = it; else big[i - spos[i]] = it;
+}
+
+template <int T, int CAP>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void spgemm_numeric_rank2_kernel(
-    int nitems, const RankItem *__restrict__ items, const int *__restrict__ bcol2 /* compact column per entry of B */, const BPack *__restrict__ bpack,
+    int nitems_max, const int *__restrict__ nitems_dev /* not NULL: the list's length (the grid is sized by nitems_max) */, const RankItem *__restrict__ items, const int *__restrict__ bcol2 /* compact column per entry of B */, const BPack *__restrict__ bpack,
     const UnitDesc *__restrict__ U, int *__restrict__ ccol, double *__restrict__ cval)
 {
-    static_assert(T == kRankT, "7 bitmap words and 8 outputs per thread");
+    static_assert(kRankWords % T == 0 && CAP % 2 == 0 && CAP <= kRankChunk, "whole bitmap words per thread; an 8-byte aligned bitmap");
     // kR ROUNDS of kU units per wave live in registers (16 waves × 2 × 8 = 256 units: a typical chunk of configs[2] has 196). With one round the units past 128
     // went through the loops below the slow way — request, wait a full memory latency, use — once in the mark step and once in the accumulate step: 39 % of
     // the kernel (profiles/r05_rank_sections_fine.txt). A product is ONE 16-byte record {compact column, column, value} in four registers: requested when the
@@ -203,14 +225,15 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     // accumulate step uses the rest. (Columns and records requested separately, columns a whole chunk ahead: 96 registers of state with the 3-register tuples
     // padded to 4, spills, and a spill reload waits for EVERY load in flight — 38.9 ms against 31.2.)
     constexpr int kGM = G4S_SPGEMM_RANK_GM, kGA = G4S_SPGEMM_RANK_GA;   // group sizes of the streamed units: mark (one register a unit), accumulate (four)
-    constexpr int kU = G4S_SPGEMM_RANK_UPR, kR = G4S_SPGEMM_RANK_ROUNDS, kWaves = T / 64, kPer = kRankChunk / T, kWPT = kRankWords / T;
+    constexpr int kU = G4S_SPGEMM_RANK_UPR, kR = G4S_SPGEMM_RANK_ROUNDS, kWaves = T / 64, kPer = (CAP + T - 1) / T, kWPT = kRankWords / T;
     static_assert(kR >= 1 && kR * kU <= 64, "a round's descriptors are lanes of one register");
-    extern __shared__ int lds_i[];                                 // [V: 8192 fp64][KC: 8192 int][BM: 7168 × 64 bit][ctrl: 64 int]
+    extern __shared__ int lds_i[];                                 // [V: CAP fp64][KC: CAP int][BM: 7168 × 64 bit][ctrl: 64 int]
     double *V = reinterpret_cast<double *>(lds_i);
-    int *KC = lds_i + 2 * kRankChunk;
-    unsigned long long *BM = reinterpret_cast<unsigned long long *>(lds_i + 3 * kRankChunk);
+    int *KC = lds_i + 2 * CAP;
+    unsigned long long *BM = reinterpret_cast<unsigned long long *>(lds_i + 3 * CAP);
     unsigned *BM32 = reinterpret_cast<unsigned *>(BM);
-    int *ctrl = lds_i + 3 * kRankChunk + 2 * kRankWords;
+    int *ctrl = lds_i + 3 * CAP + 2 * kRankWords;
+    const int nitems = nitems_dev ? min(*nitems_dev, nitems_max) : nitems_max;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int G = gridDim.x;
     BIG_PROF_DECL_RANK;
@@ -236,12 +259,12 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     auto accumulate = [&](int wr, int col, double prod) {
         if (wr < 0) return;
         const unsigned long long w = BM[wr >> 6];
-        const int slot = min((int)(w >> 48) + (int)__popcll(w & ((1ull << (wr & 63)) - 1ull)), (int)kRankChunk - 1);   // (the clamp: stay inside the chunk whatever the arrays hold; all-int, or min() goes through fp64)
+        const int slot = min((int)(w >> 48) + (int)__popcll(w & ((1ull << (wr & 63)) - 1ull)), (int)CAP - 1);   // (the clamp: stay inside the chunk whatever the arrays hold; all-int, or min() goes through fp64)
         atomicAdd(&V[slot], prod);
         KC[slot] = col;
     };
 #pragma unroll
-    for (int u = 0; u < kPer; ++u) { V[t + u * T] = 0.0; KC[t + u * T] = 0; }
+    for (int u = 0; u < kPer; ++u) if (t + u * T < CAP) { V[t + u * T] = 0.0; KC[t + u * T] = 0; }
 #pragma unroll
     for (int j = 0; j < kWPT; ++j) BM[t + j * T] = 0ull;
     int g = blockIdx.x;
