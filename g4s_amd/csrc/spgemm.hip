@@ -678,7 +678,7 @@ struct BigCfg {
 };
 constexpr int kFlatUnitsPerRound = G4S_SPGEMM_UPR;   // 64-entry units of B rows a wave loads per round (independent loads in flight per lane)
 // which shape takes which row class (G4S_SPGEMM_T_* override them for sweeps)
-constexpr int kShapeNumMedium = 256, kShapeSymMedium = 256, kShapeSymLarge = 1024, kShapeNumLarge = 256, kShapeNumM2 = 256, kShapeNumM3 = 1024, kNumM3Cut = 8192;
+constexpr int kShapeNumMedium = 256, kShapeSymMedium = 256, kShapeNumLarge = 256, kShapeNumM2 = 256, kShapeNumM3 = 1024, kNumM3Cut = 8192;
 inline int shape_of(const char *env, int dflt) { const char *e = getenv(env); const int v = e ? atoi(e) : dflt; return v == 256 || v == 512 ? v : 1024; }
 // granularity of the window splits: the column range in 16 pieces (at most — the table holds a position per piece and B row), never finer
 // than 2^16 columns; every window size is a multiple, and a value chunk's columns are bracketed by whole pieces
@@ -2692,8 +2692,12 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     const long long *pre_off = nullptr;
     int *pre_cols = nullptr;
     const bool use_units = !getenv("G4S_SPGEMM_NO_UNITS");
-    const int t_med = shape_of("G4S_SPGEMM_T_SYM_MED", kShapeSymMedium), t_large = shape_of("G4S_SPGEMM_T_SYM_LARGE", kShapeSymLarge),
-              t_win = shape_of("G4S_SPGEMM_T_SYM_WINDOW", 1024);
+    // The long classes' shape follows B's width (round 5): the count-and-cut pass is barriers and round trips per window, not bitmap work, so four 256-thread
+    // workgroups per CU that fill each other's waits beat one of 1 024 threads even with five windows per row instead of two (configs[2]: 26.55 against 27.5 ms,
+    // 512 threads 27.1: profiles/r05_spgemm_ab.txt) — while the number of windows stays small.
+    const int long_shape = N2 <= 6 * (1 << 18) ? 256 : N2 <= 6 * (1 << 19) ? 512 : 1024;
+    const int t_med = shape_of("G4S_SPGEMM_T_SYM_MED", kShapeSymMedium), t_large = shape_of("G4S_SPGEMM_T_SYM_LARGE", long_shape),
+              t_win = shape_of("G4S_SPGEMM_T_SYM_WINDOW", long_shape);
     const bool one_long_launch = x_large && t_large == t_win;   // LARGE and M2 share a shape and their lists are adjacent: one launch
     // Round 5: the long classes (more than 8 K products) write CUTS instead of columns and take the rank kernel in the numeric phase (spgemm_rank.hpp). Needs what the
     // carried columns needed (a PreSorted to carry them in) plus the unit lists and the one long launch.
