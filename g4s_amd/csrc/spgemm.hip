@@ -2561,7 +2561,7 @@ __global__ void rank_need_kernel(int M, const int *__restrict__ cls, unsigned cl
     long long v = 0;
     if (i < M && ((class_mask >> cls[i]) & 1u)) {
         const long long f = row_flop[i], nzb = f < N ? f : (long long)N;   // the row's outputs are at most min(flop, columns): so many count cuts at most
-        v = nseg + nzb / kRankChunk + 1;
+        v = nseg + nzb / kRankCut + 1;
     }
     need[i] = v;
 }
@@ -2707,7 +2707,7 @@ int spgemm_symbolic_impl(int32_t M, int32_t K, int32_t N, const int32_t *arpt, c
     long long *cut_off = nullptr;
     int *cuts = nullptr;
     if (use_rank) {
-        const long long cut_bound = (long long)n_long * (nseg + 1) + flop / kRankChunk + 1;   // Σ (nseg + min(flop_i, N2) / chunk + 1) over the long rows: no count comes back
+        const long long cut_bound = (long long)n_long * (nseg + 1) + flop / kRankCut + 1;   // Σ (nseg + min(flop_i, N2) / chunk + 1) over the long rows: no count comes back
         DevBuf need;
         if (cut_bound >= (1ll << 30) || need.alloc(sizeof(long long) * ((size_t)M + 1)) != G4S_OK || pre->cut_off_buf.alloc(sizeof(long long) * ((size_t)M + 1), pre->keep) != G4S_OK ||
             pre->cuts_buf.alloc(sizeof(int) * (size_t)cut_bound, pre->keep) != G4S_OK) { (void)hipGetLastError(); use_rank = false; }

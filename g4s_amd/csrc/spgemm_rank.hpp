@@ -32,7 +32,11 @@ constexpr int kRankWords = G4S_SPGEMM_RANK_WPT * kRankT; // words of a chunk's b
 static_assert(sizeof(int) * (3 * (size_t)kRankChunk + 2 * (size_t)kRankWords + 64) <= 160 * 1024, "the chunk's sums, columns and bitmap must fit one CU's LDS");
 constexpr int kRankWin = kRankWords * kRankWordCols;       // 344 064 columns per segment = 336 symbolic threads of 1 024 columns each
 constexpr int kRankSegThreads = kRankWin / 1024;
-static_assert(kRankWin % 1024 == 0 && kRankChunk >= 1024, "a symbolic thread (1 024 columns) holds at most one count cut and never straddles a segment");
+#ifndef G4S_SPGEMM_RANK_CUT
+#define G4S_SPGEMM_RANK_CUT (G4S_SPGEMM_RANK_PER * 1024)
+#endif
+constexpr int kRankCut = G4S_SPGEMM_RANK_CUT;               // the symbolic phase cuts a row every kRankCut outputs: no chunk holds more (= kRankChunk; smaller only for A/B builds)
+static_assert(kRankWin % 1024 == 0 && kRankCut >= 1024 && kRankCut <= kRankChunk, "a symbolic thread (1 024 columns) holds at most one count cut and never straddles a segment");
 #ifndef G4S_SPGEMM_RANK_UPR
 #define G4S_SPGEMM_RANK_UPR 8                              /* 64-entry units a wave keeps in registers per chunk (16 waves × 8 × 64 = one chunk of products at compression 1); 10: equal, 12 / 14: register spills, 31–36 ms */
 #endif
@@ -83,8 +87,8 @@ __device__ __forceinline__ int count_and_cut_window(unsigned *bm, int wi /* wind
     const int g0 = row_before + p;                                  // the row-wide index of this thread's first output
     const int A = wi * T + t;                                       // the thread's 1 024-column block, counted over the whole column range
     if (A % kRankSegThreads == 0 && A / kRankSegThreads < nseg) segstart[A / kRankSegThreads] = g0;
-    const int b = (g0 + kRankChunk - 1) / kRankChunk;               // the first multiple of the chunk size at or behind g0
-    int k = b * kRankChunk - g0;
+    const int b = (g0 + kRankCut - 1) / kRankCut;                   // the first multiple of the chunk size at or behind g0
+    int k = b * kRankCut - g0;
     if (b >= 1 && k < cnt) {                                        // output b·kRankChunk is one of this thread's bits: the k-th (at most one per thread: 1 024 < kRankChunk)
         auto word = [&](int i) { const uint4 &v = g[i >> 2]; return (i & 3) == 0 ? v.x : (i & 3) == 1 ? v.y : (i & 3) == 2 ? v.z : v.w; };
         int found = -1;
@@ -115,7 +119,7 @@ __global__ void rank_chunks_kernel(int n, const int *__restrict__ rows, const in
     if (i == n) { if constexpr (!WRITE) { tasks[n] = 0; items[n] = 0; nchunks[n] = 0; } return; }   // (the scans run over n + 1 entries)
     const int row = rows[i], nz = crpt[row + 1] - crpt[row];
     const int *seg = cuts + cut_off[row], *bc = seg + nseg;
-    const int ncut = nz > 0 ? (nz - 1) / kRankChunk : 0;
+    const int ncut = nz > 0 ? (nz - 1) / kRankCut : 0;
     RankChunk *dst = WRITE ? out + choff[i] : nullptr;
     int s = 0, b = 1, cnt = 0, cur_o = -1, cur_c = 0;
     auto flush = [&](int next_o) {
@@ -125,7 +129,7 @@ __global__ void rank_chunks_kernel(int n, const int *__restrict__ rows, const in
         }
     };
     while (s < nseg || b <= ncut) {
-        const int os = s < nseg ? min(seg[s], nz) : INT_MAX, ob = b <= ncut ? b * kRankChunk : INT_MAX;
+        const int os = s < nseg ? min(seg[s], nz) : INT_MAX, ob = b <= ncut ? b * kRankCut : INT_MAX;
         const int cs = s * kRankWin, cb = b <= ncut ? bc[b - 1] : 0;
         const bool take_seg = os != ob ? os < ob : cs <= cb;
         const int o = take_seg ? os : ob, c = take_seg ? cs : cb;
