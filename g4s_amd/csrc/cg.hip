@@ -429,6 +429,11 @@ struct g4s_cg_ws_s {
     CgState *st = nullptr;
     unsigned char *mask = nullptr;
     bool use_mask = false;
+    // the boundary mask of the last g4s_cg_begin and what it was built from; hold_mask (g4s::cg_ws_hold_mask): the owner promises that list keeps its contents
+    // for the workspace's life, so a begin with the same list does not rebuild it (a memset and a launch per solve of an Uzawa iteration)
+    const int32_t *mask_src = nullptr;
+    int mask_n = -1;
+    bool hold_mask = false;
 };
 
 G4S_API g4s_status g4s_cg_ws_create(g4s_cg_ws_t *out, int32_t n_local)
@@ -447,6 +452,9 @@ G4S_API g4s_status g4s_cg_ws_create(g4s_cg_ws_t *out, int32_t n_local)
     ws->part = reinterpret_cast<double *>(b + 6 * nbp);
     ws->st = reinterpret_cast<CgState *>(ws->part + 3 * kDotBlocks);
     ws->mask = reinterpret_cast<unsigned char *>(ws->st) + 256;
+    // once, here: the partial sums and the state (g4s_cg_begin used to zero them at every solve; the kernels reset what they use — cg_init_kernel the state,
+    // every kernel that writes partial sums the slots of workgroups that do not exist — and a multi-rank caller's first all-reduce must not meet never-written memory)
+    if (hipMemset(ws->part, 0, sizeof(double) * 3 * kDotBlocks + 256) != hipSuccess) { (void)g4s::big_free(ws->arena); delete ws; return g4s::set_error(G4S_ERR_HIP, "g4s_cg_ws_create: hipMemset failed"); }
     *out = ws;
     return G4S_OK;
 }
@@ -463,11 +471,11 @@ G4S_API g4s_status g4s_cg_begin(g4s_cg_ws_t ws, const double *F_dev, const doubl
     G4S_REQUIRE(ws && F_dev && BI_dev && d0_dev, "NULL argument");
     G4S_REQUIRE(n_zero >= 0 && (n_zero == 0 || zero_resid_dev), "zero_resid is NULL");
     hipStream_t s = g4s::as_stream(stream);
-    G4S_HIP_TRY(hipMemsetAsync(ws->part, 0, sizeof(double) * 3 * kDotBlocks + sizeof(CgState), s));
     ws->use_mask = n_zero > 0;
-    if (n_zero) {
+    if (n_zero && !(ws->hold_mask && ws->mask_src == zero_resid_dev && ws->mask_n == n_zero)) {
         G4S_HIP_TRY(hipMemsetAsync(ws->mask, 0, (size_t)ws->n, s));
         hipLaunchKernelGGL(cg_mask_kernel, dim3((n_zero + kThreads - 1) / kThreads), dim3(kThreads), 0, s, n_zero, zero_resid_dev, ws->mask);
+        ws->mask_src = zero_resid_dev; ws->mask_n = n_zero;
     }
     hipLaunchKernelGGL(cg_init_kernel, dim3(dot_blocks(ws->n)), dim3(kThreads), 0, s, ws->n, F_dev, BI_dev, ws->r1, d0_dev, ws->z, ws->part + 2 * kDotBlocks, ws->part, ws->st);
     G4S_HIP_TRY(hipGetLastError());
@@ -640,6 +648,7 @@ int dist_cg_async_start(DistCgAsync **out, g4s_cg_ws_t ws, g4s_spmv_dist_t A, co
     *out = c;
     return G4S_OK;
 }
+void cg_ws_hold_mask(g4s_cg_ws_t ws, bool hold) { if (ws) { ws->hold_mask = hold; if (!hold) { ws->mask_src = nullptr; ws->mask_n = -1; } } }
 int dist_cg_async_read(DistCgAsync *c) { return c->read(); }
 int dist_cg_async_settle(DistCgAsync *c, bool *speculation_held, int32_t *cycles, double *residual)
 {

@@ -21,6 +21,7 @@ void cg_async_free(CgAsync *c);
 struct DistCgAsync;
 int dist_cg_async_start(DistCgAsync **out, g4s_cg_ws_t ws, g4s_spmv_dist_t A, const g4s_transport *tr, const double *BI, const int32_t *zero_resid, int32_t n_zero,
                         const double *F, double *d0, double acc, int32_t steps, void *stream);
+void cg_ws_hold_mask(g4s_cg_ws_t ws, bool hold);   // the caller promises that the zero_resid list it passes keeps its contents while it holds: the mask is built once
 int dist_cg_async_read(DistCgAsync *c);
 int dist_cg_async_settle(DistCgAsync *c, bool *speculation_held, int32_t *cycles, double *residual);
 void dist_cg_async_free(DistCgAsync *c);

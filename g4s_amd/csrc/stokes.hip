@@ -494,6 +494,7 @@ G4S_API g4s_status g4s_stokes_uzawa_cg_dist(g4s_spmv_dist_t K, g4s_spmv_dist_t D
     // one CG workspace for every velocity solve of the call
     struct Ws { g4s_cg_ws_t w = nullptr; ~Ws() { (void)g4s_cg_ws_destroy(w); } } ws;
     G4S_TRY(g4s_cg_ws_create(&ws.w, neq));
+    g4s::cg_ws_hold_mask(ws.w, true);                              // zero_resid is this call's own argument: the same list for every velocity solve
     // V and P of the NEXT outer iteration are written beside the current ones (ping-pong), as in g4s_stokes_uzawa_cg: an iteration enqueued behind a
     // velocity solve whose first batch turns out not to have met its test is enqueued again, from unchanged inputs
     Scratch scr2; scr2.s = s;
