@@ -3082,11 +3082,11 @@ int spgemm_numeric_impl(int32_t M, int32_t K, int32_t N,
                                rsmall->as<RankItem>(), rcounts->as<int>());
             big_items = rbig->as<RankItem>(); n_big = rcounts->as<int>();
         }
-        auto k = spgemm_numeric_rank2_kernel<T, kRankChunk>;
+        auto k = spgemm_numeric_rank2_kernel<T, kRankChunk, G4S_SPGEMM_RANK_UPR>;
         G4S_TRY(allow_lds(k, lds));
         hipLaunchKernelGGL(k, dim3(big_grid(nchunks, 1)), dim3(T), lds, s, nchunks, n_big, big_items, wcol, (const BPack *)bpack->as<BPack>(), (const UnitDesc *)ud->as<UnitDesc>(), ccol, cval);
         if (two_shapes) {
-            auto ks = spgemm_numeric_rank2_kernel<kRankSmallT, kRankSmallCap>;
+            auto ks = spgemm_numeric_rank2_kernel<kRankSmallT, kRankSmallCap, 8>;
             constexpr size_t lds_s = rank_lds_bytes(kRankSmallCap);
             G4S_TRY(allow_lds(ks, lds_s));
             hipLaunchKernelGGL(ks, dim3(big_grid(nchunks, 2)), dim3(kRankSmallT), lds_s, s, nchunks, (const int *)(rcounts->as<int>() + 1), (const RankItem *)rsmall->as<RankItem>(), wcol,

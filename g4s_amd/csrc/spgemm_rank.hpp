@@ -216,7 +216,7 @@ __global__ void rank_split_items_kernel(int n, const RankItem *__restrict__ item
     if (it.qn <= kRankSmallCap) small[spos[i]] = it; else big[i - spos[i]] = it;
 }
 
-template <int T, int CAP>
+template <int T, int CAP, int KU>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void spgemm_numeric_rank2_kernel(
     int nitems_max, const int *__restrict__ nitems_dev /* not NULL: the list's length (the grid is sized by nitems_max) */, const RankItem *__restrict__ items, const int *__restrict__ bcol2 /* compact column per entry of B */, const BPack *__restrict__ bpack,
     const UnitDesc *__restrict__ U, int *__restrict__ ccol, double *__restrict__ cval)
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     // accumulate step uses the rest. (Columns and records requested separately, columns a whole chunk ahead: 96 registers of state with the 3-register tuples
     // padded to 4, spills, and a spill reload waits for EVERY load in flight — 38.9 ms against 31.2.)
     constexpr int kGM = G4S_SPGEMM_RANK_GM, kGA = G4S_SPGEMM_RANK_GA;   // group sizes of the streamed units: mark (one register a unit), accumulate (four)
-    constexpr int kU = G4S_SPGEMM_RANK_UPR, kR = G4S_SPGEMM_RANK_ROUNDS, kWaves = T / 64, kPer = (CAP + T - 1) / T, kWPT = kRankWords / T;
+    constexpr int kU = KU, kR = G4S_SPGEMM_RANK_ROUNDS, kWaves = T / 64, kPer = (CAP + T - 1) / T, kWPT = kRankWords / T;
     static_assert(kR >= 1 && kR * kU <= 64, "a round's descriptors are lanes of one register");
     extern __shared__ int lds_i[];                                 // [V: CAP fp64][KC: CAP int][BM: 7168 × 64 bit][ctrl: 64 int]
     double *V = reinterpret_cast<double *>(lds_i);
