@@ -372,8 +372,8 @@ def main():
         A.handle                                                   # g4s_csr_create: the plan is built here, once per matrix
         torch.cuda.synchronize()
         plan_ms = (time.perf_counter() - tp0) * 1e3
-        # the same create once more on a second handle: the first one in a process also pays for 5 GB of fresh hipMalloc (plan + transients; the library's block
-        # cache serves the second) and the first launches of the plan kernels — 25 to 42 ms by box for a build that takes 18 (profiles/r05_plan_create.txt)
+        # the same create once more on a second handle: the first one in a process also pays for the first launches of the plan kernels and the first use of
+        # 5 GB of new blocks (plan + transients; the library's block cache serves the second) — 25 to 44 ms by box for a build that takes 18.6
         A2 = host.CSR(A_full.rowptr, A_full.colids, A_full.values, n_rows, n_cols, spmv_flags=flags)
         torch.cuda.synchronize()
         tp0 = time.perf_counter()
