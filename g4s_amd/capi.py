@@ -81,6 +81,7 @@ class StokesResult(C.Structure):
 SIGNATURES = {
     "g4s_version": (C.c_char_p, []),
     "g4s_build_info": (C.c_char_p, []),
+    "g4s_warm_up": (C.c_int, []),
     "g4s_last_error": (C.c_char_p, []),
     "g4s_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "g4s_set_device": (C.c_int, [C.c_int]),

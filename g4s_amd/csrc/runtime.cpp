@@ -1,5 +1,6 @@
 // runtime.cpp — device selection, allocators and error reporting of the C-ABI (include/g4s.h, "runtime").
 #include "common.hpp"
+#include <algorithm>
 #include "readback.hpp"
 #include <cstring>
 #include <mutex>
@@ -313,6 +314,38 @@ G4S_API const char *g4s_version(void) { return "g4s-hip 0.1 (gfx950)"; }
 #endif
 // What this library was built from, for tools that pair stored measurements with a build (bench.py's roofline.traffic): the SHA-256 of the SpMV kernel sources
 // (tools/kernel_hash.py, taken by the Makefile when runtime.cpp is compiled) and the name of an A/B variant build (tools/build_variant.sh; empty for the regular one).
+// g4s_warm_up (include/g4s.h): one small matrix through every SpMV path — host arrays, so that the upload path is loaded too
+G4S_API g4s_status g4s_warm_up(void)
+{
+    const int n = 1 << 16, per = 6;                                 // (past the single-workgroup sorts and scans of short lists: the build of a large matrix launches the general ones)
+    std::vector<int32_t> rp(n + 1), ci;
+    std::vector<double> va;
+    ci.reserve((size_t)n * per); va.reserve((size_t)n * per);
+    unsigned long long st = 88172645463325252ull;                   // xorshift: scattered columns, sorted inside a row
+    for (int r = 0; r < n; ++r) {
+        rp[r] = (int32_t)ci.size();
+        int32_t c[per];
+        for (int k = 0; k < per; ++k) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; c[k] = (int32_t)(st % (unsigned)n); }
+        std::sort(c, c + per);
+        for (int k = 0; k < per; ++k) if (k == 0 || c[k] != c[k - 1]) { ci.push_back(c[k]); va.push_back(1.0); }
+    }
+    rp[n] = (int32_t)ci.size();
+    double *x = nullptr, *y = nullptr;
+    G4S_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&x), sizeof(double) * n));
+    if (hipMalloc(reinterpret_cast<void **>(&y), sizeof(double) * n) != hipSuccess) { (void)hipFree(x); return g4s::set_error(G4S_ERR_HIP, "g4s_warm_up: hipMalloc failed"); }
+    int rc = hipMemset(x, 0, sizeof(double) * n) == hipSuccess ? G4S_OK : g4s::set_error(G4S_ERR_HIP, "g4s_warm_up: hipMemset failed");
+    for (unsigned flags : {0u, (unsigned)G4S_SPMV_BLOCKED, (unsigned)G4S_SPMV_STREAM}) {
+        if (rc != G4S_OK) break;
+        g4s_csr_t A = nullptr;
+        rc = g4s_csr_create(&A, n, n, (int64_t)ci.size(), rp.data(), ci.data(), va.data(), G4S_HOST_POINTERS | flags);
+        if (rc == G4S_OK) rc = g4s_spmv(A, x, y, 1.0, 0.0, nullptr);
+        if (rc == G4S_OK && hipDeviceSynchronize() != hipSuccess) rc = g4s::set_error(G4S_ERR_HIP, "g4s_warm_up: synchronisation failed");
+        (void)g4s_csr_destroy(A);
+    }
+    (void)hipFree(x); (void)hipFree(y);
+    return rc;
+}
+
 G4S_API const char *g4s_build_info(void) { return "spmv_kernel_sources_sha256=" G4S_SPMV_KERNEL_HASH ";variant=" G4S_BUILD_VARIANT; }
 G4S_API const char *g4s_last_error(void) { return g4s::last_error_buf(); }
 
