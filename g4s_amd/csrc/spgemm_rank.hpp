@@ -35,8 +35,16 @@ constexpr int kRankSegThreads = kRankWin / 1024;
 #ifndef G4S_SPGEMM_RANK_CUT
 #define G4S_SPGEMM_RANK_CUT (G4S_SPGEMM_RANK_PER * 1024)
 #endif
-constexpr int kRankCut = G4S_SPGEMM_RANK_CUT;               // the symbolic phase cuts a row every kRankCut outputs: no chunk holds more (= kRankChunk; smaller only for A/B builds)
-static_assert(kRankWin % 1024 == 0 && kRankCut >= 1024 && kRankCut <= kRankChunk, "a symbolic thread (1 024 columns) holds at most one count cut and never straddles a segment");
+#ifndef G4S_SPGEMM_RANK_SPLIT_MAX
+#define G4S_SPGEMM_RANK_SPLIT_MAX 0
+#endif
+// The symbolic phase cuts a row every kRankCut outputs (= the chunk size: every cut is a chunk boundary). A/B builds (-DG4S_SPGEMM_RANK_CUT=2000
+// -DG4S_SPGEMM_RANK_SPLIT_MAX=6000): finer cuts of which the chunk builder takes every kRankMerge-th, and all of them inside a stretch of at most kRankSplitMax
+// outputs between two segment boundaries, so that mid-size stretches leave as chunks for the kernel's two-per-CU shape — measured 27.9 against 27.3 ms without
+// the splitting and 26.5 with plain 8 192-output cuts (profiles/r05_spgemm_ab.txt): every chunk more is a pass of the (chunk, A-entry) pre-passes over its row.
+constexpr int kRankCut = G4S_SPGEMM_RANK_CUT, kRankMerge = kRankChunk / kRankCut, kRankSplitMax = G4S_SPGEMM_RANK_SPLIT_MAX;
+static_assert(kRankWin % 1024 == 0 && kRankCut >= 1024 && kRankMerge >= 1 && kRankMerge * kRankCut <= kRankChunk,
+              "a symbolic thread (1 024 columns) holds at most one count cut and never straddles a segment; merged cuts fit a chunk");
 #ifndef G4S_SPGEMM_RANK_UPR
 #define G4S_SPGEMM_RANK_UPR 8                              /* 64-entry units a wave keeps in registers per chunk (16 waves × 8 × 64 = one chunk of products at compression 1); 10: equal, 12 / 14: register spills, 31–36 ms */
 #endif
@@ -121,7 +129,7 @@ __global__ void rank_chunks_kernel(int n, const int *__restrict__ rows, const in
     const int *seg = cuts + cut_off[row], *bc = seg + nseg;
     const int ncut = nz > 0 ? (nz - 1) / kRankCut : 0;
     RankChunk *dst = WRITE ? out + choff[i] : nullptr;
-    int s = 0, b = 1, cnt = 0, cur_o = -1, cur_c = 0;
+    int s = 0, b = 1, cnt = 0, cur_o = -1, cur_c = 0, stretch_o = 0;   // stretch_o: the output count at the last segment boundary taken
     auto flush = [&](int next_o) {
         if (cur_o >= 0 && next_o > cur_o) {
             if constexpr (WRITE) dst[cnt] = RankChunk{cur_o, next_o - cur_o, cur_c, cur_c / kRankWin};
@@ -133,7 +141,13 @@ __global__ void rank_chunks_kernel(int n, const int *__restrict__ rows, const in
         const int cs = s * kRankWin, cb = b <= ncut ? bc[b - 1] : 0;
         const bool take_seg = os != ob ? os < ob : cs <= cb;
         const int o = take_seg ? os : ob, c = take_seg ? cs : cb;
-        if (take_seg) ++s; else ++b;
+        if (take_seg) { ++s; stretch_o = o; }
+        else {
+            ++b;
+            // a count cut inside the stretch [stretch_o, next segment boundary or the row's end): every kRankMerge-th one, or every one of a short stretch
+            const int stretch_end = s < nseg ? min(seg[s], nz) : nz;
+            if ((b - 1) % kRankMerge != 0 && stretch_end - stretch_o > kRankSplitMax) continue;
+        }
         if (o != cur_o) { flush(o); cur_o = o; }
         cur_c = c;
     }
