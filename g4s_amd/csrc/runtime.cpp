@@ -317,16 +317,20 @@ G4S_API const char *g4s_version(void) { return "g4s-hip 0.1 (gfx950)"; }
 // g4s_warm_up (include/g4s.h): one small matrix through every SpMV path — host arrays, so that the upload path is loaded too
 G4S_API g4s_status g4s_warm_up(void)
 {
-    const int n = 1 << 16, per = 6;                                 // (past the single-workgroup sorts and scans of short lists: the build of a large matrix launches the general ones)
+    const int n = 1 << 16;                                          // (past the single-workgroup sorts and scans of short lists: the build of a large matrix launches the general ones)
+    // rows 64 … 191 hold 128 entries, rows 0 … 63 point 128 times at them (16 K products a row: the SpGEMM's long classes), rows 192 … 255 forty times (its
+    // rank path from 4 096 products), rows 256 … 319 twelve times (the mid-size classes); every other row six scattered entries (the short-row kernels)
     std::vector<int32_t> rp(n + 1), ci;
     std::vector<double> va;
-    ci.reserve((size_t)n * per); va.reserve((size_t)n * per);
+    ci.reserve((size_t)n * 6 + 40000); va.reserve((size_t)n * 6 + 40000);
     unsigned long long st = 88172645463325252ull;                   // xorshift: scattered columns, sorted inside a row
+    std::vector<int32_t> c(128);
     for (int r = 0; r < n; ++r) {
         rp[r] = (int32_t)ci.size();
-        int32_t c[per];
-        for (int k = 0; k < per; ++k) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; c[k] = (int32_t)(st % (unsigned)n); }
-        std::sort(c, c + per);
+        const int per = r < 192 ? 128 : r < 256 ? 40 : r < 320 ? 12 : 6;
+        const unsigned lo = r >= 64 && r < 192 ? 0u : r < 320 ? 64u : 0u, span = r >= 64 && r < 192 ? (unsigned)n : r < 320 ? 128u : (unsigned)n;
+        for (int k = 0; k < per; ++k) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; c[k] = (int32_t)(lo + st % span); }
+        std::sort(c.begin(), c.begin() + per);
         for (int k = 0; k < per; ++k) if (k == 0 || c[k] != c[k - 1]) { ci.push_back(c[k]); va.push_back(1.0); }
     }
     rp[n] = (int32_t)ci.size();
@@ -343,6 +347,13 @@ G4S_API g4s_status g4s_warm_up(void)
         (void)g4s_csr_destroy(A);
     }
     (void)hipFree(x); (void)hipFree(y);
+    if (rc == G4S_OK) {                                             // … and the square of the same matrix through g4s_spgemm_csr_i32_f64: every row class of the product
+        int32_t *crpt = nullptr, *ccol = nullptr;
+        double *cval = nullptr;
+        int64_t cnnz = 0;
+        rc = g4s_spgemm_csr_i32_f64(rp.data(), ci.data(), va.data(), rp.data(), ci.data(), va.data(), &crpt, &ccol, &cval, n, n, n, &cnnz, nullptr, G4S_HOST_POINTERS | G4S_SORT_OUTPUT);
+        g4s_free(crpt); g4s_free(ccol); g4s_free(cval);
+    }
     return rc;
 }
 

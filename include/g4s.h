@@ -53,9 +53,11 @@ const char *g4s_version(void);
 /* "spmv_kernel_sources_sha256=<hex>;variant=<name>": the SpMV kernel sources this library was built from (tools/kernel_hash.py) and the name of an A/B
  * variant build (empty for the regular one) — for tools that pair a stored measurement with the LOADED build (bench.py's roofline.traffic). */
 const char *g4s_build_info(void);
-/* Loads the device code of the plan builders and SpMV kernels now instead of inside the first g4s_csr_create / g4s_spmv of the process (HIP loads a translation
+/* Loads the device code of the plan builders, the SpMV kernels and the SpGEMM row classes now instead of inside the first g4s_csr_create / g4s_spmv /
+ * g4s_spgemm_* of the process (HIP loads a translation
  * unit's code object at its first launch: 12–25 ms of a first create of configs[1] that takes 18.6 ms afterwards). Builds, runs and destroys one small matrix on
- * the path g4s_csr_create picks for it, on the blocked and on the streaming path. Optional; synchronous; may be called again (it then costs a few milliseconds).
+ * the path g4s_csr_create picks for it, on the blocked and on the streaming path, and squares it. Optional; synchronous; may be called again (≈ 25 ms then, 0.2 s in a
+ * process that has not touched the device yet).
  * No reference counterpart (a CPU library has no such step). */
 g4s_status g4s_warm_up(void);
 const char *g4s_last_error(void);                 /* thread-local, never NULL                              */

@@ -79,6 +79,13 @@ def test_spmv_heavy_rows_inside_many_row_blocks(oracle):
     assert torch.equal(A.spmv(xd), A.spmv(xd))
 
 
+def test_warm_up_runs_every_family_once(g4s):
+    # g4s_warm_up: one small matrix through the plan builders, the SpMV paths and its own square; callable again
+    from g4s_amd import capi
+    capi.check(g4s.g4s_warm_up())
+    capi.check(g4s.g4s_warm_up())
+
+
 def test_spmv_power_law_with_hubs(oracle):
     # empty rows, short rows, medium rows (shuffle path) and hubs > TILE_NNZ / > LONG_CHUNK (chunked path)
     from g4s_amd import host
