@@ -278,8 +278,8 @@ def self_launch(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=400)               # (0.16 s of products: one 5 ms hiccup of the box moves the line by 3 %, not by 13 % as with 100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="rmat", choices=sorted(WORKLOADS))
     ap.add_argument("--exchange", default="auto", choices=["auto", "dist", "allgather"],
                     help="auto = dist: the C-ABI multi-GPU product (g4s_spmv_dist_*) with the packed exchange (RCCL send/recv of the referenced x entries, overlapped with "
@@ -326,7 +326,9 @@ def main():
     # ---- inputs, resident in HBM
     A_full = build_matrix(args.workload, host, args.small)
     n_rows, n_cols, nnz_total = A_full.rows, A_full.cols, A_full.nnz
-    offs = gdist.row_partition(A_full.rowptr, world)
+    # (one part needs no partition pass: g4s_row_partition copies the row pointers to the host — 40 MB through the runtime's staging buffers — and the first create
+    # behind that copy measured 16 ms slower every other run, 36 against 20 ms on one box)
+    offs = gdist.row_partition(A_full.rowptr, world) if world > 1 else [0, n_rows]
     r0, r1 = offs[rank], offs[rank + 1]
     flags = (capi.SPMV_NO_NT if args.no_nt else 0) | {"auto": 0, "stream": capi.SPMV_STREAM, "blocked": capi.SPMV_BLOCKED}[args.path]
     mode = args.exchange if args.exchange != "auto" else "dist"
